@@ -1,0 +1,180 @@
+/*
+ * lvdgs.h -- C ABI of the MI355X (gfx950) differentiable 3D-Gaussian tile rasterizer.
+ *
+ * This is the drop-in boundary for the path LVD-GS reaches through
+ *     gaussian_splatting.gaussian_renderer.render(viewpoint, gaussians, pipe, bg)
+ * (call sites: reference utils/slam_frontend.py:1493, utils/slam_backend.py:98,184,277,407,
+ *  utils/eval_utils_0806.py:215, utils/init_pose.py:145).  Upstream that facade calls the
+ * `diff_gaussian_rasterization` extension (reference README.md:43; sources absent from the
+ * reference checkout), whose Python-visible entry points are
+ *     _C.rasterize_gaussians(...)            -> lvdgs_forward_prepare + lvdgs_forward_render
+ *     _C.rasterize_gaussians_backward(...)   -> lvdgs_backward
+ *     _C.mark_visible(...)                   -> lvdgs_mark_visible
+ * Other absent native dependencies the north star names:
+ *     simple_knn._C.distCUDA2  (README.md:42) -> lvdgs_dist2_knn3
+ *     curope rope_2d           (README.md:49) -> lvdgs_rope2d
+ *
+ * Conventions
+ *  - plain C: raw device pointers, sizes, a hipStream_t passed as void*; no C++ exceptions
+ *    cross the boundary; every entry point returns an lvdgs_status (0 = ok) and
+ *    lvdgs_last_error() returns a thread-local message for the last failure;
+ *  - all work is enqueued on the given stream and is ordered with it; the only host
+ *    synchronisation is inside lvdgs_forward_prepare (it returns the number of
+ *    (Gaussian, tile) pairs so the caller can size the binning buffer -- the same
+ *    device->host read upstream performs);
+ *  - the library owns no device memory: the caller allocates the three state buffers
+ *    (geometry, binning, image -- upstream's geomBuffer / binningBuffer / imgBuffer) and the
+ *    scratch buffers, with the sizes the lvdgs_*_bytes functions report, and keeps the state
+ *    buffers alive until backward (PyTorch: ctx.save_for_backward);
+ *  - no global mutable state except the optional profiling counters;
+ *  - all float tensors are float32, contiguous, row-major; matrices are 4x4 in the
+ *    row-vector layout the reference's Camera produces (world_view_transform =
+ *    getWorld2View2(R,T).transpose(0,1), utils/camera_utils.py:106-116).
+ */
+#ifndef LVDGS_H
+#define LVDGS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    LVDGS_OK = 0,
+    LVDGS_E_INVALID = 1, /* bad argument (null pointer, size mismatch, buffer too small) */
+    LVDGS_E_HIP = 2,     /* a HIP runtime call or kernel launch failed                   */
+    LVDGS_E_RANGE = 3    /* problem exceeds a built-in limit (e.g. > 2^31 pairs)         */
+} lvdgs_status;
+
+/* One argument block serves the three rasterizer calls; each call reads the fields it needs
+ * (marked P = prepare, R = render, B = backward).  Zero-initialise, then fill. */
+typedef struct lvdgs_args {
+    /* ---- GaussianRasterizationSettings (P R B) ---- */
+    int32_t image_height, image_width;
+    float tanfovx, tanfovy;
+    float scale_modifier;
+    int32_t sh_degree;   /* 0..3 */
+    int32_t prefiltered; /* accepted for signature parity; unused */
+    int32_t debug;       /* 1: synchronise and check after every launch */
+    const float *bg;             /* device, 3  */
+    const float *viewmatrix;     /* device, 16 */
+    const float *projmatrix;     /* device, 16: viewmatrix * projmatrix_raw */
+    const float *projmatrix_raw; /* device, 16 (B: pose gradient) */
+    const float *campos;         /* device, 3  */
+
+    /* ---- Gaussians (P B) ---- */
+    int32_t num_gaussians; /* N */
+    int32_t sh_coeffs;     /* M: coefficients per Gaussian in `shs` (>= (sh_degree+1)^2) */
+    const float *means3D;        /* N*3 */
+    const float *opacities;      /* N   (activated, in [0,1]) */
+    const float *scales;         /* N*3 (activated) or NULL with cov3D_precomp */
+    const float *rotations;      /* N*4 (r,x,y,z; used as given) or NULL */
+    const float *cov3D_precomp;  /* N*6 (xx,xy,xz,yy,yz,zz) or NULL */
+    const float *shs;            /* N*M*3 or NULL with colors_precomp */
+    const float *colors_precomp; /* N*3 or NULL */
+
+    /* ---- state + scratch buffers (caller-allocated, 256-byte aligned) ---- */
+    void *geom_state;     size_t geom_bytes;    /* P w, R rw, B r : lvdgs_geom_bytes(N)           */
+    void *binning_state;  size_t binning_bytes; /*      R w,  B r : lvdgs_binning_bytes(D)        */
+    void *image_state;    size_t image_bytes;   /*      R w,  B r : lvdgs_image_bytes(W,H)        */
+    void *scratch;        size_t scratch_bytes; /* P: lvdgs_prepare_scratch_bytes(N)
+                                                   R: lvdgs_render_scratch_bytes(D,W,H)
+                                                   B: lvdgs_backward_scratch_bytes(N,D)           */
+    int64_t num_rendered; /* D, as returned by prepare (R B) */
+
+    /* ---- forward outputs ---- */
+    int32_t *radii;     /* N       (P w, B r) */
+    float *out_color;   /* 3*H*W   (R w, B r) */
+    float *out_depth;   /* H*W     (R w)      */
+    float *out_opacity; /* H*W     (R w)      */
+    int32_t *n_touched; /* N       (R w)      */
+
+    /* ---- backward inputs ---- */
+    const float *dL_dout_color;   /* 3*H*W         */
+    const float *dL_dout_depth;   /* H*W or NULL   */
+    const float *dL_dout_opacity; /* H*W or NULL   */
+
+    /* ---- backward outputs (every element is written) ---- */
+    float *dL_dmeans3D;   /* N*3 */
+    float *dL_dmeans2D;   /* N*3: d/d NDC x,y of the projected mean (viewspace_points.grad), z = 0 */
+    float *dL_dopacities; /* N   */
+    float *dL_dscales;    /* N*3 or NULL with cov3D_precomp */
+    float *dL_drotations; /* N*4 or NULL with cov3D_precomp */
+    float *dL_dcov3D;     /* N*6 or NULL (only written when cov3D_precomp != NULL) */
+    float *dL_dshs;       /* N*M*3 or NULL with colors_precomp */
+    float *dL_dcolors;    /* N*3 or NULL with shs */
+    float *dL_dtau;       /* 6: [d/d rho (3), d/d theta (3)] of T_w2c <- Exp(tau) T_w2c
+                             (reference utils/pose_utils.py:70-87) */
+} lvdgs_args;
+
+/* ---- sizes ---- */
+size_t lvdgs_geom_bytes(int32_t num_gaussians);
+size_t lvdgs_prepare_scratch_bytes(int32_t num_gaussians);
+size_t lvdgs_binning_bytes(int64_t num_rendered);
+size_t lvdgs_image_bytes(int32_t width, int32_t height);
+size_t lvdgs_render_scratch_bytes(int64_t num_rendered, int32_t width, int32_t height);
+size_t lvdgs_backward_scratch_bytes(int32_t num_gaussians, int64_t num_rendered);
+
+/* ---- rasterizer ---- */
+/* Projects the Gaussians, depth-sorts them and counts (Gaussian, tile) pairs.  Writes radii and
+ * geom_state; returns the pair count D in *num_rendered (synchronises the stream once). */
+int lvdgs_forward_prepare(const lvdgs_args *a, int64_t *num_rendered, void *stream);
+/* Bins pairs per tile, orders each tile's list by depth and composites front to back.
+ * Writes out_color / out_depth / out_opacity / n_touched, binning_state and image_state. */
+int lvdgs_forward_render(const lvdgs_args *a, void *stream);
+/* Gradient of the three images w.r.t. every Gaussian parameter and the camera pose. */
+int lvdgs_backward(const lvdgs_args *a, void *stream);
+/* present[i] = Gaussian i is in front of the near plane of the view (GaussianRasterizer.markVisible). */
+int lvdgs_mark_visible(int32_t num_gaussians, const float *means3D, const float *viewmatrix,
+                       const float *projmatrix, uint8_t *present, void *stream);
+
+/* ---- views into the state buffers (parity tests read intermediates through these) ---- */
+typedef struct lvdgs_state_layout {
+    /* byte offsets into geom_state */
+    size_t geom_rec;           /* N x 12 float: x, y, conic a, b, c, opacity, r, g, b, view depth,
+                                  u32 first-pair offset, i32 radius */
+    size_t geom_tiles_touched; /* N x u32 */
+    size_t geom_order;         /* N x u32: depth rank -> Gaussian id */
+    size_t geom_offsets;       /* N x u32: inclusive scan of tiles_touched in rank order */
+    /* byte offsets into binning_state */
+    size_t bin_point_list;     /* D x u32: Gaussian ids, (tile, depth, id) ordered */
+    size_t bin_tile_keys;      /* D x u32: tile id of each entry of point_list */
+    /* byte offsets into image_state */
+    size_t img_ranges;         /* T x 2 u32: [begin, end) of each tile in point_list */
+    size_t img_final_T;        /* P x float */
+    size_t img_n_contrib;      /* P x u32 */
+} lvdgs_state_layout;
+int lvdgs_state_layout_query(int32_t num_gaussians, int64_t num_rendered, int32_t width, int32_t height,
+                             lvdgs_state_layout *out);
+
+/* ---- other native dependencies of the SLAM loop ---- */
+/* mean squared distance of every point to its 3 nearest neighbours (simple_knn.distCUDA2). */
+size_t lvdgs_knn_scratch_bytes(int32_t num_points);
+int lvdgs_dist2_knn3(int32_t num_points, const float *points /* P*3 */, float *mean_dist2 /* P */,
+                     void *scratch, size_t scratch_bytes, void *stream);
+/* in-place 2-D rotary embedding of tokens (B, N, H, D) with integer positions (B, N, 2)
+ * (croco curope.rope_2d): first half of D rotates by y, second half by x; fwd = +1 or -1. */
+int lvdgs_rope2d(float *tokens, const int64_t *positions, int32_t B, int32_t N, int32_t H, int32_t D,
+                 float base, float fwd, void *stream);
+
+/* ---- diagnostics ---- */
+const char *lvdgs_last_error(void);
+const char *lvdgs_version(void);
+/* Optional per-kernel timing with HIP events recorded on the caller's stream around each
+ * launch.  Off by default; enabling it does not change results. */
+void lvdgs_profile_enable(int on);
+void lvdgs_profile_reset(void);
+/* Synchronises outstanding events, then fills up to `cap` entries; returns the entry count. */
+typedef struct lvdgs_kernel_time {
+    char name[48];
+    int64_t launches;
+    double total_ms;
+} lvdgs_kernel_time;
+int lvdgs_profile_read(lvdgs_kernel_time *out, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LVDGS_H */

@@ -1,0 +1,119 @@
+"""ctypes binding of ``lib/liblvdgs.so`` (C ABI: ``include/lvdgs.h``).
+
+The library is the only compute path: if it is missing or fails to load, importing a symbol
+from here raises -- there is no CPU or PyTorch fallback.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblvdgs.so")
+
+OK, E_INVALID, E_HIP, E_RANGE = 0, 1, 2, 3
+
+_fp = C.c_void_p
+
+
+class Args(C.Structure):
+    """struct lvdgs_args (include/lvdgs.h) -- field order must match the header."""
+    _fields_ = [
+        ("image_height", C.c_int32), ("image_width", C.c_int32),
+        ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
+        ("sh_degree", C.c_int32), ("prefiltered", C.c_int32), ("debug", C.c_int32),
+        ("bg", _fp), ("viewmatrix", _fp), ("projmatrix", _fp), ("projmatrix_raw", _fp), ("campos", _fp),
+        ("num_gaussians", C.c_int32), ("sh_coeffs", C.c_int32),
+        ("means3D", _fp), ("opacities", _fp), ("scales", _fp), ("rotations", _fp), ("cov3D_precomp", _fp),
+        ("shs", _fp), ("colors_precomp", _fp),
+        ("geom_state", _fp), ("geom_bytes", C.c_size_t),
+        ("binning_state", _fp), ("binning_bytes", C.c_size_t),
+        ("image_state", _fp), ("image_bytes", C.c_size_t),
+        ("scratch", _fp), ("scratch_bytes", C.c_size_t),
+        ("num_rendered", C.c_int64),
+        ("radii", _fp), ("out_color", _fp), ("out_depth", _fp), ("out_opacity", _fp), ("n_touched", _fp),
+        ("dL_dout_color", _fp), ("dL_dout_depth", _fp), ("dL_dout_opacity", _fp),
+        ("dL_dmeans3D", _fp), ("dL_dmeans2D", _fp), ("dL_dopacities", _fp), ("dL_dscales", _fp),
+        ("dL_drotations", _fp), ("dL_dcov3D", _fp), ("dL_dshs", _fp), ("dL_dcolors", _fp), ("dL_dtau", _fp),
+    ]
+
+
+class StateLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in (
+        "geom_rec", "geom_tiles_touched", "geom_order", "geom_offsets", "bin_point_list", "bin_tile_keys",
+        "img_ranges", "img_final_T", "img_n_contrib")]
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_int64), ("total_ms", C.c_double)]
+
+
+# every symbol include/lvdgs.h declares (checked by tests/test_abi.py)
+EXPORTS = (
+    "lvdgs_geom_bytes", "lvdgs_prepare_scratch_bytes", "lvdgs_binning_bytes", "lvdgs_image_bytes",
+    "lvdgs_render_scratch_bytes", "lvdgs_backward_scratch_bytes", "lvdgs_forward_prepare", "lvdgs_forward_render",
+    "lvdgs_backward", "lvdgs_mark_visible", "lvdgs_state_layout_query", "lvdgs_knn_scratch_bytes",
+    "lvdgs_dist2_knn3", "lvdgs_rope2d", "lvdgs_last_error", "lvdgs_version", "lvdgs_profile_enable",
+    "lvdgs_profile_reset", "lvdgs_profile_read",
+)
+
+_lib = None
+
+
+class LvdgsError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library (loads on first use; raises if the HIP build is missing)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LvdgsError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C lvd_gs-slam_amd/csrc`). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.lvdgs_last_error.restype = C.c_char_p
+        L.lvdgs_version.restype = C.c_char_p
+        for name in ("lvdgs_geom_bytes", "lvdgs_prepare_scratch_bytes"):
+            getattr(L, name).restype = C.c_size_t
+            getattr(L, name).argtypes = [C.c_int32]
+        L.lvdgs_binning_bytes.restype = C.c_size_t
+        L.lvdgs_binning_bytes.argtypes = [C.c_int64]
+        L.lvdgs_image_bytes.restype = C.c_size_t
+        L.lvdgs_image_bytes.argtypes = [C.c_int32, C.c_int32]
+        L.lvdgs_render_scratch_bytes.restype = C.c_size_t
+        L.lvdgs_render_scratch_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+        L.lvdgs_backward_scratch_bytes.restype = C.c_size_t
+        L.lvdgs_backward_scratch_bytes.argtypes = [C.c_int32, C.c_int64]
+        L.lvdgs_forward_prepare.argtypes = [C.POINTER(Args), C.POINTER(C.c_int64), C.c_void_p]
+        L.lvdgs_forward_render.argtypes = [C.POINTER(Args), C.c_void_p]
+        L.lvdgs_backward.argtypes = [C.POINTER(Args), C.c_void_p]
+        L.lvdgs_mark_visible.argtypes = [C.c_int32, _fp, _fp, _fp, _fp, C.c_void_p]
+        L.lvdgs_state_layout_query.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(StateLayout)]
+        L.lvdgs_knn_scratch_bytes.restype = C.c_size_t
+        L.lvdgs_knn_scratch_bytes.argtypes = [C.c_int32]
+        L.lvdgs_dist2_knn3.argtypes = [C.c_int32, _fp, _fp, _fp, C.c_size_t, C.c_void_p]
+        L.lvdgs_rope2d.argtypes = [_fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p]
+        L.lvdgs_profile_enable.argtypes = [C.c_int]
+        L.lvdgs_profile_read.argtypes = [C.POINTER(KernelTime), C.c_int]
+        _lib = L
+    return _lib
+
+
+def check(status, what):
+    if status != OK:
+        raise LvdgsError(f"{what} failed ({status}): {lib().lvdgs_last_error().decode()}")
+
+
+def profile_enable(on=True):
+    lib().lvdgs_profile_enable(1 if on else 0)
+
+
+def profile_reset():
+    lib().lvdgs_profile_reset()
+
+
+def profile_read():
+    """{kernel name: (launches, total_ms)} measured with HIP events on the launch stream."""
+    buf = (KernelTime * 64)()
+    n = lib().lvdgs_profile_read(buf, 64)
+    return {buf[i].name.decode(): (int(buf[i].launches), float(buf[i].total_ms)) for i in range(n)}

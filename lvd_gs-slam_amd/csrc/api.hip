@@ -1,0 +1,372 @@
+// C ABI entry points (include/lvdgs.h): argument checks, state-buffer layouts, launch sequencing.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace lvdgs {
+
+// ---------------------------------------------------------------- errors
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_hip(hipError_t e, const char *what) {
+    if (e == hipSuccess) return LVDGS_OK;
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return LVDGS_E_HIP;
+}
+
+// ---------------------------------------------------------------- profiling
+namespace {
+struct ProfSlot {
+    std::string name;
+    int64_t launches = 0;
+    double total_ms = 0.0;
+};
+struct ProfPending {
+    int slot;
+    hipEvent_t start, stop;
+};
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfSlot> g_slots;
+std::vector<ProfPending> g_pending;
+std::vector<hipEvent_t> g_free_events;
+
+hipEvent_t get_event() {
+    if (!g_free_events.empty()) {
+        hipEvent_t e = g_free_events.back();
+        g_free_events.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+int slot_of(const char *name) {
+    for (size_t i = 0; i < g_slots.size(); i++)
+        if (g_slots[i].name == name) return (int)i;
+    g_slots.push_back(ProfSlot{name});
+    return (int)g_slots.size() - 1;
+}
+void drain_locked() {
+    for (auto &p : g_pending) {
+        (void)hipEventSynchronize(p.stop);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+            g_slots[p.slot].launches++;
+            g_slots[p.slot].total_ms += ms;
+        }
+        g_free_events.push_back(p.start);
+        g_free_events.push_back(p.stop);
+    }
+    g_pending.clear();
+}
+}  // namespace
+
+ProfScope::ProfScope(const char *name, hipStream_t s) : slot(-1), stream(s) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    slot = slot_of(name);
+    ProfPending p{slot, get_event(), get_event()};
+    (void)hipEventRecord(p.start, s);
+    g_pending.push_back(p);
+}
+ProfScope::~ProfScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    // the matching entry is the last one pushed for this scope
+    for (size_t i = g_pending.size(); i-- > 0;)
+        if (g_pending[i].slot == slot) {
+            (void)hipEventRecord(g_pending[i].stop, stream);
+            break;
+        }
+}
+
+// ---------------------------------------------------------------- layouts
+template <typename T>
+static void carve(T *&ptr, size_t count, char *base, size_t &off) {
+    ptr = base ? reinterpret_cast<T *>(base + off) : nullptr;
+    off += align256(count * sizeof(T));
+}
+
+size_t geom_layout(int N, GeomView *v, void *base) {
+    GeomView tmp;
+    if (!v) v = &tmp;
+    size_t off = 0;
+    char *b = (char *)base;
+    const size_t n = (size_t)(N > 0 ? N : 1);
+    carve(v->rec, n * REC_FLOATS, b, off);
+    carve(v->tiles_touched, n, b, off);
+    carve(v->order, n, b, off);
+    carve(v->offsets, n, b, off);
+    return off;
+}
+
+static size_t scan_blocks(int N) { return (size_t)cdiv(N > 0 ? N : 1, 2048) + 1; }
+
+size_t prep_scratch_layout(int N, PrepScratch *v, void *base) {
+    PrepScratch tmp;
+    if (!v) v = &tmp;
+    size_t off = 0;
+    char *b = (char *)base;
+    const size_t n = (size_t)(N > 0 ? N : 1);
+    carve(v->keys[0], n, b, off);
+    carve(v->keys[1], n, b, off);
+    carve(v->vals[0], n, b, off);
+    carve(v->vals[1], n, b, off);
+    carve(v->hist, radix_hist_entries(N), b, off);
+    carve(v->totals, (size_t)1 << SORT_MAX_BITS, b, off);
+    carve(v->blocksums, scan_blocks(N), b, off);
+    carve(v->total, 64, b, off);
+    return off;
+}
+
+size_t bin_layout(int64_t D, BinView *v, void *base) {
+    BinView tmp;
+    if (!v) v = &tmp;
+    size_t off = 0;
+    char *b = (char *)base;
+    const size_t d = (size_t)(D > 0 ? D : 1);
+    carve(v->point_list, d, b, off);
+    carve(v->tile_keys, d, b, off);
+    return off;
+}
+
+size_t image_layout(int W, int H, ImageView *v, void *base) {
+    ImageView tmp;
+    if (!v) v = &tmp;
+    size_t off = 0;
+    char *b = (char *)base;
+    const size_t P = (size_t)W * H, T = (size_t)cdiv(W, TILE) * cdiv(H, TILE);
+    carve(v->ranges, T ? T : 1, b, off);
+    carve(v->final_T, P ? P : 1, b, off);
+    carve(v->n_contrib, P ? P : 1, b, off);
+    return off;
+}
+
+size_t render_scratch_layout(int64_t D, int W, int H, RenderScratch *v, void *base) {
+    RenderScratch tmp;
+    if (!v) v = &tmp;
+    size_t off = 0;
+    char *b = (char *)base;
+    const size_t d = (size_t)(D > 0 ? D : 1);
+    carve(v->keys, d, b, off);
+    carve(v->vals, d, b, off);
+    carve(v->hist, radix_hist_entries(D), b, off);
+    carve(v->totals, (size_t)1 << SORT_MAX_BITS, b, off);
+    return off;
+}
+
+size_t bwd_scratch_layout(int N, int64_t D, BwdScratch *v, void *base) {
+    BwdScratch tmp;
+    if (!v) v = &tmp;
+    size_t off = 0;
+    char *b = (char *)base;
+    carve(v->pair_grads, (size_t)(D > 0 ? D : 1) * PAIR_FLOATS, b, off);
+    carve(v->tau_part, (size_t)(cdiv(N > 0 ? N : 1, 256)) * 6, b, off);
+    return off;
+}
+
+int tile_sort_bits(int W, int H) {
+    const int T = cdiv(W, TILE) * cdiv(H, TILE);
+    int bits = 0;
+    while ((1 << bits) < T) bits++;
+    return bits < 1 ? 1 : bits;
+}
+
+// ---------------------------------------------------------------- argument checks
+static int check_common(const lvdgs_args *a) {
+    if (!a) { set_error("args is NULL"); return LVDGS_E_INVALID; }
+    if (a->image_width <= 0 || a->image_height <= 0) { set_error("bad image size %dx%d", a->image_width, a->image_height); return LVDGS_E_INVALID; }
+    if (a->num_gaussians < 0) { set_error("negative Gaussian count"); return LVDGS_E_INVALID; }
+    if (!(a->tanfovx > 0.f) || !(a->tanfovy > 0.f)) { set_error("tanfov must be positive"); return LVDGS_E_INVALID; }
+    if (a->sh_degree < 0 || a->sh_degree > 3) { set_error("sh_degree %d outside 0..3", a->sh_degree); return LVDGS_E_INVALID; }
+    if (!a->bg || !a->viewmatrix || !a->projmatrix) { set_error("bg / viewmatrix / projmatrix is NULL"); return LVDGS_E_INVALID; }
+    if ((int64_t)cdiv(a->image_width, TILE) * cdiv(a->image_height, TILE) > (1 << 22)) { set_error("image too large"); return LVDGS_E_RANGE; }
+    return LVDGS_OK;
+}
+
+static int check_gaussians(const lvdgs_args *a) {
+    if (a->num_gaussians == 0) return LVDGS_OK;
+    if (!a->means3D || !a->opacities) { set_error("means3D / opacities is NULL"); return LVDGS_E_INVALID; }
+    if ((a->shs == nullptr) == (a->colors_precomp == nullptr)) { set_error("provide exactly one of shs / colors_precomp"); return LVDGS_E_INVALID; }
+    const bool sr = a->scales && a->rotations;
+    if (sr == (a->cov3D_precomp != nullptr) || (!!a->scales != !!a->rotations)) { set_error("provide exactly one of scales+rotations / cov3D_precomp"); return LVDGS_E_INVALID; }
+    if (a->shs) {
+        if (!a->campos) { set_error("campos is NULL"); return LVDGS_E_INVALID; }
+        if (a->sh_coeffs < (a->sh_degree + 1) * (a->sh_degree + 1)) { set_error("sh_coeffs %d too small for degree %d", a->sh_coeffs, a->sh_degree); return LVDGS_E_INVALID; }
+    }
+    return LVDGS_OK;
+}
+
+}  // namespace lvdgs
+
+using namespace lvdgs;
+
+extern "C" {
+
+const char *lvdgs_last_error(void) { return g_err; }
+const char *lvdgs_version(void) { return "lvdgs 0.1.0 (gfx950)"; }
+
+size_t lvdgs_geom_bytes(int32_t N) { return geom_layout(N, nullptr, nullptr); }
+size_t lvdgs_prepare_scratch_bytes(int32_t N) { return prep_scratch_layout(N, nullptr, nullptr); }
+size_t lvdgs_binning_bytes(int64_t D) { return bin_layout(D, nullptr, nullptr); }
+size_t lvdgs_image_bytes(int32_t W, int32_t H) { return image_layout(W, H, nullptr, nullptr); }
+size_t lvdgs_render_scratch_bytes(int64_t D, int32_t W, int32_t H) { return render_scratch_layout(D, W, H, nullptr, nullptr); }
+size_t lvdgs_backward_scratch_bytes(int32_t N, int64_t D) { return bwd_scratch_layout(N, D, nullptr, nullptr); }
+
+int lvdgs_state_layout_query(int32_t N, int64_t D, int32_t W, int32_t H, lvdgs_state_layout *out) {
+    if (!out) { set_error("out is NULL"); return LVDGS_E_INVALID; }
+    char *base = (char *)4096;  // offsets are computed by carving from a fake base
+    GeomView g; BinView b; ImageView im;
+    geom_layout(N, &g, base); bin_layout(D, &b, base); image_layout(W, H, &im, base);
+    out->geom_rec = (char *)g.rec - base; out->geom_tiles_touched = (char *)g.tiles_touched - base;
+    out->geom_order = (char *)g.order - base; out->geom_offsets = (char *)g.offsets - base;
+    out->bin_point_list = (char *)b.point_list - base; out->bin_tile_keys = (char *)b.tile_keys - base;
+    out->img_ranges = (char *)im.ranges - base; out->img_final_T = (char *)im.final_T - base;
+    out->img_n_contrib = (char *)im.n_contrib - base;
+    return LVDGS_OK;
+}
+
+int lvdgs_forward_prepare(const lvdgs_args *a, int64_t *num_rendered, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (int e = check_common(a)) return e;
+    if (int e = check_gaussians(a)) return e;
+    if (!num_rendered) { set_error("num_rendered is NULL"); return LVDGS_E_INVALID; }
+    const int N = a->num_gaussians;
+    *num_rendered = 0;
+    if (N == 0) return LVDGS_OK;
+    if (!a->radii || !a->geom_state || !a->scratch) { set_error("radii / geom_state / scratch is NULL"); return LVDGS_E_INVALID; }
+    if (a->geom_bytes < lvdgs_geom_bytes(N) || a->scratch_bytes < lvdgs_prepare_scratch_bytes(N)) {
+        set_error("geom_state or scratch too small"); return LVDGS_E_INVALID;
+    }
+    GeomView g; PrepScratch w;
+    geom_layout(N, &g, a->geom_state);
+    prep_scratch_layout(N, &w, a->scratch);
+    if (int e = launch_preprocess_fwd(*a, g, w.keys[0], w.vals[0], s)) return e;
+    bool in_a = true;
+    if (int e = radix_sort_pairs(w.keys[0], w.vals[0], w.keys[1], w.vals[1], N, 32, w.hist, w.totals, &in_a, a->debug, s)) return e;
+    const uint32_t *order = in_a ? w.vals[0] : w.vals[1];
+    if (int e = check_hip(hipMemcpyAsync(g.order, order, sizeof(uint32_t) * (size_t)N, hipMemcpyDeviceToDevice, s), "copy order")) return e;
+    if (int e = launch_offsets_scan(g.tiles_touched, g.order, g.offsets, w.blocksums, w.total, N, a->debug, s)) return e;
+    uint32_t total = 0;
+    if (int e = check_hip(hipMemcpyAsync(&total, w.total, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read pair count")) return e;
+    if (int e = check_hip(hipStreamSynchronize(s), "synchronize after prepare")) return e;
+    if (total > 0x7FFFFFFFu) { set_error("%u (Gaussian, tile) pairs exceed the 2^31 limit", total); return LVDGS_E_RANGE; }
+    *num_rendered = (int64_t)total;
+    return LVDGS_OK;
+}
+
+int lvdgs_forward_render(const lvdgs_args *a, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (int e = check_common(a)) return e;
+    const int N = a->num_gaussians, W = a->image_width, H = a->image_height;
+    const int64_t D = N == 0 ? 0 : a->num_rendered;
+    if (D < 0) { set_error("negative num_rendered"); return LVDGS_E_INVALID; }
+    if (!a->out_color || !a->out_depth || !a->out_opacity || !a->image_state) { set_error("output image or image_state is NULL"); return LVDGS_E_INVALID; }
+    if (a->image_bytes < lvdgs_image_bytes(W, H)) { set_error("image_state too small"); return LVDGS_E_INVALID; }
+    if (N > 0 && (!a->n_touched || !a->geom_state)) { set_error("n_touched / geom_state is NULL"); return LVDGS_E_INVALID; }
+    if (D > 0) {
+        if (!a->binning_state || !a->scratch) { set_error("binning_state / scratch is NULL"); return LVDGS_E_INVALID; }
+        if (a->binning_bytes < lvdgs_binning_bytes(D) || a->scratch_bytes < lvdgs_render_scratch_bytes(D, W, H)) {
+            set_error("binning_state or scratch too small"); return LVDGS_E_INVALID;
+        }
+    }
+    GeomView g{}; BinView b{}; ImageView im; RenderScratch w{};
+    image_layout(W, H, &im, a->image_state);
+    const int num_tiles = cdiv(W, TILE) * cdiv(H, TILE);
+    if (N > 0) {
+        geom_layout(N, &g, a->geom_state);
+        if (int e = check_hip(hipMemsetAsync(a->n_touched, 0, sizeof(int32_t) * (size_t)N, s), "memset n_touched")) return e;
+    }
+    if (D > 0) {
+        bin_layout(D, &b, a->binning_state);
+        render_scratch_layout(D, W, H, &w, a->scratch);
+        const int bits = tile_sort_bits(W, H);
+        // start in the buffer that makes the sorted result land in binning_state
+        const bool start_in_state = (radix_num_passes(bits) % 2) == 0;
+        uint32_t *k0 = start_in_state ? b.tile_keys : w.keys, *v0 = start_in_state ? b.point_list : w.vals;
+        uint32_t *k1 = start_in_state ? w.keys : b.tile_keys, *v1 = start_in_state ? w.vals : b.point_list;
+        if (int e = launch_emit_pairs(*a, g, k0, v0, s)) return e;
+        bool in_first = true;
+        if (int e = radix_sort_pairs(k0, v0, k1, v1, D, bits, w.hist, w.totals, &in_first, a->debug, s)) return e;
+        if ((in_first ? k0 : k1) != b.tile_keys) { set_error("internal: sorted list not in binning_state"); return LVDGS_E_INVALID; }
+    }
+    if (int e = launch_tile_ranges(b.tile_keys, D, im.ranges, num_tiles, a->debug, s)) return e;
+    return launch_blend_fwd(*a, g, b, im, s);
+}
+
+int lvdgs_backward(const lvdgs_args *a, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (int e = check_common(a)) return e;
+    if (int e = check_gaussians(a)) return e;
+    const int N = a->num_gaussians, W = a->image_width, H = a->image_height;
+    if (!a->dL_dtau) { set_error("dL_dtau is NULL"); return LVDGS_E_INVALID; }
+    if (N == 0) return check_hip(hipMemsetAsync(a->dL_dtau, 0, 6 * sizeof(float), s), "memset tau");
+    const int64_t D = a->num_rendered;
+    if (D < 0) { set_error("negative num_rendered"); return LVDGS_E_INVALID; }
+    if (!a->dL_dout_color || !a->dL_dmeans3D || !a->dL_dmeans2D || !a->dL_dopacities || !a->projmatrix_raw || !a->radii) {
+        set_error("a required backward pointer is NULL"); return LVDGS_E_INVALID;
+    }
+    if (a->cov3D_precomp ? !a->dL_dcov3D : (!a->dL_dscales || !a->dL_drotations)) { set_error("covariance gradient output is NULL"); return LVDGS_E_INVALID; }
+    if (a->shs ? !a->dL_dshs : !a->dL_dcolors) { set_error("colour gradient output is NULL"); return LVDGS_E_INVALID; }
+    if (!a->geom_state || !a->image_state || !a->scratch || (D > 0 && !a->binning_state)) { set_error("a state / scratch buffer is NULL"); return LVDGS_E_INVALID; }
+    if (a->geom_bytes < lvdgs_geom_bytes(N) || a->image_bytes < lvdgs_image_bytes(W, H) ||
+        (D > 0 && a->binning_bytes < lvdgs_binning_bytes(D)) || a->scratch_bytes < lvdgs_backward_scratch_bytes(N, D)) {
+        set_error("a state / scratch buffer is too small"); return LVDGS_E_INVALID;
+    }
+    GeomView g; BinView b{}; ImageView im; BwdScratch w;
+    geom_layout(N, &g, a->geom_state);
+    image_layout(W, H, &im, a->image_state);
+    bwd_scratch_layout(N, D, &w, a->scratch);
+    if (D > 0) {
+        bin_layout(D, &b, a->binning_state);
+        if (int e = launch_blend_bwd(*a, g, b, im, w, s)) return e;
+    }
+    return launch_preprocess_bwd(*a, g, w, s);
+}
+
+int lvdgs_mark_visible(int32_t N, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present,
+                       void *stream) {
+    (void)projmatrix;
+    if (N < 0 || (N > 0 && (!means3D || !viewmatrix || !present))) { set_error("bad mark_visible arguments"); return LVDGS_E_INVALID; }
+    return launch_mark_visible(N, means3D, viewmatrix, present, (hipStream_t)stream);
+}
+
+void lvdgs_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+}
+void lvdgs_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    drain_locked();
+    g_slots.clear();
+}
+int lvdgs_profile_read(lvdgs_kernel_time *out, int cap) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    drain_locked();
+    int n = 0;
+    for (auto &sl : g_slots) {
+        if (n >= cap) break;
+        memset(&out[n], 0, sizeof(out[n]));
+        strncpy(out[n].name, sl.name.c_str(), sizeof(out[n].name) - 1);
+        out[n].launches = sl.launches;
+        out[n].total_ms = sl.total_ms;
+        n++;
+    }
+    return n;
+}
+
+}  // extern "C"

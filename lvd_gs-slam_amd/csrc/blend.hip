@@ -1,0 +1,357 @@
+// Per-tile alpha compositing (forward) and its gradient (backward).
+//
+// Layout of one workgroup: 256 threads = 4 waves = one 16x16 tile; each wave owns an 8x8 pixel
+// quadrant (lane -> pixel).  The tile's depth-ordered Gaussian list is consumed in rounds of 256
+// entries: every thread gathers one entry's 48-byte record from HBM/L2 into LDS, then each wave
+//   1. tests 64 staged Gaussians at once (lane -> Gaussian) against its own quadrant with an
+//      exact ellipse-vs-rectangle minimum of the exponent, giving a 64-bit survivor mask, and
+//   2. walks only the survivors (scalar loop over mask bits), broadcasting one Gaussian from LDS
+//      to all 64 pixels of the wave.
+// Skipped Gaussians are exactly those whose alpha is below 1/255 on every pixel of the quadrant,
+// so results are unchanged; a typical scene discards well over half of the (pixel, Gaussian) work.
+//
+// Backward walks the same list back to front (as published: T is recovered by dividing out
+// 1-alpha).  The per-Gaussian sums over pixels are done without atomics: a DPP wave reduction,
+// per-wave LDS slots, a fixed-order 4-wave sum, and one 48-byte record per (Gaussian, tile) pair
+// stored at the pair's slot of the unsorted pair list.  The per-Gaussian kernel then reads each
+// Gaussian's slots as one contiguous run.  Gradients are therefore bitwise reproducible.
+#include "common.hpp"
+#include "device_utils.hpp"
+
+namespace lvdgs {
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+
+struct BlendParams {
+    int W, H, gx, gy, num_tiles;
+    const uint2 *ranges;
+    const uint32_t *point_list;
+    const float *rec;
+    const float *bg;
+    // forward
+    float *out_color, *out_depth, *out_opacity, *final_T;
+    uint32_t *n_contrib;
+    int32_t *n_touched;
+    // backward
+    const float *dL_dcolor, *dL_ddepth, *dL_dopacity;
+    float *pair_grads;
+};
+
+// Workgroup -> tile.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), so
+// give every XCD one contiguous run of row-major tiles: neighbouring tiles share most of their
+// Gaussians and then find each other's record lines in the same 4 MiB L2.  Bijective for any count.
+__device__ __forceinline__ int tile_of_workgroup(int b, int n) {
+    const int xcd = b & 7, k = b >> 3, q = n >> 3, r = n & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+// Can a Gaussian (mean m, conic a,b,c, opacity op) reach alpha >= 1/255 anywhere in the pixel
+// rectangle [x0,x1] x [y0,y1]?  Exact minimum of q(d) = 1/2 (a dx^2 + c dy^2) + b dx dy over the
+// rectangle (convex: interior point or one of four clamped edge minima), compared against
+// ln(255 op) with a safety margin that covers float rounding of the per-pixel evaluation.
+__device__ __forceinline__ bool reaches_rect(float mx, float my, float a, float b, float c, float op, float x0, float y0,
+                                             float x1, float y1) {
+    if (!(op >= ALPHA_MIN)) return false;
+    if (!(a > 0.f && c > 0.f && a * c - b * b > 0.f)) return true;  // not an ellipse: let the pixel test decide
+    const float dx_lo = mx - x1, dx_hi = mx - x0, dy_lo = my - y1, dy_hi = my - y0;  // d = mean - pixel
+    if (dx_lo <= 0.f && dx_hi >= 0.f && dy_lo <= 0.f && dy_hi >= 0.f) return true;
+    const float inv_a = __builtin_amdgcn_rcpf(a), inv_c = __builtin_amdgcn_rcpf(c);
+    auto along_y = [&](float dx) {
+        const float dy = fminf(fmaxf(-b * dx * inv_c, dy_lo), dy_hi);
+        return 0.5f * (a * dx * dx + c * dy * dy) + b * dx * dy;
+    };
+    auto along_x = [&](float dy) {
+        const float dx = fminf(fmaxf(-b * dy * inv_a, dx_lo), dx_hi);
+        return 0.5f * (a * dx * dx + c * dy * dy) + b * dx * dy;
+    };
+    const float qmin = fminf(fminf(along_y(dx_lo), along_y(dx_hi)), fminf(along_x(dy_lo), along_x(dy_hi)));
+    const float dxm = fmaxf(fabsf(dx_lo), fabsf(dx_hi)), dym = fmaxf(fabsf(dy_lo), fabsf(dy_hi));
+    const float margin = 0.02f + 2e-5f * (a * dxm * dxm + c * dym * dym);
+    return qmin <= __logf(op * 255.f) + margin;
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) blend_fwd_kernel(BlendParams p) {
+    __shared__ float4 s_a[256];  // x, y, -a/2*log2e, -b*log2e
+    __shared__ float4 s_b[256];  // -c/2*log2e, opacity, depth, id bits
+    __shared__ float4 s_c[256];  // r, g, b, a (raw conic a, for the quadrant test)
+    __shared__ float2 s_d[256];  // raw conic b, c
+
+    const int tile = tile_of_workgroup(blockIdx.x, p.num_tiles);
+    const int tx = tile % p.gx, ty = tile / p.gx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool inside = px < p.W && py < p.H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float rx0 = (float)qx0, ry0 = (float)qy0, rx1 = (float)(qx0 + 7), ry1 = (float)(qy0 + 7);
+
+    const uint2 range = p.ranges[tile];
+    const int todo = (int)(range.y - range.x);
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
+    uint32_t last = 0;
+    bool done = !inside;
+
+    for (int base = 0; base < todo; base += 256) {
+        if (__syncthreads_and(done)) break;
+        const int cnt = min(256, todo - base);
+        if (tid < cnt) {
+            const uint32_t id = p.point_list[range.x + base + tid];
+            const float4 *r4 = reinterpret_cast<const float4 *>(p.rec + (size_t)id * REC_FLOATS);
+            const float4 r0 = r4[0], r1 = r4[1], r2 = r4[2];
+            s_a[tid] = make_float4(r0.x, r0.y, -0.5f * LOG2E * r0.z, -LOG2E * r0.w);
+            s_b[tid] = make_float4(-0.5f * LOG2E * r1.x, r1.y, r2.y, __uint_as_float(id));
+            s_c[tid] = make_float4(r1.z, r1.w, r2.x, r0.z);
+            s_d[tid] = make_float2(r0.w, r1.x);
+        }
+        __syncthreads();
+        if (__ballot(!done) != 0ull) {
+            for (int c0 = 0; c0 < cnt; c0 += 64) {
+                // ---- lane -> Gaussian: which of these 64 can touch this wave's quadrant? ----
+                const int jl = c0 + lane;
+                bool keep = false;
+                if (jl < cnt) {
+                    const float4 A = s_a[jl];
+                    const float4 Cc = s_c[jl];
+                    const float2 Dd = s_d[jl];
+                    keep = reaches_rect(A.x, A.y, Cc.w, Dd.x, Dd.y, s_b[jl].y, rx0, ry0, rx1, ry1);
+                }
+                uint64_t live = __ballot(keep);
+                // ---- lane -> pixel: composite the survivors in list order ----
+                while (live) {
+                    const int j = __builtin_ctzll(live);
+                    live &= live - 1;
+                    const int jj = c0 + j;
+                    const float4 A = s_a[jj];
+                    const float4 B = s_b[jj];
+                    bool hit = false, touch = false;
+                    float alpha = 0.f, test_T = 0.f;
+                    if (!done) {
+                        const float dx = A.x - pxf, dy = A.y - pyf;
+                        const float pw2 = fmaf(dx, fmaf(A.z, dx, A.w * dy), B.x * dy * dy);  // log2 of the falloff (backward repeats this exactly)
+                        alpha = fminf(ALPHA_MAX, B.y * __builtin_amdgcn_exp2f(pw2));
+                        hit = (pw2 <= 0.f) && (alpha >= ALPHA_MIN);
+                        if (hit) {
+                            test_T = T * (1.f - alpha);
+                            if (test_T < T_STOP) { done = true; hit = false; }
+                        }
+                    }
+                    const uint64_t hits = __ballot(hit);
+                    if (hits) {
+                        const float4 Cc = s_c[jj];
+                        if (hit) {
+                            const float w = alpha * T;
+                            C0 = fmaf(Cc.x, w, C0); C1 = fmaf(Cc.y, w, C1); C2 = fmaf(Cc.z, w, C2);
+                            Dp = fmaf(B.z, w, Dp);
+                            T = test_T;
+                            last = (uint32_t)(base + jj + 1);
+                            touch = test_T > T_TOUCH;
+                        }
+                        const uint64_t touched = __ballot(touch);
+                        if (touched && lane == __builtin_ctzll(touched))
+                            atomicAdd(&p.n_touched[__float_as_uint(B.w)], (int)__popcll(touched));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (inside) {
+        const size_t pix = (size_t)py * p.W + px, P = (size_t)p.W * p.H;
+        p.final_T[pix] = T;
+        p.n_contrib[pix] = last;
+        p.out_color[pix] = fmaf(T, p.bg[0], C0);
+        p.out_color[P + pix] = fmaf(T, p.bg[1], C1);
+        p.out_color[2 * P + pix] = fmaf(T, p.bg[2], C2);
+        p.out_depth[pix] = Dp;
+        p.out_opacity[pix] = 1.f - T;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+constexpr int ACC_STRIDE = 10;  // floats per (wave, entry) accumulator slot
+
+__global__ void __launch_bounds__(256) blend_bwd_kernel(BlendParams p) {
+    __shared__ float4 s_a[256];              // x, y, a, b
+    __shared__ float4 s_b[256];              // c, opacity, depth, -a/2*log2e
+    __shared__ float4 s_c[256];              // r, g, b, -b*log2e
+    __shared__ uint32_t s_slot[256];         // where this entry's partial gradient goes
+    __shared__ float s_acc[4][256 * ACC_STRIDE];
+    __shared__ unsigned long long s_mask[4][4];  // [wave][chunk]: entries this wave accumulated
+    __shared__ uint32_t s_max[4];
+
+    const int tile = tile_of_workgroup(blockIdx.x, p.num_tiles);
+    const int tx = tile % p.gx, ty = tile / p.gx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool inside = px < p.W && py < p.H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float rx0 = (float)qx0, ry0 = (float)qy0, rx1 = (float)(qx0 + 7), ry1 = (float)(qy0 + 7);
+    const size_t pix = (size_t)py * p.W + px, P = (size_t)p.W * p.H;
+
+    const uint2 range = p.ranges[tile];
+    const float T_final = inside ? p.final_T[pix] : 0.f;
+    const uint32_t my_last = inside ? p.n_contrib[pix] : 0u;
+    float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gD = 0.f, gO = 0.f;
+    if (inside) {
+        gC0 = p.dL_dcolor[pix]; gC1 = p.dL_dcolor[P + pix]; gC2 = p.dL_dcolor[2 * P + pix];
+        if (p.dL_ddepth) gD = p.dL_ddepth[pix];
+        if (p.dL_dopacity) gO = p.dL_dopacity[pix];
+    }
+    // background and the opacity image depend on alpha only through the final transmittance
+    const float tail = T_final * (p.bg[0] * gC0 + p.bg[1] * gC1 + p.bg[2] * gC2 - gO);
+
+    // deepest list position any pixel of the tile reached
+    uint32_t m = my_last;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+    if (lane == 0) s_max[wave] = m;
+    __syncthreads();
+    const int depth_max = (int)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
+    // Every pair of this tile must receive a record (zeros included): walk the whole list.
+    const int todo = (int)(range.y - range.x);
+    (void)depth_max;
+
+    float T = T_final;
+    float bh0 = 0.f, bh1 = 0.f, bh2 = 0.f, bhd = 0.f;   // colour / depth accumulated behind
+    float la = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, ld = 0.f;  // last alpha / colour / depth
+
+    const int rounds = (todo + 255) / 256;
+    for (int r = rounds - 1; r >= 0; r--) {
+        const int base = r * 256;
+        const int cnt = min(256, todo - base);
+        if (tid < cnt) {
+            const uint32_t id = p.point_list[range.x + base + tid];
+            const float4 *r4 = reinterpret_cast<const float4 *>(p.rec + (size_t)id * REC_FLOATS);
+            const float4 r0 = r4[0], r1 = r4[1], r2 = r4[2];
+            s_a[tid] = r0;
+            s_b[tid] = make_float4(r1.x, r1.y, r2.y, -0.5f * LOG2E * r0.z);
+            s_c[tid] = make_float4(r1.z, r1.w, r2.x, -LOG2E * r0.w);
+            // slot of this (Gaussian, tile) pair in the unsorted pair list
+            const int rad = __float_as_int(r2.w);
+            int x0 = (int)((r0.x - (float)rad) / (float)TILE), y0 = (int)((r0.y - (float)rad) / (float)TILE);
+            int x1 = (int)((r0.x + (float)rad + (float)(TILE - 1)) / (float)TILE);
+            x0 = min(p.gx, max(0, x0)); x1 = min(p.gx, max(0, x1)); y0 = min(p.gy, max(0, y0));
+            s_slot[tid] = __float_as_uint(r2.z) + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+        }
+        if (tid < 16) (&s_mask[0][0])[tid] = 0ull;
+        __syncthreads();
+        if (base < depth_max) {
+            for (int c0 = ((cnt - 1) / 64) * 64; c0 >= 0; c0 -= 64) {
+                const int jl = c0 + lane;
+                bool keep = false;
+                if (jl < cnt && base + c0 < depth_max) {
+                    const float4 A = s_a[jl];
+                    const float4 B = s_b[jl];
+                    keep = reaches_rect(A.x, A.y, A.z, A.w, B.x, B.y, rx0, ry0, rx1, ry1);
+                }
+                uint64_t live = __ballot(keep);
+                uint64_t wrote = 0ull;
+                while (live) {
+                    const int j = 63 - __builtin_clzll(live);
+                    live &= ~(1ull << j);
+                    const int jj = c0 + j;
+                    const float4 A = s_a[jj];
+                    const float4 B = s_b[jj];
+                    const float dx = A.x - pxf, dy = A.y - pyf;
+                    const float4 Cc = s_c[jj];
+                    // the same expression, operand for operand, as the forward pass: identical hit set
+                    const float pw2 = fmaf(dx, fmaf(B.w, dx, Cc.w * dy), (-0.5f * LOG2E * B.x) * dy * dy);
+                    const float G = __builtin_amdgcn_exp2f(pw2);
+                    const float alpha = fminf(ALPHA_MAX, B.y * G);
+                    const bool hit = ((uint32_t)(base + jj) < my_last) && (pw2 <= 0.f) && (alpha >= ALPHA_MIN);
+                    if (__ballot(hit) == 0ull) continue;
+                    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f, v9 = 0.f;
+                    if (hit) {
+                        const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
+                        T *= inv;
+                        const float w = alpha * T;
+                        bh0 = fmaf(la, lc0 - bh0, bh0); bh1 = fmaf(la, lc1 - bh1, bh1); bh2 = fmaf(la, lc2 - bh2, bh2);
+                        bhd = fmaf(la, ld - bhd, bhd);
+                        lc0 = Cc.x; lc1 = Cc.y; lc2 = Cc.z; ld = B.z; la = alpha;
+                        float dL_dalpha = (lc0 - bh0) * gC0 + (lc1 - bh1) * gC1 + (lc2 - bh2) * gC2 + (ld - bhd) * gD;
+                        dL_dalpha = fmaf(dL_dalpha, T, -tail * inv);
+                        v6 = w * gC0; v7 = w * gC1; v8 = w * gC2; v9 = w * gD;
+                        v5 = G * dL_dalpha;
+                        const float dL_dG = B.y * dL_dalpha;
+                        const float gdx = G * dx, gdy = G * dy;
+                        v0 = dL_dG * -(A.z * gdx + A.w * gdy);
+                        v1 = dL_dG * -(B.x * gdy + A.w * gdx);
+                        v2 = -0.5f * gdx * dx * dL_dG;
+                        v3 = -gdx * dy * dL_dG;
+                        v4 = -0.5f * gdy * dy * dL_dG;
+                    }
+                    v0 = wave_sum_to_lane63(v0); v1 = wave_sum_to_lane63(v1); v2 = wave_sum_to_lane63(v2);
+                    v3 = wave_sum_to_lane63(v3); v4 = wave_sum_to_lane63(v4); v5 = wave_sum_to_lane63(v5);
+                    v6 = wave_sum_to_lane63(v6); v7 = wave_sum_to_lane63(v7); v8 = wave_sum_to_lane63(v8);
+                    v9 = wave_sum_to_lane63(v9);
+                    if (lane == 63) {
+                        float2 *o = reinterpret_cast<float2 *>(&s_acc[wave][jj * ACC_STRIDE]);
+                        o[0] = make_float2(v0, v1); o[1] = make_float2(v2, v3); o[2] = make_float2(v4, v5);
+                        o[3] = make_float2(v6, v7); o[4] = make_float2(v8, v9);
+                    }
+                    wrote |= 1ull << j;
+                }
+                if (lane == 0) s_mask[wave][c0 >> 6] = wrote;
+            }
+        }
+        __syncthreads();
+        if (tid < cnt) {
+            float acc[ACC_STRIDE];
+#pragma unroll
+            for (int k = 0; k < ACC_STRIDE; k++) acc[k] = 0.f;
+            const int ch = tid >> 6;
+            const unsigned long long bit = 1ull << (tid & 63);
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+                if (s_mask[w][ch] & bit) {
+                    const float2 *o = reinterpret_cast<const float2 *>(&s_acc[w][tid * ACC_STRIDE]);
+#pragma unroll
+                    for (int k = 0; k < 5; k++) { const float2 t = o[k]; acc[2 * k] += t.x; acc[2 * k + 1] += t.y; }
+                }
+            float4 *dst = reinterpret_cast<float4 *>(p.pair_grads + (size_t)s_slot[tid] * PAIR_FLOATS);
+            dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            dst[2] = make_float4(acc[8], acc[9], 0.f, 0.f);
+        }
+        __syncthreads();
+    }
+}
+
+BlendParams make_params(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im) {
+    BlendParams p{};
+    p.W = a.image_width; p.H = a.image_height;
+    p.gx = (p.W + TILE - 1) / TILE; p.gy = (p.H + TILE - 1) / TILE; p.num_tiles = p.gx * p.gy;
+    p.ranges = im.ranges; p.point_list = b.point_list; p.rec = g.rec; p.bg = a.bg;
+    p.out_color = a.out_color; p.out_depth = a.out_depth; p.out_opacity = a.out_opacity;
+    p.final_T = im.final_T; p.n_contrib = im.n_contrib; p.n_touched = a.n_touched;
+    p.dL_dcolor = a.dL_dout_color; p.dL_ddepth = a.dL_dout_depth; p.dL_dopacity = a.dL_dout_opacity;
+    return p;
+}
+
+}  // namespace
+
+int launch_blend_fwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, hipStream_t s) {
+    BlendParams p = make_params(a, g, b, im);
+    if (p.num_tiles == 0) return LVDGS_OK;
+    ProfScope ps("blend_fwd", s);
+    hipLaunchKernelGGL(blend_fwd_kernel, dim3(p.num_tiles), dim3(256), 0, s, p);
+    LVDGS_LAUNCH_CHECK("blend_fwd", a.debug, s);
+    return LVDGS_OK;
+}
+
+int launch_blend_bwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, const BwdScratch &w,
+                     hipStream_t s) {
+    BlendParams p = make_params(a, g, b, im);
+    p.pair_grads = w.pair_grads;
+    if (p.num_tiles == 0) return LVDGS_OK;
+    ProfScope ps("blend_bwd", s);
+    hipLaunchKernelGGL(blend_bwd_kernel, dim3(p.num_tiles), dim3(256), 0, s, p);
+    LVDGS_LAUNCH_CHECK("blend_bwd", a.debug, s);
+    return LVDGS_OK;
+}
+
+}  // namespace lvdgs

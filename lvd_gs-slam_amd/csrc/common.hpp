@@ -1,0 +1,120 @@
+// Shared declarations of the gfx950 rasterizer library (see include/lvdgs.h for the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lvdgs.h"
+
+namespace lvdgs {
+
+// ---- constants of the splatting algorithm (UNPINNED against upstream) ----
+constexpr int TILE = 16;                 // tile edge in pixels; one 256-thread workgroup per tile
+constexpr float NEAR_CULL = 0.2f;        // view z at or below this is culled
+constexpr float HOMOG_EPS = 0.0000001f;  // added to w before the perspective divide
+constexpr float FOV_GUARD = 1.3f;        // x/z, y/z clamp (times tan(fov/2)) in the EWA Jacobian
+constexpr float LOWPASS = 0.3f;          // added to the 2D covariance diagonal
+constexpr float LAMBDA_FLOOR = 0.1f;     // floor under the eigenvalue discriminant
+constexpr float ALPHA_MAX = 0.99f;
+constexpr float ALPHA_MIN = 1.0f / 255.0f;
+constexpr float T_STOP = 0.0001f;
+constexpr float T_TOUCH = 0.5f;
+
+constexpr int WAVE = 64;
+constexpr int REC_FLOATS = 12;   // per-Gaussian 2D record (48 B)
+constexpr int PAIR_FLOATS = 12;  // per-(Gaussian, tile) partial gradient record (48 B, 10 used)
+
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_IPT = 16;                       // elements per thread per radix pass
+constexpr int SORT_CHUNK = SORT_THREADS * SORT_IPT; // elements per workgroup
+constexpr int SORT_MAX_BITS = 11;                  // digit width limit (LDS: 4 waves x 2048 counters)
+
+inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- error plumbing ----
+void set_error(const char *fmt, ...);
+int check_hip(hipError_t e, const char *what);
+
+// ---- profiling hooks (no-ops unless lvdgs_profile_enable(1)) ----
+struct ProfScope {
+    int slot;
+    hipStream_t stream;
+    ProfScope(const char *name, hipStream_t s);
+    ~ProfScope();
+};
+
+#define LVDGS_LAUNCH_CHECK(name, dbg, stream)                                   \
+    do {                                                                        \
+        if (int _e = ::lvdgs::check_hip(hipGetLastError(), name)) return _e;    \
+        if (dbg) {                                                              \
+            if (int _e = ::lvdgs::check_hip(hipStreamSynchronize(stream), name)) return _e; \
+        }                                                                       \
+    } while (0)
+
+// ---- state layouts ----
+struct GeomView {
+    float *rec;              // N*12
+    uint32_t *tiles_touched; // N
+    uint32_t *order;         // N
+    uint32_t *offsets;       // N
+};
+struct PrepScratch {
+    uint32_t *keys[2];   // N each (depth bits)
+    uint32_t *vals[2];   // N each
+    uint32_t *hist;      // nbins * nblk
+    uint32_t *totals;    // nbins
+    uint32_t *blocksums; // scan block sums
+    uint32_t *total;     // 1: D
+};
+struct RenderScratch {
+    uint32_t *keys;  // D (alternate tile-key buffer)
+    uint32_t *vals;  // D (alternate id buffer)
+    uint32_t *hist;
+    uint32_t *totals;
+};
+struct BinView {
+    uint32_t *point_list; // D
+    uint32_t *tile_keys;  // D
+};
+struct ImageView {
+    uint2 *ranges;       // T
+    float *final_T;      // P
+    uint32_t *n_contrib; // P
+};
+struct BwdScratch {
+    float *pair_grads; // D*12
+    float *tau_part;   // nblk*6
+};
+
+size_t geom_layout(int N, GeomView *v, void *base);
+size_t prep_scratch_layout(int N, PrepScratch *v, void *base);
+size_t bin_layout(int64_t D, BinView *v, void *base);
+size_t image_layout(int W, int H, ImageView *v, void *base);
+size_t render_scratch_layout(int64_t D, int W, int H, RenderScratch *v, void *base);
+size_t bwd_scratch_layout(int N, int64_t D, BwdScratch *v, void *base);
+int tile_sort_bits(int W, int H);  // number of key bits to sort for the tile id
+
+// ---- launchers (one per kernel family; all enqueue on `stream` and return a status) ----
+int launch_preprocess_fwd(const lvdgs_args &a, const GeomView &g, uint32_t *depth_keys, uint32_t *ids, hipStream_t s);
+int launch_preprocess_bwd(const lvdgs_args &a, const GeomView &g, const BwdScratch &b, hipStream_t s);
+int launch_mark_visible(int N, const float *means3D, const float *view, uint8_t *present, hipStream_t s);
+
+// stable LSD radix sort of (key, val) pairs on key bits [0, total_bits); result lands in
+// (keys_a, vals_a) if *result_in_a, else in (keys_b, vals_b).  n may be 0.
+int radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, int64_t n, int total_bits,
+                     uint32_t *hist, uint32_t *totals, bool *result_in_a, int dbg, hipStream_t s);
+int radix_num_passes(int total_bits);
+size_t radix_hist_entries(int64_t n);
+
+// offsets[s] = inclusive scan over s of tiles_touched[order[s]]; *total_dev = last value
+int launch_offsets_scan(const uint32_t *tiles_touched, const uint32_t *order, uint32_t *offsets, uint32_t *blocksums,
+                        uint32_t *total_dev, int N, int dbg, hipStream_t s);
+
+int launch_emit_pairs(const lvdgs_args &a, const GeomView &g, uint32_t *tile_keys, uint32_t *ids, hipStream_t s);
+int launch_tile_ranges(const uint32_t *tile_keys, int64_t D, uint2 *ranges, int num_tiles, int dbg, hipStream_t s);
+
+int launch_blend_fwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, hipStream_t s);
+int launch_blend_bwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, const BwdScratch &w,
+                     hipStream_t s);
+
+}  // namespace lvdgs

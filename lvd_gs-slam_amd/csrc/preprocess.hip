@@ -1,0 +1,557 @@
+// Per-Gaussian kernels: projection (forward), parameter / pose gradients (backward), frustum test.
+// One lane per Gaussian, wave64, 256-thread workgroups.  These are HBM-streaming kernels:
+// forward reads 56 B and writes 60 B per Gaussian, backward reads 56 + 48*(tiles touched) B and
+// writes the 14-float parameter gradient.  Compiled with -ffp-contract=off: the float expressions
+// that decide integers (radius, tile rectangle, depth sort key) are evaluated as written.
+#include "common.hpp"
+#include "device_utils.hpp"
+
+namespace lvdgs {
+
+namespace {
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                       -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                       0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                       -0.5900435899266435f};
+
+struct Cam {
+    const float *view, *proj, *proj_raw, *campos;
+    float tanx, tany, fx, fy, scale_mod;
+    int W, H, gx, gy, sh_degree, M;
+};
+
+__device__ __forceinline__ void xform3(const float p[3], const float *__restrict__ m, float o[3]) {
+    o[0] = m[0] * p[0] + m[4] * p[1] + m[8] * p[2] + m[12];
+    o[1] = m[1] * p[0] + m[5] * p[1] + m[9] * p[2] + m[13];
+    o[2] = m[2] * p[0] + m[6] * p[1] + m[10] * p[2] + m[14];
+}
+__device__ __forceinline__ float xform_w(const float p[3], const float *__restrict__ m) {
+    return m[3] * p[0] + m[7] * p[1] + m[11] * p[2] + m[15];
+}
+
+__device__ __forceinline__ void quat_rot(const float q[4], float R[3][3]) {
+    const float r = q[0], x = q[1], y = q[2], z = q[3];
+    R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
+    R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
+    R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+// Sigma = (R diag(mod*s)) (R diag(mod*s))^T as xx,xy,xz,yy,yz,zz
+__device__ __forceinline__ void cov3d_of(const float s[3], float mod, const float q[4], float c6[6]) {
+    float R[3][3], M[3][3];
+    quat_rot(q, R);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) M[i][j] = R[i][j] * (mod * s[j]);
+    c6[0] = M[0][0] * M[0][0] + M[0][1] * M[0][1] + M[0][2] * M[0][2];
+    c6[1] = M[0][0] * M[1][0] + M[0][1] * M[1][1] + M[0][2] * M[1][2];
+    c6[2] = M[0][0] * M[2][0] + M[0][1] * M[2][1] + M[0][2] * M[2][2];
+    c6[3] = M[1][0] * M[1][0] + M[1][1] * M[1][1] + M[1][2] * M[1][2];
+    c6[4] = M[1][0] * M[2][0] + M[1][1] * M[2][1] + M[1][2] * M[2][2];
+    c6[5] = M[2][0] * M[2][0] + M[2][1] * M[2][1] + M[2][2] * M[2][2];
+}
+
+struct Ewa {
+    float T[2][3];
+    float t[3];
+    bool clx, cly;
+};
+
+__device__ __forceinline__ void ewa_setup(const float pv[3], const float *__restrict__ V, const Cam &c, Ewa &e) {
+    const float limx = FOV_GUARD * c.tanx, limy = FOV_GUARD * c.tany;
+    const float txtz = pv[0] / pv[2], tytz = pv[1] / pv[2];
+    e.clx = (txtz < -limx) || (txtz > limx);
+    e.cly = (tytz < -limy) || (tytz > limy);
+    const float cx = txtz < -limx ? -limx : (txtz > limx ? limx : txtz);
+    const float cy = tytz < -limy ? -limy : (tytz > limy ? limy : tytz);
+    e.t[0] = cx * pv[2]; e.t[1] = cy * pv[2]; e.t[2] = pv[2];
+    const float j00 = c.fx / e.t[2], j02 = -(c.fx * e.t[0]) / (e.t[2] * e.t[2]);
+    const float j11 = c.fy / e.t[2], j12 = -(c.fy * e.t[1]) / (e.t[2] * e.t[2]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float w0 = V[4 * k + 0], w1 = V[4 * k + 1], w2 = V[4 * k + 2];
+        e.T[0][k] = j00 * w0 + j02 * w2;
+        e.T[1][k] = j11 * w1 + j12 * w2;
+    }
+}
+
+__device__ __forceinline__ void sym6(const float c6[6], float S[3][3]) {
+    S[0][0] = c6[0]; S[0][1] = S[1][0] = c6[1]; S[0][2] = S[2][0] = c6[2];
+    S[1][1] = c6[3]; S[1][2] = S[2][1] = c6[4]; S[2][2] = c6[5];
+}
+
+__device__ __forceinline__ void cov2d_of(const Ewa &e, const float c6[6], float &a, float &b, float &c) {
+    float S[3][3], TS[2][3];
+    sym6(c6, S);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) TS[i][j] = e.T[i][0] * S[0][j] + e.T[i][1] * S[1][j] + e.T[i][2] * S[2][j];
+    a = TS[0][0] * e.T[0][0] + TS[0][1] * e.T[0][1] + TS[0][2] * e.T[0][2] + LOWPASS;
+    b = TS[0][0] * e.T[1][0] + TS[0][1] * e.T[1][1] + TS[0][2] * e.T[1][2];
+    c = TS[1][0] * e.T[1][0] + TS[1][1] * e.T[1][1] + TS[1][2] * e.T[1][2] + LOWPASS;
+}
+
+__device__ __forceinline__ void sh_basis(int deg, const float d[3], float B[16]) {
+    const float x = d[0], y = d[1], z = d[2];
+#pragma unroll
+    for (int k = 0; k < 16; k++) B[k] = 0.f;
+    B[0] = SH_C0;
+    if (deg > 0) {
+        B[1] = -SH_C1 * y; B[2] = SH_C1 * z; B[3] = -SH_C1 * x;
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            B[4] = SH_C2[0] * xy; B[5] = SH_C2[1] * yz; B[6] = SH_C2[2] * (2.f * zz - xx - yy);
+            B[7] = SH_C2[3] * xz; B[8] = SH_C2[4] * (xx - yy);
+            if (deg > 2) {
+                B[9] = SH_C3[0] * y * (3.f * xx - yy); B[10] = SH_C3[1] * xy * z;
+                B[11] = SH_C3[2] * y * (4.f * zz - xx - yy); B[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                B[13] = SH_C3[4] * x * (4.f * zz - xx - yy); B[14] = SH_C3[5] * z * (xx - yy);
+                B[15] = SH_C3[6] * x * (xx - 3.f * yy);
+            }
+        }
+    }
+}
+
+// gradient of basis k w.r.t. the unit direction (x,y,z)
+__device__ __forceinline__ void sh_basis_grad(int deg, const float d[3], float G[16][3]) {
+    const float x = d[0], y = d[1], z = d[2];
+#pragma unroll
+    for (int k = 0; k < 16; k++) G[k][0] = G[k][1] = G[k][2] = 0.f;
+    if (deg > 0) { G[1][1] = -SH_C1; G[2][2] = SH_C1; G[3][0] = -SH_C1; }
+    if (deg > 1) {
+        G[4][0] = SH_C2[0] * y; G[4][1] = SH_C2[0] * x;
+        G[5][1] = SH_C2[1] * z; G[5][2] = SH_C2[1] * y;
+        G[6][0] = SH_C2[2] * -2.f * x; G[6][1] = SH_C2[2] * -2.f * y; G[6][2] = SH_C2[2] * 4.f * z;
+        G[7][0] = SH_C2[3] * z; G[7][2] = SH_C2[3] * x;
+        G[8][0] = SH_C2[4] * 2.f * x; G[8][1] = SH_C2[4] * -2.f * y;
+    }
+    if (deg > 2) {
+        const float xx = x * x, yy = y * y, zz = z * z;
+        G[9][0] = SH_C3[0] * 6.f * x * y; G[9][1] = SH_C3[0] * (3.f * xx - 3.f * yy);
+        G[10][0] = SH_C3[1] * y * z; G[10][1] = SH_C3[1] * x * z; G[10][2] = SH_C3[1] * x * y;
+        G[11][0] = SH_C3[2] * -2.f * x * y; G[11][1] = SH_C3[2] * (4.f * zz - xx - 3.f * yy); G[11][2] = SH_C3[2] * 8.f * y * z;
+        G[12][0] = SH_C3[3] * -6.f * x * z; G[12][1] = SH_C3[3] * -6.f * y * z; G[12][2] = SH_C3[3] * (6.f * zz - 3.f * xx - 3.f * yy);
+        G[13][0] = SH_C3[4] * (4.f * zz - 3.f * xx - yy); G[13][1] = SH_C3[4] * -2.f * x * y; G[13][2] = SH_C3[4] * 8.f * x * z;
+        G[14][0] = SH_C3[5] * 2.f * x * z; G[14][1] = SH_C3[5] * -2.f * y * z; G[14][2] = SH_C3[5] * (xx - yy);
+        G[15][0] = SH_C3[6] * (3.f * xx - 3.f * yy); G[15][1] = SH_C3[6] * -6.f * x * y;
+    }
+}
+
+struct FwdParams {
+    Cam cam;
+    int N;
+    const float *means3D, *opacities, *scales, *rotations, *cov3D_precomp, *shs, *colors_precomp;
+    float *rec;
+    uint32_t *tiles_touched, *depth_keys, *ids;
+    int32_t *radii;
+};
+
+__global__ void __launch_bounds__(256) preprocess_fwd_kernel(FwdParams p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.N) return;
+    const Cam &c = p.cam;
+    // culled unless proven visible
+    int radius = 0;
+    uint32_t tiles = 0, key = 0xFFFFFFFFu;
+    float pos[3] = {p.means3D[3 * i], p.means3D[3 * i + 1], p.means3D[3 * i + 2]};
+    float pv[3];
+    xform3(pos, c.view, pv);
+    if (pv[2] > NEAR_CULL) {
+        float ph[3];
+        xform3(pos, c.proj, ph);
+        const float phw = xform_w(pos, c.proj);
+        const float pw = 1.f / (phw + HOMOG_EPS);
+        const float ndcx = ph[0] * pw, ndcy = ph[1] * pw;
+        float c6[6];
+        if (p.cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) c6[k] = p.cov3D_precomp[6 * (size_t)i + k];
+        } else {
+            const float s[3] = {p.scales[3 * i], p.scales[3 * i + 1], p.scales[3 * i + 2]};
+            const float q[4] = {p.rotations[4 * i], p.rotations[4 * i + 1], p.rotations[4 * i + 2], p.rotations[4 * i + 3]};
+            cov3d_of(s, c.scale_mod, q, c6);
+        }
+        Ewa e;
+        ewa_setup(pv, c.view, c, e);
+        float ca, cb, cc;
+        cov2d_of(e, c6, ca, cb, cc);
+        const float det = ca * cc - cb * cb;
+        if (det != 0.f) {
+            const float det_inv = 1.f / det;
+            const float k0 = cc * det_inv, k1 = -cb * det_inv, k2 = ca * det_inv;
+            const float mid = 0.5f * (ca + cc);
+            float disc = mid * mid - det;
+            if (disc < LAMBDA_FLOOR) disc = LAMBDA_FLOOR;
+            const float l1 = mid + sqrtf(disc), l2 = mid - sqrtf(disc);
+            const float lmax = l1 > l2 ? l1 : l2;
+            const int rad = (int)ceilf(3.f * sqrtf(lmax));
+            const float px = ((ndcx + 1.f) * (float)c.W - 1.f) * 0.5f;
+            const float py = ((ndcy + 1.f) * (float)c.H - 1.f) * 0.5f;
+            int x0 = (int)((px - (float)rad) / (float)TILE), y0 = (int)((py - (float)rad) / (float)TILE);
+            int x1 = (int)((px + (float)rad + (float)(TILE - 1)) / (float)TILE);
+            int y1 = (int)((py + (float)rad + (float)(TILE - 1)) / (float)TILE);
+            x0 = min(c.gx, max(0, x0)); x1 = min(c.gx, max(0, x1));
+            y0 = min(c.gy, max(0, y0)); y1 = min(c.gy, max(0, y1));
+            const int area = (x1 - x0) * (y1 - y0);
+            if (area > 0) {
+                float rgb[3];
+                if (p.colors_precomp) {
+                    rgb[0] = p.colors_precomp[3 * i]; rgb[1] = p.colors_precomp[3 * i + 1]; rgb[2] = p.colors_precomp[3 * i + 2];
+                } else {
+                    float d[3] = {pos[0] - c.campos[0], pos[1] - c.campos[1], pos[2] - c.campos[2]};
+                    const float inv = 1.f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+                    d[0] *= inv; d[1] *= inv; d[2] *= inv;
+                    float B[16];
+                    sh_basis(c.sh_degree, d, B);
+                    const int nb = (c.sh_degree + 1) * (c.sh_degree + 1);
+                    const float *sh = p.shs + (size_t)i * c.M * 3;
+                    rgb[0] = rgb[1] = rgb[2] = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                        if (k < nb) {
+                            rgb[0] += B[k] * sh[3 * k]; rgb[1] += B[k] * sh[3 * k + 1]; rgb[2] += B[k] * sh[3 * k + 2];
+                        }
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) { rgb[ch] += 0.5f; rgb[ch] = rgb[ch] < 0.f ? 0.f : rgb[ch]; }
+                }
+                radius = rad; tiles = (uint32_t)area; key = __float_as_uint(pv[2]);
+                float4 *r4 = reinterpret_cast<float4 *>(p.rec + (size_t)i * REC_FLOATS);
+                r4[0] = make_float4(px, py, k0, k1);
+                r4[1] = make_float4(k2, p.opacities[i], rgb[0], rgb[1]);
+                r4[2] = make_float4(rgb[2], pv[2], 0.f, __int_as_float(rad));
+            }
+        }
+    }
+    p.radii[i] = radius;
+    p.tiles_touched[i] = tiles;
+    p.depth_keys[i] = key;
+    p.ids[i] = (uint32_t)i;
+}
+
+// ------------------------------------------------------------------------------------------
+struct BwdParams {
+    Cam cam;
+    int N;
+    const float *means3D, *scales, *rotations, *cov3D_precomp, *shs, *colors_precomp;
+    const int32_t *radii;
+    const float *rec;
+    const uint32_t *tiles_touched;
+    const float *pair_grads;
+    float *dmeans3D, *dmeans2D, *dopac, *dscales, *drot, *dcov3D, *dshs, *dcolors;
+    float *tau_part;
+};
+
+__global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
+    __shared__ float s_tau[4][6];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const Cam &c = p.cam;
+    const float *V = c.view, *PM = c.proj, *PR = c.proj_raw;
+    float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool live = i < p.N && p.radii[i] > 0;
+    if (i < p.N && !live) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { p.dmeans3D[3 * (size_t)i + k] = 0.f; p.dmeans2D[3 * (size_t)i + k] = 0.f; }
+        p.dopac[i] = 0.f;
+        if (p.dscales) { for (int k = 0; k < 3; k++) p.dscales[3 * (size_t)i + k] = 0.f; }
+        if (p.drot) { for (int k = 0; k < 4; k++) p.drot[4 * (size_t)i + k] = 0.f; }
+        if (p.dcov3D) { for (int k = 0; k < 6; k++) p.dcov3D[6 * (size_t)i + k] = 0.f; }
+        if (p.dcolors) { for (int k = 0; k < 3; k++) p.dcolors[3 * (size_t)i + k] = 0.f; }
+        if (p.dshs) { for (int k = 0; k < 3 * c.M; k++) p.dshs[(size_t)i * 3 * c.M + k] = 0.f; }
+    }
+    if (live) {
+        // ---- sum this Gaussian's per-tile partial gradients (contiguous run, fixed order) ----
+        const float4 *r4 = reinterpret_cast<const float4 *>(p.rec + (size_t)i * REC_FLOATS);
+        const float4 rc = r4[2];
+        const uint32_t first = __float_as_uint(rc.z), cnt = p.tiles_touched[i];
+        float A[10];
+#pragma unroll
+        for (int k = 0; k < 10; k++) A[k] = 0.f;
+        const float4 *pg = reinterpret_cast<const float4 *>(p.pair_grads) + (size_t)first * 3;
+        for (uint32_t t = 0; t < cnt; t++) {
+            const float4 a0 = pg[3 * t], a1 = pg[3 * t + 1], a2 = pg[3 * t + 2];
+            A[0] += a0.x; A[1] += a0.y; A[2] += a0.z; A[3] += a0.w;
+            A[4] += a1.x; A[5] += a1.y; A[6] += a1.z; A[7] += a1.w;
+            A[8] += a2.x; A[9] += a2.y;
+        }
+        // A: [0,1] d/d pixel mean, [2..4] d/d conic a,b,c, [5] d/d opacity, [6..8] d/d rgb, [9] d/d view depth
+        const float pos[3] = {p.means3D[3 * i], p.means3D[3 * i + 1], p.means3D[3 * i + 2]};
+        float pv[3], ph[3];
+        xform3(pos, V, pv);
+        xform3(pos, PM, ph);
+        const float phw = xform_w(pos, PM);
+        p.dopac[i] = A[5];
+        const float g_ndc[2] = {A[0] * 0.5f * (float)c.W, A[1] * 0.5f * (float)c.H};
+        p.dmeans2D[3 * (size_t)i] = g_ndc[0]; p.dmeans2D[3 * (size_t)i + 1] = g_ndc[1]; p.dmeans2D[3 * (size_t)i + 2] = 0.f;
+
+        float g_rgb[3] = {A[6], A[7], A[8]};
+        float g_pview[3] = {0.f, 0.f, A[9]};
+        float g_world[3] = {0.f, 0.f, 0.f};
+
+        // ---- colour ----
+        if (p.colors_precomp) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) p.dcolors[3 * (size_t)i + ch] = g_rgb[ch];
+        } else {
+            float d[3] = {pos[0] - c.campos[0], pos[1] - c.campos[1], pos[2] - c.campos[2]};
+            const float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            const float u[3] = {d[0] / len, d[1] / len, d[2] / len};
+            float B[16], G[16][3];
+            sh_basis(c.sh_degree, u, B);
+            sh_basis_grad(c.sh_degree, u, G);
+            const int nb = (c.sh_degree + 1) * (c.sh_degree + 1);
+            const float *sh = p.shs + (size_t)i * c.M * 3;
+            float *dsh = p.dshs + (size_t)i * c.M * 3;
+            // recompute the clamp mask
+            float val[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (k < nb) { val[0] += B[k] * sh[3 * k]; val[1] += B[k] * sh[3 * k + 1]; val[2] += B[k] * sh[3 * k + 2]; }
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) if (val[ch] + 0.5f < 0.f) g_rgb[ch] = 0.f;
+            float g_u[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (k < nb) {
+#pragma unroll
+                    for (int ch = 0; ch < 3; ch++) {
+                        dsh[3 * k + ch] = B[k] * g_rgb[ch];
+                        const float sg = sh[3 * k + ch] * g_rgb[ch];
+                        g_u[0] += G[k][0] * sg; g_u[1] += G[k][1] * sg; g_u[2] += G[k][2] * sg;
+                    }
+                }
+            for (int k = nb; k < c.M; k++) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
+            const float dot = u[0] * g_u[0] + u[1] * g_u[1] + u[2] * g_u[2];
+#pragma unroll
+            for (int a = 0; a < 3; a++) g_world[a] += (g_u[a] - u[a] * dot) / len;
+        }
+
+        // ---- conic -> cov2D -> (cov3D, T) ----
+        float c6[6];
+        float sc[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f};
+        if (p.cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) c6[k] = p.cov3D_precomp[6 * (size_t)i + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; k++) sc[k] = p.scales[3 * i + k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) q[k] = p.rotations[4 * i + k];
+            cov3d_of(sc, c.scale_mod, q, c6);
+        }
+        Ewa e;
+        ewa_setup(pv, V, c, e);
+        float ca, cb, cc;
+        cov2d_of(e, c6, ca, cb, cc);
+        const float det = ca * cc - cb * cb, di = 1.f / det;
+        const float Q00 = cc * di, Q01 = -cb * di, Q11 = ca * di;
+        const float G00 = A[2], G01 = 0.5f * A[3], G11 = A[4];
+        const float QG00 = Q00 * G00 + Q01 * G01, QG01 = Q00 * G01 + Q01 * G11;
+        const float QG10 = Q01 * G00 + Q11 * G01, QG11 = Q01 * G01 + Q11 * G11;
+        const float Gs[2][2] = {{-(QG00 * Q00 + QG01 * Q01), -(QG00 * Q01 + QG01 * Q11)},
+                                {-(QG00 * Q01 + QG01 * Q11), -(QG10 * Q01 + QG11 * Q11)}};
+        float Sg[3][3], g_S[3][3];
+        sym6(c6, Sg);
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                float v = 0.f;
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int s = 0; s < 2; s++) v += e.T[r][a] * Gs[r][s] * e.T[s][b];
+                g_S[a][b] = v;
+            }
+        if (p.dcov3D) {
+            float *o = p.dcov3D + 6 * (size_t)i;
+            o[0] = g_S[0][0]; o[1] = 2.f * g_S[0][1]; o[2] = 2.f * g_S[0][2];
+            o[3] = g_S[1][1]; o[4] = 2.f * g_S[1][2]; o[5] = g_S[2][2];
+        }
+        float TS[2][3], g_T[2][3];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) TS[r][b] = e.T[r][0] * Sg[0][b] + e.T[r][1] * Sg[1][b] + e.T[r][2] * Sg[2][b];
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) g_T[r][b] = 2.f * (Gs[r][0] * TS[0][b] + Gs[r][1] * TS[1][b]);
+        float g_J00 = 0.f, g_J02 = 0.f, g_J11 = 0.f, g_J12 = 0.f;
+        const float tz = e.t[2], tz2 = tz * tz, tz3 = tz2 * tz;
+        const float j00 = c.fx / tz, j02 = -(c.fx * e.t[0]) / tz2, j11 = c.fy / tz, j12 = -(c.fy * e.t[1]) / tz2;
+        float g_W[3][3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float w0 = V[4 * k + 0], w1 = V[4 * k + 1], w2 = V[4 * k + 2];
+            g_J00 += g_T[0][k] * w0; g_J02 += g_T[0][k] * w2;
+            g_J11 += g_T[1][k] * w1; g_J12 += g_T[1][k] * w2;
+            g_W[0][k] = j00 * g_T[0][k];
+            g_W[1][k] = j11 * g_T[1][k];
+            g_W[2][k] = j02 * g_T[0][k] + j12 * g_T[1][k];
+        }
+        g_pview[0] += e.clx ? 0.f : -(c.fx / tz2) * g_J02;
+        g_pview[1] += e.cly ? 0.f : -(c.fy / tz2) * g_J12;
+        g_pview[2] += -(c.fx / tz2) * g_J00 - (c.fy / tz2) * g_J11 + (2.f * c.fx * e.t[0] / tz3) * g_J02 +
+                      (2.f * c.fy * e.t[1] / tz3) * g_J12;
+
+        // ---- projected mean through the full projection (world) and the raw projection (pose) ----
+        const float pw = 1.f / (phw + HOMOG_EPS);
+        const float gh0 = g_ndc[0] * pw, gh1 = g_ndc[1] * pw, gh3 = -(g_ndc[0] * ph[0] + g_ndc[1] * ph[1]) * pw * pw;
+        float g_pview_proj[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            g_world[a] += PM[4 * a + 0] * gh0 + PM[4 * a + 1] * gh1 + PM[4 * a + 3] * gh3;
+            g_pview_proj[a] = PR[4 * a + 0] * gh0 + PR[4 * a + 1] * gh1 + PR[4 * a + 3] * gh3;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            g_world[a] += V[4 * a + 0] * g_pview[0] + V[4 * a + 1] * g_pview[1] + V[4 * a + 2] * g_pview[2];
+            p.dmeans3D[3 * (size_t)i + a] = g_world[a];
+        }
+
+        // ---- camera pose: T' = Exp(tau) T ----
+        const float gv[3] = {g_pview[0] + g_pview_proj[0], g_pview[1] + g_pview_proj[1], g_pview[2] + g_pview_proj[2]};
+        tau[0] = gv[0]; tau[1] = gv[1]; tau[2] = gv[2];
+        tau[3] = pv[1] * gv[2] - pv[2] * gv[1];
+        tau[4] = pv[2] * gv[0] - pv[0] * gv[2];
+        tau[5] = pv[0] * gv[1] - pv[1] * gv[0];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float w0 = V[4 * k + 0], w1 = V[4 * k + 1], w2 = V[4 * k + 2];
+            tau[3] += w1 * g_W[2][k] - w2 * g_W[1][k];
+            tau[4] += w2 * g_W[0][k] - w0 * g_W[2][k];
+            tau[5] += w0 * g_W[1][k] - w1 * g_W[0][k];
+        }
+
+        // ---- Sigma3 -> scale, quaternion ----
+        if (!p.cov3D_precomp) {
+            float R[3][3];
+            quat_rot(q, R);
+            const float sm[3] = {c.scale_mod * sc[0], c.scale_mod * sc[1], c.scale_mod * sc[2]};
+            float g_R[3][3];
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                float v = 0.f;
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    const float gm = 2.f * (g_S[a][0] * R[0][b] * sm[b] + g_S[a][1] * R[1][b] * sm[b] + g_S[a][2] * R[2][b] * sm[b]);
+                    v += gm * R[a][b];
+                    g_R[a][b] = gm * sm[b];
+                }
+                p.dscales[3 * (size_t)i + b] = v * c.scale_mod;
+            }
+            const float r = q[0], x = q[1], y = q[2], z = q[3];
+            float *dq = p.drot + 4 * (size_t)i;
+            dq[0] = 2.f * (-z * g_R[0][1] + y * g_R[0][2] + z * g_R[1][0] - x * g_R[1][2] - y * g_R[2][0] + x * g_R[2][1]);
+            dq[1] = 2.f * (y * g_R[0][1] + z * g_R[0][2] + y * g_R[1][0] - 2.f * x * g_R[1][1] - r * g_R[1][2] + z * g_R[2][0] + r * g_R[2][1] - 2.f * x * g_R[2][2]);
+            dq[2] = 2.f * (-2.f * y * g_R[0][0] + x * g_R[0][1] + r * g_R[0][2] + x * g_R[1][0] + z * g_R[1][2] - r * g_R[2][0] + z * g_R[2][1] - 2.f * y * g_R[2][2]);
+            dq[3] = 2.f * (-2.f * z * g_R[0][0] - r * g_R[0][1] + x * g_R[0][2] + r * g_R[1][0] - 2.f * z * g_R[1][1] + y * g_R[1][2] + x * g_R[2][0] + y * g_R[2][1]);
+        }
+    }
+    // ---- workgroup sum of the pose gradient -> one partial per workgroup (no atomics) ----
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const float s = wave_sum_to_lane63(tau[k]);
+        if (lane == 63) s_tau[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6)
+        p.tau_part[(size_t)blockIdx.x * 6 + threadIdx.x] =
+            ((s_tau[0][threadIdx.x] + s_tau[1][threadIdx.x]) + s_tau[2][threadIdx.x]) + s_tau[3][threadIdx.x];
+}
+
+// fixed-order reduction of the per-workgroup pose partials
+__global__ void __launch_bounds__(256) tau_reduce_kernel(const float *part, int nblk, float *out) {
+    __shared__ float s[256][6];
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = threadIdx.x; b < nblk; b += 256)
+#pragma unroll
+        for (int k = 0; k < 6; k++) acc[k] += part[(size_t)b * 6 + k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) s[threadIdx.x][k] = acc[k];
+    __syncthreads();
+    for (int stride = 128; stride > 0; stride >>= 1) {
+        if ((int)threadIdx.x < stride)
+#pragma unroll
+            for (int k = 0; k < 6; k++) s[threadIdx.x][k] += s[threadIdx.x + stride][k];
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) out[threadIdx.x] = s[0][threadIdx.x];
+}
+
+__global__ void __launch_bounds__(256) mark_visible_kernel(int N, const float *means3D, const float *view, uint8_t *present) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float pos[3] = {means3D[3 * i], means3D[3 * i + 1], means3D[3 * i + 2]};
+    float pv[3];
+    xform3(pos, view, pv);
+    present[i] = pv[2] > NEAR_CULL;
+}
+
+Cam make_cam(const lvdgs_args &a) {
+    Cam c;
+    c.view = a.viewmatrix; c.proj = a.projmatrix; c.proj_raw = a.projmatrix_raw; c.campos = a.campos;
+    c.tanx = a.tanfovx; c.tany = a.tanfovy;
+    c.W = a.image_width; c.H = a.image_height;
+    c.fx = (float)c.W / (2.0f * c.tanx); c.fy = (float)c.H / (2.0f * c.tany);
+    c.scale_mod = a.scale_modifier;
+    c.gx = (c.W + TILE - 1) / TILE; c.gy = (c.H + TILE - 1) / TILE;
+    c.sh_degree = a.sh_degree; c.M = a.sh_coeffs;
+    return c;
+}
+
+}  // namespace
+
+int launch_preprocess_fwd(const lvdgs_args &a, const GeomView &g, uint32_t *depth_keys, uint32_t *ids, hipStream_t s) {
+    if (a.num_gaussians == 0) return LVDGS_OK;
+    FwdParams p;
+    p.cam = make_cam(a); p.N = a.num_gaussians;
+    p.means3D = a.means3D; p.opacities = a.opacities; p.scales = a.scales; p.rotations = a.rotations;
+    p.cov3D_precomp = a.cov3D_precomp; p.shs = a.shs; p.colors_precomp = a.colors_precomp;
+    p.rec = g.rec; p.tiles_touched = g.tiles_touched; p.depth_keys = depth_keys; p.ids = ids; p.radii = a.radii;
+    ProfScope ps("preprocess_fwd", s);
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(cdiv(p.N, 256)), dim3(256), 0, s, p);
+    LVDGS_LAUNCH_CHECK("preprocess_fwd", a.debug, s);
+    return LVDGS_OK;
+}
+
+int launch_preprocess_bwd(const lvdgs_args &a, const GeomView &g, const BwdScratch &b, hipStream_t s) {
+    const int N = a.num_gaussians;
+    const int nblk = cdiv(N, 256);
+    if (N > 0) {
+        BwdParams p;
+        p.cam = make_cam(a); p.N = N;
+        p.means3D = a.means3D; p.scales = a.scales; p.rotations = a.rotations; p.cov3D_precomp = a.cov3D_precomp;
+        p.shs = a.shs; p.colors_precomp = a.colors_precomp; p.radii = a.radii;
+        p.rec = g.rec; p.tiles_touched = g.tiles_touched; p.pair_grads = b.pair_grads;
+        p.dmeans3D = a.dL_dmeans3D; p.dmeans2D = a.dL_dmeans2D; p.dopac = a.dL_dopacities; p.dscales = a.dL_dscales;
+        p.drot = a.dL_drotations; p.dcov3D = a.cov3D_precomp ? a.dL_dcov3D : nullptr; p.dshs = a.dL_dshs;
+        p.dcolors = a.dL_dcolors; p.tau_part = b.tau_part;
+        ProfScope ps("preprocess_bwd", s);
+        hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(256), 0, s, p);
+        LVDGS_LAUNCH_CHECK("preprocess_bwd", a.debug, s);
+    }
+    {
+        ProfScope ps("tau_reduce", s);
+        hipLaunchKernelGGL(tau_reduce_kernel, dim3(1), dim3(256), 0, s, b.tau_part, nblk, a.dL_dtau);
+        LVDGS_LAUNCH_CHECK("tau_reduce", a.debug, s);
+    }
+    return LVDGS_OK;
+}
+
+int launch_mark_visible(int N, const float *means3D, const float *view, uint8_t *present, hipStream_t s) {
+    if (N == 0) return LVDGS_OK;
+    ProfScope ps("mark_visible", s);
+    hipLaunchKernelGGL(mark_visible_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, N, means3D, view, present);
+    LVDGS_LAUNCH_CHECK("mark_visible", 0, s);
+    return LVDGS_OK;
+}
+
+}  // namespace lvdgs

@@ -1,0 +1,295 @@
+// Stable LSD radix sort of (u32 key, u32 value) pairs and the tiles-touched prefix sum.
+//
+// The sort is what gives every tile its depth-ordered Gaussian list.  Instead of one sort of
+// D 64-bit (tile | depth) keys, the N Gaussians are sorted once by their 32-bit depth key and the
+// D (Gaussian, tile) pairs -- emitted in that depth order -- are then sorted by tile id only
+// (<= 16 bits).  Both sorts are stable, so the result is the (tile, depth, Gaussian id) order a
+// stable sort of the 64-bit keys gives, at a fraction of the HBM traffic.
+//
+// One radix pass = three launches, no inter-workgroup communication inside a launch:
+//   radix_hist    per-workgroup digit histogram          -> hist[digit][workgroup]
+//   radix_rowscan exclusive scan of each digit's row over workgroups + digit totals
+//   radix_scatter stable rank inside the workgroup (wave ballot matching) + scattered store
+// Digits are up to 11 bits wide: 4 waves x 2048 counters fit in 32 KiB of the CU's 160 KiB LDS.
+#include "common.hpp"
+#include "device_utils.hpp"
+
+namespace lvdgs {
+
+namespace {
+
+__global__ void __launch_bounds__(SORT_THREADS) radix_hist_kernel(const uint32_t *__restrict__ keys, int64_t n, int shift,
+                                                                  int nbits, uint32_t *__restrict__ hist, int nblk) {
+    __shared__ uint32_t s_hist[1 << SORT_MAX_BITS];
+    const int nbins = 1 << nbits;
+    const uint32_t mask = (uint32_t)nbins - 1u;
+    for (int d = threadIdx.x; d < nbins; d += SORT_THREADS) s_hist[d] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * SORT_CHUNK;
+#pragma unroll 4
+    for (int i = 0; i < SORT_IPT; i++) {
+        const int64_t idx = base + (int64_t)i * SORT_THREADS + threadIdx.x;
+        if (idx < n) atomicAdd(&s_hist[(keys[idx] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < nbins; d += SORT_THREADS) hist[(size_t)d * nblk + blockIdx.x] = s_hist[d];
+}
+
+// one wave per digit row: in-place exclusive scan over the workgroups, row total -> totals[d]
+__global__ void __launch_bounds__(256) radix_rowscan_kernel(uint32_t *__restrict__ hist, uint32_t *__restrict__ totals,
+                                                            int nbins, int nblk) {
+    const int d = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (d >= nbins) return;
+    const int lane = threadIdx.x & 63;
+    uint32_t *row = hist + (size_t)d * nblk;
+    uint32_t carry = 0;
+    for (int b0 = 0; b0 < nblk; b0 += 64) {
+        const int b = b0 + lane;
+        const uint32_t v = b < nblk ? row[b] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += t;
+        }
+        if (b < nblk) row[b] = carry + inc - v;
+        carry += __shfl(inc, 63, 64);
+    }
+    if (lane == 0) totals[d] = carry;
+}
+
+__global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint32_t *__restrict__ keys_in,
+                                                                     const uint32_t *__restrict__ vals_in,
+                                                                     uint32_t *__restrict__ keys_out,
+                                                                     uint32_t *__restrict__ vals_out,
+                                                                     const uint32_t *__restrict__ rowprefix,
+                                                                     const uint32_t *__restrict__ totals, int64_t n,
+                                                                     int shift, int nbits, int nblk) {
+    __shared__ uint32_t s_cnt[4][1 << SORT_MAX_BITS];  // per-wave digit counters, then per-wave bases
+    __shared__ uint32_t s_scan[SORT_THREADS];
+    const int nbins = 1 << nbits;
+    const uint32_t mask = (uint32_t)nbins - 1u;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int d = tid; d < 4 * (1 << SORT_MAX_BITS); d += SORT_THREADS) (&s_cnt[0][0])[d] = 0;
+
+    // ---- global base of every digit for this workgroup: exclusive scan of totals + row prefix ----
+    const int per = (nbins + SORT_THREADS - 1) / SORT_THREADS;  // <= 8
+    uint32_t loc[8];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int d = tid * per + k;
+        loc[k] = (k < per && d < nbins) ? totals[d] : 0u;
+        sum += loc[k];
+    }
+    s_scan[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < SORT_THREADS; off <<= 1) {
+        const uint32_t t = tid >= off ? s_scan[tid - off] : 0u;
+        __syncthreads();
+        s_scan[tid] += t;
+        __syncthreads();
+    }
+    uint32_t run = s_scan[tid] - sum;  // exclusive prefix of this thread's digits
+
+    // ---- load this wave's contiguous sub-chunk and rank it (stable) ----
+    const int64_t wbase = (int64_t)blockIdx.x * SORT_CHUNK + (int64_t)wave * (64 * SORT_IPT);
+    uint32_t key[SORT_IPT], val[SORT_IPT], rank[SORT_IPT];
+    const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int i = 0; i < SORT_IPT; i++) {
+        const int64_t idx = wbase + (int64_t)i * 64 + lane;
+        const bool valid = idx < n;
+        key[i] = valid ? keys_in[idx] : 0xFFFFFFFFu;
+        val[i] = valid ? vals_in[idx] : 0u;
+    }
+    __syncthreads();  // s_cnt zeroed
+#pragma unroll
+    for (int i = 0; i < SORT_IPT; i++) {
+        const int64_t idx = wbase + (int64_t)i * 64 + lane;
+        const bool valid = idx < n;
+        const uint32_t d = (key[i] >> shift) & mask;
+        uint64_t peers = __ballot(valid);
+        for (int b = 0; b < nbits; b++) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const uint32_t before = (uint32_t)__popcll(peers & lt_mask);
+        uint32_t prior = 0;
+        if (valid) prior = s_cnt[wave][d];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && before == 0) s_cnt[wave][d] = prior + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+        rank[i] = prior + before;
+    }
+    __syncthreads();
+    // ---- per-wave bases: global digit base + counts of the lower waves ----
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int d = tid * per + k;
+        if (k < per && d < nbins) {
+            const uint32_t gbase = run + rowprefix[(size_t)d * nblk + blockIdx.x];
+            run += loc[k];
+            const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d];
+            s_cnt[0][d] = gbase;
+            s_cnt[1][d] = gbase + c0;
+            s_cnt[2][d] = gbase + c0 + c1;
+            s_cnt[3][d] = gbase + c0 + c1 + c2;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < SORT_IPT; i++) {
+        const int64_t idx = wbase + (int64_t)i * 64 + lane;
+        if (idx < n) {
+            const uint32_t d = (key[i] >> shift) & mask;
+            const uint32_t pos = s_cnt[wave][d] + rank[i];
+            keys_out[pos] = key[i];
+            vals_out[pos] = val[i];
+        }
+    }
+}
+
+// ---- prefix sum of tiles_touched taken in depth-rank order ----
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_IPT = 8;
+constexpr int SCAN_CHUNK = SCAN_THREADS * SCAN_IPT;
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s, uint32_t *total) {
+    const int tid = threadIdx.x;
+    s[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < SCAN_THREADS; off <<= 1) {
+        const uint32_t t = tid >= off ? s[tid - off] : 0u;
+        __syncthreads();
+        s[tid] += t;
+        __syncthreads();
+    }
+    const uint32_t incl = s[tid];
+    *total = s[SCAN_THREADS - 1];
+    __syncthreads();
+    return incl - v;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan_reduce_kernel(const uint32_t *__restrict__ tt,
+                                                                   const uint32_t *__restrict__ order, int N,
+                                                                   uint32_t *__restrict__ blocksums) {
+    __shared__ uint32_t s[SCAN_THREADS];
+    uint32_t sum = 0;
+    const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_IPT;
+#pragma unroll
+    for (int k = 0; k < SCAN_IPT; k++)
+        if (base + k < N) sum += tt[order[base + k]];
+    uint32_t total;
+    block_exclusive_scan(sum, s, &total);
+    if (threadIdx.x == 0) blocksums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan_blocksums_kernel(uint32_t *__restrict__ blocksums, int nblk,
+                                                                      uint32_t *__restrict__ total_out) {
+    __shared__ uint32_t s[SCAN_THREADS];
+    uint32_t carry = 0;
+    for (int b0 = 0; b0 < nblk; b0 += SCAN_THREADS) {
+        const int b = b0 + threadIdx.x;
+        const uint32_t v = b < nblk ? blocksums[b] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(v, s, &total);
+        if (b < nblk) blocksums[b] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan_apply_kernel(const uint32_t *__restrict__ tt,
+                                                                  const uint32_t *__restrict__ order, int N,
+                                                                  const uint32_t *__restrict__ blocksums,
+                                                                  uint32_t *__restrict__ offsets) {
+    __shared__ uint32_t s[SCAN_THREADS];
+    uint32_t v[SCAN_IPT];
+    uint32_t sum = 0;
+    const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_IPT;
+#pragma unroll
+    for (int k = 0; k < SCAN_IPT; k++) {
+        v[k] = base + k < N ? tt[order[base + k]] : 0u;
+        sum += v[k];
+    }
+    uint32_t total;
+    uint32_t run = block_exclusive_scan(sum, s, &total) + blocksums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_IPT; k++) {
+        run += v[k];
+        if (base + k < N) offsets[base + k] = run;  // inclusive
+    }
+}
+
+}  // namespace
+
+int radix_num_passes(int total_bits) { return total_bits <= 0 ? 0 : (total_bits + SORT_MAX_BITS - 1) / SORT_MAX_BITS; }
+
+size_t radix_hist_entries(int64_t n) { return (size_t)(1 << SORT_MAX_BITS) * (size_t)(cdiv(n > 0 ? n : 1, SORT_CHUNK)); }
+
+int radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, int64_t n, int total_bits,
+                     uint32_t *hist, uint32_t *totals, bool *result_in_a, int dbg, hipStream_t s) {
+    *result_in_a = true;
+    const int passes = radix_num_passes(total_bits);
+    if (n <= 0 || passes == 0) {
+        *result_in_a = (passes % 2) == 0;
+        return LVDGS_OK;
+    }
+    const int nblk = cdiv(n, SORT_CHUNK);
+    uint32_t *kin = keys_a, *vin = vals_a, *kout = keys_b, *vout = vals_b;
+    int shift = 0;
+    for (int p = 0; p < passes; p++) {
+        // spread the bits evenly over the passes (13 bits -> 7 + 6)
+        const int nbits = (total_bits - shift + (passes - p) - 1) / (passes - p);
+        const int nbins = 1 << nbits;
+        {
+            ProfScope ps("radix_hist", s);
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(SORT_THREADS), 0, s, kin, n, shift, nbits, hist, nblk);
+            LVDGS_LAUNCH_CHECK("radix_hist", dbg, s);
+        }
+        {
+            ProfScope ps("radix_rowscan", s);
+            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(cdiv(nbins, 4)), dim3(256), 0, s, hist, totals, nbins, nblk);
+            LVDGS_LAUNCH_CHECK("radix_rowscan", dbg, s);
+        }
+        {
+            ProfScope ps("radix_scatter", s);
+            hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(SORT_THREADS), 0, s, kin, vin, kout, vout, hist, totals,
+                               n, shift, nbits, nblk);
+            LVDGS_LAUNCH_CHECK("radix_scatter", dbg, s);
+        }
+        shift += nbits;
+        uint32_t *t = kin; kin = kout; kout = t;
+        t = vin; vin = vout; vout = t;
+    }
+    *result_in_a = (kin == keys_a);
+    return LVDGS_OK;
+}
+
+int launch_offsets_scan(const uint32_t *tiles_touched, const uint32_t *order, uint32_t *offsets, uint32_t *blocksums,
+                        uint32_t *total_dev, int N, int dbg, hipStream_t s) {
+    if (N == 0) {
+        return check_hip(hipMemsetAsync(total_dev, 0, sizeof(uint32_t), s), "memset total");
+    }
+    const int nblk = cdiv(N, SCAN_CHUNK);
+    {
+        ProfScope ps("scan_reduce", s);
+        hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblk), dim3(SCAN_THREADS), 0, s, tiles_touched, order, N, blocksums);
+        LVDGS_LAUNCH_CHECK("scan_reduce", dbg, s);
+    }
+    {
+        ProfScope ps("scan_blocksums", s);
+        hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, blocksums, nblk, total_dev);
+        LVDGS_LAUNCH_CHECK("scan_blocksums", dbg, s);
+    }
+    {
+        ProfScope ps("scan_apply", s);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(nblk), dim3(SCAN_THREADS), 0, s, tiles_touched, order, N, blocksums, offsets);
+        LVDGS_LAUNCH_CHECK("scan_apply", dbg, s);
+    }
+    return LVDGS_OK;
+}
+
+}  // namespace lvdgs

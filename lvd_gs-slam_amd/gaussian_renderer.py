@@ -1,0 +1,92 @@
+"""``render()`` facade: builds the raster settings from a ``Camera`` and returns the dict the
+SLAM loops consume.
+
+Counterpart of ``gaussian_splatting.gaussian_renderer.render`` (absent from the reference
+checkout).  The contract is pinned by the reference's call sites:
+
+* four positional arguments ``render(viewpoint, gaussians, pipeline_params, background)``
+  (utils/slam_frontend.py:1493, utils/slam_backend.py:98,184,277,407, utils/eval_utils_0806.py:215);
+* returned keys ``render, viewspace_points, visibility_filter, radii, depth, opacity, n_touched``
+  (utils/slam_backend.py:110-116);
+* ``render_with_custom_resolution(..., target_width=, target_height=)["depth"]`` (utils/init_pose.py:145-146);
+* read from the camera: ``world_view_transform, full_proj_transform, projection_matrix, camera_center,
+  FoVx, FoVy, image_height, image_width, cam_rot_delta, cam_trans_delta`` (utils/camera_utils.py);
+* read from the Gaussian model: ``get_xyz, get_opacity, get_scaling, get_rotation, get_features,
+  active_sh_degree`` (and ``get_covariance(scaling_modifier)`` when ``pipe.compute_cov3D_python``);
+* ``pipeline_params.convert_SHs_python`` / ``compute_cov3D_python`` (configs/mono/KITTI/base_config.yaml:94-96).
+Returns ``None`` for an empty model, like upstream.
+"""
+import math
+
+import torch
+
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+SH_C0 = 0.28209479177387814
+
+
+def _eval_sh_python(pc, viewpoint_camera):
+    """SH -> RGB in PyTorch (only for pipe.convert_SHs_python; degree 0..1 exactness is not the hot path)."""
+    from .sh_utils import eval_sh
+
+    shs_view = pc.get_features.transpose(1, 2).view(-1, 3, (pc.max_sh_degree + 1) ** 2)
+    dirs = pc.get_xyz - viewpoint_camera.camera_center.repeat(pc.get_features.shape[0], 1)
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    return torch.clamp_min(eval_sh(pc.active_sh_degree, shs_view, dirs) + 0.5, 0.0)
+
+
+def _render(viewpoint_camera, pc, pipe, bg_color, image_height, image_width, scaling_modifier=1.0,
+            override_color=None, mask=None):
+    xyz = pc.get_xyz
+    if xyz.shape[0] == 0:
+        return None
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+
+    raster_settings = GaussianRasterizationSettings(
+        image_height=int(image_height), image_width=int(image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
+        bg=bg_color, scale_modifier=scaling_modifier,
+        viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
+        projmatrix_raw=viewpoint_camera.projection_matrix, sh_degree=pc.active_sh_degree,
+        campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
+    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
+
+    means3D, means2D, opacity = xyz, screenspace_points, pc.get_opacity
+    scales = rotations = cov3D_precomp = None
+    if getattr(pipe, "compute_cov3D_python", False):
+        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    else:
+        scales, rotations = pc.get_scaling, pc.get_rotation
+
+    shs = colors_precomp = None
+    if override_color is not None:
+        colors_precomp = override_color
+    elif getattr(pipe, "convert_SHs_python", False):
+        colors_precomp = _eval_sh_python(pc, viewpoint_camera)
+    else:
+        shs = pc.get_features
+
+    sel = (lambda t: t) if mask is None else (lambda t: None if t is None else t[mask])
+    rendered_image, radii, depth, opacity_img, n_touched = rasterizer(
+        means3D=sel(means3D), means2D=sel(means2D), shs=sel(shs), colors_precomp=sel(colors_precomp),
+        opacities=sel(opacity), scales=sel(scales), rotations=sel(rotations), cov3D_precomp=sel(cov3D_precomp),
+        theta=viewpoint_camera.cam_rot_delta, rho=viewpoint_camera.cam_trans_delta)
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            "radii": radii, "depth": depth, "opacity": opacity_img, "n_touched": n_touched}
+
+
+def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, mask=None):
+    return _render(viewpoint_camera, pc, pipe, bg_color, viewpoint_camera.image_height, viewpoint_camera.image_width,
+                   scaling_modifier, override_color, mask)
+
+
+def render_with_custom_resolution(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None,
+                                  mask=None, target_width=None, target_height=None):
+    """Same view rendered at another raster size (the fields of view are kept, utils/init_pose.py:141-146)."""
+    H = viewpoint_camera.image_height if target_height is None else target_height
+    W = viewpoint_camera.image_width if target_width is None else target_width
+    return _render(viewpoint_camera, pc, pipe, bg_color, H, W, scaling_modifier, override_color, mask)

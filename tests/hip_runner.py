@@ -1,0 +1,107 @@
+"""Test helper: run the HIP rasterizer (through GaussianRasterizer -> C ABI) on CPU tensors and
+return numpy results, including intermediates read out of the state buffers."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from lvdgs import _lib, rasterizer
+from lvdgs.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+
+def settings_from_cam(cam, W, H, bg, sh_degree=0, scale_modifier=1.0, dev="cuda"):
+    return GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg.to(dev),
+        scale_modifier=scale_modifier, viewmatrix=cam.world_view_transform.to(dev),
+        projmatrix=cam.full_proj_transform.to(dev), projmatrix_raw=cam.projection_matrix.to(dev),
+        sh_degree=sh_degree, campos=cam.camera_center.to(dev), prefiltered=False, debug=False)
+
+
+def _view(buf, off, count, dtype):
+    nbytes = count * np.dtype(dtype).itemsize
+    return buf[off:off + nbytes].cpu().numpy().view(dtype).copy()
+
+
+def run_hip(g, cam, W, H, bg, use_sh=False, sh_degree=0, cov_precomp=None, grads=None, pose=True, dev="cuda"):
+    """g: dict of float32 CPU tensors (synthetic.make_gaussians).  grads: optional (dL_dcolor, dL_ddepth,
+    dL_dopacity) CPU tensors.  Returns (forward dict, backward dict or None)."""
+    rasterizer.KEEP_DEBUG_STATE = True
+    rs = settings_from_cam(cam, W, H, bg, sh_degree=sh_degree, dev=dev)
+    leaf = lambda t: t.to(dev).clone().requires_grad_(True)
+    means3D, opac = leaf(g["means3D"]), leaf(g["opacities"])
+    N = means3D.shape[0]
+    means2D = torch.zeros(N, 3, device=dev, requires_grad=True)
+    kw = {}
+    if cov_precomp is not None:
+        cov = leaf(cov_precomp); kw["cov3D_precomp"] = cov
+    else:
+        sc, rot = leaf(g["scales"]), leaf(g["rotations"]); kw.update(scales=sc, rotations=rot)
+    if use_sh:
+        shs = leaf(g["shs"]); kw["shs"] = shs
+    else:
+        col = leaf(g["colors"]); kw["colors_precomp"] = col
+    theta = torch.zeros(3, device=dev, requires_grad=pose)
+    rho = torch.zeros(3, device=dev, requires_grad=pose)
+    color, radii, depth, opacity, n_touched = GaussianRasterizer(rs)(
+        means3D=means3D, means2D=means2D, opacities=opac, theta=theta, rho=rho, **kw)
+    torch.cuda.synchronize()
+    st = dict(rasterizer._DEBUG_LAST)
+    D = st["num_rendered"]
+    lay = _lib.StateLayout()
+    _lib.check(_lib.lib().lvdgs_state_layout_query(N, D, W, H, C.byref(lay)), "layout")
+    NT = ((W + 15) // 16) * ((H + 15) // 16)
+    rec = _view(st["geom"], lay.geom_rec, N * 12, np.float32).reshape(N, 12) if N else np.zeros((0, 12), np.float32)
+    fwd = dict(
+        color=color.detach().cpu().numpy(), depth=depth.detach().cpu().numpy(), opacity=opacity.detach().cpu().numpy(),
+        radii=radii.cpu().numpy(), n_touched=n_touched.cpu().numpy(), num_rendered=D, rec=rec,
+        tiles_touched=_view(st["geom"], lay.geom_tiles_touched, N, np.uint32) if N else np.zeros(0, np.uint32),
+        order=_view(st["geom"], lay.geom_order, N, np.uint32) if N else np.zeros(0, np.uint32),
+        offsets=_view(st["geom"], lay.geom_offsets, N, np.uint32) if N else np.zeros(0, np.uint32),
+        point_list=_view(st["binning"], lay.bin_point_list, D, np.uint32) if D else np.zeros(0, np.uint32),
+        tile_keys=_view(st["binning"], lay.bin_tile_keys, D, np.uint32) if D else np.zeros(0, np.uint32),
+        ranges=_view(st["image"], lay.img_ranges, NT * 2, np.uint32).reshape(NT, 2),
+        final_T=_view(st["image"], lay.img_final_T, W * H, np.float32).reshape(H, W),
+        n_contrib=_view(st["image"], lay.img_n_contrib, W * H, np.uint32).reshape(H, W),
+    )
+    bwd = None
+    if grads is not None:
+        gc, gd, go = (None if t is None else t.to(dev) for t in grads)
+        loss = (color * gc).sum()
+        if gd is not None:
+            loss = loss + (depth * gd).sum()
+        if go is not None:
+            loss = loss + (opacity * go).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        z = lambda t: None if t.grad is None else t.grad.detach().cpu().numpy()
+        bwd = dict(means3D=z(means3D), means2D=z(means2D), opacities=z(opac).reshape(-1))
+        if cov_precomp is not None:
+            bwd["cov3D"] = z(cov)
+        else:
+            bwd["scales"], bwd["rotations"] = z(sc), z(rot)
+        if use_sh:
+            bwd["shs"] = z(shs)
+        else:
+            bwd["colors"] = z(col)
+        if pose:
+            bwd["tau"] = np.concatenate([z(rho), z(theta)])
+    rasterizer.KEEP_DEBUG_STATE = False
+    return fwd, bwd
+
+
+def run_oracle(orc, g, cam, W, H, bg, use_sh=False, sh_degree=0, cov_precomp=None, grads=None, prec="f32"):
+    o = orc.Oracle(prec)
+    kw = dict(scales=g["scales"].numpy(), rotations=g["rotations"].numpy())
+    if cov_precomp is not None:
+        kw = dict(cov3D_precomp=cov_precomp.numpy())
+    fwd = o.forward(means3D=g["means3D"].numpy(), opacities=g["opacities"].numpy(), W=W, H=H, tanfovx=cam.tanfovx,
+                    tanfovy=cam.tanfovy, viewmatrix=cam.world_view_transform.numpy(),
+                    projmatrix=cam.full_proj_transform.numpy(), projmatrix_raw=cam.projection_matrix.numpy(),
+                    campos=cam.camera_center.numpy(), bg=bg.numpy(), shs=g["shs"].numpy() if use_sh else None,
+                    colors_precomp=None if use_sh else g["colors"].numpy(), sh_degree=sh_degree, **kw)
+    bwd = None
+    if grads is not None:
+        gc, gd, go = grads
+        bwd = o.backward(gc.numpy(), None if gd is None else gd.numpy(), None if go is None else go.numpy())
+    o.free()
+    return fwd, bwd

@@ -1,0 +1,97 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/lvdgs.h declares,
+the ctypes mirror of struct lvdgs_args matches the C layout, and argument validation works
+without touching a GPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from lvdgs import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "lvdgs.h")
+
+
+def test_library_loads_and_reports_version():
+    L = _lib.lib()
+    assert b"gfx950" in L.lvdgs_version()
+
+
+def test_every_declared_symbol_is_exported():
+    text = open(HEADER).read()
+    declared = set(re.findall(r"\b(lvdgs_[a-z0-9_]+)\s*\(", text))
+    declared -= {"lvdgs_status"}
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_ctypes_struct_matches_c_layout(tmp_path):
+    src = tmp_path / "probe.c"
+    fields = [f for f, _ in _lib.Args._fields_]
+    lines = "\n".join(f'    printf("{f} %zu\\n", offsetof(lvdgs_args, {f}));' for f in fields)
+    src.write_text(f'#include <stdio.h>\n#include <stddef.h>\n#include "{HEADER}"\nint main(void) {{\n'
+                   f'    printf("sizeof %zu\\n", sizeof(lvdgs_args));\n{lines}\n'
+                   f'    printf("layout %zu\\n", sizeof(lvdgs_state_layout));\n'
+                   f'    printf("ktime %zu\\n", sizeof(lvdgs_kernel_time));\n    return 0;\n}}\n')
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-std=c11", "-o", str(exe), str(src)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)]).decode().splitlines())
+    assert int(out["sizeof"]) == C.sizeof(_lib.Args)
+    for f in fields:
+        assert int(out[f]) == getattr(_lib.Args, f).offset, f
+    assert int(out["layout"]) == C.sizeof(_lib.StateLayout)
+    assert int(out["ktime"]) == C.sizeof(_lib.KernelTime)
+
+
+def test_sizes_are_monotone_and_aligned():
+    L = _lib.lib()
+    assert L.lvdgs_geom_bytes(0) > 0
+    prev = 0
+    for n in (1, 1000, 100_000, 2_000_000):
+        b = L.lvdgs_geom_bytes(n)
+        assert b % 256 == 0 and b > prev and b >= n * 60
+        prev = b
+    assert L.lvdgs_binning_bytes(3_000_000) >= 3_000_000 * 8
+    assert L.lvdgs_image_bytes(1920, 1080) >= 1920 * 1080 * 8
+    assert L.lvdgs_backward_scratch_bytes(500_000, 3_000_000) >= 3_000_000 * 48
+
+
+def test_argument_validation_without_gpu():
+    L = _lib.lib()
+    a = _lib.Args()
+    n = C.c_int64(-1)
+    assert L.lvdgs_forward_prepare(C.byref(a), C.byref(n), None) == _lib.E_INVALID
+    assert b"image size" in L.lvdgs_last_error()
+    a.image_width, a.image_height, a.tanfovx, a.tanfovy = 64, 64, 1.0, 1.0
+    assert L.lvdgs_forward_prepare(C.byref(a), C.byref(n), None) == _lib.E_INVALID  # bg / matrices NULL
+    a.sh_degree = 7
+    assert L.lvdgs_forward_render(C.byref(a), None) == _lib.E_INVALID
+    assert b"sh_degree" in L.lvdgs_last_error()
+    with pytest.raises(_lib.LvdgsError):
+        _lib.check(_lib.E_INVALID, "probe")
+
+
+def test_product_package_never_imports_the_oracle():
+    """The product path may not import, link or execute anything under oracle/."""
+    pkg = os.path.join(ROOT, "lvd_gs-slam_amd")
+    bad = re.compile(r"import\s+oracle|from\s+oracle|oracle/|oracle\.py|liblvdgs_oracle|lvdgs_oracle")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not bad.search(text), (dirpath, f)
+
+
+def test_rasterizer_refuses_cpu_tensors():
+    import torch
+    from lvdgs.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+    rs = GaussianRasterizationSettings(16, 16, 1.0, 1.0, torch.zeros(3), 1.0, torch.eye(4), torch.eye(4), torch.eye(4),
+                                       0, torch.zeros(3))
+    with pytest.raises(_lib.LvdgsError):
+        GaussianRasterizer(rs)(means3D=torch.zeros(2, 3), means2D=torch.zeros(2, 3), opacities=torch.ones(2, 1),
+                               colors_precomp=torch.ones(2, 3), scales=torch.ones(2, 3), rotations=torch.ones(2, 4))
