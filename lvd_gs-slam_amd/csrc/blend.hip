@@ -172,14 +172,15 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendParams p) {
 
 // ------------------------------------------------------------------------------------------
 constexpr int ACC_STRIDE = 10;  // floats per (wave, entry) accumulator slot
+constexpr int BR = 128;         // list entries staged per round in the backward pass
 
 __global__ void __launch_bounds__(256) blend_bwd_kernel(BlendParams p) {
-    __shared__ float4 s_a[256];              // x, y, a, b
-    __shared__ float4 s_b[256];              // c, opacity, depth, -a/2*log2e
-    __shared__ float4 s_c[256];              // r, g, b, -b*log2e
-    __shared__ uint32_t s_slot[256];         // where this entry's partial gradient goes
-    __shared__ float s_acc[4][256 * ACC_STRIDE];
-    __shared__ unsigned long long s_mask[4][4];  // [wave][chunk]: entries this wave accumulated
+    __shared__ float4 s_a[BR];               // x, y, a, b
+    __shared__ float4 s_b[BR];               // c, opacity, depth, -a/2*log2e
+    __shared__ float4 s_c[BR];               // r, g, b, -b*log2e
+    __shared__ uint32_t s_slot[BR];          // where this entry's partial gradient goes
+    __shared__ float s_acc[4][BR * ACC_STRIDE];
+    __shared__ unsigned long long s_mask[4][BR / 64];  // [wave][chunk]: entries this wave accumulated
     __shared__ uint32_t s_max[4];
 
     const int tile = tile_of_workgroup(blockIdx.x, p.num_tiles);
@@ -211,18 +212,20 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(BlendParams p) {
     if (lane == 0) s_max[wave] = m;
     __syncthreads();
     const int depth_max = (int)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-    // Every pair of this tile must receive a record (zeros included): walk the whole list.
+    // every pair of this tile must receive a record (zeros included): walk the whole list
     const int todo = (int)(range.y - range.x);
-    (void)depth_max;
 
     float T = T_final;
-    float bh0 = 0.f, bh1 = 0.f, bh2 = 0.f, bhd = 0.f;   // colour / depth accumulated behind
+    float bh0 = 0.f, bh1 = 0.f, bh2 = 0.f, bhd = 0.f;           // colour / depth accumulated behind
     float la = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, ld = 0.f;  // last alpha / colour / depth
+    // which accumulator floats the lane that ends a 16-lane row writes (see the fold below)
+    const int row_off = (lane >> 4) == 0 ? 0 : ((lane >> 4) == 1 ? 3 : ((lane >> 4) == 2 ? 5 : 8));
+    const bool row_end = (lane & 15) == 15, row3 = ((lane >> 4) & 1) == 0;
 
-    const int rounds = (todo + 255) / 256;
+    const int rounds = (todo + BR - 1) / BR;
     for (int r = rounds - 1; r >= 0; r--) {
-        const int base = r * 256;
-        const int cnt = min(256, todo - base);
+        const int base = r * BR;
+        const int cnt = min(BR, todo - base);
         if (tid < cnt) {
             const uint32_t id = p.point_list[range.x + base + tid];
             const float4 *r4 = reinterpret_cast<const float4 *>(p.rec + (size_t)id * REC_FLOATS);
@@ -237,7 +240,7 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(BlendParams p) {
             x0 = min(p.gx, max(0, x0)); x1 = min(p.gx, max(0, x1)); y0 = min(p.gy, max(0, y0));
             s_slot[tid] = __float_as_uint(r2.z) + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
         }
-        if (tid < 16) (&s_mask[0][0])[tid] = 0ull;
+        if (tid < 4 * (BR / 64)) (&s_mask[0][0])[tid] = 0ull;
         __syncthreads();
         if (base < depth_max) {
             for (int c0 = ((cnt - 1) / 64) * 64; c0 >= 0; c0 -= 64) {
@@ -256,8 +259,8 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(BlendParams p) {
                     const int jj = c0 + j;
                     const float4 A = s_a[jj];
                     const float4 B = s_b[jj];
-                    const float dx = A.x - pxf, dy = A.y - pyf;
                     const float4 Cc = s_c[jj];
+                    const float dx = A.x - pxf, dy = A.y - pyf;
                     // the same expression, operand for operand, as the forward pass: identical hit set
                     const float pw2 = fmaf(dx, fmaf(B.w, dx, Cc.w * dy), (-0.5f * LOG2E * B.x) * dy * dy);
                     const float G = __builtin_amdgcn_exp2f(pw2);
@@ -284,14 +287,16 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(BlendParams p) {
                         v3 = -gdx * dy * dL_dG;
                         v4 = -0.5f * gdy * dy * dL_dG;
                     }
-                    v0 = wave_sum_to_lane63(v0); v1 = wave_sum_to_lane63(v1); v2 = wave_sum_to_lane63(v2);
-                    v3 = wave_sum_to_lane63(v3); v4 = wave_sum_to_lane63(v4); v5 = wave_sum_to_lane63(v5);
-                    v6 = wave_sum_to_lane63(v6); v7 = wave_sum_to_lane63(v7); v8 = wave_sum_to_lane63(v8);
-                    v9 = wave_sum_to_lane63(v9);
-                    if (lane == 63) {
-                        float2 *o = reinterpret_cast<float2 *>(&s_acc[wave][jj * ACC_STRIDE]);
-                        o[0] = make_float2(v0, v1); o[1] = make_float2(v2, v3); o[2] = make_float2(v4, v5);
-                        o[3] = make_float2(v6, v7); o[4] = make_float2(v8, v9);
+                    // ---- sum the ten values over the 64 pixels: two pairwise folds (64 -> 32 -> 16 lanes,
+                    //      ten registers -> five -> three), then one 16-lane DPP sum of the three ----
+                    float q0 = fold16(fold32(v0, v1), fold32(v2, v3));  // rows: v0 v2 v1 v3
+                    float q1 = fold16(fold32(v4, v5), fold32(v6, v7));  // rows: v4 v6 v5 v7
+                    float q2 = fold16(fold32(v8, v9), 0.f);             // rows: v8 -  v9 -
+                    row_sums3(q0, q1, q2);
+                    if (row_end) {
+                        float *o = &s_acc[wave][jj * ACC_STRIDE + row_off];
+                        o[0] = q0; o[1] = q1;
+                        if (row3) o[2] = q2;
                     }
                     wrote |= 1ull << j;
                 }
@@ -312,10 +317,11 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(BlendParams p) {
 #pragma unroll
                     for (int k = 0; k < 5; k++) { const float2 t = o[k]; acc[2 * k] += t.x; acc[2 * k + 1] += t.y; }
                 }
+            // slot order written above: v0 v4 v8 | v2 v6 | v1 v5 v9 | v3 v7
             float4 *dst = reinterpret_cast<float4 *>(p.pair_grads + (size_t)s_slot[tid] * PAIR_FLOATS);
-            dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-            dst[2] = make_float4(acc[8], acc[9], 0.f, 0.f);
+            dst[0] = make_float4(acc[0], acc[5], acc[3], acc[8]);
+            dst[1] = make_float4(acc[1], acc[6], acc[4], acc[9]);
+            dst[2] = make_float4(acc[2], acc[7], 0.f, 0.f);
         }
         __syncthreads();
     }

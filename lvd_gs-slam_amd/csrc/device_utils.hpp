@@ -22,6 +22,38 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
+// Pairwise folds for multi-value wave reductions (gfx950 v_permlane32_swap / v_permlane16_swap).
+// fold32(a, b): lanes 0-31 hold a[l] + a[l+32], lanes 32-63 hold b[l-32] + b[l].
+__device__ __forceinline__ float fold32(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// fold16(a, b): 16-lane rows 0 and 2 hold a's row pairs (0+1, 2+3) summed, rows 1 and 3 hold b's.
+__device__ __forceinline__ float fold16(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// In-row (16 lanes) inclusive sums of three registers at once; lane 15 of every row gets the row
+// total.  Interleaving the three keeps two instructions between a register's write and its DPP read.
+__device__ __forceinline__ void row_sums3(float &x, float &y, float &z) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+        "s_nop 1"
+        : "+v"(x), "+v"(y), "+v"(z));
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 }  // namespace lvdgs
