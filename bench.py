@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import lvdgs  # noqa: E402,F401
-from lvdgs import _lib, rasterizer, slam_utils, synthetic  # noqa: E402
+from lvdgs import _lib, rasterizer, slam_utils, synthetic, window_shard  # noqa: E402
 from lvdgs.gaussian_model import GaussianModel  # noqa: E402
 from lvdgs.gaussian_renderer import render  # noqa: E402
 
@@ -103,7 +103,7 @@ def main():
     bg = torch.zeros(3, device=dev)
     params = model.parameters()
     pose_params = [cam.cam_rot_delta, cam.cam_trans_delta, cam.exposure_a, cam.exposure_b]
-    bucket = torch.zeros(sum(p.numel() for p in params), device=dev) if world > 1 else None
+    bucket = window_shard.GradientBucket(params) if world > 1 else None
     tracking = world == 1
     stats = {}
 
@@ -118,12 +118,7 @@ def main():
         loss.backward()
         if world > 1:
             # one flat bucket: a single RCCL all-reduce per step (28 MB at 500k Gaussians)
-            off = 0
-            for p in params:
-                n = p.numel()
-                bucket[off:off + n].copy_(p.grad.reshape(-1)) if p.grad is not None else bucket[off:off + n].zero_()
-                off += n
-            dist.all_reduce(bucket)
+            bucket.all_reduce()
         return pkg
 
     def sync():
