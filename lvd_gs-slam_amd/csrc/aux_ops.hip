@@ -1,20 +1,258 @@
-// simple-knn and RoPE entry points (implemented in a later milestone of this round).
+// The two other native dependencies of the SLAM loop the north star names:
+//   lvdgs_dist2_knn3 : simple_knn.distCUDA2 -- mean squared distance to the 3 nearest neighbours,
+//                      used to seed the scale of new Gaussians (reference README.md:42; keyframe rate);
+//   lvdgs_rope2d     : croco curope rope_2d -- in-place 2-D rotary embedding of ViT tokens inside
+//                      MASt3R (reference README.md:49-50; two MASt3R passes per tracked frame).
+// Both sources are absent from the reference checkout; the algorithms are the published ones.
+#include <float.h>
+
 #include "common.hpp"
+#include "device_utils.hpp"
+
+namespace lvdgs {
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// exact 3-NN: Morton order -> boxes of 256 consecutive points -> every workgroup owns one box,
+// stages candidate boxes through LDS and prunes whole boxes by AABB-to-AABB distance against the
+// workgroup's current worst "third best".  Candidates are visited outward from the own box in
+// Morton order, so the bound tightens after the first few boxes and most boxes are skipped.
+constexpr int KNN_BOX = 256;
+
+struct KnnScratch {
+    uint32_t *keys[2], *vals[2], *hist, *totals;
+    float *bounds;   // 6: min xyz, max xyz
+    float *box_lo;   // nbox * 3
+    float *box_hi;   // nbox * 3
+};
+
+size_t knn_layout(int P, KnnScratch *v, void *base) {
+    KnnScratch tmp;
+    if (!v) v = &tmp;
+    size_t off = 0;
+    char *b = (char *)base;
+    auto carve = [&](auto *&ptr, size_t count) {
+        using T = std::remove_reference_t<decltype(*ptr)>;
+        ptr = b ? reinterpret_cast<T *>(b + off) : nullptr;
+        off += align256(count * sizeof(T));
+    };
+    const size_t n = (size_t)(P > 0 ? P : 1), nbox = (n + KNN_BOX - 1) / KNN_BOX;
+    carve(v->keys[0], n); carve(v->keys[1], n); carve(v->vals[0], n); carve(v->vals[1], n);
+    carve(v->hist, radix_hist_entries(P)); carve(v->totals, (size_t)1 << SORT_MAX_BITS);
+    carve(v->bounds, 64); carve(v->box_lo, nbox * 3); carve(v->box_hi, nbox * 3);
+    return off;
+}
+
+__global__ void __launch_bounds__(256) knn_bounds_kernel(int P, const float *__restrict__ pts, float *__restrict__ bounds) {
+    // single workgroup: grid-stride min/max, then an LDS tree (P is at most a few million)
+    __shared__ float s[6][256];
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int i = threadIdx.x; i < P; i += 256)
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float v = pts[3 * (size_t)i + a];
+            lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v);
+        }
+#pragma unroll
+    for (int a = 0; a < 3; a++) { s[a][threadIdx.x] = lo[a]; s[3 + a][threadIdx.x] = hi[a]; }
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st)
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                s[a][threadIdx.x] = fminf(s[a][threadIdx.x], s[a][threadIdx.x + st]);
+                s[3 + a][threadIdx.x] = fmaxf(s[3 + a][threadIdx.x], s[3 + a][threadIdx.x + st]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) bounds[threadIdx.x] = s[threadIdx.x][0];
+}
+
+__device__ __forceinline__ uint32_t spread10(uint32_t x) {
+    x = (x | (x << 16)) & 0x030000FFu;
+    x = (x | (x << 8)) & 0x0300F00Fu;
+    x = (x | (x << 4)) & 0x030C30C3u;
+    x = (x | (x << 2)) & 0x09249249u;
+    return x;
+}
+
+__global__ void __launch_bounds__(256) knn_morton_kernel(int P, const float *__restrict__ pts, const float *__restrict__ bounds,
+                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    uint32_t code = 0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float lo = bounds[a], ext = bounds[3 + a] - lo;
+        const float t = ext > 0.f ? (pts[3 * (size_t)i + a] - lo) / ext : 0.f;
+        const uint32_t q = (uint32_t)fminf(fmaxf(t * 1023.f, 0.f), 1023.f);
+        code |= spread10(q) << a;
+    }
+    keys[i] = code;
+    vals[i] = (uint32_t)i;
+}
+
+__global__ void __launch_bounds__(KNN_BOX) knn_boxes_kernel(int P, const float *__restrict__ pts, const uint32_t *__restrict__ order,
+                                                            float *__restrict__ box_lo, float *__restrict__ box_hi) {
+    __shared__ float s[6][KNN_BOX];
+    const int i = blockIdx.x * KNN_BOX + threadIdx.x;
+    float p[3] = {0.f, 0.f, 0.f};
+    const bool ok = i < P;
+    if (ok) { const uint32_t id = order[i]; p[0] = pts[3 * (size_t)id]; p[1] = pts[3 * (size_t)id + 1]; p[2] = pts[3 * (size_t)id + 2]; }
+#pragma unroll
+    for (int a = 0; a < 3; a++) { s[a][threadIdx.x] = ok ? p[a] : FLT_MAX; s[3 + a][threadIdx.x] = ok ? p[a] : -FLT_MAX; }
+    __syncthreads();
+    for (int st = KNN_BOX / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st)
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                s[a][threadIdx.x] = fminf(s[a][threadIdx.x], s[a][threadIdx.x + st]);
+                s[3 + a][threadIdx.x] = fmaxf(s[3 + a][threadIdx.x], s[3 + a][threadIdx.x + st]);
+            }
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) { box_lo[3 * blockIdx.x + threadIdx.x] = s[threadIdx.x][0]; box_hi[3 * blockIdx.x + threadIdx.x] = s[3 + threadIdx.x][0]; }
+}
+
+__device__ __forceinline__ void push3(float d, float &b0, float &b1, float &b2) {
+    if (d < b2) {
+        if (d < b1) {
+            b2 = b1;
+            if (d < b0) { b1 = b0; b0 = d; } else b1 = d;
+        } else b2 = d;
+    }
+}
+
+__global__ void __launch_bounds__(KNN_BOX) knn_search_kernel(int P, int nbox, const float *__restrict__ pts,
+                                                             const uint32_t *__restrict__ order, const float *__restrict__ box_lo,
+                                                             const float *__restrict__ box_hi, float *__restrict__ out) {
+    __shared__ float s_pts[KNN_BOX][3];
+    __shared__ float s_red[4];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = b * KNN_BOX + tid;
+    const bool ok = i < P;
+    uint32_t id = 0;
+    float p[3] = {0.f, 0.f, 0.f};
+    if (ok) { id = order[i]; p[0] = pts[3 * (size_t)id]; p[1] = pts[3 * (size_t)id + 1]; p[2] = pts[3 * (size_t)id + 2]; }
+    float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;
+    const float mylo[3] = {box_lo[3 * b], box_lo[3 * b + 1], box_lo[3 * b + 2]};
+    const float myhi[3] = {box_hi[3 * b], box_hi[3 * b + 1], box_hi[3 * b + 2]};
+    float bound = FLT_MAX;  // max over the workgroup's points of their current third-best distance
+    // visit boxes outward: b, b+1, b-1, b+2, b-2, ...
+    for (int step = 0; step < 2 * nbox; step++) {
+        const int off = (step + 1) >> 1;
+        const int c = (step & 1) ? b + off : b - off;
+        if (step == 0 ? false : (c < 0 || c >= nbox)) continue;
+        const int cc = step == 0 ? b : c;
+        // minimum squared distance between the two boxes (workgroup-uniform)
+        float gap2 = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float g = fmaxf(0.f, fmaxf(box_lo[3 * cc + a] - myhi[a], mylo[a] - box_hi[3 * cc + a]));
+            gap2 += g * g;
+        }
+        if (gap2 > bound) continue;
+        __syncthreads();
+        const int j = cc * KNN_BOX + tid;
+        if (j < P) {
+            const uint32_t jd = order[j];
+            s_pts[tid][0] = pts[3 * (size_t)jd]; s_pts[tid][1] = pts[3 * (size_t)jd + 1]; s_pts[tid][2] = pts[3 * (size_t)jd + 2];
+        }
+        __syncthreads();
+        const int cnt = min(KNN_BOX, P - cc * KNN_BOX);
+        if (ok) {
+            for (int k = 0; k < cnt; k++) {
+                if (cc == b && k == tid) continue;
+                const float dx = s_pts[k][0] - p[0], dy = s_pts[k][1] - p[1], dz = s_pts[k][2] - p[2];
+                push3(dx * dx + dy * dy + dz * dz, b0, b1, b2);
+            }
+        }
+        // refresh the workgroup bound
+        float m = ok ? b2 : 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        __syncthreads();
+        if (lane == 0) s_red[wave] = m;
+        __syncthreads();
+        bound = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    }
+    if (ok) {
+        // fewer than 4 points: average what exists
+        float sum = 0.f; int n = 0;
+        if (b0 < FLT_MAX) { sum += b0; n++; }
+        if (b1 < FLT_MAX) { sum += b1; n++; }
+        if (b2 < FLT_MAX) { sum += b2; n++; }
+        out[id] = n ? sum / (float)n : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// RoPE 2D: one workgroup per token (b, n).  The 2 * D/4 (cos, sin) pairs of the token are computed
+// once into LDS and reused by all H heads; the H*D floats stream through as float4.
+__global__ void __launch_bounds__(256) rope2d_kernel(float *__restrict__ tokens, const int64_t *__restrict__ pos, int H, int D,
+                                                     float base, float fwd) {
+    extern __shared__ float s_cs[];  // [2][Q][2]
+    const int Q = D / 4, Dh = D / 2;
+    const size_t tok = blockIdx.x;
+    for (int k = threadIdx.x; k < 2 * Q; k += blockDim.x) {
+        const int half = k / Q, i = k - half * Q;
+        const float inv_freq = fwd / powf(base, (float)i / (float)Q);
+        const float ang = (float)pos[tok * 2 + half] * inv_freq;
+        float sn, cs;
+        sincosf(ang, &sn, &cs);
+        s_cs[2 * k] = cs; s_cs[2 * k + 1] = sn;
+    }
+    __syncthreads();
+    float *t = tokens + tok * (size_t)H * D;
+    // work item = (head, half, i): rotates the pair (i, i + Q) of that half
+    for (int w = threadIdx.x; w < H * 2 * Q; w += blockDim.x) {
+        const int h = w / (2 * Q), r = w - h * 2 * Q, half = r / Q, i = r - half * Q;
+        float *x = t + (size_t)h * D + half * Dh;
+        const float cs = s_cs[2 * (half * Q + i)], sn = s_cs[2 * (half * Q + i) + 1];
+        const float u = x[i], v = x[i + Q];
+        x[i] = u * cs - v * sn;
+        x[i + Q] = v * cs + u * sn;
+    }
+}
+
+}  // namespace
+}  // namespace lvdgs
 
 using namespace lvdgs;
 
 extern "C" {
 
-size_t lvdgs_knn_scratch_bytes(int32_t num_points) { (void)num_points; return 256; }
+size_t lvdgs_knn_scratch_bytes(int32_t num_points) { return knn_layout(num_points, nullptr, nullptr); }
 
-int lvdgs_dist2_knn3(int32_t, const float *, float *, void *, size_t, void *) {
-    set_error("lvdgs_dist2_knn3: not implemented in this build");
-    return LVDGS_E_INVALID;
+int lvdgs_dist2_knn3(int32_t P, const float *points, float *mean_dist2, void *scratch, size_t scratch_bytes, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0 || (P > 0 && (!points || !mean_dist2 || !scratch))) { set_error("bad dist2_knn3 arguments"); return LVDGS_E_INVALID; }
+    if (P == 0) return LVDGS_OK;
+    if (scratch_bytes < lvdgs_knn_scratch_bytes(P)) { set_error("knn scratch too small"); return LVDGS_E_INVALID; }
+    KnnScratch w;
+    knn_layout(P, &w, scratch);
+    const int nbox = cdiv(P, KNN_BOX);
+    { ProfScope ps("knn_bounds", s); hipLaunchKernelGGL(knn_bounds_kernel, dim3(1), dim3(256), 0, s, P, points, w.bounds); LVDGS_LAUNCH_CHECK("knn_bounds", 0, s); }
+    { ProfScope ps("knn_morton", s); hipLaunchKernelGGL(knn_morton_kernel, dim3(cdiv(P, 256)), dim3(256), 0, s, P, points, w.bounds, w.keys[0], w.vals[0]); LVDGS_LAUNCH_CHECK("knn_morton", 0, s); }
+    bool in_a = true;
+    if (int e = radix_sort_pairs(w.keys[0], w.vals[0], w.keys[1], w.vals[1], P, 30, w.hist, w.totals, &in_a, 0, s)) return e;
+    const uint32_t *order = in_a ? w.vals[0] : w.vals[1];
+    { ProfScope ps("knn_boxes", s); hipLaunchKernelGGL(knn_boxes_kernel, dim3(nbox), dim3(KNN_BOX), 0, s, P, points, order, w.box_lo, w.box_hi); LVDGS_LAUNCH_CHECK("knn_boxes", 0, s); }
+    { ProfScope ps("knn_search", s); hipLaunchKernelGGL(knn_search_kernel, dim3(nbox), dim3(KNN_BOX), 0, s, P, nbox, points, order, w.box_lo, w.box_hi, mean_dist2); LVDGS_LAUNCH_CHECK("knn_search", 0, s); }
+    return LVDGS_OK;
 }
 
-int lvdgs_rope2d(float *, const int64_t *, int32_t, int32_t, int32_t, int32_t, float, float, void *) {
-    set_error("lvdgs_rope2d: not implemented in this build");
-    return LVDGS_E_INVALID;
+int lvdgs_rope2d(float *tokens, const int64_t *positions, int32_t B, int32_t N, int32_t H, int32_t D, float base, float fwd,
+                 void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (B < 0 || N < 0 || H <= 0 || D <= 0 || (D % 4) != 0) { set_error("rope2d: D must be a positive multiple of 4"); return LVDGS_E_INVALID; }
+    if ((int64_t)B * N == 0) return LVDGS_OK;
+    if (!tokens || !positions) { set_error("rope2d: NULL tensor"); return LVDGS_E_INVALID; }
+    ProfScope ps("rope2d", s);
+    hipLaunchKernelGGL(rope2d_kernel, dim3((unsigned)((int64_t)B * N)), dim3(256), (size_t)D * 2 * sizeof(float), s, tokens, positions,
+                       H, D, base, fwd);
+    LVDGS_LAUNCH_CHECK("rope2d", 0, s);
+    return LVDGS_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,67 @@
+"""HIP simple-knn (distCUDA2) and RoPE-2D against their CPU restatements."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,kind", [(1, "u"), (3, "u"), (4, "u"), (257, "u"), (5000, "u"), (20000, "clustered"), (3000, "plane")])
+def test_dist2_knn3_matches_brute_force(n, kind):
+    import aux_oracle
+    from lvdgs.simple_knn import distCUDA2
+    g = torch.Generator().manual_seed(n)
+    pts = torch.rand(n, 3, generator=g) * 10 - 5
+    if kind == "clustered":
+        pts = torch.randn(n, 3, generator=g) * torch.tensor([0.1, 3.0, 0.5]) + (torch.randint(0, 4, (n, 1), generator=g) * 7.0)
+    if kind == "plane":
+        pts[:, 2] = 1.5  # degenerate axis (zero extent)
+    out = distCUDA2(pts.cuda()).cpu().numpy()
+    ref = aux_oracle.dist2_knn3(pts.numpy())
+    np.testing.assert_allclose(out, ref, rtol=2e-5, atol=1e-9)
+
+
+def test_dist2_knn3_duplicates():
+    import aux_oracle
+    from lvdgs.simple_knn import distCUDA2
+    pts = torch.rand(500, 3)
+    pts[100:110] = pts[0]
+    out = distCUDA2(pts.cuda()).cpu().numpy()
+    np.testing.assert_allclose(out, aux_oracle.dist2_knn3(pts.numpy()), rtol=2e-5, atol=1e-9)
+    assert out[0] == 0.0
+
+
+@pytest.mark.parametrize("B,N,H,D", [(1, 7, 1, 4), (2, 196, 12, 64), (1, 1024, 16, 64), (3, 33, 5, 24)])
+def test_rope2d_forward_and_inverse(B, N, H, D):
+    import aux_oracle
+    from lvdgs.curope import cuRoPE2D, rope_2d
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    tokens = torch.randn(B, H, N, D, generator=g)
+    pos = torch.stack([torch.randint(0, 37, (B, N), generator=g), torch.randint(0, 53, (B, N), generator=g)], -1)
+    ref = aux_oracle.rope2d(tokens.transpose(1, 2).numpy(), pos.numpy(), base=100.0, fwd=1.0)
+    t = tokens.cuda().clone()
+    out = cuRoPE2D(freq=100.0)(t, pos.cuda())
+    assert out.data_ptr() == t.data_ptr()  # in place
+    np.testing.assert_allclose(out.transpose(1, 2).cpu().numpy(), ref, rtol=1e-5, atol=2e-5)
+    # the backward pass is the inverse rotation
+    back = out.transpose(1, 2).contiguous()
+    rope_2d(back, pos.cuda(), 100.0, -1.0)
+    np.testing.assert_allclose(back.cpu().numpy(), tokens.transpose(1, 2).numpy(), rtol=1e-5, atol=2e-5)
+
+
+def test_rope2d_autograd():
+    import aux_oracle
+    from lvdgs.curope import cuRoPE2D_func
+    B, N, H, D = 1, 16, 2, 8
+    x = torch.randn(B, N, H, D, device="cuda", requires_grad=True)
+    pos = torch.randint(0, 9, (B, N, 2), device="cuda")
+    w = torch.randn(B, N, H, D, device="cuda")
+    y = cuRoPE2D_func.apply(x.clone(), pos, 100.0, 1.0)
+    (y * w).sum().backward()
+    # d/dx of a rotation applied to x, contracted with w, is the inverse rotation of w
+    ref = aux_oracle.rope2d(w.cpu().numpy(), pos.cpu().numpy(), 100.0, -1.0)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), ref, rtol=1e-5, atol=2e-5)
