@@ -216,8 +216,8 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(BlendParams p) {
     const int todo = (int)(range.y - range.x);
 
     float T = T_final;
-    float bh0 = 0.f, bh1 = 0.f, bh2 = 0.f, bhd = 0.f;           // colour / depth accumulated behind
-    float la = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, ld = 0.f;  // last alpha / colour / depth
+    float bh0 = 0.f, bh1 = 0.f, bh2 = 0.f, bhd = 0.f;  // colour / depth accumulated behind
+    float la = 0.f, df0 = 0.f, df1 = 0.f, df2 = 0.f, dfd = 0.f;  // last alpha, last (value - behind)
     // which accumulator floats the lane that ends a 16-lane row writes (see the fold below)
     const int row_off = (lane >> 4) == 0 ? 0 : ((lane >> 4) == 1 ? 3 : ((lane >> 4) == 2 ? 5 : 8));
     const bool row_end = (lane & 15) == 15, row3 = ((lane >> 4) & 1) == 0;
@@ -267,25 +267,27 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(BlendParams p) {
                     const float alpha = fminf(ALPHA_MAX, B.y * G);
                     const bool hit = ((uint32_t)(base + jj) < my_last) && (pw2 <= 0.f) && (alpha >= ALPHA_MIN);
                     if (__ballot(hit) == 0ull) continue;
+                    // v0..v4 are accumulated without their constant factors (-1, -1, -1/2, -1, -1/2): the
+                    // flush applies them once per (Gaussian, tile) pair instead of once per pixel.
                     float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f, v9 = 0.f;
                     if (hit) {
                         const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
                         T *= inv;
                         const float w = alpha * T;
-                        bh0 = fmaf(la, lc0 - bh0, bh0); bh1 = fmaf(la, lc1 - bh1, bh1); bh2 = fmaf(la, lc2 - bh2, bh2);
-                        bhd = fmaf(la, ld - bhd, bhd);
-                        lc0 = Cc.x; lc1 = Cc.y; lc2 = Cc.z; ld = B.z; la = alpha;
-                        float dL_dalpha = (lc0 - bh0) * gC0 + (lc1 - bh1) * gC1 + (lc2 - bh2) * gC2 + (ld - bhd) * gD;
-                        dL_dalpha = fmaf(dL_dalpha, T, -tail * inv);
+                        // colour / depth accumulated behind this Gaussian: bh += last_alpha * (last_value - bh);
+                        // df* keeps (value - bh) of the previous hit so each is computed once
+                        bh0 = fmaf(la, df0, bh0); bh1 = fmaf(la, df1, bh1); bh2 = fmaf(la, df2, bh2); bhd = fmaf(la, dfd, bhd);
+                        df0 = Cc.x - bh0; df1 = Cc.y - bh1; df2 = Cc.z - bh2; dfd = B.z - bhd;
+                        la = alpha;
+                        float dL_dalpha = fmaf(dfd, gD, fmaf(df2, gC2, fmaf(df1, gC1, df0 * gC0)));
+                        dL_dalpha = fmaf(dL_dalpha, T, -(tail * inv));
                         v6 = w * gC0; v7 = w * gC1; v8 = w * gC2; v9 = w * gD;
                         v5 = G * dL_dalpha;
-                        const float dL_dG = B.y * dL_dalpha;
-                        const float gdx = G * dx, gdy = G * dy;
-                        v0 = dL_dG * -(A.z * gdx + A.w * gdy);
-                        v1 = dL_dG * -(B.x * gdy + A.w * gdx);
-                        v2 = -0.5f * gdx * dx * dL_dG;
-                        v3 = -gdx * dy * dL_dG;
-                        v4 = -0.5f * gdy * dy * dL_dG;
+                        const float h = B.y * v5;  // dL/dG * G
+                        const float hx = h * dx, hy = h * dy;
+                        v0 = fmaf(A.z, hx, A.w * hy);
+                        v1 = fmaf(B.x, hy, A.w * hx);
+                        v2 = hx * dx; v3 = hx * dy; v4 = hy * dy;
                     }
                     // ---- sum the ten values over the 64 pixels: two pairwise folds (64 -> 32 -> 16 lanes,
                     //      ten registers -> five -> three), then one 16-lane DPP sum of the three ----
@@ -319,8 +321,8 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(BlendParams p) {
                 }
             // slot order written above: v0 v4 v8 | v2 v6 | v1 v5 v9 | v3 v7
             float4 *dst = reinterpret_cast<float4 *>(p.pair_grads + (size_t)s_slot[tid] * PAIR_FLOATS);
-            dst[0] = make_float4(acc[0], acc[5], acc[3], acc[8]);
-            dst[1] = make_float4(acc[1], acc[6], acc[4], acc[9]);
+            dst[0] = make_float4(-acc[0], -acc[5], -0.5f * acc[3], -acc[8]);
+            dst[1] = make_float4(-0.5f * acc[1], acc[6], acc[4], acc[9]);
             dst[2] = make_float4(acc[2], acc[7], 0.f, 0.f);
         }
         __syncthreads();
