@@ -267,13 +267,13 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(BlendParams p) {
                     const float alpha = fminf(ALPHA_MAX, B.y * G);
                     const bool hit = ((uint32_t)(base + jj) < my_last) && (pw2 <= 0.f) && (alpha >= ALPHA_MIN);
                     if (__ballot(hit) == 0ull) continue;
-                    // v0..v4 are accumulated without their constant factors (-1, -1, -1/2, -1, -1/2): the
-                    // flush applies them once per (Gaussian, tile) pair instead of once per pixel.
-                    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f, v9 = 0.f;
+                    // Only the per-pixel state lives under the hit mask; lanes that miss keep w = v5 = 0, so
+                    // the ten products below come out zero for them without ten separate zero-initialisations.
+                    float w = 0.f, v5 = 0.f;
                     if (hit) {
                         const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
                         T *= inv;
-                        const float w = alpha * T;
+                        w = alpha * T;
                         // colour / depth accumulated behind this Gaussian: bh += last_alpha * (last_value - bh);
                         // df* keeps (value - bh) of the previous hit so each is computed once
                         bh0 = fmaf(la, df0, bh0); bh1 = fmaf(la, df1, bh1); bh2 = fmaf(la, df2, bh2); bhd = fmaf(la, dfd, bhd);
@@ -281,19 +281,21 @@ __global__ void __launch_bounds__(256) blend_bwd_kernel(BlendParams p) {
                         la = alpha;
                         float dL_dalpha = fmaf(dfd, gD, fmaf(df2, gC2, fmaf(df1, gC1, df0 * gC0)));
                         dL_dalpha = fmaf(dL_dalpha, T, -(tail * inv));
-                        v6 = w * gC0; v7 = w * gC1; v8 = w * gC2; v9 = w * gD;
                         v5 = G * dL_dalpha;
-                        const float h = B.y * v5;  // dL/dG * G
-                        const float hx = h * dx, hy = h * dy;
-                        v0 = fmaf(A.z, hx, A.w * hy);
-                        v1 = fmaf(B.x, hy, A.w * hx);
-                        v2 = hx * dx; v3 = hx * dy; v4 = hy * dy;
                     }
+                    // v0..v4 are accumulated without their constant factors (-1, -1, -1/2, -1, -1/2): the
+                    // flush applies them once per (Gaussian, tile) pair instead of once per pixel.
+                    const float v6 = w * gC0, v7 = w * gC1, v8 = w * gC2, v9 = w * gD;
+                    const float h = B.y * v5;  // dL/dG * G
+                    const float hx = h * dx, hy = h * dy;
+                    const float v0 = fmaf(A.z, hx, A.w * hy);
+                    const float v1 = fmaf(B.x, hy, A.w * hx);
+                    const float v2 = hx * dx, v3 = hx * dy, v4 = hy * dy;
                     // ---- sum the ten values over the 64 pixels: two pairwise folds (64 -> 32 -> 16 lanes,
                     //      ten registers -> five -> three), then one 16-lane DPP sum of the three ----
                     float q0 = fold16(fold32(v0, v1), fold32(v2, v3));  // rows: v0 v2 v1 v3
                     float q1 = fold16(fold32(v4, v5), fold32(v6, v7));  // rows: v4 v6 v5 v7
-                    float q2 = fold16(fold32(v8, v9), 0.f);             // rows: v8 -  v9 -
+                    float q2 = fold16(fold32(v8, v9), v7);              // rows: v8 x  v9 x (x: unused)
                     row_sums3(q0, q1, q2);
                     if (row_end) {
                         float *o = &s_acc[wave][jj * ACC_STRIDE + row_off];
