@@ -78,6 +78,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendParams p) {
     __shared__ float4 s_b[256];  // -c/2*log2e, opacity, depth, id bits
     __shared__ float4 s_c[256];  // r, g, b, a (raw conic a, for the quadrant test)
     __shared__ float2 s_d[256];  // raw conic b, c
+    __shared__ int s_touch[256]; // pixels of this tile each staged Gaussian "touched" (T after it > 0.5)
 
     const int tile = tile_of_workgroup(blockIdx.x, p.num_tiles);
     const int tx = tile % p.gx, ty = tile / p.gx;
@@ -97,15 +98,17 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendParams p) {
     for (int base = 0; base < todo; base += 256) {
         if (__syncthreads_and(done)) break;
         const int cnt = min(256, todo - base);
+        uint32_t my_id = 0;
         if (tid < cnt) {
-            const uint32_t id = p.point_list[range.x + base + tid];
-            const float4 *r4 = reinterpret_cast<const float4 *>(p.rec + (size_t)id * REC_FLOATS);
+            my_id = p.point_list[range.x + base + tid];
+            const float4 *r4 = reinterpret_cast<const float4 *>(p.rec + (size_t)my_id * REC_FLOATS);
             const float4 r0 = r4[0], r1 = r4[1], r2 = r4[2];
             s_a[tid] = make_float4(r0.x, r0.y, -0.5f * LOG2E * r0.z, -LOG2E * r0.w);
-            s_b[tid] = make_float4(-0.5f * LOG2E * r1.x, r1.y, r2.y, __uint_as_float(id));
+            s_b[tid] = make_float4(-0.5f * LOG2E * r1.x, r1.y, r2.y, 0.f);
             s_c[tid] = make_float4(r1.z, r1.w, r2.x, r0.z);
             s_d[tid] = make_float2(r0.w, r1.x);
         }
+        s_touch[tid] = 0;
         __syncthreads();
         if (__ballot(!done) != 0ull) {
             for (int c0 = 0; c0 < cnt; c0 += 64) {
@@ -121,42 +124,36 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendParams p) {
                 uint64_t live = __ballot(keep);
                 // ---- lane -> pixel: composite the survivors in list order ----
                 while (live) {
-                    const int j = __builtin_ctzll(live);
+                    const int jj = c0 + __builtin_ctzll(live);
                     live &= live - 1;
-                    const int jj = c0 + j;
                     const float4 A = s_a[jj];
                     const float4 B = s_b[jj];
-                    bool hit = false, touch = false;
-                    float alpha = 0.f, test_T = 0.f;
-                    if (!done) {
-                        const float dx = A.x - pxf, dy = A.y - pyf;
-                        const float pw2 = fmaf(dx, fmaf(A.z, dx, A.w * dy), B.x * dy * dy);  // log2 of the falloff (backward repeats this exactly)
-                        alpha = fminf(ALPHA_MAX, B.y * __builtin_amdgcn_exp2f(pw2));
-                        hit = (pw2 <= 0.f) && (alpha >= ALPHA_MIN);
-                        if (hit) {
-                            test_T = T * (1.f - alpha);
-                            if (test_T < T_STOP) { done = true; hit = false; }
-                        }
-                    }
-                    const uint64_t hits = __ballot(hit);
-                    if (hits) {
-                        const float4 Cc = s_c[jj];
-                        if (hit) {
-                            const float w = alpha * T;
-                            C0 = fmaf(Cc.x, w, C0); C1 = fmaf(Cc.y, w, C1); C2 = fmaf(Cc.z, w, C2);
-                            Dp = fmaf(B.z, w, Dp);
-                            T = test_T;
-                            last = (uint32_t)(base + jj + 1);
-                            touch = test_T > T_TOUCH;
-                        }
-                        const uint64_t touched = __ballot(touch);
-                        if (touched && lane == __builtin_ctzll(touched))
-                            atomicAdd(&p.n_touched[__float_as_uint(B.w)], (int)__popcll(touched));
-                    }
+                    const float dx = A.x - pxf, dy = A.y - pyf;
+                    const float pw2 = fmaf(dx, fmaf(A.z, dx, A.w * dy), B.x * dy * dy);  // log2 of the falloff (backward repeats this exactly)
+                    const float alpha = fminf(ALPHA_MAX, B.y * __builtin_amdgcn_exp2f(pw2));
+                    const float test_T = T * (1.f - alpha);
+                    bool hit = !done && (pw2 <= 0.f) && (alpha >= ALPHA_MIN);
+                    const bool stop = hit && (test_T < T_STOP);
+                    done = done || stop;
+                    hit = hit && !stop;
+                    if (__ballot(hit) == 0ull) continue;
+                    const float4 Cc = s_c[jj];
+                    const float w = hit ? alpha * T : 0.f;
+                    C0 = fmaf(Cc.x, w, C0); C1 = fmaf(Cc.y, w, C1); C2 = fmaf(Cc.z, w, C2);
+                    Dp = fmaf(B.z, w, Dp);
+                    T = hit ? test_T : T;
+                    last = hit ? (uint32_t)(base + jj + 1) : last;
+                    const uint64_t touched = __ballot(hit && test_T > T_TOUCH);
+                    if (touched != 0ull && lane == 0) atomicAdd(&s_touch[jj], (int)__popcll(touched));
                 }
             }
         }
         __syncthreads();
+        // one integer atomic per (tile, Gaussian) that touched anything
+        if (tid < cnt) {
+            const int n = s_touch[tid];
+            if (n) atomicAdd(&p.n_touched[my_id], n);
+        }
     }
     if (inside) {
         const size_t pix = (size_t)py * p.W + px, P = (size_t)p.W * p.H;
