@@ -159,6 +159,39 @@ int lvdgs_dist2_knn3(int32_t num_points, const float *points /* P*3 */, float *m
 int lvdgs_rope2d(float *tokens, const int64_t *positions, int32_t B, int32_t N, int32_t H, int32_t D,
                  float base, float fwd, void *stream);
 
+/* ---- fused photometric losses (reference utils/slam_utils.py:42-121) ---- */
+/*   loss = weight_rgb   * mean_{c,p} [ omega_p * |(e^a I_cp + b) m_p - G_cp m_p| ]
+ *        + weight_depth * mean_p     [ |D_p k_p - Z_p k_p| ]
+ *   m_p = (sum_c G_cp > rgb_boundary_threshold) [* grad_mask_p],  omega_p = opacity_p if weight_by_opacity else 1,
+ *   k_p = (Z_p > 0.01) [* (opacity_p > 0.95) if depth_needs_opaque].
+ * get_loss_tracking_rgb  (slam_utils.py:53-62):  weight_rgb 1, weight_by_opacity 1, grad_mask, no depth term;
+ * get_loss_tracking_rgbd (:65-79):  weight_rgb alpha, weight_depth 1-alpha, depth_needs_opaque 1;
+ * get_loss_mapping_rgb   (:95-104): weight_rgb 1;   get_loss_mapping_rgbd (:107-121): alpha, 1-alpha. */
+typedef struct lvdgs_loss_args {
+    int32_t width, height;
+    const float *image;        /* 3*H*W rendered colour                       */
+    const float *depth;        /* H*W rendered depth or NULL                  */
+    const float *opacity;      /* H*W rendered opacity or NULL                */
+    const float *gt_image;     /* 3*H*W                                       */
+    const float *gt_depth;     /* H*W or NULL (no depth term)                 */
+    const uint8_t *grad_mask;  /* H*W bytes (0 / non-0) or NULL               */
+    const float *exposure_a;   /* 1 or NULL (no exposure correction)          */
+    const float *exposure_b;   /* 1 or NULL                                   */
+    float rgb_boundary_threshold, weight_rgb, weight_depth;
+    int32_t weight_by_opacity, depth_needs_opaque;
+    void *scratch; size_t scratch_bytes;   /* lvdgs_loss_scratch_bytes(W,H)   */
+    float *loss;               /* forward out: 1                              */
+    const float *grad_loss;    /* backward in: 1 (d objective / d loss)       */
+    float *d_image;            /* backward out: 3*H*W                         */
+    float *d_depth;            /* H*W or NULL                                 */
+    float *d_opacity;          /* H*W or NULL                                 */
+    float *d_exposure_a;       /* 1 or NULL                                   */
+    float *d_exposure_b;       /* 1 or NULL                                   */
+} lvdgs_loss_args;
+size_t lvdgs_loss_scratch_bytes(int32_t width, int32_t height);
+int lvdgs_photometric_loss_forward(const lvdgs_loss_args *a, void *stream);
+int lvdgs_photometric_loss_backward(const lvdgs_loss_args *a, void *stream);
+
 /* ---- diagnostics ---- */
 const char *lvdgs_last_error(void);
 const char *lvdgs_version(void);

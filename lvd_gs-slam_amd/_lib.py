@@ -36,6 +36,20 @@ class Args(C.Structure):
     ]
 
 
+class LossArgs(C.Structure):
+    """struct lvdgs_loss_args (include/lvdgs.h)."""
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32),
+        ("image", _fp), ("depth", _fp), ("opacity", _fp), ("gt_image", _fp), ("gt_depth", _fp), ("grad_mask", _fp),
+        ("exposure_a", _fp), ("exposure_b", _fp),
+        ("rgb_boundary_threshold", C.c_float), ("weight_rgb", C.c_float), ("weight_depth", C.c_float),
+        ("weight_by_opacity", C.c_int32), ("depth_needs_opaque", C.c_int32),
+        ("scratch", _fp), ("scratch_bytes", C.c_size_t),
+        ("loss", _fp), ("grad_loss", _fp), ("d_image", _fp), ("d_depth", _fp), ("d_opacity", _fp),
+        ("d_exposure_a", _fp), ("d_exposure_b", _fp),
+    ]
+
+
 class StateLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "geom_rec", "geom_tiles_touched", "geom_order", "geom_offsets", "bin_point_list", "bin_tile_keys",
@@ -51,7 +65,8 @@ EXPORTS = (
     "lvdgs_geom_bytes", "lvdgs_prepare_scratch_bytes", "lvdgs_binning_bytes", "lvdgs_image_bytes",
     "lvdgs_render_scratch_bytes", "lvdgs_backward_scratch_bytes", "lvdgs_forward_prepare", "lvdgs_forward_render",
     "lvdgs_backward", "lvdgs_mark_visible", "lvdgs_state_layout_query", "lvdgs_knn_scratch_bytes",
-    "lvdgs_dist2_knn3", "lvdgs_rope2d", "lvdgs_last_error", "lvdgs_version", "lvdgs_profile_enable",
+    "lvdgs_dist2_knn3", "lvdgs_rope2d", "lvdgs_loss_scratch_bytes", "lvdgs_photometric_loss_forward",
+    "lvdgs_photometric_loss_backward", "lvdgs_last_error", "lvdgs_version", "lvdgs_profile_enable",
     "lvdgs_profile_reset", "lvdgs_profile_read",
 )
 
@@ -93,6 +108,10 @@ def lib():
         L.lvdgs_knn_scratch_bytes.argtypes = [C.c_int32]
         L.lvdgs_dist2_knn3.argtypes = [C.c_int32, _fp, _fp, _fp, C.c_size_t, C.c_void_p]
         L.lvdgs_rope2d.argtypes = [_fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p]
+        L.lvdgs_loss_scratch_bytes.restype = C.c_size_t
+        L.lvdgs_loss_scratch_bytes.argtypes = [C.c_int32, C.c_int32]
+        L.lvdgs_photometric_loss_forward.argtypes = [C.POINTER(LossArgs), C.c_void_p]
+        L.lvdgs_photometric_loss_backward.argtypes = [C.POINTER(LossArgs), C.c_void_p]
         L.lvdgs_profile_enable.argtypes = [C.c_int]
         L.lvdgs_profile_read.argtypes = [C.POINTER(KernelTime), C.c_int]
         _lib = L

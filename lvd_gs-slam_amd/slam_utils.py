@@ -41,15 +41,30 @@ def image_gradient_mask(image, eps=0.01):
     return full, full.clone()
 
 
+def _fusable(image):
+    """The fused HIP loss handles float32 GPU renders; anything else takes the PyTorch formulas below."""
+    return image.is_cuda and image.dtype == torch.float32 and USE_FUSED_LOSS
+
+
+USE_FUSED_LOSS = True
+
+
 def _gt_image(viewpoint, like):
     return viewpoint.original_image.to(like.device)
 
 
 def _mono_depth(viewpoint, like):
     md = viewpoint.mono_depth
-    if not torch.is_tensor(md):
-        md = torch.from_numpy(md)
-    return md.to(dtype=torch.float32, device=like.device)[None]
+    cache = getattr(viewpoint, "_lvdgs_mono_depth", None)
+    if cache is not None and cache[0] is md and cache[1].device == like.device:
+        return cache[1]
+    t = md if torch.is_tensor(md) else torch.from_numpy(md)
+    t = t.to(dtype=torch.float32, device=like.device)[None]
+    try:  # the reference re-uploads the numpy depth every call; keep the device copy with the viewpoint
+        viewpoint._lvdgs_mono_depth = (md, t)
+    except Exception:
+        pass
+    return t
 
 
 def _exposure(image, viewpoint):
@@ -60,6 +75,16 @@ def get_loss_tracking(config, image, depth, opacity, viewpoint, initialization=F
     """Tracking loss on the exposure-corrected render (utils/slam_utils.py:42-50).
     With ``monocular`` set the RGB-only branch is taken whether or not
     ``Dataset.depth_loss`` is set, exactly as in the reference."""
+    if _fusable(image):
+        from .fused_loss import photometric_loss
+        thr = config["Training"]["rgb_boundary_threshold"]
+        common = dict(opacity=opacity, exposure_a=viewpoint.exposure_a, exposure_b=viewpoint.exposure_b,
+                      grad_mask=viewpoint.grad_mask, rgb_boundary_threshold=thr, weight_by_opacity=True)
+        if config["Training"]["monocular"]:
+            return photometric_loss(image, _gt_image(viewpoint, image), **common)
+        alpha = config["Training"].get("alpha", 0.95)
+        return photometric_loss(image, _gt_image(viewpoint, image), depth=depth, gt_depth=_mono_depth(viewpoint, image),
+                                weight_rgb=alpha, weight_depth=1 - alpha, depth_needs_opaque=True, **common)
     image_ab = _exposure(image, viewpoint)
     if config["Training"]["monocular"]:
         return get_loss_tracking_rgb(config, image_ab, depth, opacity, viewpoint)
@@ -88,8 +113,19 @@ def get_loss_tracking_rgbd(config, image, depth, opacity, viewpoint, initializat
 
 def get_loss_mapping(config, image, viewpoint, depth=None, initialization=False, monodepth=True):
     """Mapping loss dispatcher (utils/slam_utils.py:82-92)."""
+    rgb_only = config["Training"]["monocular"] and not monodepth
+    if _fusable(image):
+        from .fused_loss import photometric_loss
+        kw = dict(rgb_boundary_threshold=config["Training"]["rgb_boundary_threshold"])
+        if not initialization:
+            kw.update(exposure_a=viewpoint.exposure_a, exposure_b=viewpoint.exposure_b)
+        if rgb_only:
+            return photometric_loss(image, _gt_image(viewpoint, image), **kw)
+        alpha = config["Training"].get("alpha", 0.95)
+        return photometric_loss(image, _gt_image(viewpoint, image), depth=depth, gt_depth=_mono_depth(viewpoint, image),
+                                weight_rgb=alpha, weight_depth=1 - alpha, **kw)
     image_ab = image if initialization else _exposure(image, viewpoint)
-    if config["Training"]["monocular"] and not monodepth:
+    if rgb_only:
         return get_loss_mapping_rgb(config, image_ab, viewpoint)
     return get_loss_mapping_rgbd(config, image_ab, depth, viewpoint)
 
