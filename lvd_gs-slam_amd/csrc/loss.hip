@@ -48,7 +48,8 @@ __device__ __forceinline__ float block_sum(float v, float *s /* [4] */) {
     return ((s[0] + s[1]) + s[2]) + s[3];
 }
 
-template <bool BACKWARD>
+// 4 consecutive pixels per lane: 16-byte loads / stores on every plane when P % 4 == 0 (VEC), scalar otherwise.
+template <bool BACKWARD, bool VEC>
 __global__ void __launch_bounds__(LOSS_THREADS) photometric_kernel(LossParams p) {
     __shared__ float s_red[4];
     const float ea = p.exposure_a ? __expf(p.exposure_a[0]) : 1.f;
@@ -57,35 +58,74 @@ __global__ void __launch_bounds__(LOSS_THREADS) photometric_kernel(LossParams p)
     const float Wr = p.w_rgb / (3.f * (float)p.P) * g, Wd = p.w_d / (float)p.P * g;
     float acc0 = 0.f, acc1 = 0.f;  // fwd: rgb sum, depth sum ; bwd: d_a sum, d_b sum
     const int base = (blockIdx.x * LOSS_THREADS + threadIdx.x) * LOSS_PIX_PER_THREAD;
+    const size_t P = (size_t)p.P;
+    const bool has_d = p.depth && p.gt_depth;
+    if (base < p.P) {
+        float G[3][4], I[3][4], op[4], Z[4], Dv[4], gm[4];
+        const int n = VEC ? 4 : min(4, p.P - base);
+        auto load4 = [&](const float *src, float out[4], float fill) {
+            if (VEC) {
+                const float4 v = *reinterpret_cast<const float4 *>(src + base);
+                out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+            } else {
 #pragma unroll
-    for (int k = 0; k < LOSS_PIX_PER_THREAD; k++) {
-        const int i = base + k;
-        if (i >= p.P) break;
-        const float G0 = p.gt_image[i], G1 = p.gt_image[p.P + i], G2 = p.gt_image[2 * (size_t)p.P + i];
-        const float I0 = p.image[i], I1 = p.image[p.P + i], I2 = p.image[2 * (size_t)p.P + i];
-        float m = (G0 + G1 + G2 > p.rgb_thr) ? 1.f : 0.f;
-        if (p.grad_mask) m *= p.grad_mask[i] ? 1.f : 0.f;
-        const float op = p.opacity ? p.opacity[i] : 1.f;
-        const float om = p.weight_by_opacity ? op : 1.f;
-        const float r0 = (ea * I0 + eb) * m - G0 * m, r1 = (ea * I1 + eb) * m - G1 * m, r2 = (ea * I2 + eb) * m - G2 * m;
-        float kd = 0.f, rd = 0.f;
-        if (p.depth && p.gt_depth) {
-            const float Z = p.gt_depth[i];
-            kd = Z > 0.01f ? 1.f : 0.f;
-            if (p.depth_needs_opaque) kd *= op > 0.95f ? 1.f : 0.f;
-            rd = p.depth[i] * kd - Z * kd;
+                for (int k = 0; k < 4; k++) out[k] = k < n ? src[base + k] : fill;
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < 3; c++) { load4(p.gt_image + c * P, G[c], 0.f); load4(p.image + c * P, I[c], 0.f); }
+        if (p.opacity) load4(p.opacity, op, 1.f);
+        else { op[0] = op[1] = op[2] = op[3] = 1.f; }
+        if (has_d) { load4(p.gt_depth, Z, 0.f); load4(p.depth, Dv, 0.f); }
+        if (p.grad_mask) {
+            if (VEC) {
+                const uint32_t m4 = *reinterpret_cast<const uint32_t *>(p.grad_mask + base);
+#pragma unroll
+                for (int k = 0; k < 4; k++) gm[k] = ((m4 >> (8 * k)) & 0xffu) ? 1.f : 0.f;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) gm[k] = (k < n && p.grad_mask[base + k]) ? 1.f : 0.f;
+            }
+        } else { gm[0] = gm[1] = gm[2] = gm[3] = 1.f; }
+        float dI[3][4], dO[4], dD[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool live = VEC || k < n;
+            const float m = ((G[0][k] + G[1][k] + G[2][k] > p.rgb_thr) ? 1.f : 0.f) * gm[k] * (live ? 1.f : 0.f);
+            const float om = p.weight_by_opacity ? op[k] : 1.f;
+            const float r0 = (ea * I[0][k] + eb) * m - G[0][k] * m, r1 = (ea * I[1][k] + eb) * m - G[1][k] * m,
+                        r2 = (ea * I[2][k] + eb) * m - G[2][k] * m;
+            float kd = 0.f, rd = 0.f;
+            if (has_d) {
+                kd = (Z[k] > 0.01f && live) ? 1.f : 0.f;
+                if (p.depth_needs_opaque) kd *= op[k] > 0.95f ? 1.f : 0.f;
+                rd = Dv[k] * kd - Z[k] * kd;
+            }
+            if (!BACKWARD) {
+                acc0 += om * (fabsf(r0) + fabsf(r1) + fabsf(r2));
+                acc1 += fabsf(rd);
+            } else {
+                auto sgn = [](float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); };
+                const float q0 = Wr * om * sgn(r0) * m, q1 = Wr * om * sgn(r1) * m, q2 = Wr * om * sgn(r2) * m;
+                dI[0][k] = ea * q0; dI[1][k] = ea * q1; dI[2][k] = ea * q2;
+                dO[k] = p.weight_by_opacity ? Wr * (fabsf(r0) + fabsf(r1) + fabsf(r2)) : 0.f;
+                dD[k] = Wd * sgn(rd) * kd;
+                acc0 += ea * (q0 * I[0][k] + q1 * I[1][k] + q2 * I[2][k]);
+                acc1 += q0 + q1 + q2;
+            }
         }
-        if (!BACKWARD) {
-            acc0 += om * (fabsf(r0) + fabsf(r1) + fabsf(r2));
-            acc1 += fabsf(rd);
-        } else {
-            auto sgn = [](float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); };
-            const float q0 = Wr * om * sgn(r0) * m, q1 = Wr * om * sgn(r1) * m, q2 = Wr * om * sgn(r2) * m;  // d/d(e^a I + b)
-            p.d_image[i] = ea * q0; p.d_image[p.P + i] = ea * q1; p.d_image[2 * (size_t)p.P + i] = ea * q2;
-            if (p.d_opacity) p.d_opacity[i] = p.weight_by_opacity ? Wr * (fabsf(r0) + fabsf(r1) + fabsf(r2)) : 0.f;
-            if (p.d_depth) p.d_depth[i] = Wd * sgn(rd) * kd;
-            acc0 += ea * (q0 * I0 + q1 * I1 + q2 * I2);
-            acc1 += q0 + q1 + q2;
+        if (BACKWARD) {
+            auto store4 = [&](float *dst, const float v[4]) {
+                if (VEC) *reinterpret_cast<float4 *>(dst + base) = make_float4(v[0], v[1], v[2], v[3]);
+                else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) if (k < n) dst[base + k] = v[k];
+                }
+            };
+#pragma unroll
+            for (int c = 0; c < 3; c++) store4(p.d_image + c * P, dI[c]);
+            if (p.d_opacity) store4(p.d_opacity, dO);
+            if (p.d_depth) store4(p.d_depth, dD);
         }
     }
     const float s0 = block_sum(acc0, s_red);
@@ -148,7 +188,7 @@ int lvdgs_photometric_loss_forward(const lvdgs_loss_args *a, void *stream) {
     if (int e = loss_common(a, p, nblk)) return e;
     if (!a->loss) { set_error("loss: output is NULL"); return LVDGS_E_INVALID; }
     p.loss = a->loss;
-    { ProfScope ps("loss_fwd", s); hipLaunchKernelGGL(photometric_kernel<false>, dim3(nblk), dim3(LOSS_THREADS), 0, s, p); LVDGS_LAUNCH_CHECK("loss_fwd", 0, s); }
+    { ProfScope ps("loss_fwd", s); if (p.P % 4 == 0) hipLaunchKernelGGL((photometric_kernel<false, true>), dim3(nblk), dim3(LOSS_THREADS), 0, s, p); else hipLaunchKernelGGL((photometric_kernel<false, false>), dim3(nblk), dim3(LOSS_THREADS), 0, s, p); LVDGS_LAUNCH_CHECK("loss_fwd", 0, s); }
     { ProfScope ps("loss_fwd_finish", s); hipLaunchKernelGGL(photometric_finish_kernel<false>, dim3(1), dim3(256), 0, s, p, nblk); LVDGS_LAUNCH_CHECK("loss_fwd_finish", 0, s); }
     return LVDGS_OK;
 }
@@ -160,7 +200,7 @@ int lvdgs_photometric_loss_backward(const lvdgs_loss_args *a, void *stream) {
     if (!a->grad_loss || !a->d_image) { set_error("loss backward: grad_loss / d_image is NULL"); return LVDGS_E_INVALID; }
     p.grad_out = a->grad_loss; p.d_image = a->d_image; p.d_depth = a->d_depth; p.d_opacity = a->d_opacity;
     p.d_a = a->d_exposure_a; p.d_b = a->d_exposure_b;
-    { ProfScope ps("loss_bwd", s); hipLaunchKernelGGL(photometric_kernel<true>, dim3(nblk), dim3(LOSS_THREADS), 0, s, p); LVDGS_LAUNCH_CHECK("loss_bwd", 0, s); }
+    { ProfScope ps("loss_bwd", s); if (p.P % 4 == 0) hipLaunchKernelGGL((photometric_kernel<true, true>), dim3(nblk), dim3(LOSS_THREADS), 0, s, p); else hipLaunchKernelGGL((photometric_kernel<true, false>), dim3(nblk), dim3(LOSS_THREADS), 0, s, p); LVDGS_LAUNCH_CHECK("loss_bwd", 0, s); }
     { ProfScope ps("loss_bwd_finish", s); hipLaunchKernelGGL(photometric_finish_kernel<true>, dim3(1), dim3(256), 0, s, p, nblk); LVDGS_LAUNCH_CHECK("loss_bwd_finish", 0, s); }
     return LVDGS_OK;
 }

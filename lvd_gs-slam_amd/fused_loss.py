@@ -15,8 +15,12 @@ def _p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def _aligned(t):
+    return t if t.data_ptr() % 16 == 0 else t.clone()  # the kernels use 16-byte loads
+
+
 def _c32(t):
-    return None if t is None else t.detach().to(torch.float32).contiguous()
+    return None if t is None else _aligned(t.detach().to(torch.float32).contiguous())
 
 
 class _Photometric(torch.autograd.Function):
@@ -84,7 +88,7 @@ def photometric_loss(image, gt_image, *, depth=None, opacity=None, exposure_a=No
     if grad_mask is not None:
         gm = grad_mask.reshape(-1)
         gm = gm.view(torch.uint8) if gm.dtype == torch.bool else gm.ne(0).view(torch.uint8)
-        grad_mask = gm.contiguous()
+        grad_mask = _aligned(gm.contiguous())
     if gt_depth is None or depth is None:
         weight_depth, gt_depth = 0.0, None
     return _Photometric.apply(image, depth, opacity, exposure_a, exposure_b, gt_image, gt_depth, grad_mask,
