@@ -45,7 +45,8 @@ typedef enum {
     LVDGS_OK = 0,
     LVDGS_E_INVALID = 1, /* bad argument (null pointer, size mismatch, buffer too small) */
     LVDGS_E_HIP = 2,     /* a HIP runtime call or kernel launch failed                   */
-    LVDGS_E_RANGE = 3    /* problem exceeds a built-in limit (e.g. > 2^31 pairs)         */
+    LVDGS_E_RANGE = 3,   /* problem exceeds a built-in limit (e.g. > 2^31 pairs)         */
+    LVDGS_E_CAPACITY = 4 /* lvdgs_forward: pair_capacity was too small; see lvdgs_forward */
 } lvdgs_status;
 
 /* One argument block serves the three rasterizer calls; each call reads the fields it needs
@@ -107,6 +108,9 @@ typedef struct lvdgs_args {
     float *dL_dcolors;    /* N*3 or NULL with shs */
     float *dL_dtau;       /* 6: [d/d rho (3), d/d theta (3)] of T_w2c <- Exp(tau) T_w2c
                              (reference utils/pose_utils.py:70-87) */
+
+    /* ---- single-call forward only ---- */
+    int64_t pair_capacity; /* pairs binning_state / scratch were sized for (lvdgs_forward) */
 } lvdgs_args;
 
 /* ---- sizes ---- */
@@ -124,6 +128,14 @@ int lvdgs_forward_prepare(const lvdgs_args *a, int64_t *num_rendered, void *stre
 /* Bins pairs per tile, orders each tile's list by depth and composites front to back.
  * Writes out_color / out_depth / out_opacity / n_touched, binning_state and image_state. */
 int lvdgs_forward_render(const lvdgs_args *a, void *stream);
+/* Single-call forward without a pipeline bubble.  The caller sizes binning_state and scratch for
+ * `pair_capacity` pairs (scratch >= max(lvdgs_prepare_scratch_bytes(N), lvdgs_render_scratch_bytes(cap,W,H)));
+ * all kernels are enqueued with the pair count left on the device, and only then does the host wait
+ * for the count (the GPU is busy with the tile sort and the blend meanwhile).  Returns LVDGS_OK and
+ * the count in *num_rendered, or LVDGS_E_CAPACITY when the count exceeds pair_capacity: outputs are
+ * then invalid, geom_state is valid, and the caller re-runs lvdgs_forward_render with
+ * num_rendered = *num_rendered and buffers of that size.  Results are identical to the two-call form. */
+int lvdgs_forward(const lvdgs_args *a, int64_t *num_rendered, void *stream);
 /* Gradient of the three images w.r.t. every Gaussian parameter and the camera pose. */
 int lvdgs_backward(const lvdgs_args *a, void *stream);
 /* present[i] = Gaussian i is in front of the near plane of the view (GaussianRasterizer.markVisible). */

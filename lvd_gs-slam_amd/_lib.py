@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "liblvdgs.so")
 
-OK, E_INVALID, E_HIP, E_RANGE = 0, 1, 2, 3
+OK, E_INVALID, E_HIP, E_RANGE, E_CAPACITY = 0, 1, 2, 3, 4
 
 _fp = C.c_void_p
 
@@ -33,6 +33,7 @@ class Args(C.Structure):
         ("dL_dout_color", _fp), ("dL_dout_depth", _fp), ("dL_dout_opacity", _fp),
         ("dL_dmeans3D", _fp), ("dL_dmeans2D", _fp), ("dL_dopacities", _fp), ("dL_dscales", _fp),
         ("dL_drotations", _fp), ("dL_dcov3D", _fp), ("dL_dshs", _fp), ("dL_dcolors", _fp), ("dL_dtau", _fp),
+        ("pair_capacity", C.c_int64),
     ]
 
 
@@ -64,6 +65,7 @@ class KernelTime(C.Structure):
 EXPORTS = (
     "lvdgs_geom_bytes", "lvdgs_prepare_scratch_bytes", "lvdgs_binning_bytes", "lvdgs_image_bytes",
     "lvdgs_render_scratch_bytes", "lvdgs_backward_scratch_bytes", "lvdgs_forward_prepare", "lvdgs_forward_render",
+    "lvdgs_forward",
     "lvdgs_backward", "lvdgs_mark_visible", "lvdgs_state_layout_query", "lvdgs_knn_scratch_bytes",
     "lvdgs_dist2_knn3", "lvdgs_rope2d", "lvdgs_loss_scratch_bytes", "lvdgs_photometric_loss_forward",
     "lvdgs_photometric_loss_backward", "lvdgs_last_error", "lvdgs_version", "lvdgs_profile_enable",
@@ -101,6 +103,7 @@ def lib():
         L.lvdgs_backward_scratch_bytes.argtypes = [C.c_int32, C.c_int64]
         L.lvdgs_forward_prepare.argtypes = [C.POINTER(Args), C.POINTER(C.c_int64), C.c_void_p]
         L.lvdgs_forward_render.argtypes = [C.POINTER(Args), C.c_void_p]
+        L.lvdgs_forward.argtypes = [C.POINTER(Args), C.POINTER(C.c_int64), C.c_void_p]
         L.lvdgs_backward.argtypes = [C.POINTER(Args), C.c_void_p]
         L.lvdgs_mark_visible.argtypes = [C.c_int32, _fp, _fp, _fp, _fp, C.c_void_p]
         L.lvdgs_state_layout_query.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(StateLayout)]

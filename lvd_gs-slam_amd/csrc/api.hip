@@ -111,6 +111,7 @@ size_t geom_layout(int N, GeomView *v, void *base) {
     carve(v->tiles_touched, n, b, off);
     carve(v->order, n, b, off);
     carve(v->offsets, n, b, off);
+    carve(v->total, 64, b, off);
     return off;
 }
 
@@ -240,6 +241,87 @@ int lvdgs_state_layout_query(int32_t N, int64_t D, int32_t W, int32_t H, lvdgs_s
     return LVDGS_OK;
 }
 
+// Per-thread, per-device host resources of the single-call forward: 4 pinned bytes that receive the
+// pair count and the event that says they have arrived.  Nothing else in the library is stateful.
+namespace {
+struct PairProbe {
+    int device = -1;
+    uint32_t *pinned = nullptr;
+    hipEvent_t ready = nullptr;
+};
+thread_local PairProbe g_probe[16];
+
+int get_probe(PairProbe **out) {
+    int dev = 0;
+    if (int e = check_hip(hipGetDevice(&dev), "hipGetDevice")) return e;
+    PairProbe &p = g_probe[dev & 15];
+    if (p.device != dev || !p.pinned) {
+        p.device = dev;
+        if (int e = check_hip(hipHostMalloc((void **)&p.pinned, 64, hipHostMallocDefault), "pinned pair count")) return e;
+        if (int e = check_hip(hipEventCreateWithFlags(&p.ready, hipEventDisableTiming), "pair count event")) return e;
+    }
+    *out = &p;
+    return LVDGS_OK;
+}
+
+// preprocess -> depth sort -> prefix sum of tiles touched; the pair count ends up in g.total (device)
+int enqueue_prepare(const lvdgs_args *a, const GeomView &g, hipStream_t s) {
+    const int N = a->num_gaussians;
+    PrepScratch w;
+    prep_scratch_layout(N, &w, a->scratch);
+    if (int e = launch_preprocess_fwd(*a, g, w.keys[0], w.vals[0], s)) return e;
+    bool in_a = true;
+    if (int e = radix_sort_pairs(w.keys[0], w.vals[0], w.keys[1], w.vals[1], N, 32, w.hist, w.totals, &in_a, a->debug, s)) return e;
+    const uint32_t *order = in_a ? w.vals[0] : w.vals[1];
+    if (int e = check_hip(hipMemcpyAsync(g.order, order, sizeof(uint32_t) * (size_t)N, hipMemcpyDeviceToDevice, s), "copy order")) return e;
+    return launch_offsets_scan(g.tiles_touched, g.order, g.offsets, w.blocksums, g.total, N, a->debug, s);
+}
+
+// pair emission -> tile sort -> ranges -> blend.  `cap` sizes grids and buffers; when `count_on_device`
+// the kernels take the actual pair count from g.total (clamped to cap), otherwise cap IS the count.
+int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipStream_t s) {
+    const int N = a->num_gaussians, W = a->image_width, H = a->image_height;
+    GeomView g{}; BinView b{}; ImageView im; RenderScratch w{};
+    image_layout(W, H, &im, a->image_state);
+    const int num_tiles = cdiv(W, TILE) * cdiv(H, TILE);
+    const uint32_t *count = nullptr;
+    if (N > 0) {
+        geom_layout(N, &g, a->geom_state);
+        if (int e = check_hip(hipMemsetAsync(a->n_touched, 0, sizeof(int32_t) * (size_t)N, s), "memset n_touched")) return e;
+        if (count_on_device) count = g.total;
+    }
+    if (cap > 0) {
+        bin_layout(cap, &b, a->binning_state);
+        render_scratch_layout(cap, W, H, &w, a->scratch);
+        const int bits = tile_sort_bits(W, H);
+        // start in the buffer that makes the sorted result land in binning_state
+        const bool start_in_state = (radix_num_passes(bits) % 2) == 0;
+        uint32_t *k0 = start_in_state ? b.tile_keys : w.keys, *v0 = start_in_state ? b.point_list : w.vals;
+        uint32_t *k1 = start_in_state ? w.keys : b.tile_keys, *v1 = start_in_state ? w.vals : b.point_list;
+        if (int e = launch_emit_pairs(*a, g, k0, v0, cap, s)) return e;
+        bool in_first = true;
+        if (int e = radix_sort_pairs(k0, v0, k1, v1, cap, bits, w.hist, w.totals, &in_first, a->debug, s, count)) return e;
+        if ((in_first ? k0 : k1) != b.tile_keys) { set_error("internal: sorted list not in binning_state"); return LVDGS_E_INVALID; }
+    }
+    if (int e = launch_tile_ranges(b.tile_keys, cap, count, im.ranges, num_tiles, a->debug, s)) return e;
+    return launch_blend_fwd(*a, g, b, im, s);
+}
+
+int check_render_buffers(const lvdgs_args *a, int64_t cap) {
+    const int N = a->num_gaussians, W = a->image_width, H = a->image_height;
+    if (!a->out_color || !a->out_depth || !a->out_opacity || !a->image_state) { set_error("output image or image_state is NULL"); return LVDGS_E_INVALID; }
+    if (a->image_bytes < lvdgs_image_bytes(W, H)) { set_error("image_state too small"); return LVDGS_E_INVALID; }
+    if (N > 0 && (!a->n_touched || !a->geom_state)) { set_error("n_touched / geom_state is NULL"); return LVDGS_E_INVALID; }
+    if (cap > 0) {
+        if (!a->binning_state || !a->scratch) { set_error("binning_state / scratch is NULL"); return LVDGS_E_INVALID; }
+        if (a->binning_bytes < lvdgs_binning_bytes(cap) || a->scratch_bytes < lvdgs_render_scratch_bytes(cap, W, H)) {
+            set_error("binning_state or scratch too small for %lld pairs", (long long)cap); return LVDGS_E_INVALID;
+        }
+    }
+    return LVDGS_OK;
+}
+}  // namespace
+
 int lvdgs_forward_prepare(const lvdgs_args *a, int64_t *num_rendered, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     if (int e = check_common(a)) return e;
@@ -252,17 +334,11 @@ int lvdgs_forward_prepare(const lvdgs_args *a, int64_t *num_rendered, void *stre
     if (a->geom_bytes < lvdgs_geom_bytes(N) || a->scratch_bytes < lvdgs_prepare_scratch_bytes(N)) {
         set_error("geom_state or scratch too small"); return LVDGS_E_INVALID;
     }
-    GeomView g; PrepScratch w;
+    GeomView g;
     geom_layout(N, &g, a->geom_state);
-    prep_scratch_layout(N, &w, a->scratch);
-    if (int e = launch_preprocess_fwd(*a, g, w.keys[0], w.vals[0], s)) return e;
-    bool in_a = true;
-    if (int e = radix_sort_pairs(w.keys[0], w.vals[0], w.keys[1], w.vals[1], N, 32, w.hist, w.totals, &in_a, a->debug, s)) return e;
-    const uint32_t *order = in_a ? w.vals[0] : w.vals[1];
-    if (int e = check_hip(hipMemcpyAsync(g.order, order, sizeof(uint32_t) * (size_t)N, hipMemcpyDeviceToDevice, s), "copy order")) return e;
-    if (int e = launch_offsets_scan(g.tiles_touched, g.order, g.offsets, w.blocksums, w.total, N, a->debug, s)) return e;
+    if (int e = enqueue_prepare(a, g, s)) return e;
     uint32_t total = 0;
-    if (int e = check_hip(hipMemcpyAsync(&total, w.total, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read pair count")) return e;
+    if (int e = check_hip(hipMemcpyAsync(&total, g.total, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read pair count")) return e;
     if (int e = check_hip(hipStreamSynchronize(s), "synchronize after prepare")) return e;
     if (total > 0x7FFFFFFFu) { set_error("%u (Gaussian, tile) pairs exceed the 2^31 limit", total); return LVDGS_E_RANGE; }
     *num_rendered = (int64_t)total;
@@ -272,40 +348,49 @@ int lvdgs_forward_prepare(const lvdgs_args *a, int64_t *num_rendered, void *stre
 int lvdgs_forward_render(const lvdgs_args *a, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     if (int e = check_common(a)) return e;
-    const int N = a->num_gaussians, W = a->image_width, H = a->image_height;
-    const int64_t D = N == 0 ? 0 : a->num_rendered;
+    const int64_t D = a->num_gaussians == 0 ? 0 : a->num_rendered;
     if (D < 0) { set_error("negative num_rendered"); return LVDGS_E_INVALID; }
-    if (!a->out_color || !a->out_depth || !a->out_opacity || !a->image_state) { set_error("output image or image_state is NULL"); return LVDGS_E_INVALID; }
-    if (a->image_bytes < lvdgs_image_bytes(W, H)) { set_error("image_state too small"); return LVDGS_E_INVALID; }
-    if (N > 0 && (!a->n_touched || !a->geom_state)) { set_error("n_touched / geom_state is NULL"); return LVDGS_E_INVALID; }
-    if (D > 0) {
-        if (!a->binning_state || !a->scratch) { set_error("binning_state / scratch is NULL"); return LVDGS_E_INVALID; }
-        if (a->binning_bytes < lvdgs_binning_bytes(D) || a->scratch_bytes < lvdgs_render_scratch_bytes(D, W, H)) {
-            set_error("binning_state or scratch too small"); return LVDGS_E_INVALID;
-        }
+    if (int e = check_render_buffers(a, D)) return e;
+    return enqueue_render(a, D, false, s);
+}
+
+int lvdgs_forward(const lvdgs_args *a, int64_t *num_rendered, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (int e = check_common(a)) return e;
+    if (int e = check_gaussians(a)) return e;
+    if (!num_rendered) { set_error("num_rendered is NULL"); return LVDGS_E_INVALID; }
+    const int N = a->num_gaussians;
+    *num_rendered = 0;
+    if (N == 0) {
+        if (int e = check_render_buffers(a, 0)) return e;
+        return enqueue_render(a, 0, false, s);
     }
-    GeomView g{}; BinView b{}; ImageView im; RenderScratch w{};
-    image_layout(W, H, &im, a->image_state);
-    const int num_tiles = cdiv(W, TILE) * cdiv(H, TILE);
-    if (N > 0) {
-        geom_layout(N, &g, a->geom_state);
-        if (int e = check_hip(hipMemsetAsync(a->n_touched, 0, sizeof(int32_t) * (size_t)N, s), "memset n_touched")) return e;
+    const int64_t cap = a->pair_capacity;
+    if (cap <= 0 || cap > 0x7FFFFFFFll) { set_error("pair_capacity must be in 1..2^31-1"); return LVDGS_E_INVALID; }
+    if (!a->radii || !a->geom_state || !a->scratch) { set_error("radii / geom_state / scratch is NULL"); return LVDGS_E_INVALID; }
+    if (a->geom_bytes < lvdgs_geom_bytes(N) || a->scratch_bytes < lvdgs_prepare_scratch_bytes(N)) {
+        set_error("geom_state or scratch too small"); return LVDGS_E_INVALID;
     }
-    if (D > 0) {
-        bin_layout(D, &b, a->binning_state);
-        render_scratch_layout(D, W, H, &w, a->scratch);
-        const int bits = tile_sort_bits(W, H);
-        // start in the buffer that makes the sorted result land in binning_state
-        const bool start_in_state = (radix_num_passes(bits) % 2) == 0;
-        uint32_t *k0 = start_in_state ? b.tile_keys : w.keys, *v0 = start_in_state ? b.point_list : w.vals;
-        uint32_t *k1 = start_in_state ? w.keys : b.tile_keys, *v1 = start_in_state ? w.vals : b.point_list;
-        if (int e = launch_emit_pairs(*a, g, k0, v0, s)) return e;
-        bool in_first = true;
-        if (int e = radix_sort_pairs(k0, v0, k1, v1, D, bits, w.hist, w.totals, &in_first, a->debug, s)) return e;
-        if ((in_first ? k0 : k1) != b.tile_keys) { set_error("internal: sorted list not in binning_state"); return LVDGS_E_INVALID; }
+    if (int e = check_render_buffers(a, cap)) return e;
+    PairProbe *probe = nullptr;
+    if (int e = get_probe(&probe)) return e;
+    GeomView g;
+    geom_layout(N, &g, a->geom_state);
+    if (int e = enqueue_prepare(a, g, s)) return e;
+    if (int e = check_hip(hipMemcpyAsync(probe->pinned, g.total, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read pair count")) return e;
+    if (int e = check_hip(hipEventRecord(probe->ready, s), "record pair count event")) return e;
+    // Everything after the count is enqueued BEFORE the host waits for it: the GPU keeps working on
+    // the tile sort and the blend while the host learns whether the capacity was enough.
+    if (int e = enqueue_render(a, cap, true, s)) return e;
+    if (int e = check_hip(hipEventSynchronize(probe->ready), "wait for pair count")) return e;
+    const uint32_t total = *probe->pinned;
+    if (total > 0x7FFFFFFFu) { set_error("%u (Gaussian, tile) pairs exceed the 2^31 limit", total); return LVDGS_E_RANGE; }
+    *num_rendered = (int64_t)total;
+    if ((int64_t)total > cap) {
+        set_error("%u pairs exceed pair_capacity %lld: grow binning_state / scratch and call lvdgs_forward_render", total, (long long)cap);
+        return LVDGS_E_CAPACITY;
     }
-    if (int e = launch_tile_ranges(b.tile_keys, D, im.ranges, num_tiles, a->debug, s)) return e;
-    return launch_blend_fwd(*a, g, b, im, s);
+    return LVDGS_OK;
 }
 
 int lvdgs_backward(const lvdgs_args *a, void *stream) {

@@ -13,7 +13,8 @@ namespace {
 __global__ void __launch_bounds__(256) emit_pairs_kernel(int N, int gx, int gy, const uint32_t *__restrict__ order,
                                                          const uint32_t *__restrict__ offsets,
                                                          const uint32_t *__restrict__ tiles_touched, float *__restrict__ rec,
-                                                         uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ ids) {
+                                                         uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ ids,
+                                                         uint32_t capacity) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= N) return;
     const uint32_t id = order[s];
@@ -35,14 +36,17 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int N, int gx, int gy, 
     uint32_t o = first;
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++) {
-            tile_keys[o] = (uint32_t)(y * gx + x);
-            ids[o] = id;
+            if (o < capacity) {  // pairs beyond the caller's capacity are dropped (the caller is told and re-runs)
+                tile_keys[o] = (uint32_t)(y * gx + x);
+                ids[o] = id;
+            }
             o++;
         }
 }
 
-__global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t *__restrict__ tile_keys, int64_t D,
-                                                          uint2 *__restrict__ ranges) {
+__global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t *__restrict__ tile_keys, int64_t D_cap,
+                                                          const uint32_t *__restrict__ D_dev, uint2 *__restrict__ ranges) {
+    const int64_t D = D_dev ? min((int64_t)*D_dev, D_cap) : D_cap;
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= D) return;
     const uint32_t t = tile_keys[k];
@@ -52,22 +56,23 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t *__rest
 
 }  // namespace
 
-int launch_emit_pairs(const lvdgs_args &a, const GeomView &g, uint32_t *tile_keys, uint32_t *ids, hipStream_t s) {
+int launch_emit_pairs(const lvdgs_args &a, const GeomView &g, uint32_t *tile_keys, uint32_t *ids, int64_t capacity, hipStream_t s) {
     const int N = a.num_gaussians;
     if (N == 0) return LVDGS_OK;
     const int gx = (a.image_width + TILE - 1) / TILE, gy = (a.image_height + TILE - 1) / TILE;
     ProfScope ps("emit_pairs", s);
     hipLaunchKernelGGL(emit_pairs_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, N, gx, gy, g.order, g.offsets, g.tiles_touched,
-                       g.rec, tile_keys, ids);
+                       g.rec, tile_keys, ids, (uint32_t)capacity);
     LVDGS_LAUNCH_CHECK("emit_pairs", a.debug, s);
     return LVDGS_OK;
 }
 
-int launch_tile_ranges(const uint32_t *tile_keys, int64_t D, uint2 *ranges, int num_tiles, int dbg, hipStream_t s) {
+int launch_tile_ranges(const uint32_t *tile_keys, int64_t D, const uint32_t *D_dev, uint2 *ranges, int num_tiles, int dbg,
+                       hipStream_t s) {
     if (int e = check_hip(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)num_tiles, s), "memset ranges")) return e;
     if (D == 0) return LVDGS_OK;
     ProfScope ps("tile_ranges", s);
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, tile_keys, D, ranges);
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, tile_keys, D, D_dev, ranges);
     LVDGS_LAUNCH_CHECK("tile_ranges", dbg, s);
     return LVDGS_OK;
 }

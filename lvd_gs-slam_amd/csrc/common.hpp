@@ -57,6 +57,7 @@ struct GeomView {
     uint32_t *tiles_touched; // N
     uint32_t *order;         // N
     uint32_t *offsets;       // N
+    uint32_t *total;         // 1: pair count D of this frame (device copy)
 };
 struct PrepScratch {
     uint32_t *keys[2];   // N each (depth bits)
@@ -102,7 +103,8 @@ int launch_mark_visible(int N, const float *means3D, const float *view, uint8_t 
 // stable LSD radix sort of (key, val) pairs on key bits [0, total_bits); result lands in
 // (keys_a, vals_a) if *result_in_a, else in (keys_b, vals_b).  n may be 0.
 int radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, int64_t n, int total_bits,
-                     uint32_t *hist, uint32_t *totals, bool *result_in_a, int dbg, hipStream_t s);
+                     uint32_t *hist, uint32_t *totals, bool *result_in_a, int dbg, hipStream_t s,
+                     const uint32_t *n_dev = nullptr);
 int radix_num_passes(int total_bits);
 size_t radix_hist_entries(int64_t n);
 
@@ -110,8 +112,9 @@ size_t radix_hist_entries(int64_t n);
 int launch_offsets_scan(const uint32_t *tiles_touched, const uint32_t *order, uint32_t *offsets, uint32_t *blocksums,
                         uint32_t *total_dev, int N, int dbg, hipStream_t s);
 
-int launch_emit_pairs(const lvdgs_args &a, const GeomView &g, uint32_t *tile_keys, uint32_t *ids, hipStream_t s);
-int launch_tile_ranges(const uint32_t *tile_keys, int64_t D, uint2 *ranges, int num_tiles, int dbg, hipStream_t s);
+int launch_emit_pairs(const lvdgs_args &a, const GeomView &g, uint32_t *tile_keys, uint32_t *ids, int64_t capacity, hipStream_t s);
+int launch_tile_ranges(const uint32_t *tile_keys, int64_t D, const uint32_t *D_dev, uint2 *ranges, int num_tiles, int dbg,
+                       hipStream_t s);
 
 int launch_blend_fwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, hipStream_t s);
 int launch_blend_bwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, const BwdScratch &w,

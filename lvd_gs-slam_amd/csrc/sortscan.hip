@@ -18,9 +18,12 @@ namespace lvdgs {
 
 namespace {
 
-__global__ void __launch_bounds__(SORT_THREADS) radix_hist_kernel(const uint32_t *__restrict__ keys, int64_t n, int shift,
-                                                                  int nbits, uint32_t *__restrict__ hist, int nblk) {
+__global__ void __launch_bounds__(SORT_THREADS) radix_hist_kernel(const uint32_t *__restrict__ keys, int64_t n_cap,
+                                                                  const uint32_t *__restrict__ n_dev, int shift, int nbits,
+                                                                  uint32_t *__restrict__ hist, int nblk) {
     __shared__ uint32_t s_hist[1 << SORT_MAX_BITS];
+    // the element count may live on the device (pair count of this frame): clamp it to the capacity
+    const int64_t n = n_dev ? min((int64_t)*n_dev, n_cap) : n_cap;
     const int nbins = 1 << nbits;
     const uint32_t mask = (uint32_t)nbins - 1u;
     for (int d = threadIdx.x; d < nbins; d += SORT_THREADS) s_hist[d] = 0;
@@ -63,8 +66,11 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint3
                                                                      uint32_t *__restrict__ keys_out,
                                                                      uint32_t *__restrict__ vals_out,
                                                                      const uint32_t *__restrict__ rowprefix,
-                                                                     const uint32_t *__restrict__ totals, int64_t n,
-                                                                     int shift, int nbits, int nblk) {
+                                                                     const uint32_t *__restrict__ totals, int64_t n_cap,
+                                                                     const uint32_t *__restrict__ n_dev, int shift, int nbits,
+                                                                     int nblk) {
+    const int64_t n = n_dev ? min((int64_t)*n_dev, n_cap) : n_cap;
+    if ((int64_t)blockIdx.x * SORT_CHUNK >= n) return;  // workgroup-uniform: capacity beyond this frame's count
     __shared__ uint32_t s_cnt[4][1 << SORT_MAX_BITS];  // per-wave digit counters, then per-wave bases
     __shared__ uint32_t s_scan[SORT_THREADS];
     const int nbins = 1 << nbits;
@@ -230,7 +236,7 @@ int radix_num_passes(int total_bits) { return total_bits <= 0 ? 0 : (total_bits 
 size_t radix_hist_entries(int64_t n) { return (size_t)(1 << SORT_MAX_BITS) * (size_t)(cdiv(n > 0 ? n : 1, SORT_CHUNK)); }
 
 int radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, int64_t n, int total_bits,
-                     uint32_t *hist, uint32_t *totals, bool *result_in_a, int dbg, hipStream_t s) {
+                     uint32_t *hist, uint32_t *totals, bool *result_in_a, int dbg, hipStream_t s, const uint32_t *n_dev) {
     *result_in_a = true;
     const int passes = radix_num_passes(total_bits);
     if (n <= 0 || passes == 0) {
@@ -246,7 +252,7 @@ int radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint3
         const int nbins = 1 << nbits;
         {
             ProfScope ps("radix_hist", s);
-            hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(SORT_THREADS), 0, s, kin, n, shift, nbits, hist, nblk);
+            hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(SORT_THREADS), 0, s, kin, n, n_dev, shift, nbits, hist, nblk);
             LVDGS_LAUNCH_CHECK("radix_hist", dbg, s);
         }
         {
@@ -257,7 +263,7 @@ int radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint3
         {
             ProfScope ps("radix_scatter", s);
             hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(SORT_THREADS), 0, s, kin, vin, kout, vout, hist, totals,
-                               n, shift, nbits, nblk);
+                               n, n_dev, shift, nbits, nblk);
             LVDGS_LAUNCH_CHECK("radix_scatter", dbg, s);
         }
         shift += nbits;

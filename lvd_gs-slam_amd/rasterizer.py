@@ -35,6 +35,11 @@ PROPAGATE_OPACITY_GRAD = True
 KEEP_DEBUG_STATE = False
 _DEBUG_LAST = {}
 
+# pairs the binning buffers are sized for, per device index (see _RasterizeGaussians.forward)
+_PAIR_CAPACITY = {}
+_MIN_PAIR_CAPACITY = 1 << 20      # floor of the capacity guess
+_PAIRS_PER_GAUSSIAN_GUESS = 8     # first guess before any frame has been seen
+
 
 class GaussianRasterizationSettings(NamedTuple):
     image_height: int
@@ -120,27 +125,45 @@ class _RasterizeGaussians(torch.autograd.Function):
         opac = torch.empty(1, H, W, dtype=torch.float32, device=dev)
         geom = _bytes(L.lvdgs_geom_bytes(N), dev)
         image = _bytes(L.lvdgs_image_bytes(W, H), dev)
-        scratch = _bytes(L.lvdgs_prepare_scratch_bytes(N), dev)
         a.radii, a.n_touched = _ptr(radii), _ptr(n_touched)
         a.out_color, a.out_depth, a.out_opacity = _ptr(color), _ptr(depth), _ptr(opac)
         a.geom_state, a.geom_bytes = _ptr(geom), geom.numel()
         a.image_state, a.image_bytes = _ptr(image), image.numel()
-        a.scratch, a.scratch_bytes = _ptr(scratch), scratch.numel()
 
+        # Single-call forward: buffers are sized for a pair capacity remembered per device (grown when a
+        # frame gets within 25 % of it), every kernel is enqueued before the host waits for the pair
+        # count, and an overflow (rare) re-runs only the binning + blend stage with exact sizes.
         stream = _stream()
-        num = C.c_int64(0)
-        _lib.check(L.lvdgs_forward_prepare(C.byref(a), C.byref(num), stream), "lvdgs_forward_prepare")
-        D = int(num.value)
-        binning = _bytes(L.lvdgs_binning_bytes(D), dev)
-        scratch2 = _bytes(L.lvdgs_render_scratch_bytes(D, W, H), dev)
-        a.num_rendered = D
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        cap = max(_PAIR_CAPACITY.get(key, 0), _MIN_PAIR_CAPACITY, _PAIRS_PER_GAUSSIAN_GUESS * N, 1) if N > 0 else 0
+        binning = _bytes(L.lvdgs_binning_bytes(cap), dev)
+        scratch = _bytes(max(L.lvdgs_prepare_scratch_bytes(N), L.lvdgs_render_scratch_bytes(cap, W, H)), dev)
+        a.pair_capacity = cap
         a.binning_state, a.binning_bytes = _ptr(binning), binning.numel()
-        a.scratch, a.scratch_bytes = _ptr(scratch2), scratch2.numel()
-        _lib.check(L.lvdgs_forward_render(C.byref(a), stream), "lvdgs_forward_render")
+        a.scratch, a.scratch_bytes = _ptr(scratch), scratch.numel()
+        num = C.c_int64(0)
+        status = L.lvdgs_forward(C.byref(a), C.byref(num), stream)
+        D = int(num.value)
+        binning_pairs = cap
+        if status == _lib.E_CAPACITY:
+            binning_pairs = D
+            binning = _bytes(L.lvdgs_binning_bytes(D), dev)
+            scratch = _bytes(L.lvdgs_render_scratch_bytes(D, W, H), dev)
+            a.num_rendered = D
+            a.binning_state, a.binning_bytes = _ptr(binning), binning.numel()
+            a.scratch, a.scratch_bytes = _ptr(scratch), scratch.numel()
+            _lib.check(L.lvdgs_forward_render(C.byref(a), stream), "lvdgs_forward_render")
+        else:
+            _lib.check(status, "lvdgs_forward")
+        if N > 0 and 4 * D > 3 * cap:
+            _PAIR_CAPACITY[key] = max(cap, D + D // 2)
+        else:
+            _PAIR_CAPACITY[key] = cap
 
         if KEEP_DEBUG_STATE:
             _DEBUG_LAST.clear()
-            _DEBUG_LAST.update(geom=geom, binning=binning, image=image, num_rendered=D, N=N, W=W, H=H)
+            _DEBUG_LAST.update(geom=geom, binning=binning, image=image, num_rendered=D, N=N, W=W, H=H,
+                               binning_pairs=binning_pairs, overflowed=status == _lib.E_CAPACITY)
         ctx.raster_settings = rs
         ctx.num_rendered = D
         ctx.pose = (torch.is_tensor(theta) and theta.numel() == 3, torch.is_tensor(rho) and rho.numel() == 3)

@@ -48,12 +48,12 @@ def run_hip(g, cam, W, H, bg, use_sh=False, sh_degree=0, cov_precomp=None, grads
     st = dict(rasterizer._DEBUG_LAST)
     D = st["num_rendered"]
     lay = _lib.StateLayout()
-    _lib.check(_lib.lib().lvdgs_state_layout_query(N, D, W, H, C.byref(lay)), "layout")
+    _lib.check(_lib.lib().lvdgs_state_layout_query(N, st["binning_pairs"], W, H, C.byref(lay)), "layout")
     NT = ((W + 15) // 16) * ((H + 15) // 16)
     rec = _view(st["geom"], lay.geom_rec, N * 12, np.float32).reshape(N, 12) if N else np.zeros((0, 12), np.float32)
     fwd = dict(
         color=color.detach().cpu().numpy(), depth=depth.detach().cpu().numpy(), opacity=opacity.detach().cpu().numpy(),
-        radii=radii.cpu().numpy(), n_touched=n_touched.cpu().numpy(), num_rendered=D, rec=rec,
+        radii=radii.cpu().numpy(), n_touched=n_touched.cpu().numpy(), num_rendered=D, rec=rec, overflowed=st["overflowed"],
         tiles_touched=_view(st["geom"], lay.geom_tiles_touched, N, np.uint32) if N else np.zeros(0, np.uint32),
         order=_view(st["geom"], lay.geom_order, N, np.uint32) if N else np.zeros(0, np.uint32),
         offsets=_view(st["geom"], lay.geom_offsets, N, np.uint32) if N else np.zeros(0, np.uint32),

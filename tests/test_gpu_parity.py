@@ -231,3 +231,32 @@ def test_opacity_gradient_switch():
         rasterizer.PROPAGATE_OPACITY_GRAD = True
     _, b_ref = hr.run_oracle(orc, g, cam, W, H, bg, grads=(gc, gd, None))
     _check_backward(b_off, b_ref, ["means3D", "opacities", "scales", "tau"])
+
+
+def test_pair_capacity_overflow_reruns_binning_with_identical_results():
+    """lvdgs_forward with a capacity that is too small reports the pair count; the wrapper re-runs the
+    binning + blend stage with exact sizes.  Outputs and gradients must equal the roomy-capacity run bit for bit."""
+    orc, hr, syn = _mods()
+    from lvdgs import rasterizer
+    W, H, N = 256, 144, 5000
+    g, cam = _scene(syn, N, W, H, 80, pose_seed=2)
+    bg = torch.zeros(3)
+    grads = syn.make_image_grads(W, H, 6)
+    f_ok, b_ok = hr.run_hip(g, cam, W, H, bg, grads=grads)
+    assert not f_ok["overflowed"]
+    saved = (dict(rasterizer._PAIR_CAPACITY), rasterizer._MIN_PAIR_CAPACITY, rasterizer._PAIRS_PER_GAUSSIAN_GUESS)
+    try:
+        rasterizer._PAIR_CAPACITY.clear()
+        rasterizer._MIN_PAIR_CAPACITY, rasterizer._PAIRS_PER_GAUSSIAN_GUESS = 1, 0
+        f_small, b_small = hr.run_hip(g, cam, W, H, bg, grads=grads)
+        assert f_small["overflowed"] and f_small["num_rendered"] == f_ok["num_rendered"] > 1
+        # the capacity has been raised: the next frame fits
+        f_next, _ = hr.run_hip(g, cam, W, H, bg)
+        assert not f_next["overflowed"]
+    finally:
+        rasterizer._PAIR_CAPACITY.clear(); rasterizer._PAIR_CAPACITY.update(saved[0])
+        rasterizer._MIN_PAIR_CAPACITY, rasterizer._PAIRS_PER_GAUSSIAN_GUESS = saved[1], saved[2]
+    for k in ("color", "depth", "opacity", "radii", "n_touched", "point_list", "tile_keys", "ranges", "n_contrib"):
+        np.testing.assert_array_equal(f_small[k], f_ok[k], err_msg=k)
+    for k in b_ok:
+        np.testing.assert_array_equal(b_small[k], b_ok[k], err_msg=k)
