@@ -26,7 +26,8 @@ constexpr int PAIR_FLOATS = 12;  // per-(Gaussian, tile) partial gradient record
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_IPT = 16;                       // elements per thread per radix pass
 constexpr int SORT_CHUNK = SORT_THREADS * SORT_IPT; // elements per workgroup
-constexpr int SORT_MAX_BITS = 11;                  // digit width limit (LDS: 4 waves x 2048 counters)
+constexpr int SORT_MAX_BITS = 8;                   // digit width limit: <= 256 bins keeps same-digit runs long enough
+                                                   // for the scatter's stores to coalesce
 
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

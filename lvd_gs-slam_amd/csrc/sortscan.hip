@@ -10,7 +10,9 @@
 //   radix_hist    per-workgroup digit histogram          -> hist[digit][workgroup]
 //   radix_rowscan exclusive scan of each digit's row over workgroups + digit totals
 //   radix_scatter stable rank inside the workgroup (wave ballot matching) + scattered store
-// Digits are up to 11 bits wide: 4 waves x 2048 counters fit in 32 KiB of the CU's 160 KiB LDS.
+// Digits are up to 8 bits wide (one digit per thread in the scatter); the scatter re-orders its chunk in LDS
+// so that the stores of each digit's run are consecutive addresses (4-byte scattered stores cost ~4.5x the
+// bytes in HBM write traffic, measured with WRITE_SIZE).
 #include "common.hpp"
 #include "device_utils.hpp"
 
@@ -69,36 +71,19 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint3
                                                                      const uint32_t *__restrict__ totals, int64_t n_cap,
                                                                      const uint32_t *__restrict__ n_dev, int shift, int nbits,
                                                                      int nblk) {
+    constexpr int NB = 1 << SORT_MAX_BITS;  // 256 >= nbins: one digit per thread
     const int64_t n = n_dev ? min((int64_t)*n_dev, n_cap) : n_cap;
     if ((int64_t)blockIdx.x * SORT_CHUNK >= n) return;  // workgroup-uniform: capacity beyond this frame's count
-    __shared__ uint32_t s_cnt[4][1 << SORT_MAX_BITS];  // per-wave digit counters, then per-wave bases
+    __shared__ uint32_t s_cnt[4][NB];       // per-wave digit counts, then per-wave local bases
     __shared__ uint32_t s_scan[SORT_THREADS];
+    __shared__ uint32_t s_gofs[NB];         // global position of local index 0 of each digit's run
+    __shared__ uint32_t s_key[SORT_CHUNK], s_val[SORT_CHUNK];  // the chunk in digit order
     const int nbins = 1 << nbits;
     const uint32_t mask = (uint32_t)nbins - 1u;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int d = tid; d < 4 * (1 << SORT_MAX_BITS); d += SORT_THREADS) (&s_cnt[0][0])[d] = 0;
+    for (int d = tid; d < 4 * NB; d += SORT_THREADS) (&s_cnt[0][0])[d] = 0;
 
-    // ---- global base of every digit for this workgroup: exclusive scan of totals + row prefix ----
-    const int per = (nbins + SORT_THREADS - 1) / SORT_THREADS;  // <= 8
-    uint32_t loc[8];
-    uint32_t sum = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int d = tid * per + k;
-        loc[k] = (k < per && d < nbins) ? totals[d] : 0u;
-        sum += loc[k];
-    }
-    s_scan[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < SORT_THREADS; off <<= 1) {
-        const uint32_t t = tid >= off ? s_scan[tid - off] : 0u;
-        __syncthreads();
-        s_scan[tid] += t;
-        __syncthreads();
-    }
-    uint32_t run = s_scan[tid] - sum;  // exclusive prefix of this thread's digits
-
-    // ---- load this wave's contiguous sub-chunk and rank it (stable) ----
+    // ---- load this wave's contiguous sub-chunk ----
     const int64_t wbase = (int64_t)blockIdx.x * SORT_CHUNK + (int64_t)wave * (64 * SORT_IPT);
     uint32_t key[SORT_IPT], val[SORT_IPT], rank[SORT_IPT];
     const uint64_t lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
@@ -109,7 +94,12 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint3
         key[i] = valid ? keys_in[idx] : 0xFFFFFFFFu;
         val[i] = valid ? vals_in[idx] : 0u;
     }
+    // global base of this thread's digit: exclusive scan of the digit totals + this workgroup's row prefix
+    const uint32_t my_total = tid < nbins ? totals[tid] : 0u;
+    const uint32_t my_rowprefix = tid < nbins ? rowprefix[(size_t)tid * nblk + blockIdx.x] : 0u;
     __syncthreads();  // s_cnt zeroed
+
+    // ---- stable rank inside the wave: same-digit lanes found by ballots, running per-wave counters in LDS ----
 #pragma unroll
     for (int i = 0; i < SORT_IPT; i++) {
         const int64_t idx = wbase + (int64_t)i * 64 + lane;
@@ -130,29 +120,58 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint3
         rank[i] = prior + before;
     }
     __syncthreads();
-    // ---- per-wave bases: global digit base + counts of the lower waves ----
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int d = tid * per + k;
-        if (k < per && d < nbins) {
-            const uint32_t gbase = run + rowprefix[(size_t)d * nblk + blockIdx.x];
-            run += loc[k];
-            const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d];
-            s_cnt[0][d] = gbase;
-            s_cnt[1][d] = gbase + c0;
-            s_cnt[2][d] = gbase + c0 + c1;
-            s_cnt[3][d] = gbase + c0 + c1 + c2;
-        }
-    }
+
+    // ---- one digit per thread: local (in-chunk) base of the digit, per-wave bases, global offset of the run ----
+    const uint32_t c0 = s_cnt[0][tid], c1 = s_cnt[1][tid], c2 = s_cnt[2][tid], c3 = s_cnt[3][tid];
+    const uint32_t cnt = c0 + c1 + c2 + c3;
+    // two independent workgroup scans (digit totals -> global digit base, chunk counts -> local base), interleaved
+    s_scan[tid] = cnt;
     __syncthreads();
+    for (int off = 1; off < SORT_THREADS; off <<= 1) {
+        const uint32_t t = tid >= off ? s_scan[tid - off] : 0u;
+        __syncthreads();
+        s_scan[tid] += t;
+        __syncthreads();
+    }
+    const uint32_t lbase = s_scan[tid] - cnt;
+    __syncthreads();
+    s_scan[tid] = my_total;
+    __syncthreads();
+    for (int off = 1; off < SORT_THREADS; off <<= 1) {
+        const uint32_t t = tid >= off ? s_scan[tid - off] : 0u;
+        __syncthreads();
+        s_scan[tid] += t;
+        __syncthreads();
+    }
+    const uint32_t dbase = s_scan[tid] - my_total;
+    s_cnt[0][tid] = lbase;
+    s_cnt[1][tid] = lbase + c0;
+    s_cnt[2][tid] = lbase + c0 + c1;
+    s_cnt[3][tid] = lbase + c0 + c1 + c2;
+    s_gofs[tid] = dbase + my_rowprefix - lbase;
+    __syncthreads();
+
+    // ---- reorder through LDS so that each digit's run leaves as consecutive addresses ----
 #pragma unroll
     for (int i = 0; i < SORT_IPT; i++) {
         const int64_t idx = wbase + (int64_t)i * 64 + lane;
         if (idx < n) {
             const uint32_t d = (key[i] >> shift) & mask;
-            const uint32_t pos = s_cnt[wave][d] + rank[i];
-            keys_out[pos] = key[i];
-            vals_out[pos] = val[i];
+            const uint32_t lpos = s_cnt[wave][d] + rank[i];
+            s_key[lpos] = key[i];
+            s_val[lpos] = val[i];
+        }
+    }
+    __syncthreads();
+    const int count = (int)min((int64_t)SORT_CHUNK, n - (int64_t)blockIdx.x * SORT_CHUNK);
+#pragma unroll
+    for (int i = 0; i < SORT_IPT; i++) {
+        const int li = i * SORT_THREADS + tid;
+        if (li < count) {
+            const uint32_t k = s_key[li];
+            const uint32_t pos = s_gofs[(k >> shift) & mask] + (uint32_t)li;
+            keys_out[pos] = k;
+            vals_out[pos] = s_val[li];
         }
     }
 }
