@@ -20,7 +20,16 @@ def _aligned(t):
 
 
 def _c32(t):
-    return None if t is None else _aligned(t.detach().to(torch.float32).contiguous())
+    if t is None:
+        return None
+    if t.dtype is torch.float32 and t.is_contiguous():
+        return _aligned(t.detach())
+    return _aligned(t.detach().to(torch.float32).contiguous())
+
+
+def _raw_stream(dev):
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(idx))
 
 
 class _Photometric(torch.autograd.Function):
@@ -41,7 +50,7 @@ class _Photometric(torch.autograd.Function):
         a.rgb_boundary_threshold, a.weight_rgb, a.weight_depth = float(rgb_thr), float(w_rgb), float(w_d)
         a.weight_by_opacity, a.depth_needs_opaque = int(weight_by_opacity), int(depth_needs_opaque)
         a.scratch, a.scratch_bytes, a.loss = _p(scratch), scratch.numel(), _p(loss)
-        _lib.check(L.lvdgs_photometric_loss_forward(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+        _lib.check(L.lvdgs_photometric_loss_forward(C.byref(a), _raw_stream(dev)),
                    "lvdgs_photometric_loss_forward")
         ctx.cfg = (float(rgb_thr), float(w_rgb), float(w_d), int(weight_by_opacity), int(depth_needs_opaque), H, W)
         ctx.save_for_backward(*[v for v in t.values() if v is not None])
@@ -72,7 +81,7 @@ class _Photometric(torch.autograd.Function):
         d_b = e(*ctx.shapes["exposure_b"]) if "exposure_b" in t else None
         a.scratch, a.scratch_bytes, a.grad_loss = _p(scratch), scratch.numel(), _p(g)
         a.d_image, a.d_depth, a.d_opacity, a.d_exposure_a, a.d_exposure_b = _p(d_image), _p(d_depth), _p(d_opac), _p(d_a), _p(d_b)
-        _lib.check(L.lvdgs_photometric_loss_backward(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+        _lib.check(L.lvdgs_photometric_loss_backward(C.byref(a), _raw_stream(dev)),
                    "lvdgs_photometric_loss_backward")
         if d_depth is None and ctx.shapes["depth"] is not None and ctx.needs_input_grad[1]:
             d_depth = torch.zeros(*ctx.shapes["depth"], device=dev)

@@ -47,6 +47,8 @@ class GaussianModel:
 
     @property
     def get_features(self):
+        if self._features_rest.shape[1] == 0:  # SH degree 0: nothing to concatenate
+            return self._features_dc
         return torch.cat((self._features_dc, self._features_rest), dim=1)
 
     @property

@@ -64,6 +64,8 @@ def _f32(t, device):
         t = torch.as_tensor(t)
     if t.numel() == 0:
         return None
+    if t.dtype is torch.float32 and t.device == device and t.is_contiguous():
+        return t.detach()  # the common case: no conversion kernel, no dispatcher round trip through .to()
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
@@ -86,8 +88,11 @@ def _fill_settings(a, rs, device, keep):
         setattr(a, name, _ptr(t))
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    """Raw hipStream_t of PyTorch's current stream on `device` (a direct C call: torch.cuda.current_stream()
+    goes through lazy-init and device-count checks that cost tens of microseconds per call)."""
+    idx = device.index if (device is not None and device.index is not None) else torch.cuda.current_device()
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(idx))
 
 
 class _RasterizeGaussians(torch.autograd.Function):
@@ -133,7 +138,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         # Single-call forward: buffers are sized for a pair capacity remembered per device (grown when a
         # frame gets within 25 % of it), every kernel is enqueued before the host waits for the pair
         # count, and an overflow (rare) re-runs only the binning + blend stage with exact sizes.
-        stream = _stream()
+        stream = _stream(dev)
         key = dev.index if dev.index is not None else torch.cuda.current_device()
         cap = max(_PAIR_CAPACITY.get(key, 0), _MIN_PAIR_CAPACITY, _PAIRS_PER_GAUSSIAN_GUESS * N, 1) if N > 0 else 0
         binning = _bytes(L.lvdgs_binning_bytes(cap), dev)
@@ -211,7 +216,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         a.dL_dmeans3D, a.dL_dmeans2D, a.dL_dopacities = _ptr(d_m3), _ptr(d_m2), _ptr(d_op)
         a.dL_dscales, a.dL_drotations, a.dL_dcov3D = _ptr(d_sc), _ptr(d_rot), _ptr(d_cov)
         a.dL_dshs, a.dL_dcolors, a.dL_dtau = _ptr(d_sh), _ptr(d_col), _ptr(d_tau)
-        _lib.check(L.lvdgs_backward(C.byref(a), _stream()), "lvdgs_backward")
+        _lib.check(L.lvdgs_backward(C.byref(a), _stream(dev)), "lvdgs_backward")
         # (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, theta, rho, settings)
         d_theta = d_tau[3:] if ctx.pose[0] else None
         d_rho = d_tau[:3] if ctx.pose[1] else None
