@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("LVDGS_BENCH_WORKLOAD", "cfg3_500k_1920x1080"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--step", choices=["auto", "tracking", "mapping"], default="auto",
+                    help="auto: tracking iteration on 1 GPU, mapping-window iteration on N > 1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -104,7 +106,7 @@ def main():
     params = model.parameters()
     pose_params = [cam.cam_rot_delta, cam.cam_trans_delta, cam.exposure_a, cam.exposure_b]
     bucket = window_shard.GradientBucket(params) if world > 1 else None
-    tracking = world == 1
+    tracking = (world == 1) if args.step == "auto" else args.step == "tracking"
     stats = {}
 
     def step():
