@@ -111,6 +111,12 @@ typedef struct lvdgs_args {
 
     /* ---- single-call forward only ---- */
     int64_t pair_capacity; /* pairs binning_state / scratch were sized for (lvdgs_forward) */
+
+    /* ---- optional: activations fused into the projection kernel (P B) ----
+     * bit 0: `scales` holds log-scales (exp applied), bit 1: `rotations` is un-normalised (divided by its
+     * norm), bit 2: `opacities` holds logits (sigmoid applied).  The matching gradient outputs are then
+     * w.r.t. the raw values.  0 = inputs are already activated, as upstream's render() passes them. */
+    int32_t activations;
 } lvdgs_args;
 
 /* ---- sizes ---- */

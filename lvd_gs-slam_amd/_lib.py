@@ -33,7 +33,7 @@ class Args(C.Structure):
         ("dL_dout_color", _fp), ("dL_dout_depth", _fp), ("dL_dout_opacity", _fp),
         ("dL_dmeans3D", _fp), ("dL_dmeans2D", _fp), ("dL_dopacities", _fp), ("dL_dscales", _fp),
         ("dL_drotations", _fp), ("dL_dcov3D", _fp), ("dL_dshs", _fp), ("dL_dcolors", _fp), ("dL_dtau", _fp),
-        ("pair_capacity", C.c_int64),
+        ("pair_capacity", C.c_int64), ("activations", C.c_int32),
     ]
 
 

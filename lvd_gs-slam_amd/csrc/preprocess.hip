@@ -143,9 +143,28 @@ __device__ __forceinline__ void sh_basis_grad(int deg, const float d[3], float G
     }
 }
 
+// Optional activations fused into the projection (lvdgs_args.activations): the model's raw parameters are
+// read and activated here, and preprocess_bwd applies the chain rule, instead of separate elementwise
+// kernels (exp / sigmoid / normalise and their backward) before and after the rasterizer.
+constexpr int ACT_EXP_SCALES = 1, ACT_NORMALIZE_ROT = 2, ACT_SIGMOID_OPACITY = 4;
+
+__device__ __forceinline__ void load_scale_rot(const float *__restrict__ scales, const float *__restrict__ rotations, int i,
+                                               int act, float s[3], float q[4], float &qnorm) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) s[k] = scales[3 * (size_t)i + k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) q[k] = rotations[4 * (size_t)i + k];
+    if (act & ACT_EXP_SCALES) { s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]); }
+    qnorm = 1.f;
+    if (act & ACT_NORMALIZE_ROT) {
+        qnorm = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
+        q[0] /= qnorm; q[1] /= qnorm; q[2] /= qnorm; q[3] /= qnorm;
+    }
+}
+
 struct FwdParams {
     Cam cam;
-    int N;
+    int N, act;
     const float *means3D, *opacities, *scales, *rotations, *cov3D_precomp, *shs, *colors_precomp;
     float *rec;
     uint32_t *tiles_touched, *depth_keys, *ids;
@@ -173,8 +192,8 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(FwdParams p) {
 #pragma unroll
             for (int k = 0; k < 6; k++) c6[k] = p.cov3D_precomp[6 * (size_t)i + k];
         } else {
-            const float s[3] = {p.scales[3 * i], p.scales[3 * i + 1], p.scales[3 * i + 2]};
-            const float q[4] = {p.rotations[4 * i], p.rotations[4 * i + 1], p.rotations[4 * i + 2], p.rotations[4 * i + 3]};
+            float s[3], q[4], qn;
+            load_scale_rot(p.scales, p.rotations, i, p.act, s, q, qn);
             cov3d_of(s, c.scale_mod, q, c6);
         }
         Ewa e;
@@ -223,7 +242,9 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(FwdParams p) {
                 radius = rad; tiles = (uint32_t)area; key = __float_as_uint(pv[2]);
                 float4 *r4 = reinterpret_cast<float4 *>(p.rec + (size_t)i * REC_FLOATS);
                 r4[0] = make_float4(px, py, k0, k1);
-                r4[1] = make_float4(k2, p.opacities[i], rgb[0], rgb[1]);
+                float opac = p.opacities[i];
+                if (p.act & ACT_SIGMOID_OPACITY) opac = 1.f / (1.f + expf(-opac));
+                r4[1] = make_float4(k2, opac, rgb[0], rgb[1]);
                 r4[2] = make_float4(rgb[2], pv[2], 0.f, __int_as_float(rad));
             }
         }
@@ -237,7 +258,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(FwdParams p) {
 // ------------------------------------------------------------------------------------------
 struct BwdParams {
     Cam cam;
-    int N;
+    int N, act;
     const float *means3D, *scales, *rotations, *cov3D_precomp, *shs, *colors_precomp;
     const int32_t *radii;
     const float *rec;
@@ -285,7 +306,11 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
         xform3(pos, V, pv);
         xform3(pos, PM, ph);
         const float phw = xform_w(pos, PM);
-        p.dopac[i] = A[5];
+        {
+            // d/d(logit) = d/d(opacity) * o (1 - o) when the sigmoid is fused (o is in the record)
+            const float o = r4[1].y;
+            p.dopac[i] = (p.act & ACT_SIGMOID_OPACITY) ? A[5] * o * (1.f - o) : A[5];
+        }
         const float g_ndc[2] = {A[0] * 0.5f * (float)c.W, A[1] * 0.5f * (float)c.H};
         p.dmeans2D[3 * (size_t)i] = g_ndc[0]; p.dmeans2D[3 * (size_t)i + 1] = g_ndc[1]; p.dmeans2D[3 * (size_t)i + 2] = 0.f;
 
@@ -333,15 +358,12 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
 
         // ---- conic -> cov2D -> (cov3D, T) ----
         float c6[6];
-        float sc[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f};
+        float sc[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, qnorm = 1.f;
         if (p.cov3D_precomp) {
 #pragma unroll
             for (int k = 0; k < 6; k++) c6[k] = p.cov3D_precomp[6 * (size_t)i + k];
         } else {
-#pragma unroll
-            for (int k = 0; k < 3; k++) sc[k] = p.scales[3 * i + k];
-#pragma unroll
-            for (int k = 0; k < 4; k++) q[k] = p.rotations[4 * i + k];
+            load_scale_rot(p.scales, p.rotations, i, p.act, sc, q, qnorm);
             cov3d_of(sc, c.scale_mod, q, c6);
         }
         Ewa e;
@@ -444,14 +466,23 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
                     v += gm * R[a][b];
                     g_R[a][b] = gm * sm[b];
                 }
-                p.dscales[3 * (size_t)i + b] = v * c.scale_mod;
+                // fused exp: d/d(log s) = d/ds * s
+                p.dscales[3 * (size_t)i + b] = v * c.scale_mod * ((p.act & ACT_EXP_SCALES) ? sc[b] : 1.f);
             }
             const float r = q[0], x = q[1], y = q[2], z = q[3];
-            float *dq = p.drot + 4 * (size_t)i;
+            float dq[4];
             dq[0] = 2.f * (-z * g_R[0][1] + y * g_R[0][2] + z * g_R[1][0] - x * g_R[1][2] - y * g_R[2][0] + x * g_R[2][1]);
             dq[1] = 2.f * (y * g_R[0][1] + z * g_R[0][2] + y * g_R[1][0] - 2.f * x * g_R[1][1] - r * g_R[1][2] + z * g_R[2][0] + r * g_R[2][1] - 2.f * x * g_R[2][2]);
             dq[2] = 2.f * (-2.f * y * g_R[0][0] + x * g_R[0][1] + r * g_R[0][2] + x * g_R[1][0] + z * g_R[1][2] - r * g_R[2][0] + z * g_R[2][1] - 2.f * y * g_R[2][2]);
             dq[3] = 2.f * (-2.f * z * g_R[0][0] - r * g_R[0][1] + x * g_R[0][2] + r * g_R[1][0] - 2.f * z * g_R[1][1] + y * g_R[1][2] + x * g_R[2][0] + y * g_R[2][1]);
+            if (p.act & ACT_NORMALIZE_ROT) {
+                // q = raw / |raw|: d/d raw = (g - q (q . g)) / |raw|
+                const float dot = q[0] * dq[0] + q[1] * dq[1] + q[2] * dq[2] + q[3] * dq[3];
+#pragma unroll
+                for (int k = 0; k < 4; k++) dq[k] = (dq[k] - q[k] * dot) / qnorm;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) p.drot[4 * (size_t)i + k] = dq[k];
         }
     }
     // ---- workgroup sum of the pose gradient -> one partial per workgroup (no atomics) ----
@@ -512,7 +543,7 @@ Cam make_cam(const lvdgs_args &a) {
 int launch_preprocess_fwd(const lvdgs_args &a, const GeomView &g, uint32_t *depth_keys, uint32_t *ids, hipStream_t s) {
     if (a.num_gaussians == 0) return LVDGS_OK;
     FwdParams p;
-    p.cam = make_cam(a); p.N = a.num_gaussians;
+    p.cam = make_cam(a); p.N = a.num_gaussians; p.act = a.activations;
     p.means3D = a.means3D; p.opacities = a.opacities; p.scales = a.scales; p.rotations = a.rotations;
     p.cov3D_precomp = a.cov3D_precomp; p.shs = a.shs; p.colors_precomp = a.colors_precomp;
     p.rec = g.rec; p.tiles_touched = g.tiles_touched; p.depth_keys = depth_keys; p.ids = ids; p.radii = a.radii;
@@ -527,7 +558,7 @@ int launch_preprocess_bwd(const lvdgs_args &a, const GeomView &g, const BwdScrat
     const int nblk = cdiv(N, 256);
     if (N > 0) {
         BwdParams p;
-        p.cam = make_cam(a); p.N = N;
+        p.cam = make_cam(a); p.N = N; p.act = a.activations;
         p.means3D = a.means3D; p.scales = a.scales; p.rotations = a.rotations; p.cov3D_precomp = a.cov3D_precomp;
         p.shs = a.shs; p.colors_precomp = a.colors_precomp; p.radii = a.radii;
         p.rec = g.rec; p.tiles_touched = g.tiles_touched; p.pair_grads = b.pair_grads;

@@ -14,6 +14,8 @@ from .sh_utils import RGB2SH
 
 
 class GaussianModel:
+    standard_activations = True  # exp / normalize / sigmoid, as published: render() may fuse them
+
     def __init__(self, sh_degree=0, device="cuda"):
         self.max_sh_degree = sh_degree
         self.active_sh_degree = sh_degree

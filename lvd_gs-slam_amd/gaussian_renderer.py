@@ -20,9 +20,33 @@ import math
 
 import torch
 
+from . import rasterizer as _rz
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 
 SH_C0 = 0.28209479177387814
+
+# When the model exposes its raw parameters under the published 3DGS names (_scaling, _rotation, _opacity) and
+# uses the published activations (exp, normalize, sigmoid), render() hands the raw tensors to the rasterizer,
+# which applies the activations inside its projection kernel and the chain rule inside its backward kernel:
+# same values as pc.get_scaling / get_rotation / get_opacity, about a dozen elementwise kernels fewer per
+# iteration.  Set to False to always go through the model's accessors.
+FUSE_ACTIVATIONS = True
+
+
+def _raw_parameters(pc):
+    """(log-scales, raw quaternions, opacity logits) if the fused path is safe for this model, else None."""
+    if not FUSE_ACTIVATIONS:
+        return None
+    raw = tuple(getattr(pc, n, None) for n in ("_scaling", "_rotation", "_opacity"))
+    if any(not torch.is_tensor(t) for t in raw):
+        return None
+    if getattr(pc, "standard_activations", False):
+        return raw
+    acts = (getattr(pc, "scaling_activation", None), getattr(pc, "rotation_activation", None),
+            getattr(pc, "opacity_activation", None))
+    if acts[0] is torch.exp and acts[1] is torch.nn.functional.normalize and acts[2] is torch.sigmoid:
+        return raw
+    return None
 
 
 def _eval_sh_python(pc, viewpoint_camera):
@@ -55,12 +79,19 @@ def _render(viewpoint_camera, pc, pipe, bg_color, image_height, image_width, sca
         campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
     rasterizer = GaussianRasterizer(raster_settings=raster_settings)
 
-    means3D, means2D, opacity = xyz, screenspace_points, pc.get_opacity
+    means3D, means2D = xyz, screenspace_points
     scales = rotations = cov3D_precomp = None
-    if getattr(pipe, "compute_cov3D_python", False):
-        cov3D_precomp = pc.get_covariance(scaling_modifier)
+    activations = 0
+    raw = None if getattr(pipe, "compute_cov3D_python", False) else _raw_parameters(pc)
+    if raw is not None:
+        scales, rotations, opacity = raw
+        activations = _rz.ACT_EXP_SCALES | _rz.ACT_NORMALIZE_ROTATIONS | _rz.ACT_SIGMOID_OPACITIES
     else:
-        scales, rotations = pc.get_scaling, pc.get_rotation
+        opacity = pc.get_opacity
+        if getattr(pipe, "compute_cov3D_python", False):
+            cov3D_precomp = pc.get_covariance(scaling_modifier)
+        else:
+            scales, rotations = pc.get_scaling, pc.get_rotation
 
     shs = colors_precomp = None
     if override_color is not None:
@@ -74,7 +105,7 @@ def _render(viewpoint_camera, pc, pipe, bg_color, image_height, image_width, sca
     rendered_image, radii, depth, opacity_img, n_touched = rasterizer(
         means3D=sel(means3D), means2D=sel(means2D), shs=sel(shs), colors_precomp=sel(colors_precomp),
         opacities=sel(opacity), scales=sel(scales), rotations=sel(rotations), cov3D_precomp=sel(cov3D_precomp),
-        theta=viewpoint_camera.cam_rot_delta, rho=viewpoint_camera.cam_trans_delta)
+        theta=viewpoint_camera.cam_rot_delta, rho=viewpoint_camera.cam_trans_delta, activations=activations)
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
             "radii": radii, "depth": depth, "opacity": opacity_img, "n_touched": n_touched}
 

@@ -98,7 +98,7 @@ def _stream(device=None):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, theta, rho,
-                raster_settings):
+                raster_settings, activations=0):
         L = _lib.lib()
         rs = raster_settings
         dev = means3D.device
@@ -119,6 +119,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             if ((sc is None or rot is None) and cov is None) or ((sc is not None or rot is not None) and cov is not None):
                 raise ValueError("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         a.num_gaussians = N
+        a.activations = int(activations)
         a.sh_coeffs = int(shs.shape[1]) if shs is not None else 0
         a.means3D, a.opacities, a.scales, a.rotations = _ptr(m3), _ptr(op), _ptr(sc), _ptr(rot)
         a.cov3D_precomp, a.shs, a.colors_precomp = _ptr(cov), _ptr(shs), _ptr(col)
@@ -171,6 +172,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                binning_pairs=binning_pairs, overflowed=status == _lib.E_CAPACITY)
         ctx.raster_settings = rs
         ctx.num_rendered = D
+        ctx.activations = int(activations)
         ctx.pose = (torch.is_tensor(theta) and theta.numel() == 3, torch.is_tensor(rho) and rho.numel() == 3)
         ctx.save_for_backward(m3, op, sc, rot, cov, shs, col, radii, geom, binning, image)
         ctx.mark_non_differentiable(radii, n_touched)
@@ -193,6 +195,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         a.means3D, a.opacities, a.scales, a.rotations = _ptr(m3), _ptr(op), _ptr(sc), _ptr(rot)
         a.cov3D_precomp, a.shs, a.colors_precomp = _ptr(cov), _ptr(shs), _ptr(col)
         a.radii = _ptr(radii)
+        a.activations = ctx.activations
         a.num_rendered = D
         a.geom_state, a.geom_bytes = _ptr(geom), geom.numel()
         a.binning_state, a.binning_bytes = _ptr(binning), binning.numel()
@@ -220,13 +223,17 @@ class _RasterizeGaussians(torch.autograd.Function):
         # (means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, theta, rho, settings)
         d_theta = d_tau[3:] if ctx.pose[0] else None
         d_rho = d_tau[:3] if ctx.pose[1] else None
-        return d_m3, d_m2, d_sh, d_col, d_op, d_sc, d_rot, d_cov, d_theta, d_rho, None
+        return d_m3, d_m2, d_sh, d_col, d_op, d_sc, d_rot, d_cov, d_theta, d_rho, None, None
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, theta, rho,
-                        raster_settings):
+                        raster_settings, activations=0):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                                     theta, rho, raster_settings)
+                                     theta, rho, raster_settings, activations)
+
+
+# `activations` bits (include/lvdgs.h): the rasterizer applies the model's activations itself
+ACT_EXP_SCALES, ACT_NORMALIZE_ROTATIONS, ACT_SIGMOID_OPACITIES = 1, 2, 4
 
 
 class GaussianRasterizer(nn.Module):
@@ -247,7 +254,10 @@ class GaussianRasterizer(nn.Module):
             return out.bool()
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None, theta=None, rho=None):
+                cov3D_precomp=None, theta=None, rho=None, activations=0):
+        """`activations` (lvdgs extension, default 0 = upstream behaviour): bit mask saying that `scales` are
+        log-scales, `rotations` un-normalised quaternions, `opacities` logits; the kernels then apply
+        exp / normalise / sigmoid and return gradients w.r.t. those raw values."""
         if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")
         if ((scales is None or rotations is None) and cov3D_precomp is None) or (
@@ -262,4 +272,4 @@ class GaussianRasterizer(nn.Module):
         theta = empty if theta is None else theta
         rho = empty if rho is None else rho
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
-                                   theta, rho, self.raster_settings)
+                                   theta, rho, self.raster_settings, activations)

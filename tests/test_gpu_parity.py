@@ -260,3 +260,40 @@ def test_pair_capacity_overflow_reruns_binning_with_identical_results():
         np.testing.assert_array_equal(f_small[k], f_ok[k], err_msg=k)
     for k in b_ok:
         np.testing.assert_array_equal(b_small[k], b_ok[k], err_msg=k)
+
+
+def test_fused_activations_match_the_accessor_path():
+    """render() with the model's raw parameters (activations applied inside the kernels) against render()
+    through get_scaling / get_rotation / get_opacity: same images, same gradients w.r.t. the raw parameters."""
+    from types import SimpleNamespace
+    from lvdgs import gaussian_renderer, synthetic
+    from lvdgs.gaussian_model import GaussianModel
+    from lvdgs.gaussian_renderer import render
+    W, H, N = 256, 160, 6000
+    g = synthetic.make_gaussians(N, W, H, seed=90)
+    cam = synthetic.make_camera(W, H, pose_seed=4)
+    for k in ("world_view_transform", "projection_matrix", "full_proj_transform", "camera_center"):
+        setattr(cam, k, getattr(cam, k).cuda())
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False)
+    gc, gd, go = (t.cuda() for t in synthetic.make_image_grads(W, H, 7))
+    out = {}
+    for fused in (True, False):
+        gaussian_renderer.FUSE_ACTIVATIONS = fused
+        try:
+            model = GaussianModel.from_activated(g["means3D"], g["scales"], g["rotations"] * 1.7, g["opacities"], shs=g["shs"])
+            cam.cam_rot_delta = torch.nn.Parameter(torch.zeros(3, device="cuda"))
+            cam.cam_trans_delta = torch.nn.Parameter(torch.zeros(3, device="cuda"))
+            pkg = render(cam, model, pipe, torch.zeros(3, device="cuda"))
+            ((pkg["render"] * gc).sum() + (pkg["depth"] * gd).sum() + (pkg["opacity"] * go).sum()).backward()
+            out[fused] = dict(img=pkg["render"].detach().cpu().numpy(), radii=pkg["radii"].cpu().numpy(),
+                              grads=[p.grad.cpu().numpy() for p in model.parameters() if p.grad is not None],
+                              tau=np.concatenate([cam.cam_trans_delta.grad.cpu().numpy(), cam.cam_rot_delta.grad.cpu().numpy()]))
+        finally:
+            gaussian_renderer.FUSE_ACTIVATIONS = True
+    a, b = out[True], out[False]
+    assert (a["radii"] != b["radii"]).mean() < 1e-3  # exp / normalise rounding may move a radius by one in rare cases
+    _close(a["img"], b["img"], rtol=1e-4, atol_scale=1e-4, what="image")
+    assert len(a["grads"]) == len(b["grads"]) == 5
+    for x, y in zip(a["grads"], b["grads"]):
+        _close(x, y, rtol=1e-3, atol_scale=1e-4, what="raw-parameter gradient")
+    _close(a["tau"], b["tau"], rtol=1e-3, atol_scale=1e-4, what="tau")
