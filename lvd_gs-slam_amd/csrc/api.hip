@@ -269,11 +269,13 @@ int enqueue_prepare(const lvdgs_args *a, const GeomView &g, hipStream_t s) {
     const int N = a->num_gaussians;
     PrepScratch w;
     prep_scratch_layout(N, &w, a->scratch);
-    if (int e = launch_preprocess_fwd(*a, g, w.keys[0], w.vals[0], s)) return e;
+    // ping-pong so that the sorted ids land in geom_state's `order` array without a copy
+    const bool even = (radix_num_passes(32) % 2) == 0;
+    uint32_t *va = even ? g.order : w.vals[0], *vb = even ? w.vals[0] : g.order;
+    if (int e = launch_preprocess_fwd(*a, g, w.keys[0], va, s)) return e;
     bool in_a = true;
-    if (int e = radix_sort_pairs(w.keys[0], w.vals[0], w.keys[1], w.vals[1], N, 32, w.hist, w.totals, &in_a, a->debug, s)) return e;
-    const uint32_t *order = in_a ? w.vals[0] : w.vals[1];
-    if (int e = check_hip(hipMemcpyAsync(g.order, order, sizeof(uint32_t) * (size_t)N, hipMemcpyDeviceToDevice, s), "copy order")) return e;
+    if (int e = radix_sort_pairs(w.keys[0], va, w.keys[1], vb, N, 32, w.hist, w.totals, &in_a, a->debug, s)) return e;
+    if ((in_a ? va : vb) != g.order) { set_error("internal: depth order not in geom_state"); return LVDGS_E_INVALID; }
     return launch_offsets_scan(g.tiles_touched, g.order, g.offsets, w.blocksums, g.total, N, a->debug, s);
 }
 

@@ -83,8 +83,7 @@ class _Photometric(torch.autograd.Function):
         a.d_image, a.d_depth, a.d_opacity, a.d_exposure_a, a.d_exposure_b = _p(d_image), _p(d_depth), _p(d_opac), _p(d_a), _p(d_b)
         _lib.check(L.lvdgs_photometric_loss_backward(C.byref(a), _raw_stream(dev)),
                    "lvdgs_photometric_loss_backward")
-        if d_depth is None and ctx.shapes["depth"] is not None and ctx.needs_input_grad[1]:
-            d_depth = torch.zeros(*ctx.shapes["depth"], device=dev)
+        # no depth term: the depth gradient is None (autograd's zero), not a zero-filled image
         if d_opac is not None and not wbo:
             d_opac = None
         return d_image, d_depth, d_opac, d_a, d_b, None, None, None, None, None, None, None, None

@@ -64,11 +64,9 @@ def _render(viewpoint_camera, pc, pipe, bg_color, image_height, image_width, sca
     xyz = pc.get_xyz
     if xyz.shape[0] == 0:
         return None
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # leaf that receives d(loss)/d(NDC xy) in .grad after backward (upstream builds it as zeros + 0 with
+    # retain_grad(); a plain leaf gives callers the same .grad with one kernel and one autograd node less)
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device)
 
     raster_settings = GaussianRasterizationSettings(
         image_height=int(image_height), image_width=int(image_width),
