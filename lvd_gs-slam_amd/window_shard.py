@@ -47,28 +47,20 @@ class GradientBucket:
             self.__init__(self.params)
 
     def all_reduce(self, group=None):
-        """Sum gradients over ranks in place (missing gradients count as zero)."""
+        """Sum gradients over ranks (missing gradients count as zero).
+
+        Pack = one ``torch.cat`` into the flat buffer, one all-reduce, and no unpack: afterwards every
+        ``p.grad`` is a view into the flat buffer (valid until the next call)."""
         _, world = _world(group)
         if world == 1 or not self.params:
             return
         self.rebuild_if_needed()
-        off = 0
-        for p, n in zip(self.params, self.sizes):
-            seg = self.flat[off:off + n]
-            if p.grad is None:
-                seg.zero_()
-            else:
-                seg.copy_(p.grad.reshape(-1))
-            off += n
+        parts = [(p.grad.reshape(-1) if p.grad is not None else torch.zeros(n, dtype=torch.float32, device=self.flat.device))
+                 for p, n in zip(self.params, self.sizes)]
+        torch.cat(parts, out=self.flat)
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
-        off = 0
-        for p, n in zip(self.params, self.sizes):
-            g = self.flat[off:off + n].view_as(p)
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
-            off += n
+        for p, g in zip(self.params, self.flat.split(self.sizes)):
+            p.grad = g.view_as(p)
 
 
 def owner_of(view_index: int, world: int) -> int:
