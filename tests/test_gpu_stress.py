@@ -51,3 +51,36 @@ def test_very_long_tile_lists():
     assert f["n_contrib"].max() > 5_000
     for k in b:
         assert np.isfinite(b[k]).all(), k
+
+
+@pytest.mark.parametrize("kind", ["one_depth", "two_depths", "few_visible"])
+def test_depth_order_with_degenerate_depth_distributions(kind):
+    """The depth order must stay exact when thousands of Gaussians share one depth -- ids break the
+    ties -- and when almost everything is culled."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+    import hip_runner
+    import oracle as orc
+    from lvdgs import synthetic
+    N, W, H = 40_000, 160, 96
+    g = synthetic.make_gaussians(N, W, H, seed=3, r_min=0.5, r_max=1.5)
+    cam = synthetic.make_camera(W, H)
+    z = g["means3D"][:, 2].clone()
+    if kind == "one_depth":
+        znew = torch.full_like(z, 2.0)
+    elif kind == "two_depths":
+        znew = torch.where(torch.arange(N) % 3 == 0, torch.full_like(z, 1.5), torch.full_like(z, 7.25))
+    else:
+        znew = torch.where(torch.arange(N) % 97 == 0, z, -z)  # ~1 % in front of the camera
+    g["means3D"][:, :2] *= (znew / z).abs()[:, None]
+    g["means3D"][:, 2] = znew
+    bg = torch.zeros(3)
+    f_hip, _ = hip_runner.run_hip(g, cam, W, H, bg)
+    f_ora, _ = hip_runner.run_oracle(orc, g, cam, W, H, bg)
+    np.testing.assert_array_equal(f_hip["radii"], f_ora["radii"])
+    np.testing.assert_array_equal(f_hip["point_list"], f_ora["ids_sorted"])
+    np.testing.assert_array_equal(f_hip["ranges"], f_ora["ranges"])
+    assert sorted(f_hip["order"].tolist()) == list(range(N))
+    vis = f_hip["order"][: int((f_ora["radii"] > 0).sum())]
+    d = f_hip["rec"][vis, 9]
+    assert np.all(d[1:] >= d[:-1]) and np.all(vis[1:][d[1:] == d[:-1]] > vis[:-1][d[1:] == d[:-1]])
