@@ -210,6 +210,30 @@ size_t lvdgs_loss_scratch_bytes(int32_t width, int32_t height);
 int lvdgs_photometric_loss_forward(const lvdgs_loss_args *a, void *stream);
 int lvdgs_photometric_loss_backward(const lvdgs_loss_args *a, void *stream);
 
+/* ---- fused L1 + SSIM image loss (reference utils/slam_backend.py:199-215, 438-454) ----
+ * The mapping and colour-refinement losses `(1 - lambda) * l1_loss(a, b) + lambda * (1 - ssim(a, b))` call
+ * gaussian_splatting.utils.loss_utils.l1_loss / ssim (package absent from the checkout; 11-tap Gaussian window,
+ * sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2, mean over pixels and channels).  One launch computes both
+ * means and, when d_img1 is given, the combined gradient
+ *     d_img1 = weight_l1 * d mean|a - b| / d a + weight_ssim * d mean SSIM(a, b) / d a.
+ * With keep_mask, pixels whose mask byte is 0 are first replaced by bg[plane % channels] in BOTH images
+ * (slam_backend.py:205-209); they receive zero gradient. */
+typedef struct lvdgs_ssim_args {
+    int32_t width, height;
+    int32_t planes;            /* batch * channels image planes of H*W floats  */
+    int32_t channels;          /* planes per image (bg index = plane % channels) */
+    const float *img1;         /* planes*H*W (the differentiated image)        */
+    const float *img2;         /* planes*H*W                                   */
+    const uint8_t *keep_mask;  /* H*W bytes or NULL                            */
+    const float *bg;           /* channels floats or NULL (0)                  */
+    float weight_l1, weight_ssim;
+    void *scratch; size_t scratch_bytes;   /* lvdgs_ssim_scratch_bytes(W,H,planes) */
+    float *out;                /* 2: mean |a - b|, mean SSIM                   */
+    float *d_img1;             /* planes*H*W or NULL (values only)             */
+} lvdgs_ssim_args;
+size_t lvdgs_ssim_scratch_bytes(int32_t width, int32_t height, int32_t planes);
+int lvdgs_ssim_l1(const lvdgs_ssim_args *a, void *stream);
+
 /* ---- diagnostics ---- */
 const char *lvdgs_last_error(void);
 const char *lvdgs_version(void);

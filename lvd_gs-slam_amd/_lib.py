@@ -51,6 +51,17 @@ class LossArgs(C.Structure):
     ]
 
 
+class SsimArgs(C.Structure):
+    """struct lvdgs_ssim_args (include/lvdgs.h)."""
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32), ("planes", C.c_int32), ("channels", C.c_int32),
+        ("img1", _fp), ("img2", _fp), ("keep_mask", _fp), ("bg", _fp),
+        ("weight_l1", C.c_float), ("weight_ssim", C.c_float),
+        ("scratch", _fp), ("scratch_bytes", C.c_size_t),
+        ("out", _fp), ("d_img1", _fp),
+    ]
+
+
 class StateLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "geom_rec", "geom_tiles_touched", "geom_order", "geom_offsets", "bin_point_list", "bin_tile_keys",
@@ -68,7 +79,7 @@ EXPORTS = (
     "lvdgs_forward",
     "lvdgs_backward", "lvdgs_mark_visible", "lvdgs_state_layout_query", "lvdgs_knn_scratch_bytes",
     "lvdgs_dist2_knn3", "lvdgs_rope2d", "lvdgs_loss_scratch_bytes", "lvdgs_photometric_loss_forward",
-    "lvdgs_photometric_loss_backward", "lvdgs_last_error", "lvdgs_version", "lvdgs_profile_enable",
+    "lvdgs_photometric_loss_backward", "lvdgs_ssim_scratch_bytes", "lvdgs_ssim_l1", "lvdgs_last_error", "lvdgs_version", "lvdgs_profile_enable",
     "lvdgs_profile_reset", "lvdgs_profile_read",
 )
 
@@ -115,6 +126,9 @@ def lib():
         L.lvdgs_loss_scratch_bytes.argtypes = [C.c_int32, C.c_int32]
         L.lvdgs_photometric_loss_forward.argtypes = [C.POINTER(LossArgs), C.c_void_p]
         L.lvdgs_photometric_loss_backward.argtypes = [C.POINTER(LossArgs), C.c_void_p]
+        L.lvdgs_ssim_scratch_bytes.restype = C.c_size_t
+        L.lvdgs_ssim_scratch_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+        L.lvdgs_ssim_l1.argtypes = [C.POINTER(SsimArgs), C.c_void_p]
         L.lvdgs_profile_enable.argtypes = [C.c_int]
         L.lvdgs_profile_read.argtypes = [C.POINTER(KernelTime), C.c_int]
         _lib = L

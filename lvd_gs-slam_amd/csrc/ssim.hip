@@ -1,0 +1,355 @@
+// Fused L1 + SSIM image loss with its gradient (reference utils/slam_backend.py:199-215, 438-454:
+// `(1 - lambda) * l1_loss(a, b) + lambda * (1 - ssim(a, b))` on the rendered and the ground-truth image,
+// optionally after the dynamic pixels of both were overwritten with the background colour).
+//
+// SSIM as published with 3DGS (gaussian_splatting.utils.loss_utils.ssim; the package is absent from the
+// reference checkout): 11-tap Gaussian window, sigma 1.5, zero padding, per channel,
+//   A = w*x, B = w*y, S = w*(x^2 + y^2), Z = w*(xy)
+//   m = (2AB + C1)(2(Z - AB) + C2) / ((A^2 + B^2 + C1)(S - A^2 - B^2 + C2)),   C1 = 0.01^2, C2 = 0.03^2
+// and the mean of m over every pixel and channel.
+//
+// PyTorch evaluates this with five 11x11 grouped convolutions and ~20 full-frame elementwise kernels,
+// and autograd doubles it.  Here one workgroup owns a 32x32 output tile of one plane and keeps every
+// intermediate in LDS:
+//   1. load the 52x52 input window of both images (zero outside the image, bg under the mask);
+//   2. horizontal then vertical 11-tap pass over (x, y, x^2 + y^2, xy) -> A, B, S, Z on 42x42 pixels;
+//   3. m and its partial derivatives dm/dA, dm/dS, dm/dZ on those 42x42 pixels (zero outside the image);
+//   4. horizontal then vertical pass over the three derivative maps -> on the 32x32 tile
+//        d mean(m) / d x_p = [ w*dm/dA + 2 x_p (w*dm/dS) + y_p (w*dm/dZ) ]_p / count.
+// Every thread computes 4-8 neighbouring outputs per pass so one LDS read feeds several FMAs.
+// The two means are per-workgroup partial sums finished in a fixed order (deterministic, no atomics).
+#include "common.hpp"
+#include "device_utils.hpp"
+
+namespace lvdgs {
+namespace {
+
+constexpr int ST = 32;           // output tile edge
+constexpr int SR = 5;            // window radius
+constexpr int SW = 2 * SR + 1;   // taps
+constexpr int S1 = ST + 4 * SR;  // 52: input window edge
+constexpr int S2 = ST + 2 * SR;  // 42: edge of the region where m is needed
+constexpr int P1 = S1 + 1;       // odd LDS pitches: row-strided accesses fall in different banks
+constexpr int P2 = S2 + 1;
+constexpr int P3 = ST + 1;
+constexpr int SSIM_THREADS = 256;
+constexpr float SSIM_C1 = 0.01f * 0.01f, SSIM_C2 = 0.03f * 0.03f;
+
+struct SsimParams {
+    int W, H, planes, channels;
+    const float *x, *y;          // planes*H*W
+    const uint8_t *keep;         // H*W or null
+    const float *bg;             // channels or null
+    float w_l1, w_ssim;          // gradient weights, already divided by the element count
+    float *partial;              // nwg * 2
+    float *d_x;                  // planes*H*W or null
+    float win[SW];
+};
+
+__device__ __forceinline__ float block_sum4(float v, float *s) {
+    v = wave_sum_to_lane63(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 63) s[wave] = v;
+    __syncthreads();
+    return ((s[0] + s[1]) + s[2]) + s[3];
+}
+
+template <bool GRAD>
+__global__ void __launch_bounds__(SSIM_THREADS) ssim_l1_kernel(SsimParams p) {
+    // sxy: the two input windows; later the three derivative maps (3 * S2 * P2 <= 2 * S1 * P1)
+    __shared__ float s_in[2 * S1 * P1];
+    // horizontal pass results: 4 x S1 x P2; later the horizontal pass of the derivative maps (3 x S2 x P3)
+    __shared__ float s_h[4 * S1 * P2];
+    __shared__ float s_red[4];
+    static_assert(3 * S2 * P2 <= 2 * S1 * P1, "derivative maps must fit the input windows");
+    static_assert(3 * S2 * P3 <= 4 * S1 * P2, "second horizontal pass must fit the first");
+
+    const int tid = threadIdx.x;
+    const int plane = blockIdx.z;
+    const int tx0 = blockIdx.x * ST, ty0 = blockIdx.y * ST;
+    const size_t plane_off = (size_t)plane * p.W * p.H;
+    const float *__restrict__ X = p.x + plane_off;
+    const float *__restrict__ Y = p.y + plane_off;
+    const float bgc = p.bg ? p.bg[plane % p.channels] : 0.f;
+    float w[SW];
+#pragma unroll
+    for (int k = 0; k < SW; k++) w[k] = p.win[k];
+
+    // ---- 1. input windows (+ the L1 sum over this tile's own pixels) ----
+    float l1 = 0.f;
+    float *sx = s_in, *sy = s_in + S1 * P1;
+    {
+        // all global loads of the window are issued before the first use: with 2 workgroups per CU there
+        // is nobody else to hide their latency
+        constexpr int NLD = (S1 * S1 + SSIM_THREADS - 1) / SSIM_THREADS;
+        float la[NLD], lb[NLD];
+        uint8_t lk[NLD];
+#pragma unroll
+        for (int it = 0; it < NLD; it++) {
+            const int i = tid + it * SSIM_THREADS;
+            const int r = i / S1, c = i - r * S1;
+            const int gy = ty0 - 2 * SR + r, gx = tx0 - 2 * SR + c;
+            const bool in = i < S1 * S1 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            const size_t o = in ? (size_t)gy * p.W + gx : 0;
+            la[it] = in ? X[o] : 0.f;
+            lb[it] = in ? Y[o] : 0.f;
+            lk[it] = (in && p.keep) ? p.keep[o] : (uint8_t)1;
+        }
+#pragma unroll
+        for (int it = 0; it < NLD; it++) {
+            const int i = tid + it * SSIM_THREADS;
+            if (i < S1 * S1) {
+                const int r = i / S1, c = i - r * S1;
+                const int gy = ty0 - 2 * SR + r, gx = tx0 - 2 * SR + c;
+                const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                float a = la[it], b = lb[it];
+                if (in && !lk[it]) a = b = bgc;
+                if (in && r >= 2 * SR && r < 2 * SR + ST && c >= 2 * SR && c < 2 * SR + ST) l1 += fabsf(a - b);
+                sx[r * P1 + c] = a;
+                sy[r * P1 + c] = b;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 2a. horizontal pass: rows 0..S1, output columns 0..S2; one item = 11 outputs of one row, so the
+    //      52 x 4 items fill one round of the workgroup (the last column group overlaps its neighbour) ----
+    {
+        constexpr int OUT = 11, NIN = OUT + SW - 1, GROUPS = (S2 + OUT - 1) / OUT;
+        static_assert(S1 * GROUPS <= SSIM_THREADS, "one round");
+        if (tid < S1 * GROUPS) {
+            const int r = tid % S1, g = tid / S1;
+            const int c0 = min(g * OUT, S2 - OUT);
+            float xv[NIN], yv[NIN], qs[NIN], qz[NIN];
+#pragma unroll
+            for (int i = 0; i < NIN; i++) {
+                xv[i] = sx[r * P1 + c0 + i];
+                yv[i] = sy[r * P1 + c0 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < NIN; i++) {
+                qs[i] = fmaf(xv[i], xv[i], yv[i] * yv[i]);
+                qz[i] = xv[i] * yv[i];
+            }
+#pragma unroll
+            for (int o = 0; o < OUT; o++) {
+                float a = w[0] * xv[o], b = w[0] * yv[o], sq = w[0] * qs[o], z = w[0] * qz[o];
+#pragma unroll
+                for (int k = 1; k < SW; k++) {
+                    a = fmaf(w[k], xv[o + k], a);
+                    b = fmaf(w[k], yv[o + k], b);
+                    sq = fmaf(w[k], qs[o + k], sq);
+                    z = fmaf(w[k], qz[o + k], z);
+                }
+                const int d = r * P2 + c0 + o;
+                s_h[d] = a;
+                s_h[S1 * P2 + d] = b;
+                s_h[2 * S1 * P2 + d] = sq;
+                s_h[3 * S1 * P2 + d] = z;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 2b + 3. vertical pass, m and its derivatives on the S2 x S2 region ----
+    float msum = 0.f;
+    float *sdA = s_in, *sdS = s_in + S2 * P2, *sdZ = s_in + 2 * S2 * P2;
+    {
+        constexpr int OUT = 7, NIN = OUT + SW - 1, GROUPS = S2 / OUT;  // 42 columns x 6 row groups = 252 items
+        static_assert(S2 % OUT == 0 && S2 * GROUPS <= SSIM_THREADS, "one round");
+        if (tid < S2 * GROUPS) {
+            const int c = tid % S2, r0 = (tid / S2) * OUT;
+            float va[NIN], vb[NIN], vs[NIN], vz[NIN];
+#pragma unroll
+            for (int i = 0; i < NIN; i++) {
+                const int d = (r0 + i) * P2 + c;
+                va[i] = s_h[d];
+                vb[i] = s_h[S1 * P2 + d];
+                vs[i] = s_h[2 * S1 * P2 + d];
+                vz[i] = s_h[3 * S1 * P2 + d];
+            }
+            const int gx = tx0 - SR + c;
+#pragma unroll
+            for (int o = 0; o < OUT; o++) {
+                float A = w[0] * va[o], B = w[0] * vb[o], S = w[0] * vs[o], Z = w[0] * vz[o];
+#pragma unroll
+                for (int k = 1; k < SW; k++) {
+                    A = fmaf(w[k], va[o + k], A);
+                    B = fmaf(w[k], vb[o + k], B);
+                    S = fmaf(w[k], vs[o + k], S);
+                    Z = fmaf(w[k], vz[o + k], Z);
+                }
+                const int r = r0 + o;
+                const int gy = ty0 - SR + r;
+                const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                const float AB = A * B, AA_BB = fmaf(A, A, B * B);
+                const float num1 = fmaf(2.f, AB, SSIM_C1), num2 = fmaf(2.f, Z - AB, SSIM_C2);
+                const float den1 = AA_BB + SSIM_C1, den2 = (S - AA_BB) + SSIM_C2;
+                // both denominators are >= C1, C2 > 0: the hardware reciprocal (1 ulp) is well inside the tolerance
+                const float inv1 = __builtin_amdgcn_rcpf(den1), inv2 = __builtin_amdgcn_rcpf(den2);
+                const float inv12 = inv1 * inv2;
+                const float m = (num1 * num2) * inv12;
+                if (inside && r >= SR && r < SR + ST && c >= SR && c < SR + ST) msum += m;
+                if (GRAD) {
+                    // dm/dA = 2B (num2 - num1) / (den1 den2) - 2A m (1/den1 - 1/den2); dm/dS = -m / den2; dm/dZ = 2 num1 / (den1 den2)
+                    const float dA = 2.f * B * (num2 - num1) * inv12 - 2.f * A * m * (inv1 - inv2);
+                    const float dS = -m * inv2;
+                    const float dZ = 2.f * num1 * inv12;
+                    const int d = r * P2 + c;
+                    sdA[d] = inside ? dA : 0.f;
+                    sdS[d] = inside ? dS : 0.f;
+                    sdZ[d] = inside ? dZ : 0.f;
+                }
+            }
+        }
+    }
+
+    // ---- the two sums of this workgroup ----
+    {
+        const float t1 = block_sum4(l1, s_red);
+        const float t2 = block_sum4(msum, s_red);
+        if (tid == 0) {
+            const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            p.partial[2 * wg] = t1;
+            p.partial[2 * wg + 1] = t2;
+        }
+    }
+    if (!GRAD) return;
+    __syncthreads();
+
+    // ---- 4a. horizontal pass over the derivative maps: rows 0..S2, output columns 0..ST, 6 per item
+    //      (42 x 6 = 252 items, the last column group overlaps its neighbour) ----
+    {
+        constexpr int OUT = 6, NIN = OUT + SW - 1, GROUPS = (ST + OUT - 1) / OUT;
+        static_assert(S2 * GROUPS <= SSIM_THREADS, "one round");
+        if (tid < S2 * GROUPS) {
+            const int r = tid % S2, c0 = min((tid / S2) * OUT, ST - OUT);
+            float va[NIN], vs[NIN], vz[NIN];
+#pragma unroll
+            for (int i = 0; i < NIN; i++) {
+                const int d = r * P2 + c0 + i;
+                va[i] = sdA[d];
+                vs[i] = sdS[d];
+                vz[i] = sdZ[d];
+            }
+#pragma unroll
+            for (int o = 0; o < OUT; o++) {
+                float a = w[0] * va[o], sq = w[0] * vs[o], z = w[0] * vz[o];
+#pragma unroll
+                for (int k = 1; k < SW; k++) {
+                    a = fmaf(w[k], va[o + k], a);
+                    sq = fmaf(w[k], vs[o + k], sq);
+                    z = fmaf(w[k], vz[o + k], z);
+                }
+                const int d = r * P3 + c0 + o;
+                s_h[d] = a;
+                s_h[S2 * P3 + d] = sq;
+                s_h[2 * S2 * P3 + d] = z;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 4b. vertical pass, 4 outputs per item, and the gradient of this tile ----
+    float *__restrict__ G = p.d_x + plane_off;
+    for (int item = tid; item < ST * (ST / 4); item += SSIM_THREADS) {
+        const int c = item % ST, r0 = (item / ST) * 4;
+        float va[14], vs[14], vz[14];
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            const int d = (r0 + i) * P3 + c;
+            va[i] = s_h[d];
+            vs[i] = s_h[S2 * P3 + d];
+            vz[i] = s_h[2 * S2 * P3 + d];
+        }
+        const int gx = tx0 + c;
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            float a = w[0] * va[o], s = w[0] * vs[o], z = w[0] * vz[o];
+#pragma unroll
+            for (int k = 1; k < SW; k++) {
+                a = fmaf(w[k], va[o + k], a);
+                s = fmaf(w[k], vs[o + k], s);
+                z = fmaf(w[k], vz[o + k], z);
+            }
+            const int gy = ty0 + r0 + o;
+            if (gy < p.H && gx < p.W) {
+                const size_t off = (size_t)gy * p.W + gx;
+                float g = 0.f;
+                if (!(p.keep && !p.keep[off])) {  // overwritten pixels do not depend on the input
+                    const float xv = X[off], yv = Y[off];
+                    const float diff = xv - yv;
+                    const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
+                    g = p.w_ssim * (a + 2.f * xv * s + yv * z) + p.w_l1 * sgn;
+                }
+                G[off] = g;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) ssim_finish_kernel(const float *__restrict__ partial, int nwg, float inv_count,
+                                                          float *__restrict__ out) {
+    __shared__ float s_red[4];
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < nwg; i += 256) {
+        a += partial[2 * i];
+        b += partial[2 * i + 1];
+    }
+    const float ta = block_sum4(a, s_red);
+    const float tb = block_sum4(b, s_red);
+    if (threadIdx.x == 0) {
+        out[0] = ta * inv_count;
+        out[1] = tb * inv_count;
+    }
+}
+
+}  // namespace
+}  // namespace lvdgs
+
+using namespace lvdgs;
+
+extern "C" {
+
+size_t lvdgs_ssim_scratch_bytes(int32_t width, int32_t height, int32_t planes) {
+    const size_t nwg = (size_t)cdiv(width, ST) * cdiv(height, ST) * (size_t)(planes > 0 ? planes : 0);
+    return align256(nwg * 2 * sizeof(float) + 256);
+}
+
+int lvdgs_ssim_l1(const lvdgs_ssim_args *a, void *stream) {
+    if (!a || a->width <= 0 || a->height <= 0 || a->planes <= 0 || a->channels <= 0) { set_error("ssim: bad image size"); return LVDGS_E_INVALID; }
+    if (a->planes % a->channels) { set_error("ssim: planes must be a multiple of channels"); return LVDGS_E_INVALID; }
+    if (!a->img1 || !a->img2 || !a->out || !a->scratch) { set_error("ssim: img1 / img2 / out / scratch is NULL"); return LVDGS_E_INVALID; }
+    if (a->scratch_bytes < lvdgs_ssim_scratch_bytes(a->width, a->height, a->planes)) { set_error("ssim: scratch too small"); return LVDGS_E_INVALID; }
+    if (a->planes > 65535) { set_error("ssim: more than 65535 planes"); return LVDGS_E_RANGE; }
+    hipStream_t s = (hipStream_t)stream;
+    SsimParams p{};
+    p.W = a->width; p.H = a->height; p.planes = a->planes; p.channels = a->channels;
+    p.x = a->img1; p.y = a->img2; p.keep = a->keep_mask; p.bg = a->bg;
+    const double count = (double)a->width * a->height * a->planes;
+    p.w_l1 = (float)(a->weight_l1 / count);
+    p.w_ssim = (float)(a->weight_ssim / count);
+    p.partial = (float *)a->scratch;
+    p.d_x = a->d_img1;
+    // the window upstream builds in float32: exp(-(k - 5)^2 / (2 * 1.5^2)), normalised
+    float g[SW], sum = 0.f;
+    for (int k = 0; k < SW; k++) { g[k] = expf(-(float)((k - SR) * (k - SR)) / (2.f * 1.5f * 1.5f)); sum += g[k]; }
+    for (int k = 0; k < SW; k++) p.win[k] = g[k] / sum;
+    const dim3 grid(cdiv(a->width, ST), cdiv(a->height, ST), a->planes);
+    const int nwg = (int)(grid.x * grid.y * grid.z);
+    {
+        ProfScope ps(a->d_img1 ? "ssim_l1_grad" : "ssim_l1", s);
+        if (a->d_img1) hipLaunchKernelGGL(ssim_l1_kernel<true>, grid, dim3(SSIM_THREADS), 0, s, p);
+        else hipLaunchKernelGGL(ssim_l1_kernel<false>, grid, dim3(SSIM_THREADS), 0, s, p);
+        LVDGS_LAUNCH_CHECK("ssim_l1", 0, s);
+    }
+    {
+        ProfScope ps("ssim_finish", s);
+        hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(256), 0, s, (const float *)p.partial, nwg, (float)(1.0 / count), a->out);
+        LVDGS_LAUNCH_CHECK("ssim_finish", 0, s);
+    }
+    return LVDGS_OK;
+}
+
+}  // extern "C"

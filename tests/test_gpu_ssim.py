@@ -1,0 +1,98 @@
+"""Fused L1 + SSIM kernel against the float64 oracle: values, gradients, masks, ragged and full sizes."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4  # float tolerance of the north star
+
+
+def _pair(C, H, W, seed, noise=0.1, batch=None):
+    g = torch.Generator().manual_seed(seed)
+    shape = (C, H, W) if batch is None else (batch, C, H, W)
+    a = torch.rand(*shape, generator=g)
+    b = (a + noise * torch.randn(*shape, generator=g)).clamp(0, 1)
+    return a, b
+
+
+def _close(got, want, what):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    scale = max(np.abs(want).max(), 1e-30)
+    err = np.abs(got - want).max() / scale
+    assert err < REL, f"{what}: max error {err:.3e} of the largest magnitude"
+
+
+@pytest.mark.parametrize("shape", [(3, 37, 53), (1, 8, 8), (3, 64, 96), (3, 370, 1226), (2, 33, 31)])
+def test_ssim_value_and_gradient(shape):
+    import loss_oracle as lo
+    from lvdgs.loss_utils import ssim
+    a, b = _pair(*shape, seed=sum(shape))
+    ad = a.double().requires_grad_(True)
+    want = lo.ssim(ad, b)
+    want.backward()
+    ag = a.cuda().requires_grad_(True)
+    got = ssim(ag, b.cuda())
+    got.backward()
+    assert abs(float(got) - float(want)) < 2e-6
+    _close(ag.grad.cpu().numpy(), ad.grad.numpy(), "d ssim / d img1")
+
+
+def test_batched_input_and_no_grad_path():
+    import loss_oracle as lo
+    from lvdgs.loss_utils import ssim
+    a, b = _pair(3, 45, 70, seed=9, batch=2)
+    with torch.no_grad():
+        got = ssim(a.cuda(), b.cuda())
+    want = lo.ssim_map(a.double(), b.double()).mean()
+    assert abs(float(got) - float(want)) < 2e-6
+    assert abs(float(ssim(a.cuda(), a.cuda())) - 1.0) < 1e-6
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_l1_dssim_combination(masked):
+    """(1 - l) L1 + l (1 - SSIM) with the dynamic pixels overwritten (utils/slam_backend.py:199-215)."""
+    import loss_oracle as lo
+    from lvdgs.loss_utils import l1_dssim_loss
+    H, W, lam = 90, 130, 0.2
+    a, b = _pair(3, H, W, seed=11)
+    mask = (torch.rand(H, W, generator=torch.Generator().manual_seed(12)) > 0.25) if masked else None
+    bg = torch.tensor([0.1, 0.6, 0.3])
+    ad = a.double().requires_grad_(True)
+    want = lo.l1_dssim_loss(ad, b, lam, mask, bg)
+    (want * 1.7).backward()
+    ag = a.cuda().requires_grad_(True)
+    got = l1_dssim_loss(ag, b.cuda(), lam, None if mask is None else mask.cuda(), bg.cuda())
+    (got * 1.7).backward()
+    assert abs(float(got) - float(want)) < 2e-6
+    _close(ag.grad.cpu().numpy(), ad.grad.numpy(), "d loss / d image")
+    if masked:
+        assert float(ag.grad[:, ~mask.cuda()].abs().max()) == 0.0
+
+
+def test_full_hd_properties_and_determinism():
+    """1920x1080: identity gives exactly-one SSIM and zero L1; two runs agree bit for bit."""
+    from lvdgs.loss_utils import l1_dssim_loss, ssim
+    a, b = _pair(3, 1080, 1920, seed=13)
+    a, b = a.cuda(), b.cuda()
+    assert abs(float(ssim(a, a)) - 1.0) < 1e-6
+    x = a.clone().requires_grad_(True)
+    l1 = l1_dssim_loss(x, b, 0.2)
+    l1.backward()
+    y = a.clone().requires_grad_(True)
+    l2 = l1_dssim_loss(y, b, 0.2)
+    l2.backward()
+    assert float(l1) == float(l2) and torch.equal(x.grad, y.grad)
+    # SSIM is symmetric in its arguments
+    assert abs(float(ssim(a, b)) - float(ssim(b, a))) < 1e-6
+
+
+def test_cpu_tensors_are_refused():
+    from lvdgs._lib import LvdgsError
+    from lvdgs.loss_utils import ssim
+    with pytest.raises(LvdgsError):
+        ssim(torch.rand(3, 16, 16), torch.rand(3, 16, 16))
