@@ -52,3 +52,50 @@ def test_reference_camera_imports_through_the_shim(monkeypatch):
     assert sorted(n for n, _ in a.named_parameters()) == sorted(n for n, _ in b.named_parameters())
     for m in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:
         monkeypatch.delitem(sys.modules, m)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/utils"), reason="reference checkout not present on this box")
+def test_reference_backend_constructs_and_resets_on_the_shim(monkeypatch):
+    """utils/slam_backend.py imports render / l1_loss / ssim / getProjectionMatrix2 from gaussian_splatting (:10-12);
+    with the shim on the path the reference's own BackEnd class loads, takes the KITTI-07 hyper-parameters and
+    drives GaussianModel.prune_points through BackEnd.reset (:79-92).  utils/init_pose.py (MASt3R + cv2, out of
+    scope and not installed) is replaced by an empty module for the import."""
+    import importlib
+    import json
+    import types
+    import torch
+    monkeypatch.syspath_prepend(DROPIN)
+    monkeypatch.syspath_prepend("/root/reference")
+    monkeypatch.setattr(sys, "dont_write_bytecode", True)
+    for m in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:
+        monkeypatch.delitem(sys.modules, m)
+    stub = types.ModuleType("utils.init_pose")
+    stub.save_depth_comparison = lambda *a, **k: None
+    monkeypatch.setitem(sys.modules, "utils.init_pose", stub)
+    backend = importlib.import_module("utils.slam_backend")
+    import lvdgs.gaussian_renderer
+    import lvdgs.loss_utils
+    assert backend.render is lvdgs.gaussian_renderer.render
+    assert backend.ssim is lvdgs.loss_utils.ssim and backend.l1_loss is lvdgs.loss_utils.l1_loss
+    cfg = json.load(open(os.path.join(ROOT, "tests", "golden", "config_07.json")))
+    cfg["Training"]["monocular"] = cfg["Dataset"]["sensor_type"] == "monocular"  # set by the absent slam.py entry point
+    be = backend.BackEnd(cfg)
+    be.cameras_extent = 6.0
+    be.set_hyperparams()
+    assert be.window_size == 8 and be.gaussian_extent == 6.0 and be.init_gaussian_extent == 180.0
+
+    from gaussian_splatting.scene.gaussian_model import GaussianModel
+    g = GaussianModel.from_activated(torch.rand(9, 3), torch.rand(9, 3) + 0.1, torch.nn.functional.normalize(torch.randn(9, 4)),
+                                     torch.rand(9, 1), colors=torch.rand(9, 3), device="cpu")
+    g.init_lr(6.0)
+    g.training_setup(cfg["opt_params"])
+    be.gaussians = g
+
+    class _Q:
+        def empty(self):
+            return True
+    be.backend_queue = _Q()
+    be.reset()
+    assert g.get_xyz.shape[0] == 0 and be.iteration_count == 0 and be.current_window == []
+    for m in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:
+        monkeypatch.delitem(sys.modules, m, raising=False)

@@ -38,7 +38,7 @@ def test_ssim_value_and_gradient(shape):
     ag = a.cuda().requires_grad_(True)
     got = ssim(ag, b.cuda())
     got.backward()
-    assert abs(float(got) - float(want)) < 2e-6
+    assert abs(float(got.detach()) - float(want.detach())) < 2e-6
     _close(ag.grad.cpu().numpy(), ad.grad.numpy(), "d ssim / d img1")
 
 
@@ -49,7 +49,7 @@ def test_batched_input_and_no_grad_path():
     with torch.no_grad():
         got = ssim(a.cuda(), b.cuda())
     want = lo.ssim_map(a.double(), b.double()).mean()
-    assert abs(float(got) - float(want)) < 2e-6
+    assert abs(float(got.detach()) - float(want.detach())) < 2e-6
     assert abs(float(ssim(a.cuda(), a.cuda())) - 1.0) < 1e-6
 
 
@@ -68,7 +68,7 @@ def test_l1_dssim_combination(masked):
     ag = a.cuda().requires_grad_(True)
     got = l1_dssim_loss(ag, b.cuda(), lam, None if mask is None else mask.cuda(), bg.cuda())
     (got * 1.7).backward()
-    assert abs(float(got) - float(want)) < 2e-6
+    assert abs(float(got.detach()) - float(want.detach())) < 2e-6
     _close(ag.grad.cpu().numpy(), ad.grad.numpy(), "d loss / d image")
     if masked:
         assert float(ag.grad[:, ~mask.cuda()].abs().max()) == 0.0
