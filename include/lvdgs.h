@@ -152,7 +152,7 @@ int lvdgs_mark_visible(int32_t num_gaussians, const float *means3D, const float 
 typedef struct lvdgs_state_layout {
     /* byte offsets into geom_state */
     size_t geom_rec;           /* N x 12 float: x, y, conic a, b, c, opacity, r, g, b, view depth,
-                                  u32 first-pair offset, i32 radius */
+                                  (unused), i32 radius */
     size_t geom_tiles_touched; /* N x u32 */
     size_t geom_order;         /* N x u32: depth rank -> Gaussian id */
     size_t geom_offsets;       /* N x u32: inclusive scan of tiles_touched in rank order */

@@ -111,6 +111,7 @@ size_t geom_layout(int N, GeomView *v, void *base) {
     carve(v->tiles_touched, n, b, off);
     carve(v->order, n, b, off);
     carve(v->offsets, n, b, off);
+    carve(v->slot_base, n, b, off);
     carve(v->total, 64, b, off);
     return off;
 }
@@ -129,7 +130,7 @@ size_t prep_scratch_layout(int N, PrepScratch *v, void *base) {
     carve(v->vals[1], n, b, off);
     carve(v->hist, radix_hist_entries(N), b, off);
     carve(v->totals, (size_t)1 << SORT_MAX_BITS, b, off);
-    carve(v->blocksums, scan_blocks(N), b, off);
+    carve(v->blocksums, 2 * scan_blocks(N), b, off);
     carve(v->total, 64, b, off);
     return off;
 }
@@ -276,7 +277,7 @@ int enqueue_prepare(const lvdgs_args *a, const GeomView &g, hipStream_t s) {
     bool in_a = true;
     if (int e = radix_sort_pairs(w.keys[0], va, w.keys[1], vb, N, 32, w.hist, w.totals, &in_a, a->debug, s)) return e;
     if ((in_a ? va : vb) != g.order) { set_error("internal: depth order not in geom_state"); return LVDGS_E_INVALID; }
-    return launch_offsets_scan(g.tiles_touched, g.order, g.offsets, w.blocksums, g.total, N, a->debug, s);
+    return launch_offsets_scan(g.tiles_touched, g.order, g.offsets, g.slot_base, w.blocksums, g.total, N, a->debug, s);
 }
 
 // pair emission -> tile sort -> ranges -> blend.  `cap` sizes grids and buffers; when `count_on_device`

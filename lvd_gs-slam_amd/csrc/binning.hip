@@ -7,12 +7,10 @@ namespace lvdgs {
 namespace {
 
 // One lane per depth rank.  A Gaussian's pairs occupy [offsets[s] - tiles, offsets[s]) of the
-// unsorted pair list, tiles in row-major order of its rectangle; the first index is also stored
-// in the Gaussian's record: the backward pass files each tile's partial gradient at
-// first + (ty - y0) * width + (tx - x0), which makes the per-Gaussian sum a contiguous read.
+// unsorted pair list, tiles in row-major order of its rectangle.
 __global__ void __launch_bounds__(256) emit_pairs_kernel(int N, int gx, int gy, const uint32_t *__restrict__ order,
                                                          const uint32_t *__restrict__ offsets,
-                                                         const uint32_t *__restrict__ tiles_touched, float *__restrict__ rec,
+                                                         const uint32_t *__restrict__ tiles_touched, const float *__restrict__ rec,
                                                          uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ ids,
                                                          uint32_t capacity) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -21,18 +19,15 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int N, int gx, int gy, 
     const uint32_t cnt = tiles_touched[id];
     if (cnt == 0) return;
     const uint32_t first = offsets[s] - cnt;
-    float4 *r4 = reinterpret_cast<float4 *>(rec + (size_t)id * REC_FLOATS);
+    const float4 *r4 = reinterpret_cast<const float4 *>(rec + (size_t)id * REC_FLOATS);
     const float4 r0 = r4[0];
-    float4 r2 = r4[2];
-    const int rad = __float_as_int(r2.w);
+    const int rad = __float_as_int(r4[2].w);
     const float px = r0.x, py = r0.y;
     int x0 = (int)((px - (float)rad) / (float)TILE), y0 = (int)((py - (float)rad) / (float)TILE);
     int x1 = (int)((px + (float)rad + (float)(TILE - 1)) / (float)TILE);
     int y1 = (int)((py + (float)rad + (float)(TILE - 1)) / (float)TILE);
     x0 = min(gx, max(0, x0)); x1 = min(gx, max(0, x1));
     y0 = min(gy, max(0, y0)); y1 = min(gy, max(0, y1));
-    r2.z = __uint_as_float(first);
-    r4[2] = r2;
     uint32_t o = first;
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++) {

@@ -13,8 +13,9 @@
 // Backward walks the same list back to front (as published: T is recovered by dividing out
 // 1-alpha).  The per-Gaussian sums over pixels are done without atomics: a DPP wave reduction,
 // per-wave LDS slots, a fixed-order 4-wave sum, and one 48-byte record per (Gaussian, tile) pair
-// stored at the pair's slot of the unsorted pair list.  The per-Gaussian kernel then reads each
-// Gaussian's slots as one contiguous run.  Gradients are therefore bitwise reproducible.
+// stored at slot_base[id] + (ty - y0) * width + (tx - x0): a Gaussian's records form one contiguous
+// run, and the runs follow each other in id order, so the per-Gaussian kernel (one lane per id) reads
+// whole cache lines.  Gradients are therefore bitwise reproducible.
 #include "common.hpp"
 #include "device_utils.hpp"
 
@@ -29,6 +30,7 @@ struct BlendParams {
     const uint2 *ranges;
     const uint32_t *point_list;
     const float *rec;
+    const uint32_t *slot_base;
     const float *bg;
     // forward
     float *out_color, *out_depth, *out_opacity, *final_T;
@@ -207,6 +209,7 @@ __global__ void __launch_bounds__(256, 8) blend_bwd_kernel(BlendParams p) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
     if (lane == 0) s_max[wave] = m;
+    const int wave_last = (int)m;  // no pixel of this wave's quadrant composited an entry at or beyond this position
     __syncthreads();
     const int depth_max = (int)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
     // every pair of this tile must receive a record (zeros included): walk the whole list
@@ -235,7 +238,7 @@ __global__ void __launch_bounds__(256, 8) blend_bwd_kernel(BlendParams p) {
             int x0 = (int)((r0.x - (float)rad) / (float)TILE), y0 = (int)((r0.y - (float)rad) / (float)TILE);
             int x1 = (int)((r0.x + (float)rad + (float)(TILE - 1)) / (float)TILE);
             x0 = min(p.gx, max(0, x0)); x1 = min(p.gx, max(0, x1)); y0 = min(p.gy, max(0, y0));
-            s_slot[tid] = __float_as_uint(r2.z) + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+            s_slot[tid] = p.slot_base[id] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
         }
         if (tid < 4 * (BR / 64)) (&s_mask[0][0])[tid] = 0ull;
         __syncthreads();
@@ -243,7 +246,7 @@ __global__ void __launch_bounds__(256, 8) blend_bwd_kernel(BlendParams p) {
             for (int c0 = ((cnt - 1) / 64) * 64; c0 >= 0; c0 -= 64) {
                 const int jl = c0 + lane;
                 bool keep = false;
-                if (jl < cnt && base + c0 < depth_max) {
+                if (jl < cnt && base + jl < wave_last) {
                     const float4 A = s_a[jl];
                     const float4 B = s_b[jl];
                     keep = reaches_rect(A.x, A.y, A.z, A.w, B.x, B.y, rx0, ry0, rx1, ry1);
@@ -332,7 +335,7 @@ BlendParams make_params(const lvdgs_args &a, const GeomView &g, const BinView &b
     BlendParams p{};
     p.W = a.image_width; p.H = a.image_height;
     p.gx = (p.W + TILE - 1) / TILE; p.gy = (p.H + TILE - 1) / TILE; p.num_tiles = p.gx * p.gy;
-    p.ranges = im.ranges; p.point_list = b.point_list; p.rec = g.rec; p.bg = a.bg;
+    p.ranges = im.ranges; p.point_list = b.point_list; p.rec = g.rec; p.slot_base = g.slot_base; p.bg = a.bg;
     p.out_color = a.out_color; p.out_depth = a.out_depth; p.out_opacity = a.out_opacity;
     p.final_T = im.final_T; p.n_contrib = im.n_contrib; p.n_touched = a.n_touched;
     p.dL_dcolor = a.dL_dout_color; p.dL_ddepth = a.dL_dout_depth; p.dL_dopacity = a.dL_dout_opacity;

@@ -57,7 +57,8 @@ struct GeomView {
     float *rec;              // N*12
     uint32_t *tiles_touched; // N
     uint32_t *order;         // N
-    uint32_t *offsets;       // N
+    uint32_t *offsets;       // N: inclusive scan of tiles_touched in depth-rank order
+    uint32_t *slot_base;     // N: exclusive scan of tiles_touched in id order (where a Gaussian's partial gradients go)
     uint32_t *total;         // 1: pair count D of this frame (device copy)
 };
 struct PrepScratch {
@@ -109,9 +110,10 @@ int radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint3
 int radix_num_passes(int total_bits);
 size_t radix_hist_entries(int64_t n);
 
-// offsets[s] = inclusive scan over s of tiles_touched[order[s]]; *total_dev = last value
-int launch_offsets_scan(const uint32_t *tiles_touched, const uint32_t *order, uint32_t *offsets, uint32_t *blocksums,
-                        uint32_t *total_dev, int N, int dbg, hipStream_t s);
+// offsets[s] = inclusive scan over s of tiles_touched[order[s]]; slot_base[i] = exclusive scan over i of
+// tiles_touched[i]; *total_dev = last value.  blocksums holds 2 * scan blocks entries.
+int launch_offsets_scan(const uint32_t *tiles_touched, const uint32_t *order, uint32_t *offsets, uint32_t *slot_base,
+                        uint32_t *blocksums, uint32_t *total_dev, int N, int dbg, hipStream_t s);
 
 int launch_emit_pairs(const lvdgs_args &a, const GeomView &g, uint32_t *tile_keys, uint32_t *ids, int64_t capacity, hipStream_t s);
 int launch_tile_ranges(const uint32_t *tile_keys, int64_t D, const uint32_t *D_dev, uint2 *ranges, int num_tiles, int dbg,

@@ -262,7 +262,7 @@ struct BwdParams {
     const float *means3D, *scales, *rotations, *cov3D_precomp, *shs, *colors_precomp;
     const int32_t *radii;
     const float *rec;
-    const uint32_t *tiles_touched;
+    const uint32_t *tiles_touched, *slot_base;
     const float *pair_grads;
     float *dmeans3D, *dmeans2D, *dopac, *dscales, *drot, *dcov3D, *dshs, *dcolors;
     float *tau_part;
@@ -288,8 +288,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
     if (live) {
         // ---- sum this Gaussian's per-tile partial gradients (contiguous run, fixed order) ----
         const float4 *r4 = reinterpret_cast<const float4 *>(p.rec + (size_t)i * REC_FLOATS);
-        const float4 rc = r4[2];
-        const uint32_t first = __float_as_uint(rc.z), cnt = p.tiles_touched[i];
+        const uint32_t first = p.slot_base[i], cnt = p.tiles_touched[i];
         float A[10];
 #pragma unroll
         for (int k = 0; k < 10; k++) A[k] = 0.f;
@@ -561,7 +560,7 @@ int launch_preprocess_bwd(const lvdgs_args &a, const GeomView &g, const BwdScrat
         p.cam = make_cam(a); p.N = N; p.act = a.activations;
         p.means3D = a.means3D; p.scales = a.scales; p.rotations = a.rotations; p.cov3D_precomp = a.cov3D_precomp;
         p.shs = a.shs; p.colors_precomp = a.colors_precomp; p.radii = a.radii;
-        p.rec = g.rec; p.tiles_touched = g.tiles_touched; p.pair_grads = b.pair_grads;
+        p.rec = g.rec; p.tiles_touched = g.tiles_touched; p.slot_base = g.slot_base; p.pair_grads = b.pair_grads;
         p.dmeans3D = a.dL_dmeans3D; p.dmeans2D = a.dL_dmeans2D; p.dopac = a.dL_dopacities; p.dscales = a.dL_dscales;
         p.drot = a.dL_drotations; p.dcov3D = a.cov3D_precomp ? a.dL_dcov3D : nullptr; p.dshs = a.dL_dshs;
         p.dcolors = a.dL_dcolors; p.tau_part = b.tau_part;
