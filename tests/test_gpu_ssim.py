@@ -96,3 +96,28 @@ def test_cpu_tensors_are_refused():
     from lvdgs.loss_utils import ssim
     with pytest.raises(LvdgsError):
         ssim(torch.rand(3, 16, 16), torch.rand(3, 16, 16))
+
+
+def test_frame_metrics_of_the_eval_harness():
+    """utils/eval_utils_0806.py:231-306: PSNR on non-black pixels, full-frame SSIM, static-region variants."""
+    import loss_oracle as lo
+    from lvdgs.eval_utils import frame_metrics
+    H, W = 70, 110
+    a, b = _pair(3, H, W, seed=21)
+    b[:, :5] = 0.0  # black border of the ground truth
+    static = torch.rand(H, W, generator=torch.Generator().manual_seed(22)) > 0.3
+    bg = torch.tensor([0.0, 0.0, 0.0])
+    got = frame_metrics(a.cuda() * 1.2 - 0.1, b.cuda(), static.cuda(), bg.cuda())
+    img = (a * 1.2 - 0.1).clamp(0, 1).double()
+    gt = b.double()
+    basic = gt > 0
+    psnr = lambda x, y: float(20 * torch.log10(1.0 / torch.sqrt(((x - y) ** 2).mean())))
+    assert abs(got["psnr"] - psnr(img[basic], gt[basic])) < 1e-3
+    assert abs(got["ssim"] - float(lo.ssim(img, gt))) < 2e-6
+    keep = basic & static[None].expand(3, -1, -1)
+    assert abs(got["psnr_static"] - psnr(img[keep], gt[keep])) < 1e-3
+    zero = torch.zeros_like(img)
+    assert abs(got["ssim_static"] - float(lo.ssim(torch.where(keep, img, zero), torch.where(keep, gt, zero)))) < 2e-6
+    assert abs(got["static_ratio"] - float(keep.float().mean())) < 1e-6
+    plain = frame_metrics(a.cuda(), b.cuda())
+    assert plain["psnr_static"] == plain["psnr"] and plain["ssim_static"] == plain["ssim"]
