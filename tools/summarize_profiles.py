@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 outputs of tools/profile_round.sh (merged back under gpurun_out/<tag>/) into the
+committed summaries: profiles/<tag>_kernel_stats_cfg3.csv, profiles/<tag>_pmc/<counter>_lvdgs_kernels.csv,
+profiles/<tag>_bench_cfg3.json and profiles/traffic.json.
+
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KiB and on gfx950 FETCH_SIZE
+reports half the bytes of 16-byte-per-lane reads, the access width of every bandwidth-relevant kernel here
+(MI355X_MICROARCH.md, HBM / rocprofv3 section).  Counters come from separate --pmc passes and are averaged over
+the launches of a kernel in the timed steps."""
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    m = re.search(r"(\w+)_kernel", name)
+    return m.group(1) if m else name
+
+
+def main(tag, workload="cfg3_500k_1920x1080"):
+    src = os.path.join(ROOT, "gpurun_out", tag)
+    dst = os.path.join(ROOT, "profiles")
+    stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+    if stats:
+        shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats_cfg3.csv"))
+    bench = os.path.join(src, "bench.json")
+    if os.path.exists(bench) and os.path.getsize(bench):
+        shutil.copy(bench, os.path.join(dst, f"{tag}_bench_cfg3.json"))
+    os.makedirs(os.path.join(dst, f"{tag}_pmc"), exist_ok=True)
+    per_kernel = defaultdict(lambda: defaultdict(list))
+    for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+        if not os.path.isdir(d):
+            continue
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if not files:
+            continue
+        rows = [r for r in csv.DictReader(open(files[0])) if "lvdgs" in r["Kernel_Name"]]
+        name = os.path.basename(d)[4:].lower()
+        with open(os.path.join(dst, f"{tag}_pmc", f"{name}_lvdgs_kernels.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count",
+                        "Counter_Name", "Counter_Value"])
+            for r in rows:
+                w.writerow([r["Dispatch_Id"], short(r["Kernel_Name"]) + "_kernel", r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"],
+                            r["VGPR_Count"], r["SGPR_Count"], r["Counter_Name"], r["Counter_Value"]])
+                per_kernel[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    note = ("(2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE reports half the bytes of 16-byte-per-lane reads "
+            "(MI355X_MICROARCH.md, HBM section); separate --pmc passes, averaged over launches")
+    tpath = os.path.join(dst, "traffic.json")
+    traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    entry = {}
+    for k, c in sorted(per_kernel.items()):
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            f, w = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"]), sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
+            entry[k] = {"FETCH_SIZE_KB_raw": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
+                        "hbm_bytes_per_launch": int((2 * f + w) * 1024), "note": note}
+    if entry:
+        entry["_source"] = f"gpurun_out/{tag} (tools/profile_round.sh), summarised by tools/summarize_profiles.py"
+        traffic[workload] = entry
+        json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
+    print("kernels with traffic:", [k for k in entry if not k.startswith("_")])
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r01_x")
