@@ -128,10 +128,10 @@ size_t lvdgs_render_scratch_bytes(int64_t num_rendered, int32_t width, int32_t h
 size_t lvdgs_backward_scratch_bytes(int32_t num_gaussians, int64_t num_rendered);
 
 /* ---- rasterizer ---- */
-/* Projects the Gaussians, depth-sorts them and counts (Gaussian, tile) pairs.  Writes radii and
+/* Projects the Gaussians and counts (Gaussian, tile) pairs.  Writes radii and
  * geom_state; returns the pair count D in *num_rendered (synchronises the stream once). */
 int lvdgs_forward_prepare(const lvdgs_args *a, int64_t *num_rendered, void *stream);
-/* Bins pairs per tile, orders each tile's list by depth and composites front to back.
+/* Groups the pairs by tile, orders each tile's list by (depth, id) and composites front to back.
  * Writes out_color / out_depth / out_opacity / n_touched, binning_state and image_state. */
 int lvdgs_forward_render(const lvdgs_args *a, void *stream);
 /* Single-call forward without a pipeline bubble.  The caller sizes binning_state and scratch for
@@ -154,8 +154,7 @@ typedef struct lvdgs_state_layout {
     size_t geom_rec;           /* N x 12 float: x, y, conic a, b, c, opacity, r, g, b, view depth,
                                   (unused), i32 radius */
     size_t geom_tiles_touched; /* N x u32 */
-    size_t geom_order;         /* N x u32: depth rank -> Gaussian id */
-    size_t geom_offsets;       /* N x u32: inclusive scan of tiles_touched in rank order */
+    size_t geom_slot_base;     /* N x u32: exclusive scan of tiles_touched in id order (first pair of a Gaussian) */
     /* byte offsets into binning_state */
     size_t bin_point_list;     /* D x u32: Gaussian ids, (tile, depth, id) ordered */
     size_t bin_tile_keys;      /* D x u32: tile id of each entry of point_list */

@@ -64,7 +64,7 @@ class SsimArgs(C.Structure):
 
 class StateLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
-        "geom_rec", "geom_tiles_touched", "geom_order", "geom_offsets", "bin_point_list", "bin_tile_keys",
+        "geom_rec", "geom_tiles_touched", "geom_slot_base", "bin_point_list", "bin_tile_keys",
         "img_ranges", "img_final_T", "img_n_contrib")]
 
 

@@ -109,8 +109,6 @@ size_t geom_layout(int N, GeomView *v, void *base) {
     const size_t n = (size_t)(N > 0 ? N : 1);
     carve(v->rec, n * REC_FLOATS, b, off);
     carve(v->tiles_touched, n, b, off);
-    carve(v->order, n, b, off);
-    carve(v->offsets, n, b, off);
     carve(v->slot_base, n, b, off);
     carve(v->total, 64, b, off);
     return off;
@@ -123,15 +121,7 @@ size_t prep_scratch_layout(int N, PrepScratch *v, void *base) {
     if (!v) v = &tmp;
     size_t off = 0;
     char *b = (char *)base;
-    const size_t n = (size_t)(N > 0 ? N : 1);
-    carve(v->keys[0], n, b, off);
-    carve(v->keys[1], n, b, off);
-    carve(v->vals[0], n, b, off);
-    carve(v->vals[1], n, b, off);
-    carve(v->hist, radix_hist_entries(N), b, off);
-    carve(v->totals, (size_t)1 << SORT_MAX_BITS, b, off);
-    carve(v->blocksums, 2 * scan_blocks(N), b, off);
-    carve(v->total, 64, b, off);
+    carve(v->blocksums, scan_blocks(N), b, off);
     return off;
 }
 
@@ -153,6 +143,8 @@ size_t image_layout(int W, int H, ImageView *v, void *base) {
     char *b = (char *)base;
     const size_t P = (size_t)W * H, T = (size_t)cdiv(W, TILE) * cdiv(H, TILE);
     carve(v->ranges, T ? T : 1, b, off);
+    carve(v->long_count, 64, b, off);  // directly behind ranges: one memset clears both
+    carve(v->long_tiles, 2 * (T ? T : 1), b, off);  // two queues of up to T tile ids
     carve(v->final_T, P ? P : 1, b, off);
     carve(v->n_contrib, P ? P : 1, b, off);
     return off;
@@ -235,7 +227,7 @@ int lvdgs_state_layout_query(int32_t N, int64_t D, int32_t W, int32_t H, lvdgs_s
     GeomView g; BinView b; ImageView im;
     geom_layout(N, &g, base); bin_layout(D, &b, base); image_layout(W, H, &im, base);
     out->geom_rec = (char *)g.rec - base; out->geom_tiles_touched = (char *)g.tiles_touched - base;
-    out->geom_order = (char *)g.order - base; out->geom_offsets = (char *)g.offsets - base;
+    out->geom_slot_base = (char *)g.slot_base - base;
     out->bin_point_list = (char *)b.point_list - base; out->bin_tile_keys = (char *)b.tile_keys - base;
     out->img_ranges = (char *)im.ranges - base; out->img_final_T = (char *)im.final_T - base;
     out->img_n_contrib = (char *)im.n_contrib - base;
@@ -265,22 +257,16 @@ int get_probe(PairProbe **out) {
     return LVDGS_OK;
 }
 
-// preprocess -> depth sort -> prefix sum of tiles touched; the pair count ends up in g.total (device)
+// preprocess -> prefix sum of tiles touched; the pair count ends up in g.total (device)
 int enqueue_prepare(const lvdgs_args *a, const GeomView &g, hipStream_t s) {
     const int N = a->num_gaussians;
     PrepScratch w;
     prep_scratch_layout(N, &w, a->scratch);
-    // ping-pong so that the sorted ids land in geom_state's `order` array without a copy
-    const bool even = (radix_num_passes(32) % 2) == 0;
-    uint32_t *va = even ? g.order : w.vals[0], *vb = even ? w.vals[0] : g.order;
-    if (int e = launch_preprocess_fwd(*a, g, w.keys[0], va, s)) return e;
-    bool in_a = true;
-    if (int e = radix_sort_pairs(w.keys[0], va, w.keys[1], vb, N, 32, w.hist, w.totals, &in_a, a->debug, s)) return e;
-    if ((in_a ? va : vb) != g.order) { set_error("internal: depth order not in geom_state"); return LVDGS_E_INVALID; }
-    return launch_offsets_scan(g.tiles_touched, g.order, g.offsets, g.slot_base, w.blocksums, g.total, N, a->debug, s);
+    if (int e = launch_preprocess_fwd(*a, g, s)) return e;
+    return launch_slot_scan(g.tiles_touched, g.slot_base, w.blocksums, g.total, N, a->debug, s);
 }
 
-// pair emission -> tile sort -> ranges -> blend.  `cap` sizes grids and buffers; when `count_on_device`
+// pair emission -> grouping by tile -> ranges -> depth order inside each tile -> blend.  `cap` sizes grids and buffers; when `count_on_device`
 // the kernels take the actual pair count from g.total (clamped to cap), otherwise cap IS the count.
 int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipStream_t s) {
     const int N = a->num_gaussians, W = a->image_width, H = a->image_height;
@@ -306,7 +292,10 @@ int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipSt
         if (int e = radix_sort_pairs(k0, v0, k1, v1, cap, bits, w.hist, w.totals, &in_first, a->debug, s, count)) return e;
         if ((in_first ? k0 : k1) != b.tile_keys) { set_error("internal: sorted list not in binning_state"); return LVDGS_E_INVALID; }
     }
-    if (int e = launch_tile_ranges(b.tile_keys, cap, count, im.ranges, num_tiles, a->debug, s)) return e;
+    if (int e = launch_tile_ranges(b.tile_keys, cap, count, im, num_tiles, a->debug, s)) return e;
+    // the radix ping-pong buffers are free again: they hold the 64-bit keys of over-long segments
+    if (cap > 0)
+        if (int e = launch_tile_depth_sort(im, num_tiles, g.rec, b.point_list, w.keys, a->debug, s)) return e;
     return launch_blend_fwd(*a, g, b, im, s);
 }
 

@@ -6,19 +6,17 @@ namespace lvdgs {
 
 namespace {
 
-// One lane per depth rank.  A Gaussian's pairs occupy [offsets[s] - tiles, offsets[s]) of the
+// One lane per Gaussian, in id order.  A Gaussian's pairs occupy [slot_base[i], slot_base[i] + tiles) of the
 // unsorted pair list, tiles in row-major order of its rectangle.
-__global__ void __launch_bounds__(256) emit_pairs_kernel(int N, int gx, int gy, const uint32_t *__restrict__ order,
-                                                         const uint32_t *__restrict__ offsets,
+__global__ void __launch_bounds__(256) emit_pairs_kernel(int N, int gx, int gy, const uint32_t *__restrict__ slot_base,
                                                          const uint32_t *__restrict__ tiles_touched, const float *__restrict__ rec,
                                                          uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ ids,
                                                          uint32_t capacity) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= N) return;
-    const uint32_t id = order[s];
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= (uint32_t)N) return;
     const uint32_t cnt = tiles_touched[id];
     if (cnt == 0) return;
-    const uint32_t first = offsets[s] - cnt;
+    const uint32_t first = slot_base[id];
     const float4 *r4 = reinterpret_cast<const float4 *>(rec + (size_t)id * REC_FLOATS);
     const float4 r0 = r4[0];
     const int rad = __float_as_int(r4[2].w);
@@ -56,18 +54,20 @@ int launch_emit_pairs(const lvdgs_args &a, const GeomView &g, uint32_t *tile_key
     if (N == 0) return LVDGS_OK;
     const int gx = (a.image_width + TILE - 1) / TILE, gy = (a.image_height + TILE - 1) / TILE;
     ProfScope ps("emit_pairs", s);
-    hipLaunchKernelGGL(emit_pairs_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, N, gx, gy, g.order, g.offsets, g.tiles_touched,
+    hipLaunchKernelGGL(emit_pairs_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, N, gx, gy, g.slot_base, g.tiles_touched,
                        g.rec, tile_keys, ids, (uint32_t)capacity);
     LVDGS_LAUNCH_CHECK("emit_pairs", a.debug, s);
     return LVDGS_OK;
 }
 
-int launch_tile_ranges(const uint32_t *tile_keys, int64_t D, const uint32_t *D_dev, uint2 *ranges, int num_tiles, int dbg,
+int launch_tile_ranges(const uint32_t *tile_keys, int64_t D, const uint32_t *D_dev, const ImageView &im, int num_tiles, int dbg,
                        hipStream_t s) {
-    if (int e = check_hip(hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)num_tiles, s), "memset ranges")) return e;
+    // empty tiles keep (0, 0); the counter of over-long segments sits right behind the ranges and is cleared with them
+    const size_t bytes = (size_t)((char *)(im.long_count + 64) - (char *)im.ranges);
+    if (int e = check_hip(hipMemsetAsync(im.ranges, 0, bytes, s), "memset ranges")) return e;
     if (D == 0) return LVDGS_OK;
     ProfScope ps("tile_ranges", s);
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, tile_keys, D, D_dev, ranges);
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(cdiv(D, 256)), dim3(256), 0, s, tile_keys, D, D_dev, im.ranges);
     LVDGS_LAUNCH_CHECK("tile_ranges", dbg, s);
     return LVDGS_OK;
 }

@@ -56,18 +56,11 @@ struct ProfScope {
 struct GeomView {
     float *rec;              // N*12
     uint32_t *tiles_touched; // N
-    uint32_t *order;         // N
-    uint32_t *offsets;       // N: inclusive scan of tiles_touched in depth-rank order
-    uint32_t *slot_base;     // N: exclusive scan of tiles_touched in id order (where a Gaussian's partial gradients go)
+    uint32_t *slot_base;     // N: exclusive scan of tiles_touched in id order: first pair / gradient slot of a Gaussian
     uint32_t *total;         // 1: pair count D of this frame (device copy)
 };
 struct PrepScratch {
-    uint32_t *keys[2];   // N each (depth bits)
-    uint32_t *vals[2];   // N each
-    uint32_t *hist;      // nbins * nblk
-    uint32_t *totals;    // nbins
     uint32_t *blocksums; // scan block sums
-    uint32_t *total;     // 1: D
 };
 struct RenderScratch {
     uint32_t *keys;  // D (alternate tile-key buffer)
@@ -81,6 +74,8 @@ struct BinView {
 };
 struct ImageView {
     uint2 *ranges;       // T
+    uint32_t *long_count; // 2 (+ padding): lengths of the two queues of over-long segments; zeroed with ranges
+    uint32_t *long_tiles; // 2 T: the queues (tile ids)
     float *final_T;      // P
     uint32_t *n_contrib; // P
 };
@@ -98,7 +93,7 @@ size_t bwd_scratch_layout(int N, int64_t D, BwdScratch *v, void *base);
 int tile_sort_bits(int W, int H);  // number of key bits to sort for the tile id
 
 // ---- launchers (one per kernel family; all enqueue on `stream` and return a status) ----
-int launch_preprocess_fwd(const lvdgs_args &a, const GeomView &g, uint32_t *depth_keys, uint32_t *ids, hipStream_t s);
+int launch_preprocess_fwd(const lvdgs_args &a, const GeomView &g, hipStream_t s);
 int launch_preprocess_bwd(const lvdgs_args &a, const GeomView &g, const BwdScratch &b, hipStream_t s);
 int launch_mark_visible(int N, const float *means3D, const float *view, uint8_t *present, hipStream_t s);
 
@@ -110,13 +105,15 @@ int radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint3
 int radix_num_passes(int total_bits);
 size_t radix_hist_entries(int64_t n);
 
-// offsets[s] = inclusive scan over s of tiles_touched[order[s]]; slot_base[i] = exclusive scan over i of
-// tiles_touched[i]; *total_dev = last value.  blocksums holds 2 * scan blocks entries.
-int launch_offsets_scan(const uint32_t *tiles_touched, const uint32_t *order, uint32_t *offsets, uint32_t *slot_base,
-                        uint32_t *blocksums, uint32_t *total_dev, int N, int dbg, hipStream_t s);
+// slot_base[i] = exclusive scan over i of tiles_touched[i]; *total_dev = the sum (pair count D)
+int launch_slot_scan(const uint32_t *tiles_touched, uint32_t *slot_base, uint32_t *blocksums, uint32_t *total_dev, int N, int dbg,
+                     hipStream_t s);
 
 int launch_emit_pairs(const lvdgs_args &a, const GeomView &g, uint32_t *tile_keys, uint32_t *ids, int64_t capacity, hipStream_t s);
-int launch_tile_ranges(const uint32_t *tile_keys, int64_t D, const uint32_t *D_dev, uint2 *ranges, int num_tiles, int dbg,
+// sorts every tile's segment of point_list by (view-depth bits, id); keys64: scratch for D 64-bit keys (long segments)
+int launch_tile_depth_sort(const ImageView &im, int num_tiles, const float *rec, uint32_t *point_list, void *keys64, int dbg,
+                           hipStream_t s);
+int launch_tile_ranges(const uint32_t *tile_keys, int64_t D, const uint32_t *D_dev, const ImageView &im, int num_tiles, int dbg,
                        hipStream_t s);
 
 int launch_blend_fwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, hipStream_t s);

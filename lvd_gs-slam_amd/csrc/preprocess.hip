@@ -167,7 +167,7 @@ struct FwdParams {
     int N, act;
     const float *means3D, *opacities, *scales, *rotations, *cov3D_precomp, *shs, *colors_precomp;
     float *rec;
-    uint32_t *tiles_touched, *depth_keys, *ids;
+    uint32_t *tiles_touched;
     int32_t *radii;
 };
 
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(FwdParams p) {
     const Cam &c = p.cam;
     // culled unless proven visible
     int radius = 0;
-    uint32_t tiles = 0, key = 0xFFFFFFFFu;
+    uint32_t tiles = 0;
     float pos[3] = {p.means3D[3 * i], p.means3D[3 * i + 1], p.means3D[3 * i + 2]};
     float pv[3];
     xform3(pos, c.view, pv);
@@ -239,7 +239,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(FwdParams p) {
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) { rgb[ch] += 0.5f; rgb[ch] = rgb[ch] < 0.f ? 0.f : rgb[ch]; }
                 }
-                radius = rad; tiles = (uint32_t)area; key = __float_as_uint(pv[2]);
+                radius = rad; tiles = (uint32_t)area;
                 float4 *r4 = reinterpret_cast<float4 *>(p.rec + (size_t)i * REC_FLOATS);
                 r4[0] = make_float4(px, py, k0, k1);
                 float opac = p.opacities[i];
@@ -251,8 +251,6 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(FwdParams p) {
     }
     p.radii[i] = radius;
     p.tiles_touched[i] = tiles;
-    p.depth_keys[i] = key;
-    p.ids[i] = (uint32_t)i;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -539,13 +537,13 @@ Cam make_cam(const lvdgs_args &a) {
 
 }  // namespace
 
-int launch_preprocess_fwd(const lvdgs_args &a, const GeomView &g, uint32_t *depth_keys, uint32_t *ids, hipStream_t s) {
+int launch_preprocess_fwd(const lvdgs_args &a, const GeomView &g, hipStream_t s) {
     if (a.num_gaussians == 0) return LVDGS_OK;
     FwdParams p;
     p.cam = make_cam(a); p.N = a.num_gaussians; p.act = a.activations;
     p.means3D = a.means3D; p.opacities = a.opacities; p.scales = a.scales; p.rotations = a.rotations;
     p.cov3D_precomp = a.cov3D_precomp; p.shs = a.shs; p.colors_precomp = a.colors_precomp;
-    p.rec = g.rec; p.tiles_touched = g.tiles_touched; p.depth_keys = depth_keys; p.ids = ids; p.radii = a.radii;
+    p.rec = g.rec; p.tiles_touched = g.tiles_touched; p.radii = a.radii;
     ProfScope ps("preprocess_fwd", s);
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(cdiv(p.N, 256)), dim3(256), 0, s, p);
     LVDGS_LAUNCH_CHECK("preprocess_fwd", a.debug, s);

@@ -1,10 +1,9 @@
 // Stable LSD radix sort of (u32 key, u32 value) pairs and the tiles-touched prefix sum.
 //
-// The sort is what gives every tile its depth-ordered Gaussian list.  Instead of one sort of
-// D 64-bit (tile | depth) keys, the N Gaussians are sorted once by their 32-bit depth key and the
-// D (Gaussian, tile) pairs -- emitted in that depth order -- are then sorted by tile id only
-// (<= 16 bits).  Both sorts are stable, so the result is the (tile, depth, Gaussian id) order a
-// stable sort of the 64-bit keys gives, at a fraction of the HBM traffic.
+// The sort groups the D (Gaussian, tile) pairs by tile id (<= 16 bits) instead of sorting D 64-bit
+// (tile | depth) keys; being stable, it leaves every tile's segment in emission (Gaussian id) order, and
+// tilesort.hip then orders each segment by (depth, id) in LDS.  Together that is the (tile, depth, id) order a
+// stable sort of the 64-bit keys gives, at a fraction of the HBM traffic and launches.
 //
 // One radix pass = three launches, no inter-workgroup communication inside a launch:
 //   radix_hist    per-workgroup digit histogram          -> hist[digit][workgroup]
@@ -197,72 +196,54 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
     return incl - v;
 }
 
-// Two scans of tiles_touched share the three launches: in depth-rank order (pair emission) and in id order
-// (slots of the per-pair partial gradients).  blocksums = [rank-order sums | id-order sums].
-__global__ void __launch_bounds__(SCAN_THREADS) scan_reduce_kernel(const uint32_t *__restrict__ tt,
-                                                                   const uint32_t *__restrict__ order, int N,
-                                                                   uint32_t *__restrict__ blocksums, int nblk) {
+// slot_base[i] = exclusive scan over i of tiles_touched[i]: where Gaussian i's pairs (and, in the backward pass, its
+// per-pair partial gradients) start in the unsorted pair list.
+__global__ void __launch_bounds__(SCAN_THREADS) scan_reduce_kernel(const uint32_t *__restrict__ tt, int N,
+                                                                   uint32_t *__restrict__ blocksums) {
     __shared__ uint32_t s[SCAN_THREADS];
-    uint32_t sum = 0, sum_id = 0;
+    uint32_t sum = 0;
     const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_IPT;
 #pragma unroll
     for (int k = 0; k < SCAN_IPT; k++)
-        if (base + k < N) {
-            sum += tt[order[base + k]];
-            sum_id += tt[base + k];
-        }
+        if (base + k < N) sum += tt[base + k];
     uint32_t total;
     block_exclusive_scan(sum, s, &total);
     if (threadIdx.x == 0) blocksums[blockIdx.x] = total;
-    block_exclusive_scan(sum_id, s, &total);
-    if (threadIdx.x == 0) blocksums[nblk + blockIdx.x] = total;
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS) scan_blocksums_kernel(uint32_t *__restrict__ blocksums, int nblk,
                                                                       uint32_t *__restrict__ total_out) {
     __shared__ uint32_t s[SCAN_THREADS];
-    for (int which = 0; which < 2; which++) {
-        uint32_t *sums = blocksums + (size_t)which * nblk;
-        uint32_t carry = 0;
-        for (int b0 = 0; b0 < nblk; b0 += SCAN_THREADS) {
-            const int b = b0 + threadIdx.x;
-            const uint32_t v = b < nblk ? sums[b] : 0u;
-            uint32_t total;
-            const uint32_t ex = block_exclusive_scan(v, s, &total);
-            if (b < nblk) sums[b] = carry + ex;
-            carry += total;
-        }
-        if (which == 0 && threadIdx.x == 0) *total_out = carry;
+    uint32_t carry = 0;
+    for (int b0 = 0; b0 < nblk; b0 += SCAN_THREADS) {
+        const int b = b0 + threadIdx.x;
+        const uint32_t v = b < nblk ? blocksums[b] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive_scan(v, s, &total);
+        if (b < nblk) blocksums[b] = carry + ex;
+        carry += total;
     }
+    if (threadIdx.x == 0) *total_out = carry;
 }
 
-__global__ void __launch_bounds__(SCAN_THREADS) scan_apply_kernel(const uint32_t *__restrict__ tt,
-                                                                  const uint32_t *__restrict__ order, int N,
-                                                                  const uint32_t *__restrict__ blocksums, int nblk,
-                                                                  uint32_t *__restrict__ offsets,
+__global__ void __launch_bounds__(SCAN_THREADS) scan_apply_kernel(const uint32_t *__restrict__ tt, int N,
+                                                                  const uint32_t *__restrict__ blocksums,
                                                                   uint32_t *__restrict__ slot_base) {
     __shared__ uint32_t s[SCAN_THREADS];
-    uint32_t v[SCAN_IPT], u[SCAN_IPT];
-    uint32_t sum = 0, sum_id = 0;
+    uint32_t v[SCAN_IPT];
+    uint32_t sum = 0;
     const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_IPT;
 #pragma unroll
     for (int k = 0; k < SCAN_IPT; k++) {
-        v[k] = base + k < N ? tt[order[base + k]] : 0u;
-        u[k] = base + k < N ? tt[base + k] : 0u;
+        v[k] = base + k < N ? tt[base + k] : 0u;
         sum += v[k];
-        sum_id += u[k];
     }
     uint32_t total;
     uint32_t run = block_exclusive_scan(sum, s, &total) + blocksums[blockIdx.x];
-    uint32_t run_id = block_exclusive_scan(sum_id, s, &total) + blocksums[nblk + blockIdx.x];
 #pragma unroll
     for (int k = 0; k < SCAN_IPT; k++) {
+        if (base + k < N) slot_base[base + k] = run;
         run += v[k];
-        if (base + k < N) {
-            offsets[base + k] = run;       // inclusive
-            slot_base[base + k] = run_id;  // exclusive
-        }
-        run_id += u[k];
     }
 }
 
@@ -311,15 +292,15 @@ int radix_sort_pairs(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint3
     return LVDGS_OK;
 }
 
-int launch_offsets_scan(const uint32_t *tiles_touched, const uint32_t *order, uint32_t *offsets, uint32_t *slot_base,
-                        uint32_t *blocksums, uint32_t *total_dev, int N, int dbg, hipStream_t s) {
+int launch_slot_scan(const uint32_t *tiles_touched, uint32_t *slot_base, uint32_t *blocksums, uint32_t *total_dev, int N, int dbg,
+                     hipStream_t s) {
     if (N == 0) {
         return check_hip(hipMemsetAsync(total_dev, 0, sizeof(uint32_t), s), "memset total");
     }
     const int nblk = cdiv(N, SCAN_CHUNK);
     {
         ProfScope ps("scan_reduce", s);
-        hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblk), dim3(SCAN_THREADS), 0, s, tiles_touched, order, N, blocksums, nblk);
+        hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblk), dim3(SCAN_THREADS), 0, s, tiles_touched, N, blocksums);
         LVDGS_LAUNCH_CHECK("scan_reduce", dbg, s);
     }
     {
@@ -329,8 +310,7 @@ int launch_offsets_scan(const uint32_t *tiles_touched, const uint32_t *order, ui
     }
     {
         ProfScope ps("scan_apply", s);
-        hipLaunchKernelGGL(scan_apply_kernel, dim3(nblk), dim3(SCAN_THREADS), 0, s, tiles_touched, order, N, blocksums, nblk, offsets,
-                           slot_base);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(nblk), dim3(SCAN_THREADS), 0, s, tiles_touched, N, blocksums, slot_base);
         LVDGS_LAUNCH_CHECK("scan_apply", dbg, s);
     }
     return LVDGS_OK;

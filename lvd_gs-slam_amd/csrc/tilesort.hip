@@ -1,0 +1,229 @@
+// Depth order inside every tile's list.
+//
+// The (Gaussian, tile) pairs are emitted in Gaussian-id order and grouped by tile with a stable radix sort on
+// the tile id alone, so each tile's segment of point_list arrives in id order.  This file sorts every segment by
+// the 64-bit key (view-depth bits << 32 | id): exactly the order a stable sort of (tile << 32 | depth) keys
+// over depth-presorted pairs gives (ties between equal depths go to the smaller id), without ever sorting the
+// N Gaussians globally -- that sort was 12 latency-bound launches (~115 us at 0.5 M Gaussians), while the
+// segments here are a few hundred entries each and sort independently in LDS.
+//
+// Size classes (bitonic networks throughout):
+//   <= 512 entries: ONE WAVE per tile, keys in registers (4 or 8 per lane): strides inside a lane are register
+//      compare-exchanges, strides across lanes one 64-bit lane shuffle per key; no LDS array, no barrier.  This
+//      is the common case by far (a few hundred entries per tile) and ~8x fewer instructions than a
+//      workgroup-wide LDS network, whose threads mostly wait at barriers;
+//   <= 2048 entries: queued, then one 256-thread workgroup per segment on 16 KiB of LDS;
+//   <= 16384 entries: queued again, 1024 threads on 128 KiB of LDS;
+//   longer: the same network in place on global memory (64-bit key scratch).
+// The queues are filled with one atomic per over-long segment and cleared together with the tile ranges.
+#include "common.hpp"
+#include "device_utils.hpp"
+
+namespace lvdgs {
+namespace {
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ u64 depth_key(const float *__restrict__ rec, uint32_t id) {
+    return ((u64)__float_as_uint(rec[(size_t)id * REC_FLOATS + 9]) << 32) | (u64)id;
+}
+
+// All-ascending bitonic network (every merge starts with a mirrored compare, so no direction flags).  With the
+// tail beyond n treated as +infinity an exchange whose partner lies beyond n can never swap, so a segment of
+// any length sorts in place without padding.
+// Thread t owns compare-exchange t (+ multiples of the workgroup size) of every stage; for strides j <= 64 a
+// wave's 64 exchanges stay inside one aligned block of 128 elements, the same block in every such stage, so
+// those stages only need the wave's own LDS accesses ordered -- a workgroup barrier is paid for j >= 128 only
+// (1 of 36 stages at 256 elements, 10 of 66 at 2048).
+template <bool GLOBAL, typename Ptr>
+__device__ __forceinline__ void bitonic_sort_ascending(Ptr s, int n, int tid, int nthreads) {
+    int lpad = 0;
+    while ((1 << lpad) < n) lpad++;
+    const int half = (1 << lpad) >> 1;
+    for (int lk = 1; lk <= lpad; lk++) {
+        const int k = 1 << lk;
+        for (int lj = lk - 1; lj >= 0; lj--) {
+            const int j = 1 << lj;
+            const bool mirror = lj == lk - 1;
+            for (int t = tid; t < half; t += nthreads) {
+                const int blk = t >> lj, w = t & (j - 1);
+                const int i = (blk << (lj + 1)) | w;
+                const int p = mirror ? (blk << lk) + (k - 1 - w) : i + j;
+                if (p < n) {
+                    const u64 a = s[i], b = s[p];
+                    if (a > b) { s[i] = b; s[p] = a; }
+                }
+            }
+            if (GLOBAL) {
+                __threadfence_block();
+                __syncthreads();
+            } else if (j >= 128) {
+                __syncthreads();
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        // the next merge starts with a mirrored exchange over blocks of 2k: if that crosses waves, meet first
+        if (!GLOBAL && k >= 128 && k < (1 << lpad)) __syncthreads();
+    }
+}
+
+__device__ __forceinline__ u64 shuffle_xor64(u64 v, int lane_mask) {
+    const int lo = __shfl_xor((int)(uint32_t)v, lane_mask, 64), hi = __shfl_xor((int)(uint32_t)(v >> 32), lane_mask, 64);
+    return ((u64)(uint32_t)hi << 32) | (u64)(uint32_t)lo;
+}
+
+// Classic bitonic network over 64 * E keys held E per lane (element e = lane * E + r), ascending.
+template <int E>
+__device__ __forceinline__ void wave_bitonic_sort(u64 (&key)[E], int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64 * E; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= E) {
+                // partner element e ^ j lives in lane ^ (j / E), same register; the direction of the k-block and which
+                // side of the pair this lane is on are lane-uniform
+                const bool ascending = k >= 64 * E || (lane & (k / E)) == 0;
+                const bool keep_min = ((lane & (j / E)) == 0) == ascending;
+#pragma unroll
+                for (int r = 0; r < E; r++) {
+                    const u64 other = shuffle_xor64(key[r], j / E);
+                    const bool take = keep_min ? other < key[r] : other > key[r];
+                    key[r] = take ? other : key[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < E; r++) {
+                    if ((r & j) == 0) {
+                        const bool ascending = k < E ? (r & k) == 0 : (k >= 64 * E || (lane & (k / E)) == 0);
+                        const u64 a = key[r], b = key[r | j];
+                        const bool swap = ascending ? a > b : a < b;
+                        key[r] = swap ? b : a;
+                        key[r | j] = swap ? a : b;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int E>
+__device__ __forceinline__ void wave_sort_segment(const float *__restrict__ rec, uint32_t *__restrict__ seg, int n, int lane) {
+    u64 key[E];
+#pragma unroll
+    for (int r = 0; r < E; r++) {
+        const int i = r * 64 + lane;  // any assignment of elements to slots will do before sorting
+        key[r] = i < n ? depth_key(rec, seg[i]) : ~0ull;
+    }
+    wave_bitonic_sort<E>(key, lane);
+#pragma unroll
+    for (int r = 0; r < E; r++) {
+        const int e = lane * E + r;
+        if (e < n) seg[e] = (uint32_t)key[r];
+    }
+}
+
+constexpr int CLASS_W = 512;  // longest segment one wave sorts in registers
+
+// one wave per tile; longer segments are queued for the workgroup kernels
+__global__ void __launch_bounds__(256) tile_depth_sort_wave_kernel(const uint2 *__restrict__ ranges, int num_tiles,
+                                                                   const float *__restrict__ rec, uint32_t *__restrict__ point_list,
+                                                                   uint32_t *queue_count, uint32_t *__restrict__ queue) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= num_tiles) return;
+    const uint2 r = ranges[tile];
+    const int n = (int)(r.y - r.x);
+    if (n < 2) return;
+    if (n <= 256) wave_sort_segment<4>(rec, point_list + r.x, n, lane);
+    else if (n <= CLASS_W) wave_sort_segment<8>(rec, point_list + r.x, n, lane);
+    else if (lane == 0) queue[atomicAdd(queue_count, 1u)] = (uint32_t)tile;
+}
+
+constexpr int CLASS_A = 2048, CLASS_B = 16384;
+
+// queued segments up to CLASS_A entries: one workgroup each on LDS; longer ones are queued once more
+__global__ void __launch_bounds__(256) tile_depth_sort_kernel(const uint2 *__restrict__ ranges, const float *__restrict__ rec,
+                                                              uint32_t *__restrict__ point_list, const uint32_t *queue_count,
+                                                              const uint32_t *__restrict__ queue, uint32_t *long_count,
+                                                              uint32_t *__restrict__ long_tiles) {
+    __shared__ u64 s_keys[CLASS_A];
+    const int tid = threadIdx.x;
+    const int count = (int)*queue_count;
+    for (int q = blockIdx.x; q < count; q += gridDim.x) {
+        const uint32_t tile = queue[q];
+        const uint2 r = ranges[tile];
+        const int n = (int)(r.y - r.x);
+        if (n > CLASS_A) {
+            if (tid == 0) long_tiles[atomicAdd(long_count, 1u)] = tile;
+            continue;
+        }
+        for (int i = tid; i < n; i += 256) s_keys[i] = depth_key(rec, point_list[r.x + i]);
+        __syncthreads();
+        bitonic_sort_ascending<false>(s_keys, n, tid, 256);
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) point_list[r.x + i] = (uint32_t)s_keys[i];
+        __syncthreads();
+    }
+}
+
+// queued segments: in 128 KiB of LDS up to CLASS_B entries, in place on global memory beyond
+__global__ void __launch_bounds__(1024) tile_depth_sort_long_kernel(const uint2 *__restrict__ ranges, const float *__restrict__ rec,
+                                                                    uint32_t *__restrict__ point_list, const uint32_t *long_count,
+                                                                    const uint32_t *__restrict__ long_tiles, u64 *keys) {
+    extern __shared__ u64 s_dyn[];
+    const int tid = threadIdx.x;
+    const int count = (int)*long_count;
+    for (int q = blockIdx.x; q < count; q += gridDim.x) {
+        const uint2 r = ranges[long_tiles[q]];
+        const int n = (int)(r.y - r.x);
+        if (n <= CLASS_B) {
+            for (int i = tid; i < n; i += 1024) s_dyn[i] = depth_key(rec, point_list[r.x + i]);
+            __syncthreads();
+            bitonic_sort_ascending<false>(s_dyn, n, tid, 1024);
+            __syncthreads();
+            for (int i = tid; i < n; i += 1024) point_list[r.x + i] = (uint32_t)s_dyn[i];
+        } else {
+            volatile u64 *g = keys + r.x;
+            for (int i = tid; i < n; i += 1024) g[i] = depth_key(rec, point_list[r.x + i]);
+            __threadfence_block();
+            __syncthreads();
+            bitonic_sort_ascending<true>(g, n, tid, 1024);
+            for (int i = tid; i < n; i += 1024) point_list[r.x + i] = (uint32_t)g[i];
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+int launch_tile_depth_sort(const ImageView &im, int num_tiles, const float *rec, uint32_t *point_list, void *keys64, int dbg, hipStream_t s) {
+    if (num_tiles == 0) return LVDGS_OK;
+    static const bool big_lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_depth_sort_long_kernel),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, CLASS_B * 8) == hipSuccess;
+    if (!big_lds_ok) { set_error("tile sort: cannot reserve 128 KiB of LDS"); return LVDGS_E_HIP; }
+    {
+        ProfScope ps("tile_sort", s);
+        hipLaunchKernelGGL(tile_depth_sort_wave_kernel, dim3(cdiv(num_tiles, 4)), dim3(256), 0, s, (const uint2 *)im.ranges, num_tiles, rec,
+                           point_list, im.long_count, im.long_tiles);
+        LVDGS_LAUNCH_CHECK("tile_sort", dbg, s);
+    }
+    // queue 1 (count at long_count[0], entries long_tiles[0 .. T)) -> queue 2 (long_count[1], long_tiles[T .. 2T))
+    uint32_t *q2 = im.long_tiles + num_tiles;
+    {
+        ProfScope ps("tile_sort_mid", s);
+        hipLaunchKernelGGL(tile_depth_sort_kernel, dim3(256), dim3(256), 0, s, (const uint2 *)im.ranges, rec, point_list,
+                           (const uint32_t *)im.long_count, (const uint32_t *)im.long_tiles, im.long_count + 1, q2);
+        LVDGS_LAUNCH_CHECK("tile_sort_mid", dbg, s);
+    }
+    {
+        ProfScope ps("tile_sort_long", s);
+        hipLaunchKernelGGL(tile_depth_sort_long_kernel, dim3(64), dim3(1024), CLASS_B * 8, s, (const uint2 *)im.ranges, rec, point_list,
+                           (const uint32_t *)(im.long_count + 1), (const uint32_t *)q2, (unsigned long long *)keys64);
+        LVDGS_LAUNCH_CHECK("tile_sort_long", dbg, s);
+    }
+    return LVDGS_OK;
+}
+
+}  // namespace lvdgs

@@ -55,8 +55,7 @@ def run_hip(g, cam, W, H, bg, use_sh=False, sh_degree=0, cov_precomp=None, grads
         color=color.detach().cpu().numpy(), depth=depth.detach().cpu().numpy(), opacity=opacity.detach().cpu().numpy(),
         radii=radii.cpu().numpy(), n_touched=n_touched.cpu().numpy(), num_rendered=D, rec=rec, overflowed=st["overflowed"],
         tiles_touched=_view(st["geom"], lay.geom_tiles_touched, N, np.uint32) if N else np.zeros(0, np.uint32),
-        order=_view(st["geom"], lay.geom_order, N, np.uint32) if N else np.zeros(0, np.uint32),
-        offsets=_view(st["geom"], lay.geom_offsets, N, np.uint32) if N else np.zeros(0, np.uint32),
+        slot_base=_view(st["geom"], lay.geom_slot_base, N, np.uint32) if N else np.zeros(0, np.uint32),
         point_list=_view(st["binning"], lay.bin_point_list, D, np.uint32) if D else np.zeros(0, np.uint32),
         tile_keys=_view(st["binning"], lay.bin_tile_keys, D, np.uint32) if D else np.zeros(0, np.uint32),
         ranges=_view(st["image"], lay.img_ranges, NT * 2, np.uint32).reshape(NT, 2),

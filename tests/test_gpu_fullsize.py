@@ -27,8 +27,10 @@ def scene():
 def test_lists_are_sorted_and_partitioned(scene):
     f, W, H = scene["f"], scene["W"], scene["H"]
     D = f["num_rendered"]
-    assert D == int(f["tiles_touched"].sum()) == int(f["offsets"].max())
-    assert sorted(f["order"].tolist()) == list(range(scene["N"]))  # a permutation
+    assert D == int(f["tiles_touched"].sum()) == int(f["slot_base"][-1]) + int(f["tiles_touched"][-1])
+    assert np.array_equal(f["slot_base"], np.concatenate([[0], np.cumsum(f["tiles_touched"], dtype=np.uint64)[:-1]]).astype(np.uint32))
+    # every (Gaussian, tile) pair appears exactly once: per-Gaussian multiplicities equal tiles_touched
+    assert np.array_equal(np.bincount(f["point_list"], minlength=scene["N"]).astype(np.uint32), f["tiles_touched"])
     keys = (f["tile_keys"].astype(np.uint64) << np.uint64(32)) | f["rec"][:, 9].view(np.uint32)[f["point_list"]].astype(np.uint64)
     assert np.all(keys[1:] >= keys[:-1])  # (tile, depth) non-decreasing
     same = keys[1:] == keys[:-1]
