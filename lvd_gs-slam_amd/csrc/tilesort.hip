@@ -69,43 +69,65 @@ __device__ __forceinline__ void bitonic_sort_ascending(Ptr s, int n, int tid, in
     }
 }
 
-__device__ __forceinline__ u64 shuffle_xor64(u64 v, int lane_mask) {
-    const int lo = __shfl_xor((int)(uint32_t)v, lane_mask, 64), hi = __shfl_xor((int)(uint32_t)(v >> 32), lane_mask, 64);
-    return ((u64)(uint32_t)hi << 32) | (u64)(uint32_t)lo;
+// value of lane ^ MASK.  Distances 1, 2, 4, 8 are DPP moves inside a row of 16 lanes (no LDS round trip):
+// quad_perm for 1 and 2, row_ror:8 for 8, and 4 = 7 ^ 3 (row_half_mirror, then quad_perm [3,2,1,0]);
+// 16 and 32 go through the LDS crossbar (ds_bpermute).
+template <int MASK>
+__device__ __forceinline__ uint32_t lane_xor32(uint32_t v, int lane) {
+    if (MASK == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    if (MASK == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    if (MASK == 4) {
+        const int t = __builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true);                 // row_half_mirror: i ^ 7
+        return (uint32_t)__builtin_amdgcn_mov_dpp(t, 0x1B, 0xf, 0xf, true);                    // quad_perm [3,2,1,0]: i ^ 3
+    }
+    if (MASK == 8) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xf, 0xf, true);  // row_ror:8
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ MASK) << 2, (int)v);
 }
 
-// Classic bitonic network over 64 * E keys held E per lane (element e = lane * E + r), ascending.
-template <int E>
-__device__ __forceinline__ void wave_bitonic_sort(u64 (&key)[E], int lane) {
+template <int MASK>
+__device__ __forceinline__ u64 lane_xor64(u64 v, int lane) {
+    return ((u64)lane_xor32<MASK>((uint32_t)(v >> 32), lane) << 32) | (u64)lane_xor32<MASK>((uint32_t)v, lane);
+}
+
+// Classic bitonic network over 64 * E keys held E per lane (element e = lane * E + r), ascending.  Keys are
+// distinct (the id is part of the key), so "take the other key" is one comparison xor a per-stage lane mask.
+template <int E, int K, int J>
+__device__ __forceinline__ void wave_bitonic_stage(u64 (&key)[E], int lane) {
+    if constexpr (J >= E) {
+        // partner element e ^ J lives in lane ^ (J / E), same register; the direction of the K-block and which side
+        // of the pair this lane is on are the same for all its registers
+        const bool ascending = K >= 64 * E || (lane & (K / E)) == 0;
+        const bool keep_min = ((lane & (J / E)) == 0) == ascending;
+        u64 other[E];  // all the lane exchanges first: they are independent, the selects then follow without stalls
 #pragma unroll
-    for (int k = 2; k <= 64 * E; k <<= 1) {
+        for (int r = 0; r < E; r++) other[r] = lane_xor64<J / E>(key[r], lane);
 #pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j >= E) {
-                // partner element e ^ j lives in lane ^ (j / E), same register; the direction of the k-block and which
-                // side of the pair this lane is on are lane-uniform
-                const bool ascending = k >= 64 * E || (lane & (k / E)) == 0;
-                const bool keep_min = ((lane & (j / E)) == 0) == ascending;
+        for (int r = 0; r < E; r++) key[r] = ((other[r] < key[r]) == keep_min) ? other[r] : key[r];
+    } else {
+        const bool lane_ascending = K >= 64 * E || (lane & (K / E)) == 0;  // used when K >= E
 #pragma unroll
-                for (int r = 0; r < E; r++) {
-                    const u64 other = shuffle_xor64(key[r], j / E);
-                    const bool take = keep_min ? other < key[r] : other > key[r];
-                    key[r] = take ? other : key[r];
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < E; r++) {
-                    if ((r & j) == 0) {
-                        const bool ascending = k < E ? (r & k) == 0 : (k >= 64 * E || (lane & (k / E)) == 0);
-                        const u64 a = key[r], b = key[r | j];
-                        const bool swap = ascending ? a > b : a < b;
-                        key[r] = swap ? b : a;
-                        key[r | j] = swap ? a : b;
-                    }
-                }
+        for (int r = 0; r < E; r++) {
+            if ((r & J) == 0) {
+                const bool ascending = K < E ? (r & K) == 0 : lane_ascending;
+                const u64 a = key[r], b = key[r | J];
+                const bool swap = (a > b) == ascending;
+                key[r] = swap ? b : a;
+                key[r | J] = swap ? a : b;
             }
         }
     }
+    if constexpr (J > 1) wave_bitonic_stage<E, K, J / 2>(key, lane);
+}
+
+template <int E, int K>
+__device__ __forceinline__ void wave_bitonic_merge(u64 (&key)[E], int lane) {
+    wave_bitonic_stage<E, K, K / 2>(key, lane);
+    if constexpr (K < 64 * E) wave_bitonic_merge<E, 2 * K>(key, lane);
+}
+
+template <int E>
+__device__ __forceinline__ void wave_bitonic_sort(u64 (&key)[E], int lane) {
+    wave_bitonic_merge<E, 2>(key, lane);
 }
 
 template <int E>
