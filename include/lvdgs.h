@@ -81,7 +81,7 @@ typedef struct lvdgs_args {
     void *binning_state;  size_t binning_bytes; /*      R w,  B r : lvdgs_binning_bytes(D)        */
     void *image_state;    size_t image_bytes;   /*      R w,  B r : lvdgs_image_bytes(W,H)        */
     void *scratch;        size_t scratch_bytes; /* P: lvdgs_prepare_scratch_bytes(N)
-                                                   R: lvdgs_render_scratch_bytes(D,W,H)
+                                                   R: lvdgs_render_scratch_bytes(N,D,W,H)
                                                    B: lvdgs_backward_scratch_bytes(N,D)           */
     int64_t num_rendered; /* D, as returned by prepare (R B) */
 
@@ -124,7 +124,7 @@ size_t lvdgs_geom_bytes(int32_t num_gaussians);
 size_t lvdgs_prepare_scratch_bytes(int32_t num_gaussians);
 size_t lvdgs_binning_bytes(int64_t num_rendered);
 size_t lvdgs_image_bytes(int32_t width, int32_t height);
-size_t lvdgs_render_scratch_bytes(int64_t num_rendered, int32_t width, int32_t height);
+size_t lvdgs_render_scratch_bytes(int32_t num_gaussians, int64_t num_rendered, int32_t width, int32_t height);
 size_t lvdgs_backward_scratch_bytes(int32_t num_gaussians, int64_t num_rendered);
 
 /* ---- rasterizer ---- */
@@ -135,7 +135,7 @@ int lvdgs_forward_prepare(const lvdgs_args *a, int64_t *num_rendered, void *stre
  * Writes out_color / out_depth / out_opacity / n_touched, binning_state and image_state. */
 int lvdgs_forward_render(const lvdgs_args *a, void *stream);
 /* Single-call forward without a pipeline bubble.  The caller sizes binning_state and scratch for
- * `pair_capacity` pairs (scratch >= max(lvdgs_prepare_scratch_bytes(N), lvdgs_render_scratch_bytes(cap,W,H)));
+ * `pair_capacity` pairs (scratch >= max(lvdgs_prepare_scratch_bytes(N), lvdgs_render_scratch_bytes(N,cap,W,H)));
  * all kernels are enqueued with the pair count left on the device, and only then does the host wait
  * for the count (the GPU is busy with the tile sort and the blend meanwhile).  Returns LVDGS_OK and
  * the count in *num_rendered, or LVDGS_E_CAPACITY when the count exceeds pair_capacity: outputs are

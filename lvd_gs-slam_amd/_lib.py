@@ -109,7 +109,7 @@ def lib():
         L.lvdgs_image_bytes.restype = C.c_size_t
         L.lvdgs_image_bytes.argtypes = [C.c_int32, C.c_int32]
         L.lvdgs_render_scratch_bytes.restype = C.c_size_t
-        L.lvdgs_render_scratch_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+        L.lvdgs_render_scratch_bytes.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32]
         L.lvdgs_backward_scratch_bytes.restype = C.c_size_t
         L.lvdgs_backward_scratch_bytes.argtypes = [C.c_int32, C.c_int64]
         L.lvdgs_forward_prepare.argtypes = [C.POINTER(Args), C.POINTER(C.c_int64), C.c_void_p]

@@ -7,6 +7,8 @@
 #include <string>
 #include <vector>
 
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace lvdgs {
@@ -94,6 +96,13 @@ ProfScope::~ProfScope() {
         }
 }
 
+// Images of up to group_max_tiles() tiles group their pairs by counting (binning.hip); larger ones, or every image
+// when LVDGS_FORCE_RADIX_GROUPING is set in the environment (tests), take the radix sort on the tile id.
+static bool use_counting_path(int num_tiles) {
+    static const bool forced = getenv("LVDGS_FORCE_RADIX_GROUPING") != nullptr;
+    return !forced && num_tiles <= group_max_tiles();
+}
+
 // ---------------------------------------------------------------- layouts
 template <typename T>
 static void carve(T *&ptr, size_t count, char *base, size_t &off) {
@@ -109,6 +118,7 @@ size_t geom_layout(int N, GeomView *v, void *base) {
     const size_t n = (size_t)(N > 0 ? N : 1);
     carve(v->rec, n * REC_FLOATS, b, off);
     carve(v->tiles_touched, n, b, off);
+    carve(v->rect, n, b, off);
     carve(v->slot_base, n, b, off);
     carve(v->total, 64, b, off);
     return off;
@@ -150,16 +160,23 @@ size_t image_layout(int W, int H, ImageView *v, void *base) {
     return off;
 }
 
-size_t render_scratch_layout(int64_t D, int W, int H, RenderScratch *v, void *base) {
+size_t render_scratch_layout(int N, int64_t D, int W, int H, RenderScratch *v, void *base) {
     RenderScratch tmp;
     if (!v) v = &tmp;
     size_t off = 0;
     char *b = (char *)base;
     const size_t d = (size_t)(D > 0 ? D : 1);
+    const int T = cdiv(W, TILE) * cdiv(H, TILE);
     carve(v->keys, d, b, off);
     carve(v->vals, d, b, off);
-    carve(v->hist, radix_hist_entries(D), b, off);
-    carve(v->totals, (size_t)1 << SORT_MAX_BITS, b, off);
+    v->hist = v->totals = v->group_hist = v->group_totals = nullptr;
+    if (use_counting_path(T)) {
+        carve(v->group_hist, group_hist_entries(N, T), b, off);
+        carve(v->group_totals, (size_t)(T > 0 ? T : 1), b, off);
+    } else {
+        carve(v->hist, radix_hist_entries(D), b, off);
+        carve(v->totals, (size_t)1 << SORT_MAX_BITS, b, off);
+    }
     return off;
 }
 
@@ -218,7 +235,7 @@ size_t lvdgs_geom_bytes(int32_t N) { return geom_layout(N, nullptr, nullptr); }
 size_t lvdgs_prepare_scratch_bytes(int32_t N) { return prep_scratch_layout(N, nullptr, nullptr); }
 size_t lvdgs_binning_bytes(int64_t D) { return bin_layout(D, nullptr, nullptr); }
 size_t lvdgs_image_bytes(int32_t W, int32_t H) { return image_layout(W, H, nullptr, nullptr); }
-size_t lvdgs_render_scratch_bytes(int64_t D, int32_t W, int32_t H) { return render_scratch_layout(D, W, H, nullptr, nullptr); }
+size_t lvdgs_render_scratch_bytes(int32_t N, int64_t D, int32_t W, int32_t H) { return render_scratch_layout(N, D, W, H, nullptr, nullptr); }
 size_t lvdgs_backward_scratch_bytes(int32_t N, int64_t D) { return bwd_scratch_layout(N, D, nullptr, nullptr); }
 
 int lvdgs_state_layout_query(int32_t N, int64_t D, int32_t W, int32_t H, lvdgs_state_layout *out) {
@@ -279,21 +296,30 @@ int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipSt
         if (int e = check_hip(hipMemsetAsync(a->n_touched, 0, sizeof(int32_t) * (size_t)N, s), "memset n_touched")) return e;
         if (count_on_device) count = g.total;
     }
+    bool grouped = false;
     if (cap > 0) {
         bin_layout(cap, &b, a->binning_state);
-        render_scratch_layout(cap, W, H, &w, a->scratch);
-        const int bits = tile_sort_bits(W, H);
-        // start in the buffer that makes the sorted result land in binning_state
-        const bool start_in_state = (radix_num_passes(bits) % 2) == 0;
-        uint32_t *k0 = start_in_state ? b.tile_keys : w.keys, *v0 = start_in_state ? b.point_list : w.vals;
-        uint32_t *k1 = start_in_state ? w.keys : b.tile_keys, *v1 = start_in_state ? w.vals : b.point_list;
-        if (int e = launch_emit_pairs(*a, g, k0, v0, cap, s)) return e;
-        bool in_first = true;
-        if (int e = radix_sort_pairs(k0, v0, k1, v1, cap, bits, w.hist, w.totals, &in_first, a->debug, s, count)) return e;
-        if ((in_first ? k0 : k1) != b.tile_keys) { set_error("internal: sorted list not in binning_state"); return LVDGS_E_INVALID; }
+        render_scratch_layout(N, cap, W, H, &w, a->scratch);
+        if (use_counting_path(num_tiles)) {
+            // counting path: no pair list is materialised, the tile ranges fall out of the counts
+            if (int e = launch_group_pairs(*a, g, im, w, b.point_list, cap, s)) return e;
+            grouped = true;
+        } else {
+            if (!w.hist) { set_error("internal: scratch was not laid out for the radix grouping"); return LVDGS_E_INVALID; }
+            const int bits = tile_sort_bits(W, H);
+            // start in the buffer that makes the sorted result land in binning_state
+            const bool start_in_state = (radix_num_passes(bits) % 2) == 0;
+            uint32_t *k0 = start_in_state ? b.tile_keys : w.keys, *v0 = start_in_state ? b.point_list : w.vals;
+            uint32_t *k1 = start_in_state ? w.keys : b.tile_keys, *v1 = start_in_state ? w.vals : b.point_list;
+            if (int e = launch_emit_pairs(*a, g, k0, v0, cap, s)) return e;
+            bool in_first = true;
+            if (int e = radix_sort_pairs(k0, v0, k1, v1, cap, bits, w.hist, w.totals, &in_first, a->debug, s, count)) return e;
+            if ((in_first ? k0 : k1) != b.tile_keys) { set_error("internal: sorted list not in binning_state"); return LVDGS_E_INVALID; }
+        }
     }
-    if (int e = launch_tile_ranges(b.tile_keys, cap, count, im, num_tiles, a->debug, s)) return e;
-    // the radix ping-pong buffers are free again: they hold the 64-bit keys of over-long segments
+    if (!grouped)
+        if (int e = launch_tile_ranges(b.tile_keys, cap, count, im, num_tiles, a->debug, s)) return e;
+    // w.keys / w.vals are free (again): they hold the 64-bit keys of over-long tile segments
     if (cap > 0)
         if (int e = launch_tile_depth_sort(im, num_tiles, g.rec, b.point_list, w.keys, a->debug, s)) return e;
     return launch_blend_fwd(*a, g, b, im, s);
@@ -306,7 +332,7 @@ int check_render_buffers(const lvdgs_args *a, int64_t cap) {
     if (N > 0 && (!a->n_touched || !a->geom_state)) { set_error("n_touched / geom_state is NULL"); return LVDGS_E_INVALID; }
     if (cap > 0) {
         if (!a->binning_state || !a->scratch) { set_error("binning_state / scratch is NULL"); return LVDGS_E_INVALID; }
-        if (a->binning_bytes < lvdgs_binning_bytes(cap) || a->scratch_bytes < lvdgs_render_scratch_bytes(cap, W, H)) {
+        if (a->binning_bytes < lvdgs_binning_bytes(cap) || a->scratch_bytes < lvdgs_render_scratch_bytes(N, cap, W, H)) {
             set_error("binning_state or scratch too small for %lld pairs", (long long)cap); return LVDGS_E_INVALID;
         }
     }

@@ -37,6 +37,133 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int N, int gx, int gy, 
         }
 }
 
+// ---- grouping by tile without a sort --------------------------------------------------------------------------
+// A workgroup owns GROUP_CHUNK consecutive Gaussians and keeps one counter per tile in LDS.
+//   count:    counter[tile] += 1 for every (Gaussian, tile) pair of the chunk        -> hist[chunk][tile]
+//   colscan:  per tile, exclusive prefix of hist over the chunks, and the tile total
+//   tilescan: exclusive scan of the totals                                           -> ranges[tile]
+//   scatter:  counter[tile] = ranges[tile].begin + hist[chunk][tile]; every pair takes the next slot of its tile
+//             with one returning LDS atomic and writes its Gaussian id there.
+// Rectangles larger than a wave's worth of tiles are walked by the whole wave, so one screen-filling Gaussian does
+// not serialise thousands of atomics on one lane.
+constexpr int GROUP_THREADS = 1024;
+constexpr int GROUP_PER_THREAD = 4;
+constexpr int GROUP_CHUNK = GROUP_THREADS * GROUP_PER_THREAD;
+constexpr int GROUP_MAX_TILES = 16384;  // 64 KiB of LDS counters
+constexpr int GROUP_BIG_RECT = 64;
+
+template <typename F>
+__device__ __forceinline__ void for_each_pair_of_chunk(int N, int gx, const uint2 *__restrict__ rect, F visit) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < GROUP_PER_THREAD; k++) {
+        const int i = blockIdx.x * GROUP_CHUNK + k * GROUP_THREADS + (int)threadIdx.x;
+        const uint2 r = i < N ? rect[i] : make_uint2(0u, 0u);
+        const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
+        const int w = x1 - x0, area = w * (y1 - y0);
+        if (area > 0 && area <= GROUP_BIG_RECT)
+            for (int y = y0; y < y1; y++)
+                for (int x = x0; x < x1; x++) visit(y * gx + x, (uint32_t)i);
+        uint64_t big = __ballot(area > GROUP_BIG_RECT);
+        while (big) {
+            const int src = __builtin_ctzll(big);
+            big &= big - 1;
+            const int bx0 = __shfl(x0, src, 64), by0 = __shfl(y0, src, 64), bw = __shfl(w, src, 64), barea = __shfl(area, src, 64);
+            const uint32_t bi = (uint32_t)__shfl(i, src, 64);
+            for (int t = lane; t < barea; t += 64) visit((by0 + t / bw) * gx + bx0 + t % bw, bi);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(GROUP_THREADS) count_pairs_kernel(int N, int gx, int T, const uint2 *__restrict__ rect,
+                                                                   uint32_t *__restrict__ hist) {
+    extern __shared__ uint32_t s_tile[];
+    for (int t = threadIdx.x; t < T; t += GROUP_THREADS) s_tile[t] = 0u;
+    __syncthreads();
+    for_each_pair_of_chunk(N, gx, rect, [&](int tile, uint32_t) { atomicAdd(&s_tile[tile], 1u); });
+    __syncthreads();
+    uint32_t *row = hist + (size_t)blockIdx.x * T;
+    for (int t = threadIdx.x; t < T; t += GROUP_THREADS) row[t] = s_tile[t];
+}
+
+// Exclusive prefix of hist over the chunks, per tile.  A workgroup covers 32 tiles; its 8 thread groups split the
+// chunks between them (loads of one group are independent and 128-byte coalesced over the 32 tiles), meet in LDS
+// for the group offsets, then write the prefixes.
+constexpr int COLSCAN_TILES = 32, COLSCAN_GROUPS = 8;
+__global__ void __launch_bounds__(COLSCAN_TILES * COLSCAN_GROUPS) group_colscan_kernel(int T, int nchunks, uint32_t *__restrict__ hist,
+                                                                                      uint32_t *__restrict__ totals) {
+    __shared__ uint32_t s_part[COLSCAN_GROUPS][COLSCAN_TILES];
+    const int tl = threadIdx.x % COLSCAN_TILES, cg = threadIdx.x / COLSCAN_TILES;
+    const int t = blockIdx.x * COLSCAN_TILES + tl;
+    const int per = (nchunks + COLSCAN_GROUPS - 1) / COLSCAN_GROUPS;
+    const int c0 = cg * per, c1 = min(nchunks, c0 + per);
+    uint32_t sum = 0;
+    if (t < T)
+        for (int c = c0; c < c1; c++) sum += hist[(size_t)c * T + t];
+    s_part[cg][tl] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (int g = 0; g < COLSCAN_GROUPS; g++) {
+        const uint32_t v = s_part[g][tl];
+        run += g < cg ? v : 0u;
+        total += v;
+    }
+    if (t < T) {
+        for (int c = c0; c < c1; c++) {
+            const uint32_t v = hist[(size_t)c * T + t];
+            hist[(size_t)c * T + t] = run;
+            run += v;
+        }
+        if (cg == 0) totals[t] = total;
+    }
+}
+
+// one workgroup: ranges[t] = [sum of totals before t, + totals[t]), clamped to the pair capacity
+__global__ void __launch_bounds__(1024) group_tilescan_kernel(int T, const uint32_t *__restrict__ totals, uint32_t capacity,
+                                                              uint2 *__restrict__ ranges) {
+    __shared__ uint32_t s_scan[1024];
+    constexpr int PER = GROUP_MAX_TILES / 1024;
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int t = (int)threadIdx.x * PER + k;
+        v[k] = t < T ? totals[t] : 0u;
+        sum += v[k];
+    }
+    s_scan[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t x = (int)threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_scan[threadIdx.x] += x;
+        __syncthreads();
+    }
+    uint32_t run = s_scan[threadIdx.x] - sum;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int t = (int)threadIdx.x * PER + k;
+        // empty tiles keep (0, 0), as after the radix path's memset
+        if (t < T) ranges[t] = v[k] ? make_uint2(min(run, capacity), min(run + v[k], capacity)) : make_uint2(0u, 0u);
+        run += v[k];
+    }
+}
+
+__global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int gx, int T, const uint2 *__restrict__ rect,
+                                                                     const uint32_t *__restrict__ hist,
+                                                                     const uint32_t *__restrict__ totals_unused,
+                                                                     const uint2 *__restrict__ ranges, uint32_t capacity,
+                                                                     uint32_t *__restrict__ point_list) {
+    extern __shared__ uint32_t s_tile[];
+    const uint32_t *row = hist + (size_t)blockIdx.x * T;
+    for (int t = threadIdx.x; t < T; t += GROUP_THREADS) s_tile[t] = ranges[t].x + row[t];  // (empty tiles are never visited)
+    __syncthreads();
+    for_each_pair_of_chunk(N, gx, rect, [&](int tile, uint32_t id) {
+        const uint32_t pos = atomicAdd(&s_tile[tile], 1u);
+        if (pos < capacity) point_list[pos] = id;  // beyond the caller's capacity: dropped, the caller is told and re-runs
+    });
+}
+
 __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t *__restrict__ tile_keys, int64_t D_cap,
                                                           const uint32_t *__restrict__ D_dev, uint2 *__restrict__ ranges) {
     const int64_t D = D_dev ? min((int64_t)*D_dev, D_cap) : D_cap;
@@ -48,6 +175,46 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t *__rest
 }
 
 }  // namespace
+
+int group_max_tiles() { return GROUP_MAX_TILES; }
+size_t group_hist_entries(int N, int num_tiles) { return (size_t)cdiv(N > 0 ? N : 1, GROUP_CHUNK) * (size_t)num_tiles; }
+
+int launch_group_pairs(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, uint32_t *point_list,
+                       int64_t capacity, hipStream_t s) {
+    const int N = a.num_gaussians;
+    const int gx = (a.image_width + TILE - 1) / TILE, gy = (a.image_height + TILE - 1) / TILE, T = gx * gy;
+    if (N == 0 || T == 0) return LVDGS_OK;
+    const int nchunks = cdiv(N, GROUP_CHUNK);
+    const size_t lds = (size_t)T * sizeof(uint32_t);
+    static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&count_pairs_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, GROUP_MAX_TILES * 4) == hipSuccess &&
+                               hipFuncSetAttribute(reinterpret_cast<const void *>(&scatter_pairs_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, GROUP_MAX_TILES * 4) == hipSuccess;
+    if (!lds_ok) { set_error("grouping: cannot reserve 64 KiB of LDS"); return LVDGS_E_HIP; }
+    // the queues of over-long tile segments (tilesort.hip) are cleared here, where the radix path clears the ranges
+    if (int e = check_hip(hipMemsetAsync(im.long_count, 0, 64 * sizeof(uint32_t), s), "memset tile queues")) return e;
+    {
+        ProfScope ps("group_count", s);
+        hipLaunchKernelGGL(count_pairs_kernel, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint2 *)g.rect, w.group_hist);
+        LVDGS_LAUNCH_CHECK("group_count", a.debug, s);
+    }
+    {
+        ProfScope ps("group_scan", s);
+        hipLaunchKernelGGL(group_colscan_kernel, dim3(cdiv(T, COLSCAN_TILES)), dim3(COLSCAN_TILES * COLSCAN_GROUPS), 0, s, T, nchunks, w.group_hist,
+                           w.group_totals);
+        hipLaunchKernelGGL(group_tilescan_kernel, dim3(1), dim3(1024), 0, s, T, (const uint32_t *)w.group_totals, (uint32_t)capacity,
+                           im.ranges);
+        LVDGS_LAUNCH_CHECK("group_scan", a.debug, s);
+    }
+    {
+        ProfScope ps("group_scatter", s);
+        hipLaunchKernelGGL(scatter_pairs_kernel, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint2 *)g.rect,
+                           (const uint32_t *)w.group_hist, (const uint32_t *)w.group_totals, (const uint2 *)im.ranges, (uint32_t)capacity,
+                           point_list);
+        LVDGS_LAUNCH_CHECK("group_scatter", a.debug, s);
+    }
+    return LVDGS_OK;
+}
 
 int launch_emit_pairs(const lvdgs_args &a, const GeomView &g, uint32_t *tile_keys, uint32_t *ids, int64_t capacity, hipStream_t s) {
     const int N = a.num_gaussians;

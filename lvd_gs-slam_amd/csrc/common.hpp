@@ -56,6 +56,7 @@ struct ProfScope {
 struct GeomView {
     float *rec;              // N*12
     uint32_t *tiles_touched; // N
+    uint2 *rect;             // N: tile rectangle, x0 | x1 << 16, y0 | y1 << 16 (empty for culled Gaussians)
     uint32_t *slot_base;     // N: exclusive scan of tiles_touched in id order: first pair / gradient slot of a Gaussian
     uint32_t *total;         // 1: pair count D of this frame (device copy)
 };
@@ -63,10 +64,12 @@ struct PrepScratch {
     uint32_t *blocksums; // scan block sums
 };
 struct RenderScratch {
-    uint32_t *keys;  // D (alternate tile-key buffer)
+    uint32_t *keys;  // D (alternate tile-key buffer of the radix path; 64-bit keys of over-long tile segments)
     uint32_t *vals;  // D (alternate id buffer)
-    uint32_t *hist;
-    uint32_t *totals;
+    uint32_t *hist;         // radix path only
+    uint32_t *totals;       // radix path only
+    uint32_t *group_hist;   // counting path: [Gaussian chunk][tile] pair counts, then exclusive prefixes over the chunks
+    uint32_t *group_totals; // counting path: pairs per tile
 };
 struct BinView {
     uint32_t *point_list; // D
@@ -88,7 +91,7 @@ size_t geom_layout(int N, GeomView *v, void *base);
 size_t prep_scratch_layout(int N, PrepScratch *v, void *base);
 size_t bin_layout(int64_t D, BinView *v, void *base);
 size_t image_layout(int W, int H, ImageView *v, void *base);
-size_t render_scratch_layout(int64_t D, int W, int H, RenderScratch *v, void *base);
+size_t render_scratch_layout(int N, int64_t D, int W, int H, RenderScratch *v, void *base);
 size_t bwd_scratch_layout(int N, int64_t D, BwdScratch *v, void *base);
 int tile_sort_bits(int W, int H);  // number of key bits to sort for the tile id
 
@@ -109,6 +112,13 @@ size_t radix_hist_entries(int64_t n);
 int launch_slot_scan(const uint32_t *tiles_touched, uint32_t *slot_base, uint32_t *blocksums, uint32_t *total_dev, int N, int dbg,
                      hipStream_t s);
 
+// Grouping of the (Gaussian, tile) pairs by tile without sorting (binning.hip): counts per (Gaussian chunk, tile) in
+// LDS, prefix sums, then every pair is placed with one LDS atomic.  The order inside a tile's segment is arbitrary;
+// the tile sort makes it canonical.  Only for images of at most group_max_tiles() tiles (LDS counters).
+int group_max_tiles();
+size_t group_hist_entries(int N, int num_tiles);
+int launch_group_pairs(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, uint32_t *point_list,
+                       int64_t capacity, hipStream_t s);
 int launch_emit_pairs(const lvdgs_args &a, const GeomView &g, uint32_t *tile_keys, uint32_t *ids, int64_t capacity, hipStream_t s);
 // sorts every tile's segment of point_list by (view-depth bits, id); keys64: scratch for D 64-bit keys (long segments)
 int launch_tile_depth_sort(const ImageView &im, int num_tiles, const float *rec, uint32_t *point_list, void *keys64, int dbg,

@@ -143,7 +143,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         key = dev.index if dev.index is not None else torch.cuda.current_device()
         cap = max(_PAIR_CAPACITY.get(key, 0), _MIN_PAIR_CAPACITY, _PAIRS_PER_GAUSSIAN_GUESS * N, 1) if N > 0 else 0
         binning = _bytes(L.lvdgs_binning_bytes(cap), dev)
-        scratch = _bytes(max(L.lvdgs_prepare_scratch_bytes(N), L.lvdgs_render_scratch_bytes(cap, W, H)), dev)
+        scratch = _bytes(max(L.lvdgs_prepare_scratch_bytes(N), L.lvdgs_render_scratch_bytes(N, cap, W, H)), dev)
         a.pair_capacity = cap
         a.binning_state, a.binning_bytes = _ptr(binning), binning.numel()
         a.scratch, a.scratch_bytes = _ptr(scratch), scratch.numel()
@@ -154,7 +154,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         if status == _lib.E_CAPACITY:
             binning_pairs = D
             binning = _bytes(L.lvdgs_binning_bytes(D), dev)
-            scratch = _bytes(L.lvdgs_render_scratch_bytes(D, W, H), dev)
+            scratch = _bytes(L.lvdgs_render_scratch_bytes(N, D, W, H), dev)
             a.num_rendered = D
             a.binning_state, a.binning_bytes = _ptr(binning), binning.numel()
             a.scratch, a.scratch_bytes = _ptr(scratch), scratch.numel()

@@ -57,11 +57,14 @@ def run_hip(g, cam, W, H, bg, use_sh=False, sh_degree=0, cov_precomp=None, grads
         tiles_touched=_view(st["geom"], lay.geom_tiles_touched, N, np.uint32) if N else np.zeros(0, np.uint32),
         slot_base=_view(st["geom"], lay.geom_slot_base, N, np.uint32) if N else np.zeros(0, np.uint32),
         point_list=_view(st["binning"], lay.bin_point_list, D, np.uint32) if D else np.zeros(0, np.uint32),
-        tile_keys=_view(st["binning"], lay.bin_tile_keys, D, np.uint32) if D else np.zeros(0, np.uint32),
         ranges=_view(st["image"], lay.img_ranges, NT * 2, np.uint32).reshape(NT, 2),
         final_T=_view(st["image"], lay.img_final_T, W * H, np.float32).reshape(H, W),
         n_contrib=_view(st["image"], lay.img_n_contrib, W * H, np.uint32).reshape(H, W),
     )
+    # tile id of every entry of point_list, from the ranges (the counting path never materialises tile keys)
+    r = fwd["ranges"].astype(np.int64)
+    fwd["tile_keys"] = np.repeat(np.arange(NT, dtype=np.uint32), np.maximum(r[:, 1] - r[:, 0], 0))
+    assert fwd["overflowed"] or len(fwd["tile_keys"]) == D, (len(fwd["tile_keys"]), D)
     bwd = None
     if grads is not None:
         gc, gd, go = (None if t is None else t.to(dev) for t in grads)

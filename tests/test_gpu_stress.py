@@ -38,15 +38,17 @@ def test_two_million_gaussians_1920x1280():
         np.testing.assert_array_equal(b[k], b2[k])
 
 
-def test_very_long_tile_lists():
+@pytest.mark.parametrize("N,longest", [(60_000, 10_000), (140_000, 16_384)])
+def test_very_long_tile_lists(N, longest):
+    """Segments of more than 2048 entries sort on LDS with 1024 threads, beyond 16384 in place on global memory."""
     import hip_runner
     from lvdgs import synthetic
-    N, W, H = 60_000, 64, 64
+    W, H = 64, 64
     g = synthetic.make_gaussians(N, W, H, seed=2, r_min=4.0, r_max=9.0, z_min=1.0, z_max=3.0)
     g["opacities"][:] = 0.02  # faint: nothing saturates, every list is walked to its end
     cam = synthetic.make_camera(W, H)
     f, b = hip_runner.run_hip(g, cam, W, H, torch.zeros(3), grads=synthetic.make_image_grads(W, H, 1))
-    assert (f["ranges"][:, 1] - f["ranges"][:, 0]).max() > 10_000
+    assert (f["ranges"][:, 1] - f["ranges"][:, 0]).max() > longest
     _invariants(f, N)
     assert f["n_contrib"].max() > 5_000
     for k in b:
@@ -85,3 +87,36 @@ def test_depth_order_with_degenerate_depth_distributions(kind):
     for b, e in rg[rg[:, 1] > rg[:, 0]][:: max(1, len(rg) // 50)]:
         ids, dd = pl[b:e].astype(np.int64), d[pl[b:e]]
         assert np.all(dd[1:] >= dd[:-1]) and np.all(ids[1:][dd[1:] == dd[:-1]] > ids[:-1][dd[1:] == dd[:-1]])
+
+
+def test_image_with_more_tiles_than_lds_counters_takes_the_radix_grouping():
+    """2576x1712 is 161 x 107 = 17227 tiles, above the 16384 LDS counters of the counting path."""
+    import hip_runner
+    from lvdgs import synthetic
+    N, W, H = 150_000, 2576, 1712
+    g = synthetic.make_gaussians(N, W, H, seed=4)
+    cam = synthetic.make_camera(W, H)
+    grads = synthetic.make_image_grads(W, H, 2)
+    f, b = hip_runner.run_hip(g, cam, W, H, torch.zeros(3), grads=grads)
+    f2, b2 = hip_runner.run_hip(g, cam, W, H, torch.zeros(3), grads=grads)
+    _invariants(f, N)
+    for k in ("color", "depth", "opacity", "point_list", "ranges", "n_touched", "n_contrib"):
+        np.testing.assert_array_equal(f[k], f2[k])
+    for k in b:
+        assert np.isfinite(b[k]).all(), k
+        np.testing.assert_array_equal(b[k], b2[k])
+
+
+def test_radix_grouping_gives_the_same_lists_as_the_counting_path():
+    """LVDGS_FORCE_RADIX_GROUPING (read once per process) selects the radix path at any image size: run the oracle
+    parity cases in a fresh interpreter with it set."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LVDGS_FORCE_RADIX_GROUPING="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu", "-x",
+                        "-k", "test_forward_and_backward_match_oracle or overflow", "-p", "no:cacheprovider"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
