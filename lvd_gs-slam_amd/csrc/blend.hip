@@ -95,9 +95,14 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendParams p) {
     const int todo = (int)(range.y - range.x);
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
     uint32_t last = 0;
-    bool done = !inside;
+    // A finished pixel (transmittance below 1e-4, or outside the image) is moved to x = 1e30: every later Gaussian
+    // then evaluates to alpha = 0 there and fails the 1/255 test by itself, so the per-Gaussian code carries no
+    // "done" mask (that mask cost five scalar instructions per Gaussian, on a scalar unit shared by four SIMDs).
+    constexpr float FAR_AWAY = 1e30f;
+    float pxe = inside ? pxf : FAR_AWAY;
 
     for (int base = 0; base < todo; base += 256) {
+        const bool done = pxe == FAR_AWAY;
         if (__syncthreads_and(done)) break;
         const int cnt = min(256, todo - base);
         uint32_t my_id = 0;
@@ -124,19 +129,22 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendParams p) {
                     keep = reaches_rect(A.x, A.y, Cc.w, Dd.x, Dd.y, s_b[jl].y, rx0, ry0, rx1, ry1);
                 }
                 uint64_t live = __ballot(keep);
+                // n_touched only counts pixels whose transmittance is still above 1/2: once no pixel of the quadrant
+                // is (transmittance never grows), the rest of the list skips that bookkeeping
+                const bool wave_touching = __ballot(T > T_TOUCH && pxe != FAR_AWAY) != 0ull;
                 // ---- lane -> pixel: composite the survivors in list order ----
                 while (live) {
                     const int jj = c0 + __builtin_ctzll(live);
                     live &= live - 1;
                     const float4 A = s_a[jj];
                     const float4 B = s_b[jj];
-                    const float dx = A.x - pxf, dy = A.y - pyf;
+                    const float dx = A.x - pxe, dy = A.y - pyf;
                     const float pw2 = fmaf(dx, fmaf(A.z, dx, A.w * dy), B.x * dy * dy);  // log2 of the falloff (backward repeats this exactly)
                     const float alpha = fminf(ALPHA_MAX, B.y * __builtin_amdgcn_exp2f(pw2));
                     const float test_T = T * (1.f - alpha);
-                    bool hit = !done && (pw2 <= 0.f) && (alpha >= ALPHA_MIN);
+                    bool hit = (pw2 <= 0.f) && (alpha >= ALPHA_MIN);
                     const bool stop = hit && (test_T < T_STOP);
-                    done = done || stop;
+                    pxe = stop ? FAR_AWAY : pxe;
                     hit = hit && !stop;
                     if (__ballot(hit) == 0ull) continue;
                     const float4 Cc = s_c[jj];
@@ -145,8 +153,10 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendParams p) {
                     Dp = fmaf(B.z, w, Dp);
                     T = hit ? test_T : T;
                     last = hit ? (uint32_t)(base + jj + 1) : last;
-                    const uint64_t touched = __ballot(hit && test_T > T_TOUCH);
-                    if (touched != 0ull && lane == 0) atomicAdd(&s_touch[jj], (int)__popcll(touched));
+                    if (wave_touching) {
+                        const uint64_t touched = __ballot(hit && test_T > T_TOUCH);
+                        if (touched != 0ull && lane == 0) atomicAdd(&s_touch[jj], (int)__popcll(touched));
+                    }
                 }
             }
         }
