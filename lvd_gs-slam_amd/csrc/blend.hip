@@ -134,8 +134,9 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendParams p) {
                 const bool wave_touching = __ballot(T > T_TOUCH && pxe != FAR_AWAY) != 0ull;
                 // ---- lane -> pixel: composite the survivors in list order ----
                 while (live) {
-                    const int jj = c0 + __builtin_ctzll(live);
-                    live &= live - 1;
+                    const int jb = __builtin_ctzll(live);
+                    const int jj = c0 + jb;
+                    live = mask_clear_bit(live, jb);
                     const float4 A = s_a[jj];
                     const float4 B = s_b[jj];
                     const float dx = A.x - pxe, dy = A.y - pyf;
@@ -143,10 +144,10 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendParams p) {
                     const float alpha = fminf(ALPHA_MAX, B.y * __builtin_amdgcn_exp2f(pw2));
                     const float test_T = T * (1.f - alpha);
                     bool hit = (pw2 <= 0.f) && (alpha >= ALPHA_MIN);
+                    if (__ballot(hit) == 0ull) continue;
                     const bool stop = hit && (test_T < T_STOP);
                     pxe = stop ? FAR_AWAY : pxe;
                     hit = hit && !stop;
-                    if (__ballot(hit) == 0ull) continue;
                     const float4 Cc = s_c[jj];
                     const float w = hit ? alpha * T : 0.f;
                     C0 = fmaf(Cc.x, w, C0); C1 = fmaf(Cc.y, w, C1); C2 = fmaf(Cc.z, w, C2);
@@ -265,7 +266,7 @@ __global__ void __launch_bounds__(256, 8) blend_bwd_kernel(BlendParams p) {
                 uint64_t wrote = 0ull;
                 while (live) {
                     const int j = 63 - __builtin_clzll(live);
-                    live &= ~(1ull << j);
+                    live = mask_clear_bit(live, j);
                     const int jj = c0 + j;
                     const float4 A = s_a[jj];
                     const float4 B = s_b[jj];
@@ -312,7 +313,7 @@ __global__ void __launch_bounds__(256, 8) blend_bwd_kernel(BlendParams p) {
                         o[0] = q0; o[1] = q1;
                         if (row3) o[2] = q2;
                     }
-                    wrote |= 1ull << j;
+                    wrote = mask_set_bit(wrote, j);
                 }
                 if (lane == 0) s_mask[wave][c0 >> 6] = wrote;
             }

@@ -54,6 +54,17 @@ __device__ __forceinline__ void row_sums3(float &x, float &y, float &z) {
         : "+v"(x), "+v"(y), "+v"(z));
 }
 
+// Clear / set one bit of a wave-uniform 64-bit mask in one scalar instruction (the compiler's shift + and-not, or
+// subtract-with-carry + and for m &= m - 1, are two to three on a scalar unit four SIMDs share).
+__device__ __forceinline__ uint64_t mask_clear_bit(uint64_t m, int bit) {
+    asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(bit));
+    return m;
+}
+__device__ __forceinline__ uint64_t mask_set_bit(uint64_t m, int bit) {
+    asm("s_bitset1_b64 %0, %1" : "+s"(m) : "s"(bit));
+    return m;
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 }  // namespace lvdgs
