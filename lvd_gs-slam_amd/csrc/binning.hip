@@ -1,4 +1,4 @@
-// (Gaussian, tile) pair emission in depth-rank order, and per-tile ranges of the sorted list.
+// Grouping of the (Gaussian, tile) pairs by tile: by counting (default), or pair emission + tile ranges for the radix path.
 #include "common.hpp"
 #include "device_utils.hpp"
 

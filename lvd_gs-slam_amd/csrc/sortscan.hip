@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(SORT_THREADS) radix_scatter_kernel(const uint3
     }
 }
 
-// ---- prefix sum of tiles_touched taken in depth-rank order ----
+// ---- prefix sum of tiles_touched in id order ----
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_IPT = 8;
 constexpr int SCAN_CHUNK = SCAN_THREADS * SCAN_IPT;
