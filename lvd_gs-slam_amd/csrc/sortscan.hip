@@ -211,25 +211,16 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_reduce_kernel(const uint32_
     if (threadIdx.x == 0) blocksums[blockIdx.x] = total;
 }
 
-__global__ void __launch_bounds__(SCAN_THREADS) scan_blocksums_kernel(uint32_t *__restrict__ blocksums, int nblk,
-                                                                      uint32_t *__restrict__ total_out) {
-    __shared__ uint32_t s[SCAN_THREADS];
-    uint32_t carry = 0;
-    for (int b0 = 0; b0 < nblk; b0 += SCAN_THREADS) {
-        const int b = b0 + threadIdx.x;
-        const uint32_t v = b < nblk ? blocksums[b] : 0u;
-        uint32_t total;
-        const uint32_t ex = block_exclusive_scan(v, s, &total);
-        if (b < nblk) blocksums[b] = carry + ex;
-        carry += total;
-    }
-    if (threadIdx.x == 0) *total_out = carry;
-}
-
+// Second of two launches: every workgroup first adds up the sums of the workgroups before it (a few hundred
+// values: cheaper than a third launch for a one-workgroup scan of them), then scans its own chunk.
 __global__ void __launch_bounds__(SCAN_THREADS) scan_apply_kernel(const uint32_t *__restrict__ tt, int N,
                                                                   const uint32_t *__restrict__ blocksums,
-                                                                  uint32_t *__restrict__ slot_base) {
+                                                                  uint32_t *__restrict__ slot_base, uint32_t *__restrict__ total_out) {
     __shared__ uint32_t s[SCAN_THREADS];
+    uint32_t before = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += SCAN_THREADS) before += blocksums[b];
+    uint32_t prefix;
+    block_exclusive_scan(before, s, &prefix);  // only the total is of interest
     uint32_t v[SCAN_IPT];
     uint32_t sum = 0;
     const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_IPT;
@@ -239,12 +230,13 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_apply_kernel(const uint32_t
         sum += v[k];
     }
     uint32_t total;
-    uint32_t run = block_exclusive_scan(sum, s, &total) + blocksums[blockIdx.x];
+    uint32_t run = block_exclusive_scan(sum, s, &total) + prefix;
 #pragma unroll
     for (int k = 0; k < SCAN_IPT; k++) {
         if (base + k < N) slot_base[base + k] = run;
         run += v[k];
     }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = prefix + total;
 }
 
 }  // namespace
@@ -304,13 +296,9 @@ int launch_slot_scan(const uint32_t *tiles_touched, uint32_t *slot_base, uint32_
         LVDGS_LAUNCH_CHECK("scan_reduce", dbg, s);
     }
     {
-        ProfScope ps("scan_blocksums", s);
-        hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, blocksums, nblk, total_dev);
-        LVDGS_LAUNCH_CHECK("scan_blocksums", dbg, s);
-    }
-    {
         ProfScope ps("scan_apply", s);
-        hipLaunchKernelGGL(scan_apply_kernel, dim3(nblk), dim3(SCAN_THREADS), 0, s, tiles_touched, N, blocksums, slot_base);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(nblk), dim3(SCAN_THREADS), 0, s, tiles_touched, N, (const uint32_t *)blocksums, slot_base,
+                           total_dev);
         LVDGS_LAUNCH_CHECK("scan_apply", dbg, s);
     }
     return LVDGS_OK;
