@@ -155,6 +155,23 @@ def test_precomputed_covariance_path():
     _check_backward(b_hip, b_ora, ["means3D", "opacities", "cov3D", "colors", "tau"])
 
 
+def test_large_gaussians_far_from_their_tiles():
+    """Footprints of 40-400 pixels: most (quadrant, Gaussian) pairs have the mean hundreds of pixels outside the
+    quadrant, the regime where the backward pass's quadrant-local moments lose the most to cancellation."""
+    orc, hr, syn = _mods()
+    N, W, H = 400, 640, 480
+    g, cam = _scene(syn, N, W, H, 7, pose_seed=3, r_min=40.0, r_max=400.0, z_min=2.0, z_max=20.0)
+    with torch.no_grad():
+        g["opacities"].mul_(0.25)  # faint enough that hundreds of them contribute to a pixel
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    grads = syn.make_image_grads(W, H, 7)
+    f_hip, b_hip = hr.run_hip(g, cam, W, H, bg, grads=grads)
+    f_ora, b_ora = hr.run_oracle(orc, g, cam, W, H, bg, grads=grads)
+    assert np.median(f_ora["radii"][f_ora["radii"] > 0]) > 100
+    _check_forward(f_hip, f_ora, W, H)
+    _check_backward(b_hip, b_ora, ["means3D", "means2D", "opacities", "scales", "rotations", "colors", "tau"])
+
+
 def test_edge_cases_empty_culled_single_and_huge():
     orc, hr, syn = _mods()
     W, H = 96, 80
