@@ -118,6 +118,7 @@ size_t geom_layout(int N, GeomView *v, void *base) {
     const size_t n = (size_t)(N > 0 ? N : 1);
     carve(v->rec, n * REC_FLOATS, b, off);
     carve(v->tiles_touched, n, b, off);
+    carve(v->depth_bits, n, b, off);
     carve(v->rect, n, b, off);
     carve(v->slot_base, n, b, off);
     carve(v->total, 64, b, off);
@@ -302,7 +303,7 @@ int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipSt
         render_scratch_layout(N, cap, W, H, &w, a->scratch);
         if (use_counting_path(num_tiles)) {
             // counting path: no pair list is materialised, the tile ranges fall out of the counts
-            if (int e = launch_group_pairs(*a, g, im, w, b.point_list, cap, s)) return e;
+            if (int e = launch_group_pairs(*a, g, im, w, (unsigned long long *)w.keys, cap, s)) return e;
             grouped = true;
         } else {
             if (!w.hist) { set_error("internal: scratch was not laid out for the radix grouping"); return LVDGS_E_INVALID; }
@@ -319,9 +320,9 @@ int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipSt
     }
     if (!grouped)
         if (int e = launch_tile_ranges(b.tile_keys, cap, count, im, num_tiles, a->debug, s)) return e;
-    // w.keys / w.vals are free (again): they hold the 64-bit keys of over-long tile segments
+    // w.keys + w.vals: the (depth, id) keys the counting path scattered, or scratch for over-long segments after the radix path
     if (cap > 0)
-        if (int e = launch_tile_depth_sort(im, num_tiles, g.rec, b.point_list, w.keys, a->debug, s)) return e;
+        if (int e = launch_tile_depth_sort(im, num_tiles, g.rec, b.point_list, w.keys, grouped, a->debug, s)) return e;
     return launch_blend_fwd(*a, g, b, im, s);
 }
 

@@ -153,14 +153,17 @@ __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int
                                                                      const uint32_t *__restrict__ hist,
                                                                      const uint32_t *__restrict__ totals_unused,
                                                                      const uint2 *__restrict__ ranges, uint32_t capacity,
-                                                                     uint32_t *__restrict__ point_list) {
+                                                                     const uint32_t *__restrict__ depth_bits,
+                                                                     unsigned long long *__restrict__ keys64) {
     extern __shared__ uint32_t s_tile[];
     const uint32_t *row = hist + (size_t)blockIdx.x * T;
     for (int t = threadIdx.x; t < T; t += GROUP_THREADS) s_tile[t] = ranges[t].x + row[t];  // (empty tiles are never visited)
     __syncthreads();
     for_each_pair_of_chunk(N, gx, rect, [&](int tile, uint32_t id) {
         const uint32_t pos = atomicAdd(&s_tile[tile], 1u);
-        if (pos < capacity) point_list[pos] = id;  // beyond the caller's capacity: dropped, the caller is told and re-runs
+        // the tile sort's key, so that it need not gather depths; beyond the caller's capacity: dropped (the caller
+        // is told and re-runs)
+        if (pos < capacity) keys64[pos] = ((unsigned long long)depth_bits[id] << 32) | (unsigned long long)id;
     });
 }
 
@@ -179,7 +182,7 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t *__rest
 int group_max_tiles() { return GROUP_MAX_TILES; }
 size_t group_hist_entries(int N, int num_tiles) { return (size_t)cdiv(N > 0 ? N : 1, GROUP_CHUNK) * (size_t)num_tiles; }
 
-int launch_group_pairs(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, uint32_t *point_list,
+int launch_group_pairs(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, unsigned long long *keys64,
                        int64_t capacity, hipStream_t s) {
     const int N = a.num_gaussians;
     const int gx = (a.image_width + TILE - 1) / TILE, gy = (a.image_height + TILE - 1) / TILE, T = gx * gy;
@@ -210,7 +213,7 @@ int launch_group_pairs(const lvdgs_args &a, const GeomView &g, const ImageView &
         ProfScope ps("group_scatter", s);
         hipLaunchKernelGGL(scatter_pairs_kernel, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint2 *)g.rect,
                            (const uint32_t *)w.group_hist, (const uint32_t *)w.group_totals, (const uint2 *)im.ranges, (uint32_t)capacity,
-                           point_list);
+                           (const uint32_t *)g.depth_bits, keys64);
         LVDGS_LAUNCH_CHECK("group_scatter", a.debug, s);
     }
     return LVDGS_OK;

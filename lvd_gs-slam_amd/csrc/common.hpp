@@ -56,6 +56,7 @@ struct ProfScope {
 struct GeomView {
     float *rec;              // N*12
     uint32_t *tiles_touched; // N
+    uint32_t *depth_bits;    // N: view depth as ordered bits (positive floats compare like unsigned integers)
     uint2 *rect;             // N: tile rectangle, x0 | x1 << 16, y0 | y1 << 16 (empty for culled Gaussians)
     uint32_t *slot_base;     // N: exclusive scan of tiles_touched in id order: first pair / gradient slot of a Gaussian
     uint32_t *total;         // 1: pair count D of this frame (device copy)
@@ -117,12 +118,14 @@ int launch_slot_scan(const uint32_t *tiles_touched, uint32_t *slot_base, uint32_
 // the tile sort makes it canonical.  Only for images of at most group_max_tiles() tiles (LDS counters).
 int group_max_tiles();
 size_t group_hist_entries(int N, int num_tiles);
-int launch_group_pairs(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, uint32_t *point_list,
+int launch_group_pairs(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, unsigned long long *keys64,
                        int64_t capacity, hipStream_t s);
 int launch_emit_pairs(const lvdgs_args &a, const GeomView &g, uint32_t *tile_keys, uint32_t *ids, int64_t capacity, hipStream_t s);
-// sorts every tile's segment of point_list by (view-depth bits, id); keys64: scratch for D 64-bit keys (long segments)
-int launch_tile_depth_sort(const ImageView &im, int num_tiles, const float *rec, uint32_t *point_list, void *keys64, int dbg,
-                           hipStream_t s);
+// Sorts every tile's segment by (view-depth bits, id) and leaves the ids in point_list.  keys64 holds D 64-bit
+// keys: already filled per segment (counting path, keys_ready), or scratch for over-long segments whose keys are
+// gathered from the ids in point_list (radix path).
+int launch_tile_depth_sort(const ImageView &im, int num_tiles, const float *rec, uint32_t *point_list, void *keys64, bool keys_ready,
+                           int dbg, hipStream_t s);
 int launch_tile_ranges(const uint32_t *tile_keys, int64_t D, const uint32_t *D_dev, const ImageView &im, int num_tiles, int dbg,
                        hipStream_t s);
 

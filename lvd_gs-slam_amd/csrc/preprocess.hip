@@ -167,7 +167,7 @@ struct FwdParams {
     int N, act;
     const float *means3D, *opacities, *scales, *rotations, *cov3D_precomp, *shs, *colors_precomp;
     float *rec;
-    uint32_t *tiles_touched;
+    uint32_t *tiles_touched, *depth_bits;
     uint2 *rect;
     int32_t *radii;
 };
@@ -180,6 +180,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(FwdParams p) {
     int radius = 0;
     uint32_t tiles = 0;
     uint2 rect = make_uint2(0u, 0u);
+    uint32_t depth_bits = 0u;
     float pos[3] = {p.means3D[3 * i], p.means3D[3 * i + 1], p.means3D[3 * i + 2]};
     float pv[3];
     xform3(pos, c.view, pv);
@@ -243,6 +244,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(FwdParams p) {
                 }
                 radius = rad; tiles = (uint32_t)area;
                 rect = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
+                depth_bits = __float_as_uint(pv[2]);
                 float4 *r4 = reinterpret_cast<float4 *>(p.rec + (size_t)i * REC_FLOATS);
                 r4[0] = make_float4(px, py, k0, k1);
                 float opac = p.opacities[i];
@@ -255,6 +257,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(FwdParams p) {
     p.radii[i] = radius;
     p.tiles_touched[i] = tiles;
     p.rect[i] = rect;
+    p.depth_bits[i] = depth_bits;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -547,7 +550,7 @@ int launch_preprocess_fwd(const lvdgs_args &a, const GeomView &g, hipStream_t s)
     p.cam = make_cam(a); p.N = a.num_gaussians; p.act = a.activations;
     p.means3D = a.means3D; p.opacities = a.opacities; p.scales = a.scales; p.rotations = a.rotations;
     p.cov3D_precomp = a.cov3D_precomp; p.shs = a.shs; p.colors_precomp = a.colors_precomp;
-    p.rec = g.rec; p.tiles_touched = g.tiles_touched; p.rect = g.rect; p.radii = a.radii;
+    p.rec = g.rec; p.tiles_touched = g.tiles_touched; p.depth_bits = g.depth_bits; p.rect = g.rect; p.radii = a.radii;
     ProfScope ps("preprocess_fwd", s);
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(cdiv(p.N, 256)), dim3(256), 0, s, p);
     LVDGS_LAUNCH_CHECK("preprocess_fwd", a.debug, s);

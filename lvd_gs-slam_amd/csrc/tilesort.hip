@@ -24,9 +24,18 @@ namespace {
 
 typedef unsigned long long u64;
 
-__device__ __forceinline__ u64 depth_key(const float *__restrict__ rec, uint32_t id) {
-    return ((u64)__float_as_uint(rec[(size_t)id * REC_FLOATS + 9]) << 32) | (u64)id;
-}
+// Where a segment's keys come from: already scattered as 64-bit keys (counting path), or gathered from the ids in
+// point_list and the depths in the records (radix path).  The choice is uniform over the launch.
+struct KeySource {
+    const float *rec;
+    const uint32_t *point_list;
+    const u64 *keys;  // null: gather
+    __device__ __forceinline__ u64 load(uint32_t pos) const {
+        if (keys) return keys[pos];
+        const uint32_t id = point_list[pos];
+        return ((u64)__float_as_uint(rec[(size_t)id * REC_FLOATS + 9]) << 32) | (u64)id;
+    }
+};
 
 // All-ascending bitonic network (every merge starts with a mirrored compare, so no direction flags).  With the
 // tail beyond n treated as +infinity an exchange whose partner lies beyond n can never swap, so a segment of
@@ -131,12 +140,12 @@ __device__ __forceinline__ void wave_bitonic_sort(u64 (&key)[E], int lane) {
 }
 
 template <int E>
-__device__ __forceinline__ void wave_sort_segment(const float *__restrict__ rec, uint32_t *__restrict__ seg, int n, int lane) {
+__device__ __forceinline__ void wave_sort_segment(const KeySource &src, uint32_t first, uint32_t *__restrict__ seg, int n, int lane) {
     u64 key[E];
 #pragma unroll
     for (int r = 0; r < E; r++) {
         const int i = r * 64 + lane;  // any assignment of elements to slots will do before sorting
-        key[r] = i < n ? depth_key(rec, seg[i]) : ~0ull;
+        key[r] = i < n ? src.load(first + i) : ~0ull;
     }
     wave_bitonic_sort<E>(key, lane);
 #pragma unroll
@@ -149,24 +158,27 @@ __device__ __forceinline__ void wave_sort_segment(const float *__restrict__ rec,
 constexpr int CLASS_W = 512;  // longest segment one wave sorts in registers
 
 // one wave per tile; longer segments are queued for the workgroup kernels
-__global__ void __launch_bounds__(256) tile_depth_sort_wave_kernel(const uint2 *__restrict__ ranges, int num_tiles,
-                                                                   const float *__restrict__ rec, uint32_t *__restrict__ point_list,
-                                                                   uint32_t *queue_count, uint32_t *__restrict__ queue) {
+__global__ void __launch_bounds__(256) tile_depth_sort_wave_kernel(const uint2 *__restrict__ ranges, int num_tiles, KeySource src,
+                                                                   uint32_t *__restrict__ point_list, uint32_t *queue_count,
+                                                                   uint32_t *__restrict__ queue) {
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile >= num_tiles) return;
     const uint2 r = ranges[tile];
     const int n = (int)(r.y - r.x);
-    if (n < 2) return;
-    if (n <= 256) wave_sort_segment<4>(rec, point_list + r.x, n, lane);
-    else if (n <= CLASS_W) wave_sort_segment<8>(rec, point_list + r.x, n, lane);
+    if (n < 2) {
+        if (n == 1 && src.keys && lane == 0) point_list[r.x] = (uint32_t)src.keys[r.x];  // nothing to sort, but the id must land
+        return;
+    }
+    if (n <= 256) wave_sort_segment<4>(src, r.x, point_list + r.x, n, lane);
+    else if (n <= CLASS_W) wave_sort_segment<8>(src, r.x, point_list + r.x, n, lane);
     else if (lane == 0) queue[atomicAdd(queue_count, 1u)] = (uint32_t)tile;
 }
 
 constexpr int CLASS_A = 2048, CLASS_B = 16384;
 
 // queued segments up to CLASS_A entries: one workgroup each on LDS; longer ones are queued once more
-__global__ void __launch_bounds__(256) tile_depth_sort_kernel(const uint2 *__restrict__ ranges, const float *__restrict__ rec,
+__global__ void __launch_bounds__(256) tile_depth_sort_kernel(const uint2 *__restrict__ ranges, KeySource src,
                                                               uint32_t *__restrict__ point_list, const uint32_t *queue_count,
                                                               const uint32_t *__restrict__ queue, uint32_t *long_count,
                                                               uint32_t *__restrict__ long_tiles) {
@@ -181,7 +193,7 @@ __global__ void __launch_bounds__(256) tile_depth_sort_kernel(const uint2 *__res
             if (tid == 0) long_tiles[atomicAdd(long_count, 1u)] = tile;
             continue;
         }
-        for (int i = tid; i < n; i += 256) s_keys[i] = depth_key(rec, point_list[r.x + i]);
+        for (int i = tid; i < n; i += 256) s_keys[i] = src.load(r.x + i);
         __syncthreads();
         bitonic_sort_ascending<false>(s_keys, n, tid, 256);
         __syncthreads();
@@ -191,7 +203,7 @@ __global__ void __launch_bounds__(256) tile_depth_sort_kernel(const uint2 *__res
 }
 
 // queued segments: in 128 KiB of LDS up to CLASS_B entries, in place on global memory beyond
-__global__ void __launch_bounds__(1024) tile_depth_sort_long_kernel(const uint2 *__restrict__ ranges, const float *__restrict__ rec,
+__global__ void __launch_bounds__(1024) tile_depth_sort_long_kernel(const uint2 *__restrict__ ranges, KeySource src,
                                                                     uint32_t *__restrict__ point_list, const uint32_t *long_count,
                                                                     const uint32_t *__restrict__ long_tiles, u64 *keys) {
     extern __shared__ u64 s_dyn[];
@@ -201,16 +213,18 @@ __global__ void __launch_bounds__(1024) tile_depth_sort_long_kernel(const uint2 
         const uint2 r = ranges[long_tiles[q]];
         const int n = (int)(r.y - r.x);
         if (n <= CLASS_B) {
-            for (int i = tid; i < n; i += 1024) s_dyn[i] = depth_key(rec, point_list[r.x + i]);
+            for (int i = tid; i < n; i += 1024) s_dyn[i] = src.load(r.x + i);
             __syncthreads();
             bitonic_sort_ascending<false>(s_dyn, n, tid, 1024);
             __syncthreads();
             for (int i = tid; i < n; i += 1024) point_list[r.x + i] = (uint32_t)s_dyn[i];
         } else {
             volatile u64 *g = keys + r.x;
-            for (int i = tid; i < n; i += 1024) g[i] = depth_key(rec, point_list[r.x + i]);
-            __threadfence_block();
-            __syncthreads();
+            if (!src.keys) {  // otherwise the keys are already in place
+                for (int i = tid; i < n; i += 1024) g[i] = src.load(r.x + i);
+                __threadfence_block();
+                __syncthreads();
+            }
             bitonic_sort_ascending<true>(g, n, tid, 1024);
             for (int i = tid; i < n; i += 1024) point_list[r.x + i] = (uint32_t)g[i];
         }
@@ -220,14 +234,16 @@ __global__ void __launch_bounds__(1024) tile_depth_sort_long_kernel(const uint2 
 
 }  // namespace
 
-int launch_tile_depth_sort(const ImageView &im, int num_tiles, const float *rec, uint32_t *point_list, void *keys64, int dbg, hipStream_t s) {
+int launch_tile_depth_sort(const ImageView &im, int num_tiles, const float *rec, uint32_t *point_list, void *keys64, bool keys_ready,
+                           int dbg, hipStream_t s) {
     if (num_tiles == 0) return LVDGS_OK;
     static const bool big_lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_depth_sort_long_kernel),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, CLASS_B * 8) == hipSuccess;
     if (!big_lds_ok) { set_error("tile sort: cannot reserve 128 KiB of LDS"); return LVDGS_E_HIP; }
+    const KeySource src{rec, point_list, keys_ready ? (const u64 *)keys64 : nullptr};
     {
         ProfScope ps("tile_sort", s);
-        hipLaunchKernelGGL(tile_depth_sort_wave_kernel, dim3(cdiv(num_tiles, 4)), dim3(256), 0, s, (const uint2 *)im.ranges, num_tiles, rec,
+        hipLaunchKernelGGL(tile_depth_sort_wave_kernel, dim3(cdiv(num_tiles, 4)), dim3(256), 0, s, (const uint2 *)im.ranges, num_tiles, src,
                            point_list, im.long_count, im.long_tiles);
         LVDGS_LAUNCH_CHECK("tile_sort", dbg, s);
     }
@@ -235,13 +251,13 @@ int launch_tile_depth_sort(const ImageView &im, int num_tiles, const float *rec,
     uint32_t *q2 = im.long_tiles + num_tiles;
     {
         ProfScope ps("tile_sort_mid", s);
-        hipLaunchKernelGGL(tile_depth_sort_kernel, dim3(256), dim3(256), 0, s, (const uint2 *)im.ranges, rec, point_list,
+        hipLaunchKernelGGL(tile_depth_sort_kernel, dim3(256), dim3(256), 0, s, (const uint2 *)im.ranges, src, point_list,
                            (const uint32_t *)im.long_count, (const uint32_t *)im.long_tiles, im.long_count + 1, q2);
         LVDGS_LAUNCH_CHECK("tile_sort_mid", dbg, s);
     }
     {
         ProfScope ps("tile_sort_long", s);
-        hipLaunchKernelGGL(tile_depth_sort_long_kernel, dim3(64), dim3(1024), CLASS_B * 8, s, (const uint2 *)im.ranges, rec, point_list,
+        hipLaunchKernelGGL(tile_depth_sort_long_kernel, dim3(64), dim3(1024), CLASS_B * 8, s, (const uint2 *)im.ranges, src, point_list,
                            (const uint32_t *)(im.long_count + 1), (const uint32_t *)q2, (unsigned long long *)keys64);
         LVDGS_LAUNCH_CHECK("tile_sort_long", dbg, s);
     }

@@ -1,6 +1,7 @@
 """Test helper: run the HIP rasterizer (through GaussianRasterizer -> C ABI) on CPU tensors and
 return numpy results, including intermediates read out of the state buffers."""
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -14,7 +15,7 @@ def settings_from_cam(cam, W, H, bg, sh_degree=0, scale_modifier=1.0, dev="cuda"
         image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg.to(dev),
         scale_modifier=scale_modifier, viewmatrix=cam.world_view_transform.to(dev),
         projmatrix=cam.full_proj_transform.to(dev), projmatrix_raw=cam.projection_matrix.to(dev),
-        sh_degree=sh_degree, campos=cam.camera_center.to(dev), prefiltered=False, debug=False)
+        sh_degree=sh_degree, campos=cam.camera_center.to(dev), prefiltered=False, debug=bool(os.environ.get("LVDGS_TEST_DEBUG")))
 
 
 def _view(buf, off, count, dtype):

@@ -54,7 +54,7 @@ def test_sizes_are_monotone_and_aligned():
     prev = 0
     for n in (1, 1000, 100_000, 2_000_000):
         b = L.lvdgs_geom_bytes(n)
-        assert b % 256 == 0 and b > prev and b >= n * 56
+        assert b % 256 == 0 and b > prev and b >= n * 60
         prev = b
     assert L.lvdgs_binning_bytes(3_000_000) >= 3_000_000 * 8
     assert L.lvdgs_image_bytes(1920, 1080) >= 1920 * 1080 * 8
