@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendParams p) {
 constexpr int ACC_STRIDE = 10;  // floats per (wave, entry) accumulator slot
 constexpr int BR = 64;          // list entries staged per round in the backward pass
 
-__global__ void __launch_bounds__(256, 8) blend_bwd_kernel(BlendParams p) {
+__global__ void __launch_bounds__(256, 6) blend_bwd_kernel(BlendParams p) {
     __shared__ float4 s_a[BR];               // x, y, a, b
     __shared__ float4 s_b[BR];               // c, opacity, depth, -a/2*log2e
     __shared__ float4 s_c[BR];               // r, g, b, -b*log2e
