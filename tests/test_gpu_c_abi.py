@@ -1,0 +1,89 @@
+"""The C ABI driven directly with ctypes, the way INTEGRATION.md's binding does: the two-call forward
+(lvdgs_forward_prepare + lvdgs_forward_render) and lvdgs_backward give bit-identical results to the autograd
+path (single-call lvdgs_forward)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def test_two_call_forward_and_backward_through_ctypes():
+    import hip_runner
+    from lvdgs import _lib, synthetic
+    L = _lib.lib()
+    N, W, H = 3000, 200, 120
+    g = synthetic.make_gaussians(N, W, H, seed=3)
+    cam = synthetic.make_camera(W, H, pose_seed=4)
+    grads = synthetic.make_image_grads(W, H, 5)
+    bg = torch.tensor([0.3, 0.2, 0.1])
+    f_ref, b_ref = hip_runner.run_hip(g, cam, W, H, bg, grads=grads)
+
+    dev = torch.device("cuda")
+    t = {k: v.to(dev).contiguous() for k, v in g.items()}
+    mats = {k: getattr(cam, k).to(dev).contiguous() for k in ("world_view_transform", "full_proj_transform", "projection_matrix",
+                                                              "camera_center")}
+    bgd = bg.to(dev)
+    buf = lambda n: torch.empty(max(int(n), 256), dtype=torch.uint8, device=dev)
+    a = _lib.Args()
+    a.image_height, a.image_width, a.tanfovx, a.tanfovy = H, W, cam.tanfovx, cam.tanfovy
+    a.scale_modifier, a.sh_degree = 1.0, 0
+    a.bg, a.viewmatrix, a.projmatrix = _p(bgd), _p(mats["world_view_transform"]), _p(mats["full_proj_transform"])
+    a.projmatrix_raw, a.campos = _p(mats["projection_matrix"]), _p(mats["camera_center"])
+    a.num_gaussians, a.sh_coeffs = N, 0
+    a.means3D, a.opacities, a.scales, a.rotations = _p(t["means3D"]), _p(t["opacities"]), _p(t["scales"]), _p(t["rotations"])
+    a.colors_precomp = _p(t["colors"])
+    radii = torch.empty(N, dtype=torch.int32, device=dev)
+    n_touched = torch.empty(N, dtype=torch.int32, device=dev)
+    color, depth, opacity = (torch.empty(c, H, W, device=dev) for c in (3, 1, 1))
+    geom, image = buf(L.lvdgs_geom_bytes(N)), buf(L.lvdgs_image_bytes(W, H))
+    scratch = buf(L.lvdgs_prepare_scratch_bytes(N))
+    a.radii, a.n_touched, a.out_color, a.out_depth, a.out_opacity = _p(radii), _p(n_touched), _p(color), _p(depth), _p(opacity)
+    a.geom_state, a.geom_bytes, a.image_state, a.image_bytes = _p(geom), geom.numel(), _p(image), image.numel()
+    a.scratch, a.scratch_bytes = _p(scratch), scratch.numel()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    D = C.c_int64()
+    _lib.check(L.lvdgs_forward_prepare(C.byref(a), C.byref(D), stream), "prepare")
+    assert D.value == f_ref["num_rendered"]
+    binning, scratch2 = buf(L.lvdgs_binning_bytes(D.value)), buf(L.lvdgs_render_scratch_bytes(N, D.value, W, H))
+    a.num_rendered, a.binning_state, a.binning_bytes = D.value, _p(binning), binning.numel()
+    a.scratch, a.scratch_bytes = _p(scratch2), scratch2.numel()
+    _lib.check(L.lvdgs_forward_render(C.byref(a), stream), "render")
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(color.cpu().numpy(), f_ref["color"])
+    np.testing.assert_array_equal(depth.cpu().numpy(), f_ref["depth"])
+    np.testing.assert_array_equal(opacity.cpu().numpy(), f_ref["opacity"])
+    np.testing.assert_array_equal(radii.cpu().numpy(), f_ref["radii"])
+    np.testing.assert_array_equal(n_touched.cpu().numpy(), f_ref["n_touched"])
+
+    gc, gd, go = (x.to(dev).contiguous() for x in grads)
+    scratch3 = buf(L.lvdgs_backward_scratch_bytes(N, D.value))
+    a.scratch, a.scratch_bytes = _p(scratch3), scratch3.numel()
+    a.dL_dout_color, a.dL_dout_depth, a.dL_dout_opacity = _p(gc), _p(gd), _p(go)
+    e = lambda *s: torch.empty(*s, device=dev)
+    out = dict(means3D=e(N, 3), means2D=e(N, 3), opacities=e(N, 1), scales=e(N, 3), rotations=e(N, 4), colors=e(N, 3), tau=e(6))
+    a.dL_dmeans3D, a.dL_dmeans2D, a.dL_dopacities = _p(out["means3D"]), _p(out["means2D"]), _p(out["opacities"])
+    a.dL_dscales, a.dL_drotations, a.dL_dcolors, a.dL_dtau = _p(out["scales"]), _p(out["rotations"]), _p(out["colors"]), _p(out["tau"])
+    _lib.check(L.lvdgs_backward(C.byref(a), stream), "backward")
+    torch.cuda.synchronize()
+    for k in ("means3D", "means2D", "opacities", "scales", "rotations", "colors"):
+        np.testing.assert_array_equal(out[k].cpu().numpy().reshape(b_ref[k].shape), b_ref[k], err_msg=k)
+    np.testing.assert_array_equal(out["tau"].cpu().numpy(), b_ref["tau"].reshape(-1))
+    assert b"lvdgs" in L.lvdgs_version()
+
+
+def test_errors_are_reported_not_thrown():
+    from lvdgs import _lib
+    L = _lib.lib()
+    a = _lib.Args()
+    a.image_height, a.image_width, a.num_gaussians = 64, 64, 10
+    D = C.c_int64()
+    assert L.lvdgs_forward(C.byref(a), C.byref(D), None) == _lib.E_INVALID
+    assert len(L.lvdgs_last_error()) > 0
+    assert L.lvdgs_backward(C.byref(a), None) == _lib.E_INVALID
