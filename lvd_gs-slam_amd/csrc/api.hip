@@ -294,7 +294,9 @@ int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipSt
     const uint32_t *count = nullptr;
     if (N > 0) {
         geom_layout(N, &g, a->geom_state);
-        if (int e = check_hip(hipMemsetAsync(a->n_touched, 0, sizeof(int32_t) * (size_t)N, s), "memset n_touched")) return e;
+        // blend_fwd accumulates into n_touched: the counting path clears it in its first kernel, the radix path here
+        if (!(cap > 0 && use_counting_path(num_tiles)))
+            if (int e = check_hip(hipMemsetAsync(a->n_touched, 0, sizeof(int32_t) * (size_t)N, s), "memset n_touched")) return e;
         if (count_on_device) count = g.total;
     }
     bool grouped = false;

@@ -75,10 +75,19 @@ __device__ __forceinline__ void for_each_pair_of_chunk(int N, int gx, const uint
     }
 }
 
+// (Also clears what the later kernels of the frame accumulate into: n_touched and the tile-sort queues -- two
+// memset launches less.)
 __global__ void __launch_bounds__(GROUP_THREADS) count_pairs_kernel(int N, int gx, int T, const uint2 *__restrict__ rect,
-                                                                   uint32_t *__restrict__ hist) {
+                                                                   uint32_t *__restrict__ hist, int32_t *__restrict__ n_touched,
+                                                                   uint32_t *__restrict__ queue_counts) {
     extern __shared__ uint32_t s_tile[];
     for (int t = threadIdx.x; t < T; t += GROUP_THREADS) s_tile[t] = 0u;
+#pragma unroll
+    for (int k = 0; k < GROUP_PER_THREAD; k++) {
+        const int i = blockIdx.x * GROUP_CHUNK + k * GROUP_THREADS + (int)threadIdx.x;
+        if (i < N) n_touched[i] = 0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) queue_counts[threadIdx.x] = 0u;
     __syncthreads();
     for_each_pair_of_chunk(N, gx, rect, [&](int tile, uint32_t) { atomicAdd(&s_tile[tile], 1u); });
     __syncthreads();
@@ -194,11 +203,10 @@ int launch_group_pairs(const lvdgs_args &a, const GeomView &g, const ImageView &
                                hipFuncSetAttribute(reinterpret_cast<const void *>(&scatter_pairs_kernel),
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, GROUP_MAX_TILES * 4) == hipSuccess;
     if (!lds_ok) { set_error("grouping: cannot reserve 64 KiB of LDS"); return LVDGS_E_HIP; }
-    // the queues of over-long tile segments (tilesort.hip) are cleared here, where the radix path clears the ranges
-    if (int e = check_hip(hipMemsetAsync(im.long_count, 0, 64 * sizeof(uint32_t), s), "memset tile queues")) return e;
     {
         ProfScope ps("group_count", s);
-        hipLaunchKernelGGL(count_pairs_kernel, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint2 *)g.rect, w.group_hist);
+        hipLaunchKernelGGL(count_pairs_kernel, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint2 *)g.rect, w.group_hist,
+                           a.n_touched, im.long_count);
         LVDGS_LAUNCH_CHECK("group_count", a.debug, s);
     }
     {
