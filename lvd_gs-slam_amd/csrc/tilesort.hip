@@ -8,7 +8,7 @@
 // segments here are a few hundred entries each and sort independently in LDS.
 //
 // Size classes (bitonic networks throughout):
-//   <= 512 entries: ONE WAVE per tile, keys in registers (4 or 8 per lane): strides inside a lane are register
+//   <= 1024 entries: ONE WAVE per tile, keys in registers (4, 8 or 16 per lane): strides inside a lane are register
 //      compare-exchanges, strides across lanes one 64-bit lane shuffle per key; no LDS array, no barrier.  This
 //      is the common case by far (a few hundred entries per tile) and ~8x fewer instructions than a
 //      workgroup-wide LDS network, whose threads mostly wait at barriers;
@@ -155,7 +155,7 @@ __device__ __forceinline__ void wave_sort_segment(const KeySource &src, uint32_t
     }
 }
 
-constexpr int CLASS_W = 512;  // longest segment one wave sorts in registers
+constexpr int CLASS_W = 1024;  // longest segment one wave sorts in registers (16 keys per lane)
 
 // one wave per tile; longer segments are queued for the workgroup kernels
 __global__ void __launch_bounds__(256) tile_depth_sort_wave_kernel(const uint2 *__restrict__ ranges, int num_tiles, KeySource src,
@@ -171,7 +171,8 @@ __global__ void __launch_bounds__(256) tile_depth_sort_wave_kernel(const uint2 *
         return;
     }
     if (n <= 256) wave_sort_segment<4>(src, r.x, point_list + r.x, n, lane);
-    else if (n <= CLASS_W) wave_sort_segment<8>(src, r.x, point_list + r.x, n, lane);
+    else if (n <= 512) wave_sort_segment<8>(src, r.x, point_list + r.x, n, lane);
+    else if (n <= CLASS_W) wave_sort_segment<16>(src, r.x, point_list + r.x, n, lane);
     else if (lane == 0) queue[atomicAdd(queue_count, 1u)] = (uint32_t)tile;
 }
 
@@ -251,7 +252,7 @@ int launch_tile_depth_sort(const ImageView &im, int num_tiles, const float *rec,
     uint32_t *q2 = im.long_tiles + num_tiles;
     {
         ProfScope ps("tile_sort_mid", s);
-        hipLaunchKernelGGL(tile_depth_sort_kernel, dim3(256), dim3(256), 0, s, (const uint2 *)im.ranges, src, point_list,
+        hipLaunchKernelGGL(tile_depth_sort_kernel, dim3(2048), dim3(256), 0, s, (const uint2 *)im.ranges, src, point_list,
                            (const uint32_t *)im.long_count, (const uint32_t *)im.long_tiles, im.long_count + 1, q2);
         LVDGS_LAUNCH_CHECK("tile_sort_mid", dbg, s);
     }
