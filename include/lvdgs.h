@@ -157,7 +157,8 @@ typedef struct lvdgs_state_layout {
     size_t geom_slot_base;     /* N x u32: exclusive scan of tiles_touched in id order (first pair of a Gaussian) */
     /* byte offsets into binning_state */
     size_t bin_point_list;     /* D x u32: Gaussian ids, (tile, depth, id) ordered */
-    size_t bin_tile_keys;      /* D x u32: tile id of each entry of point_list */
+    size_t bin_tile_keys;      /* D x u32: tile id of each entry of point_list -- written only on the radix
+                                  path (images above 16384 tiles); otherwise derive it from img_ranges */
     /* byte offsets into image_state */
     size_t img_ranges;         /* T x 2 u32: [begin, end) of each tile in point_list */
     size_t img_final_T;        /* P x float */

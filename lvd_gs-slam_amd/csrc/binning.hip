@@ -160,7 +160,6 @@ __global__ void __launch_bounds__(1024) group_tilescan_kernel(int T, const uint3
 
 __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int gx, int T, const uint2 *__restrict__ rect,
                                                                      const uint32_t *__restrict__ hist,
-                                                                     const uint32_t *__restrict__ totals_unused,
                                                                      const uint2 *__restrict__ ranges, uint32_t capacity,
                                                                      const uint32_t *__restrict__ depth_bits,
                                                                      unsigned long long *__restrict__ keys64) {
@@ -220,7 +219,7 @@ int launch_group_pairs(const lvdgs_args &a, const GeomView &g, const ImageView &
     {
         ProfScope ps("group_scatter", s);
         hipLaunchKernelGGL(scatter_pairs_kernel, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint2 *)g.rect,
-                           (const uint32_t *)w.group_hist, (const uint32_t *)w.group_totals, (const uint2 *)im.ranges, (uint32_t)capacity,
+                           (const uint32_t *)w.group_hist, (const uint2 *)im.ranges, (uint32_t)capacity,
                            (const uint32_t *)g.depth_bits, keys64);
         LVDGS_LAUNCH_CHECK("group_scatter", a.debug, s);
     }
