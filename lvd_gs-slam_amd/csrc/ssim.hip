@@ -32,7 +32,7 @@ constexpr int S2 = ST + 2 * SR;  // 42: edge of the region where m is needed
 constexpr int P1 = S1 + 1;       // odd LDS pitches: row-strided accesses fall in different banks
 constexpr int P2 = S2 + 1;
 constexpr int P3 = ST + 1;
-constexpr int SSIM_THREADS = 256;
+constexpr int SSIM_THREADS = 512;  // 8 waves per workgroup, 2 workgroups per CU (LDS): 4 waves per SIMD
 constexpr float SSIM_C1 = 0.01f * 0.01f, SSIM_C2 = 0.03f * 0.03f;
 
 struct SsimParams {
@@ -45,6 +45,15 @@ struct SsimParams {
     float *d_x;                  // planes*H*W or null
     float win[SW];
 };
+
+__device__ __forceinline__ float block_sum8(float v, float *s) {
+    v = wave_sum_to_lane63(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 63) s[wave] = v;
+    __syncthreads();
+    return (((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7])));
+}
 
 __device__ __forceinline__ float block_sum4(float v, float *s) {
     v = wave_sum_to_lane63(v);
@@ -61,7 +70,7 @@ __global__ void __launch_bounds__(SSIM_THREADS) ssim_l1_kernel(SsimParams p) {
     __shared__ float s_in[2 * S1 * P1];
     // horizontal pass results: 4 x S1 x P2; later the horizontal pass of the derivative maps (3 x S2 x P3)
     __shared__ float s_h[4 * S1 * P2];
-    __shared__ float s_red[4];
+    __shared__ float s_red[8];
     static_assert(3 * S2 * P2 <= 2 * S1 * P1, "derivative maps must fit the input windows");
     static_assert(3 * S2 * P3 <= 4 * S1 * P2, "second horizontal pass must fit the first");
 
@@ -113,10 +122,10 @@ __global__ void __launch_bounds__(SSIM_THREADS) ssim_l1_kernel(SsimParams p) {
     }
     __syncthreads();
 
-    // ---- 2a. horizontal pass: rows 0..S1, output columns 0..S2; one item = 11 outputs of one row, so the
-    //      52 x 4 items fill one round of the workgroup (the last column group overlaps its neighbour) ----
+    // ---- 2a. horizontal pass: rows 0..S1, output columns 0..S2; one item = 5 outputs of one row, so the
+    //      52 x 9 items fill one round of the workgroup (the last column group overlaps its neighbour) ----
     {
-        constexpr int OUT = 11, NIN = OUT + SW - 1, GROUPS = (S2 + OUT - 1) / OUT;
+        constexpr int OUT = 5, NIN = OUT + SW - 1, GROUPS = (S2 + OUT - 1) / OUT;  // 52 rows x 9 column groups = 468 items
         static_assert(S1 * GROUPS <= SSIM_THREADS, "one round");
         if (tid < S1 * GROUPS) {
             const int r = tid % S1, g = tid / S1;
@@ -156,10 +165,10 @@ __global__ void __launch_bounds__(SSIM_THREADS) ssim_l1_kernel(SsimParams p) {
     float msum = 0.f;
     float *sdA = s_in, *sdS = s_in + S2 * P2, *sdZ = s_in + 2 * S2 * P2;
     {
-        constexpr int OUT = 7, NIN = OUT + SW - 1, GROUPS = S2 / OUT;  // 42 columns x 6 row groups = 252 items
-        static_assert(S2 % OUT == 0 && S2 * GROUPS <= SSIM_THREADS, "one round");
+        constexpr int OUT = 4, NIN = OUT + SW - 1, GROUPS = (S2 + OUT - 1) / OUT;  // 42 columns x 11 row groups = 462 items
+        static_assert(S2 * GROUPS <= SSIM_THREADS, "one round");
         if (tid < S2 * GROUPS) {
-            const int c = tid % S2, r0 = (tid / S2) * OUT;
+            const int c = tid % S2, rfirst = (tid / S2) * OUT, r0 = min(rfirst, S2 - OUT);  // the last group overlaps
             float va[NIN], vb[NIN], vs[NIN], vz[NIN];
 #pragma unroll
             for (int i = 0; i < NIN; i++) {
@@ -190,7 +199,7 @@ __global__ void __launch_bounds__(SSIM_THREADS) ssim_l1_kernel(SsimParams p) {
                 const float inv1 = __builtin_amdgcn_rcpf(den1), inv2 = __builtin_amdgcn_rcpf(den2);
                 const float inv12 = inv1 * inv2;
                 const float m = (num1 * num2) * inv12;
-                if (inside && r >= SR && r < SR + ST && c >= SR && c < SR + ST) msum += m;
+                if (inside && r >= rfirst && r >= SR && r < SR + ST && c >= SR && c < SR + ST) msum += m;  // overlapped rows count once
                 if (GRAD) {
                     // dm/dA = 2B (num2 - num1) / (den1 den2) - 2A m (1/den1 - 1/den2); dm/dS = -m / den2; dm/dZ = 2 num1 / (den1 den2)
                     const float dA = 2.f * B * (num2 - num1) * inv12 - 2.f * A * m * (inv1 - inv2);
@@ -207,8 +216,8 @@ __global__ void __launch_bounds__(SSIM_THREADS) ssim_l1_kernel(SsimParams p) {
 
     // ---- the two sums of this workgroup ----
     {
-        const float t1 = block_sum4(l1, s_red);
-        const float t2 = block_sum4(msum, s_red);
+        const float t1 = block_sum8(l1, s_red);
+        const float t2 = block_sum8(msum, s_red);
         if (tid == 0) {
             const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
             p.partial[2 * wg] = t1;
@@ -218,10 +227,10 @@ __global__ void __launch_bounds__(SSIM_THREADS) ssim_l1_kernel(SsimParams p) {
     if (!GRAD) return;
     __syncthreads();
 
-    // ---- 4a. horizontal pass over the derivative maps: rows 0..S2, output columns 0..ST, 6 per item
-    //      (42 x 6 = 252 items, the last column group overlaps its neighbour) ----
+    // ---- 4a. horizontal pass over the derivative maps: rows 0..S2, output columns 0..ST, 3 per item
+    //      (42 x 11 = 462 items, the last column group overlaps its neighbour) ----
     {
-        constexpr int OUT = 6, NIN = OUT + SW - 1, GROUPS = (ST + OUT - 1) / OUT;
+        constexpr int OUT = 3, NIN = OUT + SW - 1, GROUPS = (ST + OUT - 1) / OUT;  // 42 rows x 11 column groups = 462 items
         static_assert(S2 * GROUPS <= SSIM_THREADS, "one round");
         if (tid < S2 * GROUPS) {
             const int r = tid % S2, c0 = min((tid / S2) * OUT, ST - OUT);
@@ -251,13 +260,13 @@ __global__ void __launch_bounds__(SSIM_THREADS) ssim_l1_kernel(SsimParams p) {
     }
     __syncthreads();
 
-    // ---- 4b. vertical pass, 4 outputs per item, and the gradient of this tile ----
+    // ---- 4b. vertical pass, 2 outputs per item (32 columns x 16 row pairs = 512 items), and the gradient of this tile ----
     float *__restrict__ G = p.d_x + plane_off;
-    for (int item = tid; item < ST * (ST / 4); item += SSIM_THREADS) {
-        const int c = item % ST, r0 = (item / ST) * 4;
-        float va[14], vs[14], vz[14];
+    for (int item = tid; item < ST * (ST / 2); item += SSIM_THREADS) {
+        const int c = item % ST, r0 = (item / ST) * 2;
+        float va[12], vs[12], vz[12];
 #pragma unroll
-        for (int i = 0; i < 14; i++) {
+        for (int i = 0; i < 12; i++) {
             const int d = (r0 + i) * P3 + c;
             va[i] = s_h[d];
             vs[i] = s_h[S2 * P3 + d];
@@ -265,7 +274,7 @@ __global__ void __launch_bounds__(SSIM_THREADS) ssim_l1_kernel(SsimParams p) {
         }
         const int gx = tx0 + c;
 #pragma unroll
-        for (int o = 0; o < 4; o++) {
+        for (int o = 0; o < 2; o++) {
             float a = w[0] * va[o], s = w[0] * vs[o], z = w[0] * vz[o];
 #pragma unroll
             for (int k = 1; k < SW; k++) {
@@ -289,16 +298,19 @@ __global__ void __launch_bounds__(SSIM_THREADS) ssim_l1_kernel(SsimParams p) {
     }
 }
 
-__global__ void __launch_bounds__(256) ssim_finish_kernel(const float *__restrict__ partial, int nwg, float inv_count,
+__global__ void __launch_bounds__(512) ssim_finish_kernel(const float2 *__restrict__ partial, int nwg, float inv_count,
                                                           float *__restrict__ out) {
-    __shared__ float s_red[4];
+    __shared__ float s_red[8];
     float a = 0.f, b = 0.f;
-    for (int i = threadIdx.x; i < nwg; i += 256) {
-        a += partial[2 * i];
-        b += partial[2 * i + 1];
+    for (int i0 = threadIdx.x; i0 < nwg; i0 += 4 * 512) {  // four independent 8-byte loads in flight per thread
+        float2 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = i0 + k * 512 < nwg ? partial[i0 + k * 512] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { a += v[k].x; b += v[k].y; }
     }
-    const float ta = block_sum4(a, s_red);
-    const float tb = block_sum4(b, s_red);
+    const float ta = block_sum8(a, s_red);
+    const float tb = block_sum8(b, s_red);
     if (threadIdx.x == 0) {
         out[0] = ta * inv_count;
         out[1] = tb * inv_count;
@@ -346,7 +358,7 @@ int lvdgs_ssim_l1(const lvdgs_ssim_args *a, void *stream) {
     }
     {
         ProfScope ps("ssim_finish", s);
-        hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(256), 0, s, (const float *)p.partial, nwg, (float)(1.0 / count), a->out);
+        hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(512), 0, s, (const float2 *)p.partial, nwg, (float)(1.0 / count), a->out);
         LVDGS_LAUNCH_CHECK("ssim_finish", 0, s);
     }
     return LVDGS_OK;
