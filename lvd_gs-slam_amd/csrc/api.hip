@@ -96,6 +96,17 @@ ProfScope::~ProfScope() {
         }
 }
 
+int allow_dynamic_lds(const void *kernel, int bytes, unsigned char (&done)[16]) {
+    int dev = 0;
+    if (int e = check_hip(hipGetDevice(&dev), "hipGetDevice")) return e;
+    unsigned char &flag = done[dev & 15];
+    if (!flag) {
+        if (int e = check_hip(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), "reserve dynamic LDS")) return e;
+        flag = 1;
+    }
+    return LVDGS_OK;
+}
+
 // Images of up to group_max_tiles() tiles group their pairs by counting (binning.hip); larger ones, or every image
 // when LVDGS_FORCE_RADIX_GROUPING is set in the environment (tests), take the radix sort on the tile id.
 static bool use_counting_path(int num_tiles) {

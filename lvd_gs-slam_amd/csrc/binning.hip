@@ -197,11 +197,9 @@ int launch_group_pairs(const lvdgs_args &a, const GeomView &g, const ImageView &
     if (N == 0 || T == 0) return LVDGS_OK;
     const int nchunks = cdiv(N, GROUP_CHUNK);
     const size_t lds = (size_t)T * sizeof(uint32_t);
-    static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&count_pairs_kernel),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, GROUP_MAX_TILES * 4) == hipSuccess &&
-                               hipFuncSetAttribute(reinterpret_cast<const void *>(&scatter_pairs_kernel),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, GROUP_MAX_TILES * 4) == hipSuccess;
-    if (!lds_ok) { set_error("grouping: cannot reserve 64 KiB of LDS"); return LVDGS_E_HIP; }
+    static unsigned char count_done[16], scatter_done[16];
+    if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&count_pairs_kernel), GROUP_MAX_TILES * 4, count_done)) return e;
+    if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&scatter_pairs_kernel), GROUP_MAX_TILES * 4, scatter_done)) return e;
     {
         ProfScope ps("group_count", s);
         hipLaunchKernelGGL(count_pairs_kernel, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint2 *)g.rect, w.group_hist,

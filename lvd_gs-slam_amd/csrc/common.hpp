@@ -36,6 +36,10 @@ inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 void set_error(const char *fmt, ...);
 int check_hip(hipError_t e, const char *what);
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per device and kernel (the attribute is per device; one process
+// per GPU is the intended use, but a process may still touch several devices)
+int allow_dynamic_lds(const void *kernel, int bytes, unsigned char (&done)[16]);
+
 // ---- profiling hooks (no-ops unless lvdgs_profile_enable(1)) ----
 struct ProfScope {
     int slot;

@@ -238,9 +238,8 @@ __global__ void __launch_bounds__(1024) tile_depth_sort_long_kernel(const uint2 
 int launch_tile_depth_sort(const ImageView &im, int num_tiles, const float *rec, uint32_t *point_list, void *keys64, bool keys_ready,
                            int dbg, hipStream_t s) {
     if (num_tiles == 0) return LVDGS_OK;
-    static const bool big_lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&tile_depth_sort_long_kernel),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, CLASS_B * 8) == hipSuccess;
-    if (!big_lds_ok) { set_error("tile sort: cannot reserve 128 KiB of LDS"); return LVDGS_E_HIP; }
+    static unsigned char lds_done[16];
+    if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&tile_depth_sort_long_kernel), CLASS_B * 8, lds_done)) return e;
     const KeySource src{rec, point_list, keys_ready ? (const u64 *)keys64 : nullptr};
     {
         ProfScope ps("tile_sort", s);
