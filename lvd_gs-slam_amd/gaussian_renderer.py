@@ -75,7 +75,6 @@ def _render(viewpoint_camera, pc, pipe, bg_color, image_height, image_width, sca
         viewmatrix=viewpoint_camera.world_view_transform, projmatrix=viewpoint_camera.full_proj_transform,
         projmatrix_raw=viewpoint_camera.projection_matrix, sh_degree=pc.active_sh_degree,
         campos=viewpoint_camera.camera_center, prefiltered=False, debug=False)
-    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
 
     means3D, means2D = xyz, screenspace_points
     scales = rotations = cov3D_precomp = None
@@ -100,10 +99,10 @@ def _render(viewpoint_camera, pc, pipe, bg_color, image_height, image_width, sca
         shs = pc.get_features
 
     sel = (lambda t: t) if mask is None else (lambda t: None if t is None else t[mask])
-    rendered_image, radii, depth, opacity_img, n_touched = rasterizer(
-        means3D=sel(means3D), means2D=sel(means2D), shs=sel(shs), colors_precomp=sel(colors_precomp),
-        opacities=sel(opacity), scales=sel(scales), rotations=sel(rotations), cov3D_precomp=sel(cov3D_precomp),
-        theta=viewpoint_camera.cam_rot_delta, rho=viewpoint_camera.cam_trans_delta, activations=activations)
+    # GaussianRasterizer(raster_settings)(...) without building an nn.Module per frame (same autograd function)
+    rendered_image, radii, depth, opacity_img, n_touched = _rz.rasterize_gaussians(
+        sel(means3D), sel(means2D), sel(shs), sel(colors_precomp), sel(opacity), sel(scales), sel(rotations),
+        sel(cov3D_precomp), viewpoint_camera.cam_rot_delta, viewpoint_camera.cam_trans_delta, raster_settings, activations)
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
             "radii": radii, "depth": depth, "opacity": opacity_img, "n_touched": n_touched}
 
