@@ -13,15 +13,18 @@ namespace lvdgs {
 namespace {
 
 // ------------------------------------------------------------------------------------------
-// exact 3-NN: Morton order -> boxes of 256 consecutive points -> every workgroup owns one box,
-// stages candidate boxes through LDS and prunes whole boxes by AABB-to-AABB distance against the
-// workgroup's current worst "third best".  Candidates are visited outward from the own box in
-// Morton order, so the bound tightens after the first few boxes and most boxes are skipped.
-constexpr int KNN_BOX = 256;
+// exact 3-NN: Morton order -> boxes of 64 or 256 consecutive points -> every workgroup owns one box, scans itself and
+// its eight Morton neighbours, then tests all other boxes in parallel (AABB-to-AABB gap against the workgroup's
+// current worst "third best") and stages only the survivors through LDS.
+constexpr int KNN_BOUNDS_BLOCKS = 128;
+constexpr int KNN_BOX_SMALL = 64, KNN_BOX_LARGE = 256;  // points per box: small boxes prune better and give small inputs
+                                                        // enough workgroups; large inputs want fewer boxes to test
+constexpr int KNN_SMALL_LIMIT = 200000;
+inline int knn_box_size(int P) { return P <= KNN_SMALL_LIMIT ? KNN_BOX_SMALL : KNN_BOX_LARGE; }
 
 struct KnnScratch {
     uint32_t *keys[2], *vals[2], *hist, *totals;
-    float *bounds;   // 6: min xyz, max xyz
+    float *bounds;   // partial bounding boxes: KNN_BOUNDS_BLOCKS x (min xyz, max xyz)
     float *box_lo;   // nbox * 3
     float *box_hi;   // nbox * 3
 };
@@ -36,18 +39,18 @@ size_t knn_layout(int P, KnnScratch *v, void *base) {
         ptr = b ? reinterpret_cast<T *>(b + off) : nullptr;
         off += align256(count * sizeof(T));
     };
-    const size_t n = (size_t)(P > 0 ? P : 1), nbox = (n + KNN_BOX - 1) / KNN_BOX;
+    const size_t n = (size_t)(P > 0 ? P : 1), nbox = (n + KNN_BOX_SMALL - 1) / KNN_BOX_SMALL;
     carve(v->keys[0], n); carve(v->keys[1], n); carve(v->vals[0], n); carve(v->vals[1], n);
     carve(v->hist, radix_hist_entries(P)); carve(v->totals, (size_t)1 << SORT_MAX_BITS);
-    carve(v->bounds, 64); carve(v->box_lo, nbox * 3); carve(v->box_hi, nbox * 3);
+    carve(v->bounds, KNN_BOUNDS_BLOCKS * 6); carve(v->box_lo, nbox * 3); carve(v->box_hi, nbox * 3);
     return off;
 }
 
-__global__ void __launch_bounds__(256) knn_bounds_kernel(int P, const float *__restrict__ pts, float *__restrict__ bounds) {
-    // single workgroup: grid-stride min/max, then an LDS tree (P is at most a few million)
+// per-workgroup bounding boxes of a grid-stride share of the points: partial[block][6] (min xyz, max xyz)
+__global__ void __launch_bounds__(256) knn_bounds_kernel(int P, const float *__restrict__ pts, float *__restrict__ partial) {
     __shared__ float s[6][256];
     float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    for (int i = threadIdx.x; i < P; i += 256)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256)
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             const float v = pts[3 * (size_t)i + a];
@@ -65,7 +68,7 @@ __global__ void __launch_bounds__(256) knn_bounds_kernel(int P, const float *__r
             }
         __syncthreads();
     }
-    if (threadIdx.x < 6) bounds[threadIdx.x] = s[threadIdx.x][0];
+    if (threadIdx.x < 6) partial[blockIdx.x * 6 + threadIdx.x] = s[threadIdx.x][0];
 }
 
 __device__ __forceinline__ uint32_t spread10(uint32_t x) {
@@ -76,14 +79,26 @@ __device__ __forceinline__ uint32_t spread10(uint32_t x) {
     return x;
 }
 
-__global__ void __launch_bounds__(256) knn_morton_kernel(int P, const float *__restrict__ pts, const float *__restrict__ bounds,
-                                                         uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+__global__ void __launch_bounds__(256) knn_morton_kernel(int P, const float *__restrict__ pts, const float *__restrict__ partial,
+                                                         int nparts, uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    // every workgroup folds the partial bounding boxes itself (a few KB from L2): no separate reduction launch
+    __shared__ float s_b[6];
+    if (threadIdx.x < 6) {
+        const bool is_min = threadIdx.x < 3;
+        float v = is_min ? FLT_MAX : -FLT_MAX;
+        for (int k = 0; k < nparts; k++) {
+            const float x = partial[k * 6 + threadIdx.x];
+            v = is_min ? fminf(v, x) : fmaxf(v, x);
+        }
+        s_b[threadIdx.x] = v;
+    }
+    __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= P) return;
     uint32_t code = 0;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        const float lo = bounds[a], ext = bounds[3 + a] - lo;
+        const float lo = s_b[a], ext = s_b[3 + a] - lo;
         const float t = ext > 0.f ? (pts[3 * (size_t)i + a] - lo) / ext : 0.f;
         const uint32_t q = (uint32_t)fminf(fmaxf(t * 1023.f, 0.f), 1023.f);
         code |= spread10(q) << a;
@@ -92,6 +107,7 @@ __global__ void __launch_bounds__(256) knn_morton_kernel(int P, const float *__r
     vals[i] = (uint32_t)i;
 }
 
+template <int KNN_BOX>
 __global__ void __launch_bounds__(KNN_BOX) knn_boxes_kernel(int P, const float *__restrict__ pts, const uint32_t *__restrict__ order,
                                                             float *__restrict__ box_lo, float *__restrict__ box_hi) {
     __shared__ float s[6][KNN_BOX];
@@ -123,11 +139,19 @@ __device__ __forceinline__ void push3(float d, float &b0, float &b1, float &b2) 
     }
 }
 
+// One workgroup per box.  Order of work: the own box (gives every point a first bound), the eight Morton neighbours,
+// then ALL other boxes are tested 256 at a time -- one box per thread, AABB-to-AABB gap against the workgroup's worst
+// "third best" -- and only the survivors are staged and scanned.  Inside a staged box a point whose own third best is
+// already closer than the box's AABB skips the scan.  (The first version walked the boxes one by one: two dependent
+// global loads per box per workgroup, 54 ms at 0.5 M points.)
+template <int KNN_BOX>
 __global__ void __launch_bounds__(KNN_BOX) knn_search_kernel(int P, int nbox, const float *__restrict__ pts,
                                                              const uint32_t *__restrict__ order, const float *__restrict__ box_lo,
                                                              const float *__restrict__ box_hi, float *__restrict__ out) {
     __shared__ float s_pts[KNN_BOX][3];
-    __shared__ float s_red[4];
+    __shared__ float s_red[KNN_BOX / 64];
+    __shared__ int s_list[KNN_BOX];
+    __shared__ int s_count;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = b * KNN_BOX + tid;
     const bool ok = i < P;
@@ -137,21 +161,8 @@ __global__ void __launch_bounds__(KNN_BOX) knn_search_kernel(int P, int nbox, co
     float b0 = FLT_MAX, b1 = FLT_MAX, b2 = FLT_MAX;
     const float mylo[3] = {box_lo[3 * b], box_lo[3 * b + 1], box_lo[3 * b + 2]};
     const float myhi[3] = {box_hi[3 * b], box_hi[3 * b + 1], box_hi[3 * b + 2]};
-    float bound = FLT_MAX;  // max over the workgroup's points of their current third-best distance
-    // visit boxes outward: b, b+1, b-1, b+2, b-2, ...
-    for (int step = 0; step < 2 * nbox; step++) {
-        const int off = (step + 1) >> 1;
-        const int c = (step & 1) ? b + off : b - off;
-        if (step == 0 ? false : (c < 0 || c >= nbox)) continue;
-        const int cc = step == 0 ? b : c;
-        // minimum squared distance between the two boxes (workgroup-uniform)
-        float gap2 = 0.f;
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            const float g = fmaxf(0.f, fmaxf(box_lo[3 * cc + a] - myhi[a], mylo[a] - box_hi[3 * cc + a]));
-            gap2 += g * g;
-        }
-        if (gap2 > bound) continue;
+
+    auto scan_box = [&](int cc) {  // workgroup-uniform cc
         __syncthreads();
         const int j = cc * KNN_BOX + tid;
         if (j < P) {
@@ -160,21 +171,73 @@ __global__ void __launch_bounds__(KNN_BOX) knn_search_kernel(int P, int nbox, co
         }
         __syncthreads();
         const int cnt = min(KNN_BOX, P - cc * KNN_BOX);
-        if (ok) {
+        // this point against the candidate box: nothing in the box can beat a third best that is already closer
+        float gap2 = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float g = fmaxf(0.f, fmaxf(box_lo[3 * cc + a] - p[a], p[a] - box_hi[3 * cc + a]));
+            gap2 += g * g;
+        }
+        if (ok && gap2 < b2) {
             for (int k = 0; k < cnt; k++) {
                 if (cc == b && k == tid) continue;
                 const float dx = s_pts[k][0] - p[0], dy = s_pts[k][1] - p[1], dz = s_pts[k][2] - p[2];
                 push3(dx * dx + dy * dy + dz * dz, b0, b1, b2);
             }
         }
-        // refresh the workgroup bound
+    };
+    auto workgroup_bound = [&]() {  // max over the workgroup's points of their current third-best distance
         float m = ok ? b2 : 0.f;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (KNN_BOX == 64) return m;
         __syncthreads();
         if (lane == 0) s_red[wave] = m;
         __syncthreads();
-        bound = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+        float r = s_red[0];
+        for (int w = 1; w < KNN_BOX / 64; w++) r = fmaxf(r, s_red[w]);
+        return r;
+    };
+
+    constexpr int NEAR = 4;
+    scan_box(b);
+    for (int off = 1; off <= NEAR; off++) {
+        if (b - off >= 0) scan_box(b - off);
+        if (b + off < nbox) scan_box(b + off);
+    }
+    float bound = workgroup_bound();
+    for (int c0 = 0; c0 < nbox; c0 += KNN_BOX) {
+        // one candidate box per thread
+        const int cc = c0 + tid;
+        bool take = false;
+        if (cc < nbox && (cc < b - NEAR || cc > b + NEAR)) {
+            float gap2 = 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const float g = fmaxf(0.f, fmaxf(box_lo[3 * cc + a] - myhi[a], mylo[a] - box_hi[3 * cc + a]));
+                gap2 += g * g;
+            }
+            take = gap2 <= bound;
+        }
+        if (tid == 0) s_count = 0;
+        __syncthreads();
+        if (take) s_list[atomicAdd(&s_count, 1)] = cc;  // any order: the result is a minimum
+        __syncthreads();
+        const int n = s_count;
+        for (int q = 0; q < n; q++) {
+            const int cq = s_list[q];
+            // the bound may have tightened since the test
+            float gap2 = 0.f;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const float g = fmaxf(0.f, fmaxf(box_lo[3 * cq + a] - myhi[a], mylo[a] - box_hi[3 * cq + a]));
+                gap2 += g * g;
+            }
+            if (gap2 > bound) continue;
+            scan_box(cq);
+            bound = workgroup_bound();
+        }
+        __syncthreads();
     }
     if (ok) {
         // fewer than 4 points: average what exists
@@ -231,14 +294,24 @@ int lvdgs_dist2_knn3(int32_t P, const float *points, float *mean_dist2, void *sc
     if (scratch_bytes < lvdgs_knn_scratch_bytes(P)) { set_error("knn scratch too small"); return LVDGS_E_INVALID; }
     KnnScratch w;
     knn_layout(P, &w, scratch);
-    const int nbox = cdiv(P, KNN_BOX);
-    { ProfScope ps("knn_bounds", s); hipLaunchKernelGGL(knn_bounds_kernel, dim3(1), dim3(256), 0, s, P, points, w.bounds); LVDGS_LAUNCH_CHECK("knn_bounds", 0, s); }
-    { ProfScope ps("knn_morton", s); hipLaunchKernelGGL(knn_morton_kernel, dim3(cdiv(P, 256)), dim3(256), 0, s, P, points, w.bounds, w.keys[0], w.vals[0]); LVDGS_LAUNCH_CHECK("knn_morton", 0, s); }
+    const int box = knn_box_size(P), nbox = cdiv(P, box);
+    { ProfScope ps("knn_bounds", s); hipLaunchKernelGGL(knn_bounds_kernel, dim3(KNN_BOUNDS_BLOCKS), dim3(256), 0, s, P, points, w.bounds); LVDGS_LAUNCH_CHECK("knn_bounds", 0, s); }
+    { ProfScope ps("knn_morton", s); hipLaunchKernelGGL(knn_morton_kernel, dim3(cdiv(P, 256)), dim3(256), 0, s, P, points, w.bounds, KNN_BOUNDS_BLOCKS, w.keys[0], w.vals[0]); LVDGS_LAUNCH_CHECK("knn_morton", 0, s); }
     bool in_a = true;
     if (int e = radix_sort_pairs(w.keys[0], w.vals[0], w.keys[1], w.vals[1], P, 30, w.hist, w.totals, &in_a, 0, s)) return e;
     const uint32_t *order = in_a ? w.vals[0] : w.vals[1];
-    { ProfScope ps("knn_boxes", s); hipLaunchKernelGGL(knn_boxes_kernel, dim3(nbox), dim3(KNN_BOX), 0, s, P, points, order, w.box_lo, w.box_hi); LVDGS_LAUNCH_CHECK("knn_boxes", 0, s); }
-    { ProfScope ps("knn_search", s); hipLaunchKernelGGL(knn_search_kernel, dim3(nbox), dim3(KNN_BOX), 0, s, P, nbox, points, order, w.box_lo, w.box_hi, mean_dist2); LVDGS_LAUNCH_CHECK("knn_search", 0, s); }
+    {
+        ProfScope ps("knn_boxes", s);
+        if (box == KNN_BOX_SMALL) hipLaunchKernelGGL(knn_boxes_kernel<KNN_BOX_SMALL>, dim3(nbox), dim3(KNN_BOX_SMALL), 0, s, P, points, order, w.box_lo, w.box_hi);
+        else hipLaunchKernelGGL(knn_boxes_kernel<KNN_BOX_LARGE>, dim3(nbox), dim3(KNN_BOX_LARGE), 0, s, P, points, order, w.box_lo, w.box_hi);
+        LVDGS_LAUNCH_CHECK("knn_boxes", 0, s);
+    }
+    {
+        ProfScope ps("knn_search", s);
+        if (box == KNN_BOX_SMALL) hipLaunchKernelGGL(knn_search_kernel<KNN_BOX_SMALL>, dim3(nbox), dim3(KNN_BOX_SMALL), 0, s, P, nbox, points, order, w.box_lo, w.box_hi, mean_dist2);
+        else hipLaunchKernelGGL(knn_search_kernel<KNN_BOX_LARGE>, dim3(nbox), dim3(KNN_BOX_LARGE), 0, s, P, nbox, points, order, w.box_lo, w.box_hi, mean_dist2);
+        LVDGS_LAUNCH_CHECK("knn_search", 0, s);
+    }
     return LVDGS_OK;
 }
 

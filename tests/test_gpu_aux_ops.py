@@ -25,6 +25,20 @@ def test_dist2_knn3_matches_brute_force(n, kind):
     np.testing.assert_allclose(out, ref, rtol=2e-5, atol=1e-9)
 
 
+def test_dist2_knn3_large_input_sampled_against_brute_force():
+    """Above 200 000 points the search switches to 256-point boxes: check 400 random points of 260 000 exactly."""
+    from lvdgs.simple_knn import distCUDA2
+    g = torch.Generator().manual_seed(7)
+    n = 260_000
+    pts = torch.randn(n, 3, generator=g) * torch.tensor([10.0, 2.0, 30.0])
+    out = distCUDA2(pts.cuda()).cpu().numpy()
+    pick = torch.randperm(n, generator=g)[:400]
+    d2 = ((pts[pick].double()[:, None, :] - pts.double()[None, :, :]) ** 2).sum(-1)  # 400 x n
+    d2[torch.arange(400), pick] = float("inf")
+    ref = d2.topk(3, dim=1, largest=False).values.mean(1).numpy()
+    np.testing.assert_allclose(out[pick.numpy()], ref, rtol=2e-5, atol=1e-9)
+
+
 def test_dist2_knn3_duplicates():
     import aux_oracle
     from lvdgs.simple_knn import distCUDA2
