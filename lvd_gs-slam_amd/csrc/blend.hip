@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendParams p) {
 constexpr int ACC_STRIDE = 10;  // floats per (wave, entry) accumulator slot
 constexpr int BR = 64;          // list entries staged per round in the backward pass
 
-__global__ void __launch_bounds__(256, 6) blend_bwd_kernel(BlendParams p) {
+__global__ void __launch_bounds__(256, 8) blend_bwd_kernel(BlendParams p) {
     __shared__ float4 s_a[BR];               // x, y, a, b
     __shared__ float4 s_b[BR];               // c, opacity, depth, -a/2*log2e
     __shared__ float4 s_c[BR];               // r, g, b, -b*log2e
@@ -232,9 +232,6 @@ __global__ void __launch_bounds__(256, 6) blend_bwd_kernel(BlendParams p) {
     // which accumulator floats the lane that ends a 16-lane row writes (see the fold below)
     const int row_off = (lane >> 4) == 0 ? 0 : ((lane >> 4) == 1 ? 3 : ((lane >> 4) == 2 ? 5 : 8));
     const bool row_end = (lane & 15) == 15, row3 = ((lane >> 4) & 1) == 0;
-
-    // pixel offsets inside the quadrant (per-lane constants of the moment sums)
-    const float lx = (float)(lane & 7), ly = (float)(lane >> 3);
 
     const int rounds = (todo + BR - 1) / BR;
     for (int r = rounds - 1; r >= 0; r--) {
@@ -297,18 +294,19 @@ __global__ void __launch_bounds__(256, 6) blend_bwd_kernel(BlendParams p) {
                         dL_dalpha = fmaf(dL_dalpha, T, -(tail * inv));
                         v5 = G * dL_dalpha;
                     }
-                    // Six of the ten sums are moments of u = G * dL/dalpha over the quadrant's pixel offsets,
-                    //   sum u * (1, lx, ly, lx^2, lx ly, ly^2),
-                    // from which the flush derives the gradients w.r.t. opacity, 2-D mean and conic once per pair:
-                    // five multiplications by per-lane constants here instead of ten with the per-Gaussian dx, dy.
-                    const float u = v5;
-                    const float a1 = u * lx, a2 = u * ly, a3 = a1 * lx, a4 = a1 * ly, a5 = a2 * ly;
-                    const float a6 = w * gC0, a7 = w * gC1, a8 = w * gC2, a9 = w * gD;
+                    // v0..v4 are accumulated without their constant factors (-1, -1, -1/2, -1, -1/2): the
+                    // flush applies them once per (Gaussian, tile) pair instead of once per pixel.
+                    const float v6 = w * gC0, v7 = w * gC1, v8 = w * gC2, v9 = w * gD;
+                    const float h = B.y * v5;  // dL/dG * G
+                    const float hx = h * dx, hy = h * dy;
+                    const float v0 = fmaf(A.z, hx, A.w * hy);
+                    const float v1 = fmaf(B.x, hy, A.w * hx);
+                    const float v2 = hx * dx, v3 = hx * dy, v4 = hy * dy;
                     // ---- sum the ten values over the 64 pixels: two pairwise folds (64 -> 32 -> 16 lanes,
                     //      ten registers -> five -> three), then one 16-lane DPP sum of the three ----
-                    float q0 = fold16(fold32(u, a1), fold32(a2, a3));    // rows: S0  Sy  Sx  Sxx
-                    float q1 = fold16(fold32(a4, a5), fold32(a6, a7));   // rows: Sxy c0  Syy c1
-                    float q2 = fold16(fold32(a8, a9), a7);               // rows: c2  x   c3  x (x: unused)
+                    float q0 = fold16(fold32(v0, v1), fold32(v2, v3));  // rows: v0 v2 v1 v3
+                    float q1 = fold16(fold32(v4, v5), fold32(v6, v7));  // rows: v4 v6 v5 v7
+                    float q2 = fold16(fold32(v8, v9), v7);              // rows: v8 x  v9 x (x: unused)
                     row_sums3(q0, q1, q2);
                     if (row_end) {
                         float *o = &s_acc[wave][jj * ACC_STRIDE + row_off];
@@ -322,36 +320,23 @@ __global__ void __launch_bounds__(256, 6) blend_bwd_kernel(BlendParams p) {
         }
         __syncthreads();
         if (tid < cnt) {
-            const float4 A = s_a[tid];
-            const float4 B = s_b[tid];
-            float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;                          // sum w * dL/d(r, g, b, depth)
-            float h0 = 0.f, hx = 0.f, hy = 0.f, hxx = 0.f, hxy = 0.f, hyy = 0.f;  // sum u * (1, dx, dy, dx^2, dx dy, dy^2)
+            float acc[ACC_STRIDE];
+#pragma unroll
+            for (int k = 0; k < ACC_STRIDE; k++) acc[k] = 0.f;
             const int ch = tid >> 6;
             const unsigned long long bit = 1ull << (tid & 63);
 #pragma unroll
             for (int w = 0; w < 4; w++)
                 if (s_mask[w][ch] & bit) {
-                    // slot order written above: S0 Sxy c2 | Sy c0 | Sx Syy c3 | Sxx c1
                     const float2 *o = reinterpret_cast<const float2 *>(&s_acc[w][tid * ACC_STRIDE]);
-                    const float2 t0 = o[0], t1 = o[1], t2 = o[2], t3 = o[3], t4 = o[4];
-                    const float S0 = t0.x, Sxy = t0.y, Sy = t1.y, Sx = t2.y, Syy = t3.x, Sxx = t4.x;
-                    c0 += t2.x; c1 += t4.y; c2 += t1.x; c3 += t3.y;
-                    // the offsets are local to the wave's quadrant: d = (mean - origin) - l
-                    const float ax = A.x - (float)(tx * TILE + (w & 1) * 8), ay = A.y - (float)(ty * TILE + (w >> 1) * 8);
-                    h0 += S0;
-                    hx += ax * S0 - Sx;
-                    hy += ay * S0 - Sy;
-                    hxx += ax * (ax * S0 - 2.f * Sx) + Sxx;
-                    hxy += ax * (ay * S0 - Sy) - ay * Sx + Sxy;
-                    hyy += ay * (ay * S0 - 2.f * Sy) + Syy;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) { const float2 t = o[k]; acc[2 * k] += t.x; acc[2 * k + 1] += t.y; }
                 }
-            // h = opacity * u carries the geometric terms (conic a, b, c = A.z, A.w, B.x)
-            const float op = B.y;
-            const float gx = op * hx, gy = op * hy;
+            // slot order written above: v0 v4 v8 | v2 v6 | v1 v5 v9 | v3 v7
             float4 *dst = reinterpret_cast<float4 *>(p.pair_grads + (size_t)s_slot[tid] * PAIR_FLOATS);
-            dst[0] = make_float4(-(A.z * gx + A.w * gy), -(B.x * gy + A.w * gx), -0.5f * op * hxx, -op * hxy);
-            dst[1] = make_float4(-0.5f * op * hyy, h0, c0, c1);
-            dst[2] = make_float4(c2, c3, 0.f, 0.f);
+            dst[0] = make_float4(-acc[0], -acc[5], -0.5f * acc[3], -acc[8]);
+            dst[1] = make_float4(-0.5f * acc[1], acc[6], acc[4], acc[9]);
+            dst[2] = make_float4(acc[2], acc[7], 0.f, 0.f);
         }
         __syncthreads();
     }
