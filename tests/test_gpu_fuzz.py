@@ -1,6 +1,8 @@
 """Randomised parity sweep: scene sizes, image shapes (not multiples of the tile), footprint and opacity ranges and
 camera poses drawn from a seeded generator; every case is checked like the fixed parity cases (integers exact, floats
 1e-4).  Sizes are kept small enough for the CPU oracle to finish each case in about a second."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -22,7 +24,7 @@ def _case(rng):
                 seed=int(rng.integers(0, 10_000)))
 
 
-@pytest.mark.parametrize("case_seed", list(range(24)))
+@pytest.mark.parametrize("case_seed", list(range(int(os.environ.get("LVDGS_FUZZ_CASES", "24")))))  # more: set the variable
 def test_random_scene_matches_oracle(case_seed):
     orc, hr, syn = tp._mods()
     c = _case(np.random.default_rng(1000 + case_seed))
