@@ -50,3 +50,53 @@ def test_random_scene_matches_oracle(case_seed):
     if solid.all():
         np.testing.assert_array_equal(f_hip["n_touched"], f_ora["n_touched"], err_msg=str(c))
         tp._check_backward(b_hip, b_ora, ["means3D", "means2D", "opacities", "scales", "rotations", "colors", "tau"])
+
+
+@pytest.mark.parametrize("case_seed", list(range(16)))
+def test_random_ssim_l1_cases(case_seed):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+    import loss_oracle as lo
+    from lvdgs.loss_utils import l1_dssim_loss
+    rng = np.random.default_rng(2000 + case_seed)
+    C = int(rng.choice([1, 3]))
+    H, W = int(rng.integers(1, 150)), int(rng.integers(1, 200))
+    lam = float(rng.choice([0.0, 0.2, 1.0]))
+    g = torch.Generator().manual_seed(case_seed)
+    a = torch.rand(C, H, W, generator=g)
+    b = (a + float(rng.choice([0.02, 0.3])) * torch.randn(C, H, W, generator=g)).clamp(0, 1)
+    mask = (torch.rand(H, W, generator=g) > float(rng.choice([0.1, 0.6]))) if rng.random() < 0.6 else None
+    bg = torch.rand(C, generator=g)
+    ad = a.double().requires_grad_(True)
+    want = lo.l1_dssim_loss(ad, b, lam, mask, bg)
+    want.backward()
+    ag = a.cuda().requires_grad_(True)
+    got = l1_dssim_loss(ag, b.cuda(), lam, None if mask is None else mask.cuda(), bg.cuda())
+    got.backward()
+    assert abs(float(got.detach()) - float(want.detach())) < 3e-6, (C, H, W, lam)
+    ref = ad.grad.numpy()
+    err = np.abs(ag.grad.cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-30)
+    assert err < 1e-4, (C, H, W, lam, err)
+
+
+@pytest.mark.parametrize("case_seed", list(range(12)))
+def test_random_point_clouds_knn(case_seed):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+    import aux_oracle
+    from lvdgs.simple_knn import distCUDA2
+    rng = np.random.default_rng(3000 + case_seed)
+    n = int(rng.choice([1, 2, 3, 5, 63, 64, 65, 129, 1000, 4097, 9000]))
+    g = torch.Generator().manual_seed(case_seed)
+    kind = rng.choice(["ball", "sheet", "line", "clusters", "grid"])
+    pts = torch.randn(n, 3, generator=g)
+    if kind == "sheet":
+        pts[:, 1] *= 1e-3
+    elif kind == "line":
+        pts[:, 1:] *= 1e-4
+    elif kind == "clusters":
+        pts = pts * 0.01 + torch.randint(0, 5, (n, 1), generator=g).float() * 10.0
+    elif kind == "grid":
+        pts = torch.round(pts * 2.0)  # many exact duplicates and ties
+    out = distCUDA2(pts.cuda()).cpu().numpy()
+    np.testing.assert_allclose(out, aux_oracle.dist2_knn3(pts.numpy()), rtol=3e-5, atol=1e-9, err_msg=f"{n} {kind}")
