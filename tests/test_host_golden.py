@@ -143,3 +143,46 @@ def test_image_gradient_self_consistency():
     mv, mh = slam_utils.image_gradient_mask(img2)
     assert not mv[0, 3:6, 4:7].any() and mv[0, 0, 0] == (img2[0, :2, :2].abs() > 0.01).all()
     assert torch.equal(mv, mh)
+
+
+def test_camera_matrices_are_cached_per_pose_and_replica_edge_mask_matches_the_block_loop():
+    """Camera caches its derived matrices until R / T change (replaced or written in place); the replica branch of
+    compute_grad_mask equals the reference's sequential per-block assignment (utils/camera_utils.py:135-153)."""
+    import torch
+    from lvdgs import slam_utils
+    from lvdgs.camera_utils import Camera
+    from lvdgs.graphics_utils import getProjectionMatrix2
+    from lvdgs.pose_utils import SE3_exp
+    W, H = 96, 64
+    proj = getProjectionMatrix2(znear=0.01, zfar=100.0, fx=90.0, fy=92.0, cx=47.0, cy=31.0, W=W, H=H).transpose(0, 1)
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand(3, H, W, generator=g)
+    cam = Camera(0, img, None, None, torch.eye(4), proj, 90.0, 92.0, 47.0, 31.0, 1.0, 0.7, H, W, device="cpu")
+    a = cam.world_view_transform
+    assert cam.world_view_transform is a and cam.full_proj_transform is cam.full_proj_transform
+    T = SE3_exp(torch.tensor([0.1, 0.2, -0.3, 0.05, -0.02, 0.01]))
+    cam.update_RT(T[:3, :3], T[:3, 3])
+    b = cam.world_view_transform
+    assert b is not a and torch.allclose(b.t()[:3, :3], T[:3, :3]) and torch.allclose(b.t()[:3, 3], T[:3, 3])
+    moved = T[:3, 3].clone() + 1.0
+    cam.T.add_(1.0)  # in-place edit bumps the version: the cache must notice
+    assert torch.allclose(cam.world_view_transform.t()[:3, 3], moved)
+    assert torch.allclose(cam.camera_center, torch.linalg.inv(cam.world_view_transform)[3, :3])
+
+    cfg = {"Training": {"edge_threshold": 1.1}, "Dataset": {"type": "replica"}}
+    cam.compute_grad_mask(cfg)
+    got = cam.grad_mask.clone()
+    gray = img.mean(dim=0, keepdim=True)
+    gv, gh = slam_utils.image_gradient(gray)
+    mv, mh = slam_utils.image_gradient_mask(gray)
+    mag = torch.sqrt((gv * mv) ** 2 + (gh * mh) ** 2)
+    bh, bw = H // 32, W // 32
+    for r in range(32):
+        for c in range(32):
+            blk = mag[:, r * bh:(r + 1) * bh, c * bw:(c + 1) * bw]
+            cut = blk.median() * 1.1
+            blk[blk > cut] = 1
+            blk[blk <= cut] = 0
+    assert torch.equal(got, mag)
+    cam.clean()
+    assert cam.original_image is None and cam.cam_rot_delta is None and cam.exposure_b is None
