@@ -91,4 +91,6 @@ CONFIGS = {
     "cfg3_500k_1920x1080": dict(N=500_000, W=1920, H=1080),
     # KITTI-07 geometry (configs/mono/KITTI/07.yaml:8-18)
     "kitti07_geom": dict(N=200_000, W=1226, H=370, fx=707.0912, fy=707.0912, cx=601.8873, cy=183.1104),
+    # BASELINE.json configs[4] shape: 2 M Gaussians, waymo-sized frames (configs/mono/waymo/405841.yaml:15-16)
+    "cfg5_2m_1920x1280": dict(N=2_000_000, W=1920, H=1280),
 }
