@@ -88,8 +88,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 as `python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path for the product)")
     torch.cuda.set_device(local_rank)
@@ -183,7 +184,7 @@ def main():
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(g_cpu, N, W, H)
+        cpu_baseline = run_cpu_baseline(g_cpu, args.workload, N, W, H)
 
     if rank == 0:
         value = world * args.steps / elapsed
@@ -208,13 +209,16 @@ def main():
 CPU_BASELINE_ITERS = 2  # about 16 s of CPU work at config 3: inside the 10-30 s window, never extrapolated
 
 
-def run_cpu_baseline(g, N, W, H):
-    """Forward + backward of the CPU oracle (scalar C port, 1 core) on the same scene, CPU_BASELINE_ITERS times."""
+def run_cpu_baseline(g, workload, N, W, H):
+    """Forward + backward of the CPU oracle (scalar C port, 1 core) on the same scene and camera, CPU_BASELINE_ITERS
+    times.  The backward is fed fixed image gradients (colour, depth, opacity), not the tracking loss's: the oracle
+    restates the rasterizer, the loss is outside it."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import oracle as orc
 
-    cam = synthetic.make_camera(W, H)
+    cfg = synthetic.CONFIGS[workload]
+    cam = synthetic.make_camera(W, H, **{k: cfg[k] for k in ("fx", "fy", "cx", "cy") if k in cfg})
     gc, gd, go = synthetic.make_image_grads(W, H, 0)
     o = orc.Oracle("f32")
     t0 = time.perf_counter()
@@ -227,7 +231,8 @@ def run_cpu_baseline(g, N, W, H):
     dt = time.perf_counter() - t0
     o.free()
     return {"value": round(CPU_BASELINE_ITERS / dt, 5), "unit": "iters/s", "cores": 1, "kind": "port",
-            "sample": f"{CPU_BASELINE_ITERS} iterations (forward + backward) of the same {N}-Gaussian {W}x{H} scene, {dt:.1f} s",
+            "sample": f"{CPU_BASELINE_ITERS} iterations (rasterizer forward + backward with fixed image gradients; the loss is "
+                      f"not part of the oracle) of the same {N}-Gaussian {W}x{H} scene, scalar C oracle on 1 core, {dt:.1f} s",
             "host_cores_available": os.cpu_count()}
 
 

@@ -176,6 +176,13 @@ int lvdgs_dist2_knn3(int32_t num_points, const float *points /* P*3 */, float *m
  * (croco curope.rope_2d): first half of D rotates by y, second half by x; fwd = +1 or -1. */
 int lvdgs_rope2d(float *tokens, const int64_t *positions, int32_t B, int32_t N, int32_t H, int32_t D,
                  float base, float fwd, void *stream);
+/* The same rotation for f32 / f16 / bf16 tokens addressed through element strides (D contiguous): element (b, n, h, d)
+ * lives at tokens + b*stride_b + n*stride_n + h*stride_h + d.  croco calls curope on q / k in their (B, H, N, D)
+ * attention layout, i.e. stride_h = N*D, stride_n = D, under autocast in half precision; arithmetic is f32 and each
+ * element is rounded once when stored.  `dtype` is one of the LVDGS_F32 / LVDGS_F16 / LVDGS_BF16 codes. */
+enum { LVDGS_F32 = 0, LVDGS_F16 = 1, LVDGS_BF16 = 2 };
+int lvdgs_rope2d_strided(void *tokens, int32_t dtype, const int64_t *positions, int32_t B, int32_t N, int32_t H, int32_t D,
+                         int64_t stride_b, int64_t stride_n, int64_t stride_h, float base, float fwd, void *stream);
 
 /* ---- fused photometric losses (reference utils/slam_utils.py:42-121) ---- */
 /*   loss = weight_rgb   * mean_{c,p} [ omega_p * |(e^a I_cp + b) m_p - G_cp m_p| ]
@@ -209,6 +216,26 @@ typedef struct lvdgs_loss_args {
 size_t lvdgs_loss_scratch_bytes(int32_t width, int32_t height);
 int lvdgs_photometric_loss_forward(const lvdgs_loss_args *a, void *stream);
 int lvdgs_photometric_loss_backward(const lvdgs_loss_args *a, void *stream);
+
+/* ---- depth term of the static-mask mapping loss (reference utils/slam_backend.py:216-261) ----
+ *   M    = static_mask & (mono_depth > 0) & (rendered depth > 0)          (static_mask NULL = every pixel)
+ *   loss = depth_lambda-free mean over M of |D_p - Z_p|;  0 when M is empty (the reference then adds nothing)
+ * The mean is over |M|, not over the image (that is what distinguishes it from lvdgs_loss_args' depth term).
+ * forward writes out[0] = loss, out[1] = |M|; backward reads out[1] back and writes
+ *   d_depth_p = grad_loss * sign(D_p - Z_p) / |M| on M, 0 elsewhere. */
+typedef struct lvdgs_masked_depth_args {
+    int32_t width, height;
+    const float *depth;          /* H*W rendered depth                           */
+    const float *gt_depth;       /* H*W mono depth                               */
+    const uint8_t *static_mask;  /* H*W bytes (non-0 = static) or NULL           */
+    void *scratch; size_t scratch_bytes;   /* lvdgs_masked_depth_scratch_bytes(W,H); forward only */
+    float *out;                  /* 2 floats: loss, |M|  (forward writes, backward reads [1]) */
+    const float *grad_loss;      /* backward in: 1                               */
+    float *d_depth;              /* backward out: H*W                            */
+} lvdgs_masked_depth_args;
+size_t lvdgs_masked_depth_scratch_bytes(int32_t width, int32_t height);
+int lvdgs_masked_depth_l1_forward(const lvdgs_masked_depth_args *a, void *stream);
+int lvdgs_masked_depth_l1_backward(const lvdgs_masked_depth_args *a, void *stream);
 
 /* ---- fused L1 + SSIM image loss (reference utils/slam_backend.py:199-215, 438-454) ----
  * The mapping and colour-refinement losses `(1 - lambda) * l1_loss(a, b) + lambda * (1 - ssim(a, b))` call

@@ -51,6 +51,16 @@ class LossArgs(C.Structure):
     ]
 
 
+class MaskedDepthArgs(C.Structure):
+    """struct lvdgs_masked_depth_args (include/lvdgs.h)."""
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32),
+        ("depth", _fp), ("gt_depth", _fp), ("static_mask", _fp),
+        ("scratch", _fp), ("scratch_bytes", C.c_size_t),
+        ("out", _fp), ("grad_loss", _fp), ("d_depth", _fp),
+    ]
+
+
 class SsimArgs(C.Structure):
     """struct lvdgs_ssim_args (include/lvdgs.h)."""
     _fields_ = [
@@ -78,8 +88,9 @@ EXPORTS = (
     "lvdgs_render_scratch_bytes", "lvdgs_backward_scratch_bytes", "lvdgs_forward_prepare", "lvdgs_forward_render",
     "lvdgs_forward",
     "lvdgs_backward", "lvdgs_mark_visible", "lvdgs_state_layout_query", "lvdgs_knn_scratch_bytes",
-    "lvdgs_dist2_knn3", "lvdgs_rope2d", "lvdgs_loss_scratch_bytes", "lvdgs_photometric_loss_forward",
-    "lvdgs_photometric_loss_backward", "lvdgs_ssim_scratch_bytes", "lvdgs_ssim_l1", "lvdgs_last_error", "lvdgs_version", "lvdgs_profile_enable",
+    "lvdgs_dist2_knn3", "lvdgs_rope2d", "lvdgs_rope2d_strided", "lvdgs_loss_scratch_bytes", "lvdgs_photometric_loss_forward",
+    "lvdgs_photometric_loss_backward", "lvdgs_masked_depth_scratch_bytes", "lvdgs_masked_depth_l1_forward",
+    "lvdgs_masked_depth_l1_backward", "lvdgs_ssim_scratch_bytes", "lvdgs_ssim_l1", "lvdgs_last_error", "lvdgs_version", "lvdgs_profile_enable",
     "lvdgs_profile_reset", "lvdgs_profile_read",
 )
 
@@ -122,10 +133,16 @@ def lib():
         L.lvdgs_knn_scratch_bytes.argtypes = [C.c_int32]
         L.lvdgs_dist2_knn3.argtypes = [C.c_int32, _fp, _fp, _fp, C.c_size_t, C.c_void_p]
         L.lvdgs_rope2d.argtypes = [_fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p]
+        L.lvdgs_rope2d_strided.argtypes = [_fp, C.c_int32, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64,
+                                           C.c_int64, C.c_float, C.c_float, C.c_void_p]
         L.lvdgs_loss_scratch_bytes.restype = C.c_size_t
         L.lvdgs_loss_scratch_bytes.argtypes = [C.c_int32, C.c_int32]
         L.lvdgs_photometric_loss_forward.argtypes = [C.POINTER(LossArgs), C.c_void_p]
         L.lvdgs_photometric_loss_backward.argtypes = [C.POINTER(LossArgs), C.c_void_p]
+        L.lvdgs_masked_depth_scratch_bytes.restype = C.c_size_t
+        L.lvdgs_masked_depth_scratch_bytes.argtypes = [C.c_int32, C.c_int32]
+        L.lvdgs_masked_depth_l1_forward.argtypes = [C.POINTER(MaskedDepthArgs), C.c_void_p]
+        L.lvdgs_masked_depth_l1_backward.argtypes = [C.POINTER(MaskedDepthArgs), C.c_void_p]
         L.lvdgs_ssim_scratch_bytes.restype = C.c_size_t
         L.lvdgs_ssim_scratch_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
         L.lvdgs_ssim_l1.argtypes = [C.POINTER(SsimArgs), C.c_void_p]
@@ -133,6 +150,38 @@ def lib():
         L.lvdgs_profile_read.argtypes = [C.POINTER(KernelTime), C.c_int]
         _lib = L
     return _lib
+
+
+def raw_stream(device):
+    """hipStream_t of PyTorch's current stream ON `device` (the tensor's device, which need not be the current one),
+    as a c_void_p.  A direct C call: torch.cuda.current_stream() costs tens of microseconds of Python per call."""
+    import torch
+    idx = device.index if (device is not None and device.index is not None) else torch.cuda.current_device()
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(idx))
+
+
+class on_device:
+    """Make `device` the current HIP device for the duration of a library call when it is not already (kernels are
+    launched on the current device; a stream of another device would be rejected)."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, device):
+        self.idx = device.index
+
+    def __enter__(self):
+        import torch
+        self.prev = None
+        if self.idx is not None:
+            cur = torch.cuda.current_device()
+            if cur != self.idx:
+                self.prev = cur
+                torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            import torch
+            torch.cuda.set_device(self.prev)
+        return False
 
 
 def check(status, what):

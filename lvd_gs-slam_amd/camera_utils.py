@@ -5,8 +5,8 @@ Same constructor, attributes, properties and static constructors as the class in
 difference in how the derived matrices are produced: the reference recomputes ``world_view_transform``,
 ``full_proj_transform`` and ``camera_center`` from ``R, T`` with a handful of small PyTorch kernels at every
 attribute access -- three accesses per ``render()``.  Here they are computed once per pose and cached until
-``R`` or ``T`` is replaced or written in place (the cache key is the identity and version of both tensors), which
-takes about ten launches off every tracking / mapping iteration.
+``R`` or ``T`` is replaced or written in place (the cache entry keeps references to both tensors and their
+versions and compares by identity), which takes about ten launches off every tracking / mapping iteration.
 """
 import torch
 from torch import nn
@@ -56,12 +56,17 @@ class Camera(nn.Module):
 
     # ---- matrices derived from the pose, cached per (R, T, projection) ----------------------------
     def _matrices(self):
-        key = (id(self.R), self.R._version, id(self.T), self.T._version, id(self.projection_matrix))
-        if key != self._derived_key:
-            view = getWorld2View2(self.R, self.T).transpose(0, 1)          # row-vector convention
-            full = view.unsqueeze(0).bmm(self.projection_matrix.unsqueeze(0)).squeeze(0)
+        # The cache entry holds the tensors themselves (compared by identity) next to their versions: an `id()` can be
+        # handed to a new tensor as soon as the old one is freed (two update_RT() calls in a row do exactly that,
+        # utils/slam_frontend.py sync_backend), a held reference cannot.
+        R, T, P = self.R, self.T, self.projection_matrix
+        k = self._derived_key
+        if (k is None or k[0] is not R or k[1] != R._version or k[2] is not T or k[3] != T._version
+                or k[4] is not P or k[5] != P._version):
+            view = getWorld2View2(R, T).transpose(0, 1)          # row-vector convention
+            full = view.unsqueeze(0).bmm(P.unsqueeze(0)).squeeze(0)
             centre = view.inverse()[3, :3]
-            self._derived, self._derived_key = (view, full, centre), key
+            self._derived, self._derived_key = (view, full, centre), (R, R._version, T, T._version, P, P._version)
         return self._derived
 
     @property

@@ -250,11 +250,31 @@ __global__ void __launch_bounds__(KNN_BOX) knn_search_kernel(int P, int nbox, co
 }
 
 // ------------------------------------------------------------------------------------------
-// RoPE 2D: one workgroup per token (b, n).  The 2 * D/4 (cos, sin) pairs of the token are computed
-// once into LDS and reused by all H heads; the H*D floats stream through as float4.
-__global__ void __launch_bounds__(256) rope2d_kernel(float *__restrict__ tokens, const int64_t *__restrict__ pos, int H, int D,
-                                                     float base, float fwd) {
+// RoPE 2D: one workgroup per token (b, n).  The 2 * D/4 (cos, sin) pairs of the token are computed once into LDS
+// and reused by all H heads.  Tokens are addressed through (batch, token, head) strides with the D axis contiguous, so
+// both the (B, N, H, D) layout and the (B, H, N, D) layout croco's attention keeps are rotated where they lie (no
+// transposed copy); elements are f32, f16 or bf16, the arithmetic is f32 and every element is rounded once at the store.
+// A work item rotates V neighbouring pairs (i .. i+V-1, i+Q .. i+Q+V-1) of one half of one head: two V-wide loads and
+// two V-wide stores (16 bytes for f32, 8 for the 16-bit types at V = 4).
+template <typename T> struct RopeIO;
+template <> struct RopeIO<float> {
+    static __device__ __forceinline__ float ld(const float *p) { return *p; }
+    static __device__ __forceinline__ void st(float *p, float v) { *p = v; }
+};
+template <> struct RopeIO<_Float16> {
+    static __device__ __forceinline__ float ld(const _Float16 *p) { return (float)*p; }
+    static __device__ __forceinline__ void st(_Float16 *p, float v) { *p = (_Float16)v; }
+};
+template <> struct RopeIO<__bf16> {
+    static __device__ __forceinline__ float ld(const __bf16 *p) { return (float)*p; }
+    static __device__ __forceinline__ void st(__bf16 *p, float v) { *p = (__bf16)v; }  // round to nearest even; NaN stays NaN
+};
+
+template <typename T, int V>
+__global__ void __launch_bounds__(256) rope2d_kernel(T *__restrict__ tokens, const int64_t *__restrict__ pos, int N, int H, int D,
+                                                     int64_t stride_b, int64_t stride_n, int64_t stride_h, float base, float fwd) {
     extern __shared__ float s_cs[];  // [2][Q][2]
+    typedef T vec_t __attribute__((ext_vector_type(V)));
     const int Q = D / 4, Dh = D / 2;
     const size_t tok = blockIdx.x;
     for (int k = threadIdx.x; k < 2 * Q; k += blockDim.x) {
@@ -266,16 +286,45 @@ __global__ void __launch_bounds__(256) rope2d_kernel(float *__restrict__ tokens,
         s_cs[2 * k] = cs; s_cs[2 * k + 1] = sn;
     }
     __syncthreads();
-    float *t = tokens + tok * (size_t)H * D;
-    // work item = (head, half, i): rotates the pair (i, i + Q) of that half
-    for (int w = threadIdx.x; w < H * 2 * Q; w += blockDim.x) {
-        const int h = w / (2 * Q), r = w - h * 2 * Q, half = r / Q, i = r - half * Q;
-        float *x = t + (size_t)h * D + half * Dh;
-        const float cs = s_cs[2 * (half * Q + i)], sn = s_cs[2 * (half * Q + i) + 1];
-        const float u = x[i], v = x[i + Q];
-        x[i] = u * cs - v * sn;
-        x[i + Q] = v * cs + u * sn;
+    const int64_t b = (int64_t)(tok / (size_t)N), n = (int64_t)(tok % (size_t)N);
+    T *t = tokens + b * stride_b + n * stride_n;
+    const int QV = Q / V;  // V divides Q (checked by the launcher)
+    for (int w = threadIdx.x; w < H * 2 * QV; w += blockDim.x) {
+        const int h = w / (2 * QV), r = w - h * 2 * QV, half = r / QV, i = (r - half * QV) * V;
+        T *x = t + (int64_t)h * stride_h + half * Dh + i;
+        const float *cs = s_cs + 2 * (half * Q + i);
+        if constexpr (V == 1) {
+            const float u = RopeIO<T>::ld(x), v = RopeIO<T>::ld(x + Q);
+            RopeIO<T>::st(x, u * cs[0] - v * cs[1]);
+            RopeIO<T>::st(x + Q, v * cs[0] + u * cs[1]);
+        } else {
+            const vec_t U = *reinterpret_cast<const vec_t *>(x), W = *reinterpret_cast<const vec_t *>(x + Q);
+            vec_t A, Bv;
+#pragma unroll
+            for (int k = 0; k < V; k++) {
+                const float u = (float)U[k], v = (float)W[k];
+                A[k] = (T)(u * cs[2 * k] - v * cs[2 * k + 1]);
+                Bv[k] = (T)(v * cs[2 * k] + u * cs[2 * k + 1]);
+            }
+            *reinterpret_cast<vec_t *>(x) = A;
+            *reinterpret_cast<vec_t *>(x + Q) = Bv;
+        }
     }
+}
+
+template <typename T>
+int launch_rope2d(void *tokens, const int64_t *positions, int B, int N, int H, int D, int64_t sb, int64_t sn, int64_t sh,
+                  float base, float fwd, hipStream_t s) {
+    const int Q = D / 4;
+    // 4-wide accesses need every (token, head, half, i) address aligned to 4 elements
+    const bool wide = (Q % 4 == 0) && (sb % 4 == 0) && (sn % 4 == 0) && (sh % 4 == 0) && ((uintptr_t)tokens % (4 * sizeof(T)) == 0);
+    ProfScope ps("rope2d", s);
+    const dim3 grid((unsigned)((int64_t)B * N)), block(256);
+    const size_t lds = (size_t)D * 2 * sizeof(float);
+    if (wide) hipLaunchKernelGGL((rope2d_kernel<T, 4>), grid, block, lds, s, (T *)tokens, positions, N, H, D, sb, sn, sh, base, fwd);
+    else hipLaunchKernelGGL((rope2d_kernel<T, 1>), grid, block, lds, s, (T *)tokens, positions, N, H, D, sb, sn, sh, base, fwd);
+    LVDGS_LAUNCH_CHECK("rope2d", 0, s);
+    return LVDGS_OK;
 }
 
 }  // namespace
@@ -315,17 +364,28 @@ int lvdgs_dist2_knn3(int32_t P, const float *points, float *mean_dist2, void *sc
     return LVDGS_OK;
 }
 
-int lvdgs_rope2d(float *tokens, const int64_t *positions, int32_t B, int32_t N, int32_t H, int32_t D, float base, float fwd,
-                 void *stream) {
+int lvdgs_rope2d_strided(void *tokens, int32_t dtype, const int64_t *positions, int32_t B, int32_t N, int32_t H, int32_t D,
+                         int64_t stride_b, int64_t stride_n, int64_t stride_h, float base, float fwd, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     if (B < 0 || N < 0 || H <= 0 || D <= 0 || (D % 4) != 0) { set_error("rope2d: D must be a positive multiple of 4"); return LVDGS_E_INVALID; }
+    if (dtype < LVDGS_F32 || dtype > LVDGS_BF16) { set_error("rope2d: dtype must be LVDGS_F32, LVDGS_F16 or LVDGS_BF16"); return LVDGS_E_INVALID; }
     if ((int64_t)B * N == 0) return LVDGS_OK;
+    if ((int64_t)B * N > 0x7fffffffLL) { set_error("rope2d: more than 2^31 - 1 tokens"); return LVDGS_E_RANGE; }
     if (!tokens || !positions) { set_error("rope2d: NULL tensor"); return LVDGS_E_INVALID; }
-    ProfScope ps("rope2d", s);
-    hipLaunchKernelGGL(rope2d_kernel, dim3((unsigned)((int64_t)B * N)), dim3(256), (size_t)D * 2 * sizeof(float), s, tokens, positions,
-                       H, D, base, fwd);
-    LVDGS_LAUNCH_CHECK("rope2d", 0, s);
-    return LVDGS_OK;
+    if (stride_b < 0 || stride_n < 0 || stride_h < 0 || (H > 1 && stride_h < D) || (N > 1 && stride_n < D)) {
+        set_error("rope2d: strides must be non-negative, heads and tokens at least D elements apart (rotated in place)");
+        return LVDGS_E_INVALID;
+    }
+    switch (dtype) {
+        case LVDGS_F16: return launch_rope2d<_Float16>(tokens, positions, B, N, H, D, stride_b, stride_n, stride_h, base, fwd, s);
+        case LVDGS_BF16: return launch_rope2d<__bf16>(tokens, positions, B, N, H, D, stride_b, stride_n, stride_h, base, fwd, s);
+        default: return launch_rope2d<float>(tokens, positions, B, N, H, D, stride_b, stride_n, stride_h, base, fwd, s);
+    }
+}
+
+int lvdgs_rope2d(float *tokens, const int64_t *positions, int32_t B, int32_t N, int32_t H, int32_t D, float base, float fwd,
+                 void *stream) {
+    return lvdgs_rope2d_strided(tokens, LVDGS_F32, positions, B, N, H, D, (int64_t)N * H * D, (int64_t)H * D, D, base, fwd, stream);
 }
 
 }  // extern "C"

@@ -154,6 +154,94 @@ __global__ void __launch_bounds__(256) photometric_finish_kernel(LossParams p, i
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Depth term of the static-mask mapping loss (reference utils/slam_backend.py:216-261):
+//     M = static_mask & (mono_depth > 0) & (rendered depth > 0)
+//     loss = mean over M of |D - Z|        (nothing is added when M is empty)
+// Unlike the photometric depth term above the mean runs over the pixels of M, not over the whole image, so the
+// pass keeps an exact integer count next to the sum; the finish kernel divides.  Backward: sign(D - Z) / |M| on M.
+struct MaskedDepthParams {
+    int P;
+    const float *depth, *gt_depth;
+    const uint8_t *mask;      // P bytes or null (every pixel static)
+    float *partial_sum;       // nblk
+    uint32_t *partial_cnt;    // nblk
+    float *out;               // [0] loss, [1] |M| as a float
+    const float *grad_out;    // 1
+    float *d_depth;           // P
+};
+
+template <bool BACKWARD, bool VEC>
+__global__ void __launch_bounds__(LOSS_THREADS) masked_depth_kernel(MaskedDepthParams p) {
+    __shared__ float s_red[4];
+    __shared__ uint32_t s_cnt[4];
+    const int base = (blockIdx.x * LOSS_THREADS + threadIdx.x) * LOSS_PIX_PER_THREAD;
+    float acc = 0.f;
+    uint32_t cnt = 0;
+    float scale = 0.f;
+    if (BACKWARD) { const float n = p.out[1]; scale = n > 0.f ? p.grad_out[0] / n : 0.f; }
+    if (base < p.P) {
+        const int n = VEC ? 4 : min(4, p.P - base);
+        float D[4], Z[4], dD[4];
+        bool m[4];
+        if (VEC) {
+            const float4 d4 = *reinterpret_cast<const float4 *>(p.depth + base), z4 = *reinterpret_cast<const float4 *>(p.gt_depth + base);
+            D[0] = d4.x; D[1] = d4.y; D[2] = d4.z; D[3] = d4.w; Z[0] = z4.x; Z[1] = z4.y; Z[2] = z4.z; Z[3] = z4.w;
+            const uint32_t m4 = p.mask ? *reinterpret_cast<const uint32_t *>(p.mask + base) : 0x01010101u;
+#pragma unroll
+            for (int k = 0; k < 4; k++) m[k] = ((m4 >> (8 * k)) & 0xffu) != 0u;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                D[k] = k < n ? p.depth[base + k] : 0.f; Z[k] = k < n ? p.gt_depth[base + k] : 0.f;
+                m[k] = k < n && (!p.mask || p.mask[base + k]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const bool in = m[k] && Z[k] > 0.f && D[k] > 0.f;
+            const float r = D[k] - Z[k];
+            if (!BACKWARD) { acc += in ? fabsf(r) : 0.f; cnt += in ? 1u : 0u; }
+            else dD[k] = in ? (r > 0.f ? scale : (r < 0.f ? -scale : 0.f)) : 0.f;
+        }
+        if (BACKWARD) {
+            if (VEC) *reinterpret_cast<float4 *>(p.d_depth + base) = make_float4(dD[0], dD[1], dD[2], dD[3]);
+            else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (k < n) p.d_depth[base + k] = dD[k];
+            }
+        }
+    }
+    if (!BACKWARD) {
+        const float s0 = block_sum(acc, s_red);
+        // exact integer count: wave popcount-free sum through the same lane-63 reduction on floats would round above 2^24
+        uint32_t c = cnt;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) c += (uint32_t)__shfl_xor((int)c, off, 64);
+        if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) { p.partial_sum[blockIdx.x] = s0; p.partial_cnt[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3]; }
+    }
+}
+
+__global__ void __launch_bounds__(256) masked_depth_finish_kernel(MaskedDepthParams p, int nblk) {
+    __shared__ float s[256];
+    __shared__ unsigned long long c[256];
+    float a = 0.f;
+    unsigned long long n = 0ull;
+    for (int b = threadIdx.x; b < nblk; b += 256) { a += p.partial_sum[b]; n += p.partial_cnt[b]; }
+    s[threadIdx.x] = a; c[threadIdx.x] = n;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) { s[threadIdx.x] += s[threadIdx.x + st]; c[threadIdx.x] += c[threadIdx.x + st]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        p.out[0] = c[0] ? s[0] / (float)c[0] : 0.f;
+        p.out[1] = (float)c[0];
+    }
+}
+
 }  // namespace
 }  // namespace lvdgs
 
@@ -202,6 +290,52 @@ int lvdgs_photometric_loss_backward(const lvdgs_loss_args *a, void *stream) {
     p.d_a = a->d_exposure_a; p.d_b = a->d_exposure_b;
     { ProfScope ps("loss_bwd", s); if (p.P % 4 == 0) hipLaunchKernelGGL((photometric_kernel<true, true>), dim3(nblk), dim3(LOSS_THREADS), 0, s, p); else hipLaunchKernelGGL((photometric_kernel<true, false>), dim3(nblk), dim3(LOSS_THREADS), 0, s, p); LVDGS_LAUNCH_CHECK("loss_bwd", 0, s); }
     { ProfScope ps("loss_bwd_finish", s); hipLaunchKernelGGL(photometric_finish_kernel<true>, dim3(1), dim3(256), 0, s, p, nblk); LVDGS_LAUNCH_CHECK("loss_bwd_finish", 0, s); }
+    return LVDGS_OK;
+}
+
+size_t lvdgs_masked_depth_scratch_bytes(int32_t width, int32_t height) {
+    const int64_t P = (int64_t)width * height;
+    return align256((size_t)cdiv(P, LOSS_THREADS * LOSS_PIX_PER_THREAD) * (sizeof(float) + sizeof(uint32_t)) + 256);
+}
+
+static int masked_depth_common(const lvdgs_masked_depth_args *a, MaskedDepthParams &p, int &nblk, bool &vec) {
+    if (!a || a->width <= 0 || a->height <= 0) { set_error("masked depth loss: bad image size"); return LVDGS_E_INVALID; }
+    if (!a->depth || !a->gt_depth || !a->out) { set_error("masked depth loss: depth / gt_depth / out is NULL"); return LVDGS_E_INVALID; }
+    p = MaskedDepthParams{};
+    p.P = a->width * a->height;
+    p.depth = a->depth; p.gt_depth = a->gt_depth; p.mask = a->static_mask; p.out = a->out;
+    nblk = cdiv(p.P, LOSS_THREADS * LOSS_PIX_PER_THREAD);
+    vec = p.P % 4 == 0 && ((uintptr_t)a->depth | (uintptr_t)a->gt_depth | (uintptr_t)a->d_depth) % 16 == 0 && (uintptr_t)a->static_mask % 4 == 0;
+    return LVDGS_OK;
+}
+
+int lvdgs_masked_depth_l1_forward(const lvdgs_masked_depth_args *a, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MaskedDepthParams p; int nblk; bool vec;
+    if (int e = masked_depth_common(a, p, nblk, vec)) return e;
+    if (!a->scratch || a->scratch_bytes < lvdgs_masked_depth_scratch_bytes(a->width, a->height)) { set_error("masked depth loss: scratch missing or too small"); return LVDGS_E_INVALID; }
+    p.partial_sum = (float *)a->scratch;
+    p.partial_cnt = (uint32_t *)(p.partial_sum + nblk);
+    {
+        ProfScope ps("masked_depth_fwd", s);
+        if (vec) hipLaunchKernelGGL((masked_depth_kernel<false, true>), dim3(nblk), dim3(LOSS_THREADS), 0, s, p);
+        else hipLaunchKernelGGL((masked_depth_kernel<false, false>), dim3(nblk), dim3(LOSS_THREADS), 0, s, p);
+        LVDGS_LAUNCH_CHECK("masked_depth_fwd", 0, s);
+    }
+    { ProfScope ps("masked_depth_finish", s); hipLaunchKernelGGL(masked_depth_finish_kernel, dim3(1), dim3(256), 0, s, p, nblk); LVDGS_LAUNCH_CHECK("masked_depth_finish", 0, s); }
+    return LVDGS_OK;
+}
+
+int lvdgs_masked_depth_l1_backward(const lvdgs_masked_depth_args *a, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    MaskedDepthParams p; int nblk; bool vec;
+    if (int e = masked_depth_common(a, p, nblk, vec)) return e;
+    if (!a->grad_loss || !a->d_depth) { set_error("masked depth loss backward: grad_loss / d_depth is NULL"); return LVDGS_E_INVALID; }
+    p.grad_out = a->grad_loss; p.d_depth = a->d_depth;
+    ProfScope ps("masked_depth_bwd", s);
+    if (vec) hipLaunchKernelGGL((masked_depth_kernel<true, true>), dim3(nblk), dim3(LOSS_THREADS), 0, s, p);
+    else hipLaunchKernelGGL((masked_depth_kernel<true, false>), dim3(nblk), dim3(LOSS_THREADS), 0, s, p);
+    LVDGS_LAUNCH_CHECK("masked_depth_bwd", 0, s);
     return LVDGS_OK;
 }
 

@@ -14,17 +14,27 @@ from torch import nn
 from . import _lib
 
 
+_DTYPES = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}  # LVDGS_F32 / LVDGS_F16 / LVDGS_BF16
+
+
 def rope_2d(tokens: torch.Tensor, positions: torch.Tensor, base: float, fwd: float) -> None:
-    """In place on ``tokens`` (B, N, H, D) float32 contiguous."""
+    """In place on ``tokens`` (B, N, H, D): float32, float16 or bfloat16 (MASt3R runs under autocast), any strides over
+    (B, N, H) as long as the D axis is contiguous -- so the transposed view of a (B, H, N, D) tensor is rotated where it
+    lies.  Arithmetic is float32; half-precision elements are rounded once when stored."""
     if tokens.device.type != "cuda":
         raise _lib.LvdgsError("rope_2d needs GPU tensors (there is no CPU path)")
     B, N, H, D = tokens.shape
     assert positions.shape == (B, N, 2) and D % 4 == 0
-    assert tokens.dtype == torch.float32 and tokens.is_contiguous(), "rope_2d: float32 contiguous (B,N,H,D) tokens"
-    pos = positions.to(torch.int64).contiguous()
-    st = _lib.lib().lvdgs_rope2d(C.c_void_p(tokens.data_ptr()), C.c_void_p(pos.data_ptr()), B, N, H, D, float(base),
-                                 float(fwd), C.c_void_p(torch.cuda.current_stream().cuda_stream))
-    _lib.check(st, "lvdgs_rope2d")
+    if tokens.dtype not in _DTYPES:
+        raise TypeError(f"rope_2d: float32, float16 or bfloat16 tokens, got {tokens.dtype}")
+    sb, sn, sh, sd = tokens.stride()
+    if tokens.numel() and sd != 1 and D > 1:
+        raise ValueError("rope_2d: the last (feature) axis of the tokens must be contiguous")
+    pos = positions.to(device=tokens.device, dtype=torch.int64).contiguous()
+    with _lib.on_device(tokens.device):
+        st = _lib.lib().lvdgs_rope2d_strided(C.c_void_p(tokens.data_ptr()), _DTYPES[tokens.dtype], C.c_void_p(pos.data_ptr()),
+                                             B, N, H, D, sb, sn, sh, float(base), float(fwd), _lib.raw_stream(tokens.device))
+    _lib.check(st, "lvdgs_rope2d_strided")
 
 
 class cuRoPE2D_func(torch.autograd.Function):
@@ -39,7 +49,8 @@ class cuRoPE2D_func(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_res):
         (positions,) = ctx.saved_tensors
-        grad_res = grad_res.contiguous()
+        if grad_res.stride(-1) != 1:
+            grad_res = grad_res.contiguous()
         rope_2d(grad_res, positions, ctx.saved_base, -ctx.saved_F0)
         return grad_res, None, None, None
 
@@ -51,12 +62,6 @@ class cuRoPE2D(nn.Module):
         self.F0 = F0
 
     def forward(self, tokens, positions):
-        """tokens: (B, H, N, D); rotated in place (through the (B, N, H, D) view) and returned."""
-        t = tokens.transpose(1, 2)
-        if not t.is_contiguous():
-            tc = t.contiguous()
-            cuRoPE2D_func.apply(tc, positions, self.base, self.F0)
-            tokens.copy_(tc.transpose(1, 2))
-            return tokens
-        cuRoPE2D_func.apply(t, positions, self.base, self.F0)
+        """tokens: (B, H, N, D); rotated in place through the (B, N, H, D) view -- no transposed copy -- and returned."""
+        cuRoPE2D_func.apply(tokens.transpose(1, 2), positions, self.base, self.F0)
         return tokens

@@ -9,6 +9,10 @@ the keyframe carries a ``static_mask`` (``utils/slam_backend.py:199-215``) and i
 ``l1_dssim_loss`` evaluates the whole combination (mask overwrite included) in ONE launch that also
 produces the gradient image; ``ssim`` and ``l1_loss`` keep the upstream signatures.  GPU float32 only:
 there is no PyTorch convolution fallback.
+
+``masked_depth_l1`` is the depth term the same branch adds (``utils/slam_backend.py:216-261``): the mean of
+``|depth - mono_depth|`` over ``static_mask & (mono_depth > 0) & (depth > 0)`` -- normalised by the number of
+such pixels, not by the image size -- and ``masked_mapping_loss`` is that branch as a whole.
 """
 import ctypes as C
 
@@ -106,3 +110,90 @@ def l1_dssim_loss(image, gt_image, lambda_dssim, static_mask=None, background=No
     bg = _c32(background) if (background is not None and keep is not None) else None
     lam = float(lambda_dssim)
     return _L1Ssim.apply(image, gt_image, keep, bg, 1.0 - lam, -lam) + lam
+
+
+# ---- depth term of the static-mask branch (utils/slam_backend.py:216-261) ------------------------------------
+def _squeeze_hw(t):
+    """(1,H,W) or (H,W,1) -> (H,W), as the reference does before combining depth, mono depth and mask (:223-236)."""
+    if t.dim() == 3 and t.shape[0] == 1:
+        return t.squeeze(0)
+    if t.dim() == 3 and t.shape[-1] == 1:
+        return t.squeeze(-1)
+    return t
+
+
+class _MaskedDepthL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, gt_depth, mask_bytes):
+        L = _lib.lib()
+        H, W = depth.shape
+        dev = depth.device
+        d, z = _c32(depth), _c32(gt_depth)
+        a = _lib.MaskedDepthArgs()
+        a.width, a.height = W, H
+        a.depth, a.gt_depth, a.static_mask = _p(d), _p(z), _p(mask_bytes)
+        scratch = torch.empty(int(L.lvdgs_masked_depth_scratch_bytes(W, H)), dtype=torch.uint8, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        a.scratch, a.scratch_bytes, a.out = _p(scratch), scratch.numel(), _p(out)
+        with _lib.on_device(dev):
+            _lib.check(L.lvdgs_masked_depth_l1_forward(C.byref(a), _raw_stream(dev)), "lvdgs_masked_depth_l1_forward")
+        ctx.save_for_backward(d, z, out) if mask_bytes is None else ctx.save_for_backward(d, z, out, mask_bytes)
+        return out  # [loss, |M|]; only the first entry carries a gradient
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.lib()
+        d, z, out, *m = ctx.saved_tensors
+        H, W = d.shape
+        dev = d.device
+        a = _lib.MaskedDepthArgs()
+        a.width, a.height = W, H
+        a.depth, a.gt_depth, a.static_mask = _p(d), _p(z), _p(m[0] if m else None)
+        gl = g.detach().to(torch.float32).contiguous()  # the kernel reads element 0: d objective / d loss
+        dd = torch.empty_like(d)
+        a.out, a.grad_loss, a.d_depth = _p(out), _p(gl), _p(dd)
+        with _lib.on_device(dev):
+            _lib.check(L.lvdgs_masked_depth_l1_backward(C.byref(a), _raw_stream(dev)), "lvdgs_masked_depth_l1_backward")
+        return dd, None, None
+
+
+def masked_depth_l1(depth, mono_depth, static_mask=None, return_count=False):
+    """``|depth - mono_depth|[static_mask & (mono_depth > 0) & (depth > 0)].mean()``; 0 (and zero gradient) when no
+    pixel qualifies -- the reference then skips the term (``if depth_mask.any()``, utils/slam_backend.py:250).
+    Shapes (1,H,W) / (H,W,1) / (H,W) are accepted and, like the reference, cropped to the common top-left
+    (min_h, min_w) window when they differ (:240-246).  One pass for the value and the pixel count, one for the gradient."""
+    if not depth.is_cuda:
+        raise _lib.LvdgsError("masked_depth_l1 runs on the GPU only (HIP kernel); got a CPU tensor")
+    d = _squeeze_hw(depth)
+    z = _squeeze_hw(mono_depth if torch.is_tensor(mono_depth) else torch.from_numpy(mono_depth)).to(d.device)
+    m = None if static_mask is None else _squeeze_hw(static_mask).to(d.device)
+    if d.dim() != 2 or z.dim() != 2 or (m is not None and m.dim() != 2):
+        raise ValueError(f"masked_depth_l1: expected 2-D maps after squeezing, got {tuple(depth.shape)}, "
+                         f"{tuple(z.shape)}, {None if m is None else tuple(m.shape)}")
+    hs = [d.shape[0], z.shape[0]] + ([] if m is None else [m.shape[0]])
+    ws = [d.shape[1], z.shape[1]] + ([] if m is None else [m.shape[1]])
+    h, w = min(hs), min(ws)
+    if (d.shape[0], d.shape[1]) != (h, w):
+        d = d[:h, :w].contiguous()
+    if (z.shape[0], z.shape[1]) != (h, w):
+        z = z[:h, :w]
+    if m is not None and (m.shape[0], m.shape[1]) != (h, w):
+        m = m[:h, :w]
+    out = _MaskedDepthL1.apply(d, z, _mask_bytes(m, h, w))
+    return (out[0], out[1].detach()) if return_count else out[0]
+
+
+def masked_mapping_loss(image, depth, viewpoint, background, lambda_dssim, depth_lambda=0.1):
+    """The mapping loss of a keyframe that carries a ``static_mask`` (utils/slam_backend.py:199-261):
+    ``(1 - l) * L1 + l * (1 - SSIM)`` on the images with the dynamic pixels overwritten by the background colour,
+    plus ``depth_lambda * masked_depth_l1`` when the keyframe has a ``mono_depth``.  Two fused launches forward."""
+    gt = viewpoint.original_image
+    if gt.device != image.device:
+        gt = gt.to(image.device)
+    mask = viewpoint.static_mask
+    if mask.device != image.device:
+        mask = mask.to(image.device)
+    loss = l1_dssim_loss(image, gt, lambda_dssim, mask, background)
+    if depth is not None and getattr(viewpoint, "mono_depth", None) is not None:
+        loss = loss + depth_lambda * masked_depth_l1(depth, viewpoint.mono_depth, mask)
+    return loss

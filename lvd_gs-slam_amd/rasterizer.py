@@ -26,10 +26,12 @@ from torch import nn
 
 from . import _lib
 
-# d(loss)/d(opacity image) is propagated to the Gaussians (opacity = 1 - final transmittance).
-# Set to False to drop that path (the tracking loss multiplies the residual by the opacity image,
-# reference utils/slam_utils.py:60; whether upstream's backward consumes that gradient is unpinned).
-PROPAGATE_OPACITY_GRAD = True
+# d(loss)/d(opacity image) is NOT propagated by default: the backward binding this module mirrors
+# (`rasterize_gaussians_backward(..., dL_dout_color, dL_dout_depth, ...)`) takes the gradients of
+# the colour and depth images only, so the opacity image acts as a detached weight in the tracking loss
+# (reference utils/slam_utils.py:60 multiplies the residual by it).  The kernels do implement the path
+# (opacity = 1 - final transmittance; checked against the oracle); set this to True to use it.
+PROPAGATE_OPACITY_GRAD = False
 
 # Parity tests set this to read intermediates (state buffers) of the most recent forward.
 KEEP_DEBUG_STATE = False
@@ -249,7 +251,7 @@ class GaussianRasterizer(nn.Module):
             N = int(positions.shape[0])
             out = torch.empty(N, dtype=torch.uint8, device=positions.device)
             view, proj = _f32(rs.viewmatrix, positions.device), _f32(rs.projmatrix, positions.device)
-            _lib.check(_lib.lib().lvdgs_mark_visible(N, _ptr(pos), _ptr(view), _ptr(proj), _ptr(out), _stream()),
+            _lib.check(_lib.lib().lvdgs_mark_visible(N, _ptr(pos), _ptr(view), _ptr(proj), _ptr(out), _stream(positions.device)),
                        "lvdgs_mark_visible")
             return out.bool()
 

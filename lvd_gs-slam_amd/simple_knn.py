@@ -19,7 +19,8 @@ def distCUDA2(points: torch.Tensor) -> torch.Tensor:
     out = torch.empty(P, dtype=torch.float32, device=pts.device)
     L = _lib.lib()
     scratch = torch.empty(max(int(L.lvdgs_knn_scratch_bytes(P)), 256), dtype=torch.uint8, device=pts.device)
-    st = L.lvdgs_dist2_knn3(P, C.c_void_p(pts.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(scratch.data_ptr()),
-                            scratch.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    with _lib.on_device(pts.device):
+        st = L.lvdgs_dist2_knn3(P, C.c_void_p(pts.data_ptr()), C.c_void_p(out.data_ptr()), C.c_void_p(scratch.data_ptr()),
+                                scratch.numel(), _lib.raw_stream(pts.device))
     _lib.check(st, "lvdgs_dist2_knn3")
     return out

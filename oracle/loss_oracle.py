@@ -65,6 +65,37 @@ def l1_dssim_loss(image, gt, lambda_dssim, static_mask=None, background=None):
     return (1.0 - lambda_dssim) * l1_loss(a, b) + lambda_dssim * (1.0 - ssim(a, b))
 
 
+def masked_depth_l1(depth, mono_depth, static_mask):
+    """utils/slam_backend.py:216-261, statement for statement (float64): squeeze (1,H,W)/(H,W,1) to (H,W) (:223-236),
+    crop all three to the common top-left window (:240-246), depth_mask = static & (mono > 0) & (depth > 0) (:249),
+    mean of |depth - mono| over the mask if it has any pixel (:250-253), else no term."""
+    def squeeze(t):
+        if t.dim() == 3 and t.shape[0] == 1:
+            return t.squeeze(0)
+        if t.dim() == 3 and t.shape[-1] == 1:
+            return t.squeeze(-1)
+        return t
+    depth, mono_depth = squeeze(depth.double()), squeeze(mono_depth.double())
+    if static_mask.dim() == 3:
+        static_mask = static_mask.squeeze(-1) if static_mask.shape[-1] == 1 else static_mask.squeeze(0)
+    assert depth.dim() == 2 and mono_depth.dim() == 2 and static_mask.dim() == 2
+    min_h = min(depth.shape[0], mono_depth.shape[0], static_mask.shape[0])
+    min_w = min(depth.shape[1], mono_depth.shape[1], static_mask.shape[1])
+    depth, mono_depth, static_mask = depth[:min_h, :min_w], mono_depth[:min_h, :min_w], static_mask[:min_h, :min_w]
+    depth_mask = static_mask.bool() & (mono_depth > 0) & (depth > 0)
+    if depth_mask.any():
+        return torch.abs(depth[depth_mask] - mono_depth[depth_mask]).mean(), int(depth_mask.sum())
+    return depth.sum() * 0.0, 0
+
+
+def masked_mapping_loss(image, depth, gt, mono_depth, static_mask, background, lambda_dssim, depth_lambda=0.1):
+    """The whole static-mask branch of the mapping loss, utils/slam_backend.py:199-261."""
+    loss = l1_dssim_loss(image, gt, lambda_dssim, static_mask, background)
+    if depth is not None and mono_depth is not None:
+        loss = loss + depth_lambda * masked_depth_l1(depth, mono_depth, static_mask)[0]
+    return loss
+
+
 def ssim_direct(img1, img2, size=11):
     """Plain loops over pixels and taps (numpy float64); small images only."""
     a, b = np.asarray(img1, np.float64), np.asarray(img2, np.float64)

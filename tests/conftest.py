@@ -40,6 +40,18 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _name_the_test_for_the_parity_report(request):
+    import parity_stats
+    parity_stats.set_test(request.node.nodeid.replace("tests/", ""))
+    yield
+
+
+def pytest_sessionfinish(session, exitstatus):
+    import parity_stats
+    parity_stats.dump(ROOT)
+
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 

@@ -23,10 +23,14 @@ def _view(buf, off, count, dtype):
     return buf[off:off + nbytes].cpu().numpy().view(dtype).copy()
 
 
-def run_hip(g, cam, W, H, bg, use_sh=False, sh_degree=0, cov_precomp=None, grads=None, pose=True, dev="cuda"):
+def run_hip(g, cam, W, H, bg, use_sh=False, sh_degree=0, cov_precomp=None, grads=None, pose=True, dev="cuda",
+            propagate_opacity=True):
     """g: dict of float32 CPU tensors (synthetic.make_gaussians).  grads: optional (dL_dcolor, dL_ddepth,
     dL_dopacity) CPU tensors.  Returns (forward dict, backward dict or None)."""
     rasterizer.KEEP_DEBUG_STATE = True
+    # the parity tests feed a gradient of the opacity image too: switch that (non-default) path on for the run
+    propagate_before = rasterizer.PROPAGATE_OPACITY_GRAD
+    rasterizer.PROPAGATE_OPACITY_GRAD = bool(propagate_opacity)
     rs = settings_from_cam(cam, W, H, bg, sh_degree=sh_degree, dev=dev)
     leaf = lambda t: t.to(dev).clone().requires_grad_(True)
     means3D, opac = leaf(g["means3D"]), leaf(g["opacities"])
@@ -89,6 +93,7 @@ def run_hip(g, cam, W, H, bg, use_sh=False, sh_degree=0, cov_precomp=None, grads
         if pose:
             bwd["tau"] = np.concatenate([z(rho), z(theta)])
     rasterizer.KEEP_DEBUG_STATE = False
+    rasterizer.PROPAGATE_OPACITY_GRAD = propagate_before
     return fwd, bwd
 
 

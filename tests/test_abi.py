@@ -76,6 +76,18 @@ def test_argument_validation_without_gpu():
         _lib.check(_lib.E_INVALID, "probe")
 
 
+def test_rope2d_strided_argument_validation_without_gpu():
+    L = _lib.lib()
+    tok, pos = C.c_void_p(256), C.c_void_p(512)  # never dereferenced: every call below is rejected before a launch
+    call = lambda dtype, B, N, H, D, sb, sn, sh: L.lvdgs_rope2d_strided(tok, dtype, pos, B, N, H, D, sb, sn, sh, 100.0, 1.0, None)
+    assert call(0, 1, 4, 2, 6, 48, 12, 6) == _lib.E_INVALID and b"multiple of 4" in L.lvdgs_last_error()
+    assert call(3, 1, 4, 2, 8, 64, 16, 8) == _lib.E_INVALID and b"dtype" in L.lvdgs_last_error()
+    assert call(1, 1, 4, 2, 8, 64, 16, 4) == _lib.E_INVALID and b"strides" in L.lvdgs_last_error()   # heads overlap
+    assert call(2, 1, 4, 2, 8, 64, -16, 8) == _lib.E_INVALID
+    assert call(0, 0, 4, 2, 8, 64, 16, 8) == _lib.OK                                                    # no tokens: nothing to do
+    assert L.lvdgs_rope2d_strided(None, 0, pos, 1, 4, 2, 8, 64, 16, 8, 100.0, 1.0, None) == _lib.E_INVALID
+
+
 def test_product_package_never_imports_the_oracle():
     """The product path may not import, link or execute anything under oracle/."""
     pkg = os.path.join(ROOT, "lvd_gs-slam_amd")

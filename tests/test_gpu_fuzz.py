@@ -47,9 +47,34 @@ def test_random_scene_matches_oracle(case_seed):
         m = np.broadcast_to(solid, f_ora[k].shape)
         tp._close(np.where(m, f_hip[k], 0), np.where(m, f_ora[k], 0), what=f"{k} {c}")
     np.testing.assert_array_equal(f_hip["n_contrib"][solid], f_ora["n_contrib"][solid], err_msg=str(c))
+    names = ["means3D", "means2D", "opacities", "scales", "rotations", "colors"]
     if solid.all():
         np.testing.assert_array_equal(f_hip["n_touched"], f_ora["n_touched"], err_msg=str(c))
-        tp._check_backward(b_hip, b_ora, ["means3D", "means2D", "opacities", "scales", "rotations", "colors", "tau"])
+        tp._check_backward(b_hip, b_ora, names + ["tau"])
+        return
+    # Some pixel sat within 1e-5 of a threshold: one faint Gaussian may be in on one side and out on the other, which
+    # perturbs that pixel's contribution to every Gaussian composited in it.  All of those overlap the pixel's tile, so
+    # every Gaussian whose tile rectangle holds no fragile pixel must still agree to the full tolerance; the rest
+    # (and the pose gradient, a sum over all of them) to the size of the perturbation, alpha ~ 4e-3.
+    gx, gy = (c["W"] + 15) // 16, (c["H"] + 15) // 16
+    pad = np.zeros((gy * 16, gx * 16), bool)
+    pad[:c["H"], :c["W"]] = ~solid
+    frag_tile = pad.reshape(gy, 16, gx, 16).any(axis=(1, 3))
+    cum = np.zeros((gy + 1, gx + 1), np.int64)
+    cum[1:, 1:] = frag_tile.cumsum(0).cumsum(1)
+    r = f_ora["rect"].astype(np.int64)
+    x0, y0, x1, y1 = r[:, 0], r[:, 1], r[:, 2], r[:, 3]
+    n_frag = cum[y1, x1] - cum[y0, x1] - cum[y1, x0] + cum[y0, x0]
+    clean = (n_frag == 0)
+    for n in names:
+        ref = b_ora[n].reshape(b_hip[n].shape)
+        if clean.any():
+            tp._close(b_hip[n][clean], ref[clean], what=f"grad {n} (Gaussians away from fragile pixels) {c}")
+        scale = max(np.abs(ref).max(), 1e-30)
+        assert np.abs(b_hip[n] - ref).max() <= 2e-2 * scale, (n, c)
+    assert np.abs(b_hip["tau"] - b_ora["tau"]).max() <= 2e-2 * max(np.abs(b_ora["tau"]).max(), 1e-30), c
+    same = clean & (f_ora["radii"] > 0)
+    np.testing.assert_array_equal(f_hip["n_touched"][same], f_ora["n_touched"][same], err_msg=str(c))
 
 
 @pytest.mark.parametrize("case_seed", list(range(16)))

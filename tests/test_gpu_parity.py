@@ -31,12 +31,20 @@ def _scene(synthetic, N, W, H, seed, pose_seed=None, sh_degree=0, **kw):
     return g, cam
 
 
-def _close(a, b, rtol=RTOL, atol_scale=1e-5, what=""):
-    """|a-b| <= rtol*|b| + atol_scale*max|b| elementwise."""
+def _close(a, b, rtol=RTOL, atol_scale=1e-5, what="", rel_l2=2e-5, max_rel_sig=1e-3):
+    """Three requirements (achieved errors of every call go to gpurun_out/parity_report.*, see parity_stats.py):
+      * |a-b| <= rtol*|b| + atol_scale*max|b| elementwise;
+      * ||a-b||_2 <= rel_l2 * ||b||_2 (the tensor as a whole is far inside the north star's 1e-4);
+      * elements that are not cancellation residues (|b| >= 1e-3 max|b|) are within max_rel_sig of their own value."""
+    import parity_stats
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    st = parity_stats.record(what, a, b)
     tol = rtol * np.abs(b) + atol_scale * max(np.abs(b).max(), 1e-30)
     bad = np.abs(a - b) > tol
     assert not bad.any(), f"{what}: {bad.sum()} / {bad.size} outside tolerance, worst {np.abs(a - b).max():.3e} (scale {np.abs(b).max():.3e})"
+    if st is not None and st["scale"] > 0:
+        assert st["rel_l2"] <= rel_l2, f"{what}: relative L2 error {st['rel_l2']:.3e}"
+        assert st["max_rel_sig"] <= max_rel_sig, f"{what}: max relative error on significant elements {st['max_rel_sig']:.3e}"
 
 
 def _check_forward(f_hip, f_ora, W, H):
@@ -234,18 +242,17 @@ def test_mark_visible_matches_oracle():
 
 
 def test_opacity_gradient_switch():
-    """PROPAGATE_OPACITY_GRAD=False drops exactly the d/d(opacity image) path."""
+    """By default (PROPAGATE_OPACITY_GRAD = False, the backward binding INTEGRATION.md cites takes dL/dcolor and
+    dL/ddepth only) a gradient arriving at the opacity image is dropped -- exactly that path and nothing else."""
     orc, hr, syn = _mods()
     from lvdgs import rasterizer
+    assert rasterizer.PROPAGATE_OPACITY_GRAD is False
     W, H, N = 96, 64, 800
     g, cam = _scene(syn, N, W, H, 70)
     bg = torch.zeros(3)
     gc, gd, go = syn.make_image_grads(W, H, 5)
-    try:
-        rasterizer.PROPAGATE_OPACITY_GRAD = False
-        _, b_off = hr.run_hip(g, cam, W, H, bg, grads=(gc, gd, go))
-    finally:
-        rasterizer.PROPAGATE_OPACITY_GRAD = True
+    _, b_off = hr.run_hip(g, cam, W, H, bg, grads=(gc, gd, go), propagate_opacity=False)
+    assert rasterizer.PROPAGATE_OPACITY_GRAD is False
     _, b_ref = hr.run_oracle(orc, g, cam, W, H, bg, grads=(gc, gd, None))
     _check_backward(b_off, b_ref, ["means3D", "opacities", "scales", "tau"])
 
@@ -309,8 +316,8 @@ def test_fused_activations_match_the_accessor_path():
             gaussian_renderer.FUSE_ACTIVATIONS = True
     a, b = out[True], out[False]
     assert (a["radii"] != b["radii"]).mean() < 1e-3  # exp / normalise rounding may move a radius by one in rare cases
-    _close(a["img"], b["img"], rtol=1e-4, atol_scale=1e-4, what="image")
+    _close(a["img"], b["img"], rtol=1e-4, atol_scale=1e-4, what="image", rel_l2=1e-4, max_rel_sig=5e-2)
     assert len(a["grads"]) == len(b["grads"]) == 5
     for x, y in zip(a["grads"], b["grads"]):
-        _close(x, y, rtol=1e-3, atol_scale=1e-4, what="raw-parameter gradient")
-    _close(a["tau"], b["tau"], rtol=1e-3, atol_scale=1e-4, what="tau")
+        _close(x, y, rtol=1e-3, atol_scale=1e-4, what="raw-parameter gradient", rel_l2=1e-3, max_rel_sig=5e-2)
+    _close(a["tau"], b["tau"], rtol=1e-3, atol_scale=1e-4, what="tau", rel_l2=1e-3, max_rel_sig=5e-2)

@@ -145,6 +145,35 @@ def test_image_gradient_self_consistency():
     assert torch.equal(mv, mh)
 
 
+def test_camera_matrices_follow_two_pose_updates_without_an_access_in_between():
+    """The front end's backend sync calls update_RT(R.clone(), T.clone()) on many keyframes with no render in between
+    (reference utils/slam_frontend.py sync_backend); the freed tensors' addresses get reused, so a cache keyed on
+    id() + _version returned the OLD pose's matrices (31 of 50 trials).  The reference recomputes on every access
+    (utils/camera_utils.py:106-120) and can never be stale."""
+    import torch
+    from lvdgs.camera_utils import Camera
+    from lvdgs.graphics_utils import getProjectionMatrix2, getWorld2View2
+    from lvdgs.pose_utils import SE3_exp
+    W, H = 64, 48
+    proj = getProjectionMatrix2(znear=0.01, zfar=100.0, fx=60.0, fy=60.0, cx=32.0, cy=24.0, W=W, H=H).transpose(0, 1)
+    cam = Camera(0, None, None, None, torch.eye(4), proj, 60.0, 60.0, 32.0, 24.0, 1.0, 0.8, H, W, device="cpu")
+    g = torch.Generator().manual_seed(3)
+    for trial in range(60):
+        _ = cam.world_view_transform                       # fill the cache
+        A = SE3_exp(torch.randn(6, generator=g) * 0.2)
+        B = SE3_exp(torch.randn(6, generator=g) * 0.2)
+        cam.update_RT(A[:3, :3].clone(), A[:3, 3].clone())
+        cam.update_RT(B[:3, :3].clone(), B[:3, 3].clone())  # A's tensors are freed here: their ids are up for reuse
+        view = cam.world_view_transform
+        assert torch.equal(view, getWorld2View2(cam.R, cam.T).transpose(0, 1)), trial
+        assert torch.allclose(view[3, :3], B[:3, 3]), trial
+        assert torch.allclose(cam.full_proj_transform, view @ proj, atol=1e-6)
+        assert torch.allclose(cam.camera_center, torch.linalg.inv(view)[3, :3], atol=1e-6)
+        # whether an address is reused depends on the allocator; what rules the hazard out is that the cache entry
+        # keeps the very tensors it was computed from alive and compares them by identity
+        assert cam._derived_key[0] is cam.R and cam._derived_key[2] is cam.T
+
+
 def test_camera_matrices_are_cached_per_pose_and_replica_edge_mask_matches_the_block_loop():
     """Camera caches its derived matrices until R / T change (replaced or written in place); the replica branch of
     compute_grad_mask equals the reference's sequential per-block assignment (utils/camera_utils.py:135-153)."""

@@ -61,3 +61,27 @@ def test_gradient_of_the_oracle_against_finite_differences():
         am[0, y, x] -= eps
         fd = (float(lo.ssim(ap, b)) - float(lo.ssim(am, b))) / (2 * eps)
         assert abs(fd - float(a.grad[0, y, x])) < 1e-7
+
+
+def test_masked_depth_term_against_a_pixel_loop():
+    """utils/slam_backend.py:216-261: mean |depth - mono| over static & mono > 0 & depth > 0, written as a loop."""
+    g = torch.Generator().manual_seed(9)
+    H, W = 9, 13
+    depth = torch.rand(H, W, generator=g) * 5
+    depth[torch.rand(H, W, generator=g) < 0.2] = 0.0
+    mono = torch.rand(H, W, generator=g) * 5 - 0.5
+    mask = torch.rand(H, W, generator=g) < 0.6
+    total, n = 0.0, 0
+    for y in range(H):
+        for x in range(W):
+            if mask[y, x] and mono[y, x] > 0 and depth[y, x] > 0:
+                total += abs(float(depth[y, x]) - float(mono[y, x]))
+                n += 1
+    got, cnt = lo.masked_depth_l1(depth[None], mono[..., None], mask[None])
+    assert cnt == n and abs(float(got) - total / n) < 1e-12
+    got, cnt = lo.masked_depth_l1(depth, mono, torch.zeros(H, W, dtype=torch.bool))
+    assert cnt == 0 and float(got) == 0.0
+    # cropped to the common window
+    got, cnt = lo.masked_depth_l1(depth, mono[:5], mask[:, :7])
+    ref = (depth[:5, :7] - mono[:5, :7]).abs()[mask[:5, :7] & (mono[:5, :7] > 0) & (depth[:5, :7] > 0)]
+    assert cnt == ref.numel() and abs(float(got) - float(ref.double().mean())) < 1e-6
