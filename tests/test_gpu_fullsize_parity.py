@@ -48,7 +48,7 @@ def test_full_size_forward_and_backward_match_oracle(name, pose_seed):
     f_ora, b_ora = hr.run_oracle(orc, g, cam, W, H, bg, grads=grads)
     assert f_ora["num_rendered"] > 2 * N
     tp._check_forward(f_hip, f_ora, W, H)
-    tp._check_backward(b_hip, b_ora, GRADS)
+    tp._check_backward(b_hip, b_ora, GRADS, f_ora, W, H)
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -115,8 +115,7 @@ def test_render_with_custom_resolution_matches_oracle_at_the_target_size(target)
     got = dict(means3D=model.get_xyz.grad, means2D=pkg["viewspace_points"].grad, opacities=model.get_opacity.grad.reshape(-1),
                scales=model.get_scaling.grad, rotations=model.get_rotation.grad, shs=model.get_features.grad,
                tau=torch.cat([gpu.cam_trans_delta.grad, gpu.cam_rot_delta.grad]))
-    for k, t in got.items():
-        tp._close(t.cpu().numpy(), b_ora[k].reshape(tuple(t.shape)), what=f"grad {k} at {W1}x{H1}")
+    tp._check_backward({k: t.cpu().numpy() for k, t in got.items()}, b_ora, list(got), f_ora, W1, H1)
 
     # geometry of the resize (what utils/init_pose.py:149-158 relies on when it scales fx, fy, cx, cy by W1/W, H1/H):
     # pixel centres map affinely, (u + 1/2) * W1/W - 1/2, and depth along a ray does not change

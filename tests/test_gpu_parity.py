@@ -89,9 +89,50 @@ def _check_forward(f_hip, f_ora, W, H):
     assert not f_hip["n_touched"][~vis].any()
 
 
-def _check_backward(b_hip, b_ora, names):
+def gaussians_away_from_fragile_pixels(f_ora, W, H):
+    """Boolean (N,): Gaussians whose support holds no fragile pixel.
+
+    A pixel is fragile when the oracle saw a threshold comparison (alpha vs 1/255, T vs 1e-4 or 0.5) within 1e-5
+    relative: there exp() rounding may composite one faint Gaussian on one side and not on the other, which perturbs
+    that pixel's contribution (by alpha ~ 4e-3 of it) to EVERY Gaussian composited at that pixel.  A Gaussian can reach
+    alpha >= 1/255 only where its exponent is above -ln(255): within sqrt(2 ln 255) = 3.33 sigma of its centre, i.e.
+    inside the square of half-width 1.12 * radius + 1 around it (radius = ceil(3 sigma_max))."""
+    frag = f_ora["fragile"] != 0
+    N = f_ora["radii"].shape[0]
+    if not frag.any():
+        return np.ones(N, bool)
+    cum = np.zeros((H + 1, W + 1), np.int64)
+    cum[1:, 1:] = frag.cumsum(0).cumsum(1)
+    r = np.ceil(1.12 * f_ora["radii"].astype(np.float64) + 1.0)
+    m = f_ora["means2D"].astype(np.float64)
+    x0 = np.clip(np.floor(m[:, 0] - r), 0, W).astype(np.int64); x1 = np.clip(np.ceil(m[:, 0] + r) + 1, 0, W).astype(np.int64)
+    y0 = np.clip(np.floor(m[:, 1] - r), 0, H).astype(np.int64); y1 = np.clip(np.ceil(m[:, 1] + r) + 1, 0, H).astype(np.int64)
+    x1, y1 = np.maximum(x1, x0), np.maximum(y1, y0)
+    n = cum[y1, x1] - cum[y0, x1] - cum[y1, x0] + cum[y0, x0]
+    return (n == 0) | (f_ora["radii"] <= 0)
+
+
+def _check_backward(b_hip, b_ora, names, f_ora=None, W=None, H=None):
+    """Every gradient within the tolerances of _close.  With the oracle's forward results given, per-Gaussian gradients
+    are held to them on the Gaussians no fragile pixel can reach; on the others (and on the pose gradient, a sum over
+    all of them) the perturbation of a fragile pixel -- alpha ~ 4e-3 of one pixel's contribution -- is allowed for."""
+    clean = None if f_ora is None else gaussians_away_from_fragile_pixels(f_ora, W, H)
     for n in names:
-        _close(b_hip[n], b_ora[n].reshape(b_hip[n].shape), what="grad " + n)
+        ref = b_ora[n].reshape(b_hip[n].shape)
+        if clean is None or clean.all() or n == "tau":
+            _close(b_hip[n], ref, what="grad " + n)
+            continue
+        assert clean.mean() > 0.05, clean.mean()
+        _close(b_hip[n][clean], ref[clean], what="grad " + n + " (away from fragile pixels)")
+        st = parity_stats_record("grad " + n + " (all Gaussians)", b_hip[n], ref)
+        scale = max(np.abs(ref).max(), 1e-30)
+        assert st["rel_l2"] <= 2e-5, (n, st)
+        assert np.abs(b_hip[n] - ref).max() <= 1e-2 * scale, (n, st)
+
+
+def parity_stats_record(what, a, b):
+    import parity_stats
+    return parity_stats.record(what, a, b)
 
 
 @pytest.mark.parametrize("N,W,H,seed,pose", [(2000, 160, 96, 0, None), (5000, 256, 144, 1, 2), (300, 1226, 370, 2, 5)])
