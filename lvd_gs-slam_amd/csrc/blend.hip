@@ -16,6 +16,8 @@
 // stored at slot_base[id] + (ty - y0) * width + (tx - x0): a Gaussian's records form one contiguous
 // run, and the runs follow each other in id order, so the per-Gaussian kernel (one lane per id) reads
 // whole cache lines.  Gradients are therefore bitwise reproducible.
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "device_utils.hpp"
 
@@ -344,6 +346,216 @@ __global__ void __launch_bounds__(256, 8) blend_bwd_kernel(BlendParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Backward pass in two phases per batch of NB surviving entries ("pixel pass" + "splat pass").
+//
+// The single-pass kernel above spends more than half of its vector instructions summing ten values over the 64 pixels
+// of a quadrant for every surviving (quadrant, Gaussian): cross-lane folds (v_permlane*_swap cost 2.7, DPP adds 1.5
+// plain instructions each).  But per (pixel, Gaussian) hit only TWO numbers depend on the sequential compositing
+// state: u = G dL/dalpha and w = alpha T.  Everything else in the ten sums is a product of u or w with quantities
+// of the pixel alone (position, image gradients) or of the Gaussian alone.  So:
+//   pixel pass (lane -> pixel, as before): walk the survivors back to front, update T and R, and store (u, w) of
+//     the lane's pixel into an LDS matrix M[slot][pixel] -- no sums at all;
+//   splat pass (lane -> (slot, group of 64/NB lanes)): every lane owns one Gaussian of the batch and loops over NB
+//     pixels of its 16-pixel row, accumulating the ten sums in its OWN registers (the pixel's coordinates come by a
+//     DPP rotation inside the row, its image gradients from LDS); one fold over the 64/NB lanes of a slot per
+//     BATCH instead of one per Gaussian finishes the sums.
+// Same arithmetic per product as the single-pass kernel (dx, dy are formed from the Gaussian's centre and the
+// pixel's coordinates, no shifted moments), same hit set, same per-pair records, still no atomics.
+template <int NB>
+struct Bwd2Shared {
+    float4 a[BR];                        // x, y, a, b
+    float4 b[BR];                        // c, opacity, depth, -a/2*log2e
+    float4 c[BR];                        // r, g, b, -b*log2e
+    uint32_t slot[BR];
+    float acc[4][BR * ACC_STRIDE];       // per wave: Sx Sy Sxx Sxy Syy Su C0 C1 C2 CD of every entry it accumulated
+    unsigned long long mask[4];
+    uint32_t wmax[4];
+    float2 M[4][NB][64];                 // per wave: (u, w) of [batch slot][pixel]
+    float4 pixg[4][64];                  // per wave: dL/d(colour, depth) of its 64 pixels
+    uint32_t bj[4][NB];                  // per wave: entry (position in the round) of every batch slot
+};
+
+template <int NB>
+__global__ void __launch_bounds__(256, 4) blend_bwd2_kernel(BlendParams p) {
+    static_assert(NB == 8 || NB == 16, "batch of 8 or 16 entries");
+    constexpr int STEPS = NB;            // pixels a lane visits per batch (16-pixel row / lanes per slot in the row)
+    __shared__ Bwd2Shared<NB> sh;
+
+    const int tile = tile_of_workgroup(blockIdx.x, p.num_tiles);
+    const int tx = tile % p.gx, ty = tile / p.gx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool inside = px < p.W && py < p.H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float rx0 = (float)qx0, ry0 = (float)qy0, rx1 = (float)(qx0 + 7), ry1 = (float)(qy0 + 7);
+    const size_t pix = (size_t)py * p.W + px, P = (size_t)p.W * p.H;
+
+    const uint2 range = p.ranges[tile];
+    const float T_final = inside ? p.final_T[pix] : 0.f;
+    const uint32_t my_last = inside ? p.n_contrib[pix] : 0u;
+    float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gD = 0.f, gO = 0.f;
+    if (inside) {
+        gC0 = p.dL_dcolor[pix]; gC1 = p.dL_dcolor[P + pix]; gC2 = p.dL_dcolor[2 * P + pix];
+        if (p.dL_ddepth) gD = p.dL_ddepth[pix];
+        if (p.dL_dopacity) gO = p.dL_dopacity[pix];
+    }
+    sh.pixg[wave][lane] = make_float4(gC0, gC1, gC2, gD);
+    const float tail = T_final * (p.bg[0] * gC0 + p.bg[1] * gC1 + p.bg[2] * gC2 - gO);
+
+    uint32_t m = my_last;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+    if (lane == 0) sh.wmax[wave] = m;
+    const int wave_last = (int)m;
+    __syncthreads();
+    const int depth_max = (int)max(max(sh.wmax[0], sh.wmax[1]), max(sh.wmax[2], sh.wmax[3]));
+    const int todo = (int)(range.y - range.x);
+
+    float T = T_final, R = tail;  // see the single-pass kernel for the scalar recurrence
+    // splat pass: this lane's slot in the batch, its 16-lane row, and where the folded sums of the row go
+    const int row = lane >> 4, col = lane & 15;
+    const int my_slot = col & (NB - 1);
+    const float2 *Mrow = &sh.M[wave][my_slot][row * 16];
+    const float4 *Grow = &sh.pixg[wave][row * 16];
+
+    const int rounds = (todo + BR - 1) / BR;
+    for (int r = rounds - 1; r >= 0; r--) {
+        const int base = r * BR;
+        const int cnt = min(BR, todo - base);
+        if (tid < cnt) {
+            const uint32_t id = p.point_list[range.x + base + tid];
+            const float4 *r4 = reinterpret_cast<const float4 *>(p.rec + (size_t)id * REC_FLOATS);
+            const float4 r0 = r4[0], r1 = r4[1], r2 = r4[2];
+            sh.a[tid] = r0;
+            sh.b[tid] = make_float4(r1.x, r1.y, r2.y, -0.5f * LOG2E * r0.z);
+            sh.c[tid] = make_float4(r1.z, r1.w, r2.x, -LOG2E * r0.w);
+            const int rad = __float_as_int(r2.w);
+            int x0 = (int)((r0.x - (float)rad) / (float)TILE), y0 = (int)((r0.y - (float)rad) / (float)TILE);
+            int x1 = (int)((r0.x + (float)rad + (float)(TILE - 1)) / (float)TILE);
+            x0 = min(p.gx, max(0, x0)); x1 = min(p.gx, max(0, x1)); y0 = min(p.gy, max(0, y0));
+            sh.slot[tid] = p.slot_base[id] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+        }
+        __syncthreads();
+        uint64_t wrote = 0ull;
+        if (base < depth_max) {
+            bool keep = false;
+            if (lane < cnt && base + lane < wave_last) {
+                const float4 A = sh.a[lane];
+                const float4 B = sh.b[lane];
+                keep = reaches_rect(A.x, A.y, A.z, A.w, B.x, B.y, rx0, ry0, rx1, ry1);
+            }
+            uint64_t live = __ballot(keep);
+            while (live) {
+                // ---------------- pixel pass: up to NB entries with at least one hit ----------------
+                uint64_t batch = 0ull;
+                int nb = 0;
+                while (live && nb < NB) {
+                    const int j = 63 - __builtin_clzll(live);
+                    live = mask_clear_bit(live, j);
+                    const float4 A = sh.a[j];
+                    const float4 B = sh.b[j];
+                    const float4 Cc = sh.c[j];
+                    const float dx = A.x - pxf, dy = A.y - pyf;
+                    // the same expression, operand for operand, as the forward pass: identical hit set
+                    const float pw2 = fmaf(dx, fmaf(B.w, dx, Cc.w * dy), (-0.5f * LOG2E * B.x) * dy * dy);
+                    const float G = __builtin_amdgcn_exp2f(pw2);
+                    const float alpha = fminf(ALPHA_MAX, B.y * G);
+                    const bool hit = ((uint32_t)(base + j) < my_last) && (pw2 <= 0.f) && (alpha >= ALPHA_MIN);
+                    if (__ballot(hit) == 0ull) continue;
+                    float u = 0.f, w = 0.f;
+                    if (hit) {
+                        const float k = fmaf(B.z, gD, fmaf(Cc.z, gC2, fmaf(Cc.y, gC1, Cc.x * gC0)));
+                        const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
+                        T *= inv;
+                        w = alpha * T;
+                        const float dL_dalpha = fmaf(k, T, -(R * inv));
+                        R = fmaf(k, w, R);
+                        u = G * dL_dalpha;
+                    }
+                    sh.M[wave][nb][lane] = make_float2(u, w);
+                    batch = mask_set_bit(batch, j);
+                    nb++;
+                }
+                if (nb == 0) break;
+                wrote |= batch;
+                // slot table: the entry at bit position `lane` of the batch was given slot = number of batch bits above it
+                if ((batch >> lane) & 1ull) sh.bj[wave][__popcll(batch >> lane) - 1] = (uint32_t)lane;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // ---------------- splat pass: lane -> (slot, 8 or 16 pixels of its row) ----------------
+                const bool valid = my_slot < nb;
+                const int jj = valid ? (int)sh.bj[wave][my_slot] : 0;
+                const float4 Aj = sh.a[jj];
+                float rx = pxf, ry = pyf;  // coordinates of the pixel this lane looks at; rotate through the row
+                float Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Su = 0.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, CD = 0.f;
+#pragma unroll
+                for (int s = 0; s < STEPS; s++) {
+                    const int q = (col - s) & 15;  // row_ror:1 hands lane i the value of lane i-1: after s steps, of lane i-s
+                    const float2 uw = Mrow[q];
+                    const float4 g = Grow[q];
+                    const float dx = Aj.x - rx, dy = Aj.y - ry;
+                    const float t1 = uw.x * dx, t2 = uw.x * dy;
+                    Sx += t1; Sy += t2;
+                    Sxx = fmaf(t1, dx, Sxx); Sxy = fmaf(t1, dy, Sxy); Syy = fmaf(t2, dy, Syy);
+                    Su += uw.x;
+                    C0 = fmaf(uw.y, g.x, C0); C1 = fmaf(uw.y, g.y, C1); C2 = fmaf(uw.y, g.z, C2); CD = fmaf(uw.y, g.w, CD);
+                    if (s + 1 < STEPS) {
+                        rx = row_rotate<1>(rx);
+                        ry = row_rotate<1>(ry);
+                    }
+                }
+                // fold the 64/NB partial sums of every slot: rows first (two pairwise folds, ten registers -> three) ...
+                float q0 = fold16(fold32(Sx, Sy), fold32(Sxx, Sxy));   // rows: Sx Sxx Sy Sxy
+                float q1 = fold16(fold32(Syy, Su), fold32(C0, C1));    // rows: Syy C0 Su C1
+                float q2 = fold16(fold32(C2, CD), C1);                  // rows: C2 x CD x
+                if constexpr (NB == 8) {  // ... then the two half-rows that share a slot
+                    q0 += row_rotate<8>(q0);
+                    q1 += row_rotate<8>(q1);
+                    q2 += row_rotate<8>(q2);
+                }
+                if (valid && col < NB) {
+                    // value index held by this row: q0 -> {Sx, Sxx, Sy, Sxy}, q1 -> {Syy, C0, Su, C1}, q2 -> {C2, -, CD, -}
+                    const int i0 = row == 0 ? 0 : (row == 1 ? 2 : (row == 2 ? 1 : 3));
+                    const int i1 = row == 0 ? 4 : (row == 1 ? 6 : (row == 2 ? 5 : 7));
+                    float *o = &sh.acc[wave][jj * ACC_STRIDE];
+                    o[i0] = q0; o[i1] = q1;
+                    if ((row & 1) == 0) o[row == 0 ? 8 : 9] = q2;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (lane == 0) sh.mask[wave] = wrote;
+        __syncthreads();
+        if (tid < cnt) {
+            float acc[ACC_STRIDE];
+#pragma unroll
+            for (int k = 0; k < ACC_STRIDE; k++) acc[k] = 0.f;
+            const unsigned long long bit = 1ull << tid;
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+                if (sh.mask[w] & bit) {
+                    const float2 *o = reinterpret_cast<const float2 *>(&sh.acc[w][tid * ACC_STRIDE]);
+#pragma unroll
+                    for (int k = 0; k < 5; k++) { const float2 t = o[k]; acc[2 * k] += t.x; acc[2 * k + 1] += t.y; }
+                }
+            // acc: Sx Sy Sxx Sxy Syy Su C0 C1 C2 CD (sums of u, not yet of h = opacity * u)
+            const float4 A = sh.a[tid];
+            const float4 B = sh.b[tid];
+            const float op = B.y;
+            const float sx = op * acc[0], sy = op * acc[1];
+            float4 *dst = reinterpret_cast<float4 *>(p.pair_grads + (size_t)sh.slot[tid] * PAIR_FLOATS);
+            dst[0] = make_float4(-fmaf(A.z, sx, A.w * sy), -fmaf(B.x, sy, A.w * sx), -0.5f * (op * acc[2]), -(op * acc[3]));
+            dst[1] = make_float4(-0.5f * (op * acc[4]), acc[5], acc[6], acc[7]);
+            dst[2] = make_float4(acc[8], acc[9], 0.f, 0.f);
+        }
+        __syncthreads();
+    }
+}
+
 BlendParams make_params(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im) {
     BlendParams p{};
     p.W = a.image_width; p.H = a.image_height;
@@ -366,13 +578,28 @@ int launch_blend_fwd(const lvdgs_args &a, const GeomView &g, const BinView &b, c
     return LVDGS_OK;
 }
 
+// LVDGS_BLEND_BWD selects the backward kernel: "1" single pass, "2" two passes with batches of 8 (default),
+// "3" two passes with batches of 16.  Read once per process.
+static int blend_bwd_variant() {
+    static const int v = [] {
+        const char *e = getenv("LVDGS_BLEND_BWD");
+        const int x = e ? atoi(e) : 2;
+        return (x >= 1 && x <= 3) ? x : 2;
+    }();
+    return v;
+}
+
 int launch_blend_bwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, const BwdScratch &w,
                      hipStream_t s) {
     BlendParams p = make_params(a, g, b, im);
     p.pair_grads = w.pair_grads;
     if (p.num_tiles == 0) return LVDGS_OK;
     ProfScope ps("blend_bwd", s);
-    hipLaunchKernelGGL(blend_bwd_kernel, dim3(p.num_tiles), dim3(256), 0, s, p);
+    switch (blend_bwd_variant()) {
+        case 1: hipLaunchKernelGGL(blend_bwd_kernel, dim3(p.num_tiles), dim3(256), 0, s, p); break;
+        case 3: hipLaunchKernelGGL(blend_bwd2_kernel<16>, dim3(p.num_tiles), dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL(blend_bwd2_kernel<8>, dim3(p.num_tiles), dim3(256), 0, s, p); break;
+    }
     LVDGS_LAUNCH_CHECK("blend_bwd", a.debug, s);
     return LVDGS_OK;
 }

@@ -10,6 +10,15 @@ __device__ __forceinline__ float dpp_or_zero(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, BANK_MASK, false));
 }
 
+// Rotate a register by N lanes inside every 16-lane row (row_ror:N): lane i receives the value of lane (i - N) mod 16 of
+// its row.  Every lane has a source, so the "old" operand is never used; passing the input itself spares the
+// zero-initialisation the compiler emits for a constant.
+template <int N>
+__device__ __forceinline__ float row_rotate(float x) {
+    const int v = __float_as_int(x);
+    return __int_as_float(__builtin_amdgcn_update_dpp(v, v, 0x120 + N, 0xf, 0xf, false));
+}
+
 // Sum over the 64 lanes of the wave; the total is valid in lane 63 only.
 // row_shr:1,2,4,8 build inclusive prefixes inside each 16-lane row, row_bcast:15 / :31 chain the rows.
 __device__ __forceinline__ float wave_sum_to_lane63(float v) {
