@@ -51,7 +51,7 @@ def quat_to_rot(q):
 
 def render_dense(means3D, opacities, H, W, tanfovx, tanfovy, bg, viewmatrix, projmatrix, campos,
                  scales=None, rotations=None, cov3D_precomp=None, colors_precomp=None, shs=None,
-                 sh_degree=0, scale_modifier=1.0):
+                 sh_degree=0, scale_modifier=1.0, ndc_offset=None):
     """Returns dict(color (3,H,W), depth (1,H,W), opacity (1,H,W), radii, n_touched, n_contrib,
     means2D_pix (N,2) retain-grad leaf-like tensor for the viewspace gradient)."""
     N = means3D.shape[0]
@@ -101,6 +101,11 @@ def render_dense(means3D, opacities, H, W, tanfovx, tanfovy, bg, viewmatrix, pro
     radius = torch.ceil(3.0 * torch.sqrt(lam.detach())).to(torch.int64)
     px = ((p_proj[:, 0] + 1.0) * W - 1.0) * 0.5
     py = ((p_proj[:, 1] + 1.0) * H - 1.0) * 0.5
+    if ndc_offset is not None:
+        # render()'s "viewspace points": an (N,3) zero leaf added to the NDC position, whose .grad the densification
+        # statistics read (d pixel = W/2 d ndc_x, H/2 d ndc_y)
+        px = px + 0.5 * W * ndc_offset[:, 0].to(dt)
+        py = py + 0.5 * H * ndc_offset[:, 1].to(dt)
     pix = torch.stack([px, py], -1)
     if pix.requires_grad:
         pix.retain_grad()

@@ -132,7 +132,7 @@ def test_render_with_custom_resolution_matches_oracle_at_the_target_size(target)
         assert both.mean() > 0.2
         # per-pixel normalised depth agrees up to the smoothing the coarser raster applies (low-pass + sampling)
         r = (d1 / np.maximum(o1, 1e-6))[both] / (d0 / np.maximum(o0, 1e-6))[both]
-        assert abs(np.median(r) - 1.0) < 0.02, np.median(r)
+        assert abs(np.median(r) - 1.0) < 0.05, np.median(r)
 
 
 def test_custom_resolution_projects_means_affinely():

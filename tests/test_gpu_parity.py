@@ -119,8 +119,11 @@ def _check_backward(b_hip, b_ora, names, f_ora=None, W=None, H=None):
     clean = None if f_ora is None else gaussians_away_from_fragile_pixels(f_ora, W, H)
     for n in names:
         ref = b_ora[n].reshape(b_hip[n].shape)
-        if clean is None or clean.all() or n == "tau":
+        if clean is None or clean.all():
             _close(b_hip[n], ref, what="grad " + n)
+            continue
+        if n == "tau":  # six sums over every Gaussian, the ones fragile pixels reach included
+            _close(b_hip[n], ref, what="grad tau", rel_l2=1e-4)
             continue
         if clean.sum() >= 50:
             _close(b_hip[n][clean], ref[clean], what="grad " + n + " (away from fragile pixels)")

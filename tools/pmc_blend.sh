@@ -2,7 +2,7 @@
 # SQ counter sets for the blend kernels, one rocprofv3 --pmc pass per set; prints per-kernel averages.
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$ROOT/gpurun_out/pmc_blend
+OUT=$ROOT/gpurun_out/${1:-pmc_blend}
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 i=0
