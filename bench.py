@@ -7,10 +7,13 @@ N = 1 (default): BASELINE.json configs[2] -- 500k Gaussians, 1920x1080, one trac
 step: render(viewpoint, gaussians, pipe, bg) -> get_loss_tracking -> backward, with gradients to
 every Gaussian parameter and to the 6-DoF camera pose (cam_rot_delta / cam_trans_delta) and the
 exposure parameters (reference utils/slam_frontend.py:1492-1521).
-N > 1 (launched by torch.distributed.run, one process per GPU): the mapping-window case -- every
-rank renders its own keyframe of the same Gaussians with the mapping loss and the packed
-Gaussian gradient (N x 14 floats) is sum-all-reduced with RCCL each step (weak scaling: one
-keyframe per GPU, reference utils/slam_backend.py:180-306 sums the window's losses before one backward).
+N > 1 (launched by torch.distributed.run, one process per GPU): one WHOLE mapping iteration of the back end
+(lvdgs.backend_map.map_window = reference utils/slam_backend.py:167-390) on a window of N keyframes, one per GPU
+(weak scaling): render + mapping loss + backward of the rank's keyframe, the two RCCL collectives (float SUM
+bucket: Gaussian gradients, keyframe pose / exposure gradients, densification statistics; int MAX bucket: radii
+and visibility flags), the bookkeeping, the Adam step over all Gaussians, the keyframe Adam step and the pose
+retraction.  `value` counts keyframe renders+backwards per second over the job; the time the collectives take is
+measured in a separate pass and reported as config.comm_us_per_step.
 
 Rank 0 prints ONE JSON line.  `value` is whole-job iterations/s with all inputs resident in HBM.
 `roofline` prices the dominant kernel (by HIP-event time measured here) against the 8 TB/s HBM
@@ -30,13 +33,21 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 import lvdgs  # noqa: E402,F401
-from lvdgs import _lib, rasterizer, slam_utils, synthetic, window_shard  # noqa: E402
+from lvdgs import _lib, backend_map, rasterizer, slam_utils, synthetic  # noqa: E402
 from lvdgs.gaussian_model import GaussianModel  # noqa: E402
 from lvdgs.gaussian_renderer import render  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-CONFIG = {"Training": {"monocular": True, "rgb_boundary_threshold": 0.01, "alpha": 0.98},
+VALU_PEAK_G = 1228.8   # 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction
+VALU_MEASURED_G = 853.0  # independent v_fma_f32 at 8 waves/SIMD, tools/valu_clock.hip (the chip clocks down to ~2.05 GHz)
+# the values of configs/mono/KITTI/base_config.yaml the step reads (densification and opacity resets are pushed out of the
+# benchmark's horizon so that the Gaussian count stays the workload's)
+CONFIG = {"Training": {"monocular": True, "rgb_boundary_threshold": 0.01, "alpha": 0.98, "pose_window": 3, "window_size": 8,
+                       "prune_mode": "slam", "prune_num": 1, "lr": {"cam_rot_delta": 0.003, "cam_trans_delta": 0.001}},
           "Dataset": {"depth_loss": True}}
+OPT = dict(position_lr_init=0.0016, position_lr_final=0.00016, position_lr_delay_mult=0.01, position_lr_max_steps=30000,
+           feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.001, rotation_lr=0.001, percent_dense=0.01,
+           densify_grad_threshold=0.0002, lambda_dssim=0.2)
 
 
 def algorithmic_bytes(kernel, N, V, D, P, T):
@@ -74,6 +85,48 @@ def build_scene(workload, rank, dev):
     return model, cam, g, (N, W, H)
 
 
+def build_window(workload, world, dev, model):
+    """A BackEnd-shaped object (the attributes reference utils/slam_backend.py:21-72 sets) holding `world` keyframes
+    of the workload's scene, every one from its own seeded pose with its own seeded target image, built identically
+    on every rank."""
+    from lvdgs.camera_utils import Camera
+    from lvdgs.graphics_utils import focal2fov, getProjectionMatrix2
+    from lvdgs.pose_utils import SE3_exp
+    cfg = synthetic.CONFIGS[workload]
+    W, H = cfg["W"], cfg["H"]
+    fx, fy = cfg.get("fx", float(W)), cfg.get("fy", float(W))
+    cx, cy = cfg.get("cx", W / 2.0), cfg.get("cy", H / 2.0)
+    proj = getProjectionMatrix2(znear=0.01, zfar=100.0, fx=fx, fy=fy, cx=cx, cy=cy, W=W, H=H).transpose(0, 1).to(dev)
+    viewpoints = {}
+    for k in range(world):
+        gen = torch.Generator().manual_seed(4242 + k)
+        image = torch.rand(3, H, W, generator=gen).to(dev)
+        mono = (torch.rand(H, W, generator=gen) * 40 + 1).numpy()
+        cam = Camera(k + 1, image, None, mono, torch.eye(4), proj, fx, fy, cx, cy, focal2fov(fx, W), focal2fov(fy, H), H, W, device=dev)
+        pose = SE3_exp(torch.randn(6, generator=torch.Generator().manual_seed(1000 + k)) * 0.05)
+        cam.update_RT(pose[:3, :3], pose[:3, 3])
+        viewpoints[k + 1] = cam
+    window = list(range(world, 0, -1))  # newest first
+    model.init_lr(6.0)
+    model.training_setup(OPT)
+    kf_groups = []
+    for idx, kf in enumerate(window):
+        vp = viewpoints[kf]
+        if idx < CONFIG["Training"]["pose_window"]:
+            kf_groups += [{"params": [vp.cam_rot_delta], "lr": 0.0015, "name": f"rot_{kf}"},
+                          {"params": [vp.cam_trans_delta], "lr": 0.0005, "name": f"trans_{kf}"}]
+        kf_groups += [{"params": [vp.exposure_a], "lr": 0.01, "name": f"exposure_a_{kf}"},
+                      {"params": [vp.exposure_b], "lr": 0.01, "name": f"exposure_b_{kf}"}]
+    far = 1 << 60
+    be = SimpleNamespace(
+        config=CONFIG, gaussians=model, pipeline_params=SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False),
+        background=torch.zeros(3, device=dev), opt_params=SimpleNamespace(**OPT), monocular=True, iteration_count=0, last_sent=0,
+        occ_aware_visibility={}, viewpoints=viewpoints, current_window=window, initialized=True,
+        keyframe_optimizers=torch.optim.Adam(kf_groups), gaussian_update_every=far, gaussian_update_offset=far - 1,
+        gaussian_th=0.7, gaussian_extent=6.0, gaussian_reset=far, size_threshold=20)
+    return be, window
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,36 +146,41 @@ def main():
                          f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus} ...`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU path for the product)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # LVDGS_BENCH_BACKEND=gloo lets the N > 1 code path be exercised on a box with fewer GPUs than ranks (several ranks
+    # share a device, collectives go through the host); numbers from such a run are not benchmark results.
+    backend_name = os.environ.get("LVDGS_BENCH_BACKEND", "nccl")
+    local_dev = local_rank if backend_name == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend_name == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend_name, rank=rank, world_size=world)
 
     model, cam, g_cpu, (N, W, H) = build_scene(args.workload, rank, dev)
     pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False)
     bg = torch.zeros(3, device=dev)
     params = model.parameters()
     pose_params = [cam.cam_rot_delta, cam.cam_trans_delta, cam.exposure_a, cam.exposure_b]
-    bucket = window_shard.GradientBucket(params) if world > 1 else None
     tracking = (world == 1) if args.step == "auto" else args.step == "tracking"
     stats = {}
+    backend = window = None
+    if not tracking:
+        backend, window = build_window(args.workload, world, dev, model)
 
     def step():
-        for p in params + pose_params:
-            p.grad = None
-        pkg = render(cam, model, pipe, bg)
         if tracking:
-            loss = slam_utils.get_loss_tracking(CONFIG, pkg["render"], pkg["depth"], pkg["opacity"], cam)
-        else:
-            loss = slam_utils.get_loss_mapping(CONFIG, pkg["render"], cam, depth=pkg["depth"])
-        loss.backward()
-        if world > 1:
-            # one flat bucket: a single RCCL all-reduce per step (28 MB at 500k Gaussians)
-            bucket.all_reduce()
-        return pkg
+            for p in params + pose_params:
+                p.grad = None
+            pkg = render(cam, model, pipe, bg)
+            slam_utils.get_loss_tracking(CONFIG, pkg["render"], pkg["depth"], pkg["opacity"], cam).backward()
+            return pkg["radii"]
+        backend_map.map_window(backend, window, iters=1)
+        return None
 
     def sync():
         if world > 1:
@@ -130,11 +188,11 @@ def main():
         torch.cuda.synchronize()
 
     rasterizer.KEEP_DEBUG_STATE = True
-    for _ in range(args.warmup):
-        pkg = step()
+    for _ in range(max(args.warmup, 1)):
+        radii = step()
     sync()
     stats["D"] = int(rasterizer._DEBUG_LAST.get("num_rendered", 0))
-    stats["V"] = int((pkg["radii"] > 0).sum().item())
+    stats["V"] = int((radii > 0).sum().item()) if radii is not None else int((backend.gaussians.max_radii2D > 0).sum().item())
     rasterizer.KEEP_DEBUG_STATE = False
     rasterizer._DEBUG_LAST.clear()
 
@@ -169,18 +227,42 @@ def main():
         n, ms = times[dom]
         avg_s = ms / 1e3 / max(n, 1)
         nbytes = algorithmic_bytes(dom, N, stats["V"], stats["D"], P, T)
-        traffic = None
+        traffic = valu_insts = source = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             ent = tj.get(args.workload, {}).get(dom)
             if ent:
                 traffic = ent.get("hbm_bytes_per_launch")
+                valu_insts = ent.get("valu_wave_instructions_per_launch")
+                source = tj.get(args.workload, {}).get("_source")
         if nbytes:
             achieved = nbytes / avg_s / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "traffic_source": ("separate rocprofv3 --pmc passes of this workload, NOT measured in this run: profiles/traffic.json"
+                                           + (f" <- {source}" if source else "")) if traffic else None,
                         "algorithmic_bytes_per_launch": int(nbytes), "avg_launch_us": round(avg_s * 1e6, 2)}
+            if valu_insts:
+                # The resource that actually binds the blend kernels: vector-instruction issue.
+                # peak: one wave64 instruction per 2 cycles per SIMD, 1024 SIMDs, 2.4 GHz (MI355X_MICROARCH.md);
+                # ceiling: what a stream of independent v_fma_f32 reaches on this chip at the clock it then runs at
+                # (tools/valu_clock.hip: 2.88 cycles at the nominal clock, 8 waves/SIMD).
+                g_per_s = valu_insts / avg_s / 1e9
+                roofline["valu"] = {"wave_instructions_per_launch": int(valu_insts), "achieved": round(g_per_s, 1), "unit": "G wave-instructions/s",
+                                    "peak": VALU_PEAK_G, "frac": round(g_per_s / VALU_PEAK_G, 4), "measured_issue_ceiling": VALU_MEASURED_G,
+                                    "frac_of_measured_ceiling": round(g_per_s / VALU_MEASURED_G, 4),
+                                    "source": "SQ_INSTS_VALU of a separate rocprofv3 --pmc pass (profiles/traffic.json), not measured in this run"}
+
+    comm_us = None
+    if world > 1 and not tracking:
+        # the collectives' share, measured apart (the timers synchronise the device around them)
+        st = {}
+        for _ in range(5):
+            backend_map.map_window(backend, window, iters=1, stats=st)
+        comm = torch.tensor([sum(r["comm_s"] for r in st["iterations"]) / len(st["iterations"])], device=dev, dtype=torch.float64)
+        dist.all_reduce(comm, op=dist.ReduceOp.MAX)
+        comm_us = round(float(comm.item()) * 1e6, 1)
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -197,8 +279,12 @@ def main():
                        "pairs": stats["D"], "sh_degree": 0,
                        "step": ("tracking iteration: render + get_loss_tracking + backward (pose + all Gaussian grads)"
                                 if tracking else
-                                "mapping window: one keyframe per GPU, render + get_loss_mapping + backward + RCCL all-reduce of the N x 14 gradient"),
-                       "parallelism": f"keyframe-per-gpu x{world}" if world > 1 else "single"},
+                                "mapping iteration (backend_map.map_window): one keyframe per GPU -- render + get_loss_mapping + backward, "
+                                "2 RCCL collectives (gradients + statistics, radii + flags), bookkeeping, Adam over all Gaussians, "
+                                "keyframe Adam, pose retraction"),
+                       "parallelism": f"keyframe-per-gpu x{world}" if world > 1 else "single",
+                       "comm_us_per_step": comm_us},
+            **({"collective_backend": backend_name + " (functional check only, not a benchmark result)"} if world > 1 and backend_name != "nccl" else {}),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels_us_per_step": {k: round(v["us_per_step"], 2) for k, v in kernels.items()},
         }
         print(json.dumps(out))

@@ -10,7 +10,10 @@ Import as ``lvdgs`` (see ``/lvdgs.py``).  Submodules:
   pose_utils         SE(3) retraction (update_pose)
   slam_utils         tracking / mapping losses
   synthetic          seeded benchmark scenes
-  window_shard       mapping-window keyframe sharding over ranks (RCCL)
+  backend_map        the back end's mapping iteration, its views sharded over ranks (two RCCL collectives per iteration)
+  slam_loops         map initialisation and per-frame pose tracking loops
+  loss_utils         fused L1 + SSIM and masked depth losses; fused_loss: photometric losses
+  gaussian_model     the Gaussian map (parameters, Adam groups, seeding, densify / prune)
 
 Nothing here falls back to a CPU implementation: the HIP library
 (``lib/liblvdgs.so``) must be present for any render call.

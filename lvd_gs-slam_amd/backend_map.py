@@ -158,12 +158,15 @@ def view_loss(backend, viewpoint, pkg):
 
 
 def map_window(backend, current_window, prune=False, iters=1, up_pose=True, group=None, reducer: Optional[FlatReducer] = None,
-               render_fn=render, stats: Optional[Dict] = None):
+               render_fn=render, view_loss_fn=None, stats: Optional[Dict] = None):
     """``BackEnd.map(current_window, prune, iters, up_pose)`` (reference utils/slam_backend.py:153-390) with the
     iteration's views sharded over ``group``.  Returns ``gaussian_split`` of the last iteration like the reference.
-    ``stats`` (optional dict) receives per-iteration records: loss, views of this rank, collective time."""
+    ``stats`` (optional dict) receives per-iteration records: loss, views of this rank, collective time.
+    ``render_fn`` / ``view_loss_fn`` default to the HIP renderer and the fused losses; the CPU tests of the loop logic
+    pass the dense renderer and the float64 loss statements instead."""
     if len(current_window) == 0:
         return
+    view_loss_fn = view_loss if view_loss_fn is None else view_loss_fn
     rank, world = _world(group)
     reducer = reducer if reducer is not None else getattr(backend, "_lvdgs_reducer", None) or FlatReducer()
     try:
@@ -199,7 +202,7 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
             pkg = render_fn(views[i], G, backend.pipeline_params, backend.background)
             pkgs[i] = pkg
             if i < n_window:
-                loss_mapping = loss_mapping + view_loss(backend, views[i], pkg)
+                loss_mapping = loss_mapping + view_loss_fn(backend, views[i], pkg)
             else:
                 loss_mapping = loss_mapping + get_loss_mapping(cfg, pkg["render"], views[i], depth=pkg["depth"], monodepth=True)
         if rank == 0:

@@ -88,7 +88,10 @@ class GaussianModel:
         self.opacity_activation, self.inverse_opacity_activation = torch.sigmoid, inverse_sigmoid
         self.rotation_activation = torch.nn.functional.normalize
         self.rng = np.random.default_rng(0)  # pixel subsampling of new keyframes
-        self.generator = None                # torch generator for densify_and_split (None = global RNG)
+        # Samples of densify_and_split.  A CPU generator with a fixed seed: the draw is made on the host and copied,
+        # so every replica of the map (one per GPU in the sharded mapping loop) and a CPU run of the same loop split
+        # their Gaussians identically.  Set to None for torch's global generator on the model's device.
+        self.generator = torch.Generator().manual_seed(0)
 
     # ------------------------------------------------------------------ construction helpers
     @classmethod
@@ -339,7 +342,10 @@ class GaussianModel:
         padded[: grads.shape[0]] = grads.squeeze()
         sel = (padded >= grad_threshold) & (self.get_scaling.max(dim=1).values > self.percent_dense * scene_extent)
         stds = self.get_scaling[sel].repeat(N, 1)
-        samples = torch.randn(stds.shape, device=self.device, generator=self.generator) * stds
+        if self.generator is not None and self.generator.device.type == "cpu":
+            samples = torch.randn(stds.shape, generator=self.generator).to(stds.device) * stds
+        else:
+            samples = torch.randn(stds.shape, device=stds.device, generator=self.generator) * stds
         rots = build_rotation(self._rotation[sel]).repeat(N, 1, 1)
         new_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + self._xyz[sel].repeat(N, 1)
         new_scaling = self.scaling_inverse_activation(self.get_scaling[sel].repeat(N, 1) / (0.8 * N))

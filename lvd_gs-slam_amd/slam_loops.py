@@ -1,0 +1,85 @@
+"""The two single-view optimisation loops around ``render()``: map initialisation and per-frame pose tracking.
+
+Statements of the loop bodies of the reference's ``BackEnd.initialize_map`` (utils/slam_backend.py:95-149) and
+``FrontEnd.tracking`` (utils/slam_frontend.py:1467-1536, everything after the MASt3R pose initialisation), written
+against duck-typed ``backend`` / ``viewpoint`` objects so that the reference's own classes can be passed in.  One view
+per iteration: nothing to shard (on several GPUs these run as replicas); the sharded loop is
+``backend_map.map_window``.
+
+Both are pinned by ``tests/golden/loops.npz``, produced by running the reference's own methods
+(tests/golden/make_loop_golden.py): on the CPU with the same dense renderer (loop logic, exact), on the GPU with the
+HIP rasterizer (tests/test_gpu_loop_golden.py).
+"""
+import torch
+
+from .gaussian_renderer import render
+from .pose_utils import update_pose
+from .slam_utils import get_loss_mapping, get_loss_tracking, get_median_depth
+
+
+def initialize_map(backend, cur_frame_idx, viewpoint, render_fn=render, on_iteration=None):
+    """``init_itr_num`` iterations of render -> get_loss_mapping(initialization=True) -> backward -> bookkeeping ->
+    Adam step on one view (reference utils/slam_backend.py:95-149).  Returns the last render package."""
+    G = backend.gaussians
+    render_pkg = None
+    for mapping_iteration in range(backend.init_itr_num):
+        backend.iteration_count += 1
+        render_pkg = render_fn(viewpoint, G, backend.pipeline_params, backend.background)
+        image, viewspace_point_tensor, visibility_filter = render_pkg["render"], render_pkg["viewspace_points"], render_pkg["visibility_filter"]
+        radii, depth, n_touched = render_pkg["radii"], render_pkg["depth"], render_pkg["n_touched"]
+        loss_init = get_loss_mapping(backend.config, image, viewpoint, depth=depth, initialization=True)
+        loss_init.backward()
+        if on_iteration is not None:
+            on_iteration(mapping_iteration, loss_init, render_pkg)
+        with torch.no_grad():
+            G.max_radii2D[visibility_filter] = torch.max(G.max_radii2D[visibility_filter], radii[visibility_filter])
+            G.add_densification_stats(viewspace_point_tensor, visibility_filter)
+            if mapping_iteration % backend.init_gaussian_update == 0:
+                # replaces every parameter: the step below then finds no gradients (the reference does the same)
+                G.densify_and_prune(backend.opt_params.densify_grad_threshold, backend.init_gaussian_th,
+                                    backend.init_gaussian_extent, None)
+            if backend.iteration_count == backend.init_gaussian_reset or (
+                    backend.iteration_count == backend.opt_params.densify_from_iter):
+                G.reset_opacity()
+            G.optimizer.step()
+            G.optimizer.zero_grad(set_to_none=True)
+    backend.occ_aware_visibility[cur_frame_idx] = (n_touched > 0).long()
+    return render_pkg
+
+
+def make_pose_optimizer(viewpoint, config):
+    """Adam over the frame's pose deltas and exposure (reference utils/slam_frontend.py:1467-1490)."""
+    lr = config["Training"]["lr"]
+    return torch.optim.Adam([
+        {"params": [viewpoint.cam_rot_delta], "lr": lr["cam_rot_delta"], "name": "rot_{}".format(viewpoint.uid)},
+        {"params": [viewpoint.cam_trans_delta], "lr": lr["cam_trans_delta"], "name": "trans_{}".format(viewpoint.uid)},
+        {"params": [viewpoint.exposure_a], "lr": 0.01, "name": "exposure_a_{}".format(viewpoint.uid)},
+        {"params": [viewpoint.exposure_b], "lr": 0.01, "name": "exposure_b_{}".format(viewpoint.uid)},
+    ])
+
+
+def track_frame(viewpoint, gaussians, config, pipeline_params, background, tracking_itr_num=None, render_fn=render,
+                on_iteration=None):
+    """Pose + exposure optimisation of one frame against the map (reference utils/slam_frontend.py:1467-1536): up to
+    ``tracking_itr_num`` iterations of render -> get_loss_tracking -> backward -> Adam step -> ``update_pose``, stopping
+    when the pose update falls under 1e-4 (utils/pose_utils.py:82).  The frame's initial ``R, T`` (MASt3R / PnP, out of
+    scope here) must already be set.  Returns (last render package, median depth :1535, iterations run)."""
+    n_iter = config["Training"]["tracking_itr_num"] if tracking_itr_num is None else tracking_itr_num
+    pose_optimizer = make_pose_optimizer(viewpoint, config)
+    render_pkg, it = None, 0
+    for tracking_itr in range(n_iter):
+        render_pkg = render_fn(viewpoint, gaussians, pipeline_params, background)
+        image, depth, opacity = render_pkg["render"], render_pkg["depth"], render_pkg["opacity"]
+        pose_optimizer.zero_grad()
+        loss_tracking = get_loss_tracking(config, image, depth, opacity, viewpoint)
+        loss_tracking.backward()
+        if on_iteration is not None:
+            on_iteration(tracking_itr, loss_tracking, render_pkg)
+        with torch.no_grad():
+            pose_optimizer.step()
+            converged = update_pose(viewpoint)
+        it = tracking_itr + 1
+        if converged:
+            break
+    median_depth = get_median_depth(render_pkg["depth"], render_pkg["opacity"])
+    return render_pkg, median_depth, it

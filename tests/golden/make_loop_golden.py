@@ -41,7 +41,7 @@ for p in (os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), ROOT, os.pa
 import lvdgs  # noqa: E402,F401
 import loss_oracle as lo  # noqa: E402
 from dense_render import dense_render  # noqa: E402
-from loop_scene import CONFIG_OVERRIDES, build_scene  # noqa: E402  (tests/loop_scene.py: shared with the replay tests)
+from loop_scene import build_scene, loop_config  # noqa: E402  (tests/loop_scene.py: shared with the replay tests)
 
 
 def _stub(name, **attrs):
@@ -78,7 +78,7 @@ class Recorder:
 
     def hook_optimizer(self, opt, tag):
         def pre(optimizer, args, kwargs):
-            row = {"tag": tag}
+            row = {"tag": tag, "n": int(optimizer.param_groups[0]["params"][0].shape[0])}
             for gp in optimizer.param_groups:
                 p = gp["params"][0]
                 row["grad_" + gp["name"]] = None if p.grad is None else p.grad.detach().clone().numpy()
@@ -95,15 +95,13 @@ def snapshot(gaussians):
 
 def main():
     backend_mod, frontend_mod = load_reference()
-    cfg = json.load(open(os.path.join(HERE, "config_07.json")))
-    cfg["Training"]["monocular"] = cfg["Dataset"]["sensor_type"] == "monocular"  # set by the absent slam.py entry point
-    for sec, kv in CONFIG_OVERRIDES.items():
-        cfg.setdefault(sec, {}).update(kv)
+    cfg = loop_config()
+    from utils.camera_utils import Camera as RefCamera  # the reference's own Camera class (imports through the shims)
     out = {}
 
     # ------------------------------------------------------------------ BackEnd.initialize_map
     torch.manual_seed(0)
-    sc = build_scene("cpu")
+    sc = build_scene("cpu", RefCamera)
     be = backend_mod.BackEnd(cfg)
     be.gaussians, be.background, be.pipeline_params = sc["gaussians"], sc["background"], sc["pipe"]
     be.opt_params = types.SimpleNamespace(**cfg["opt_params"])
@@ -117,9 +115,14 @@ def main():
     be.viewpoints[0] = sc["cameras"][0]
     be.initialize_map(0, sc["cameras"][0])
     out["init_losses"] = np.array(losses)
-    out["init_n_per_iter"] = np.array([r["grad_xyz"].shape[0] for r in rec.rows])
-    for k in ("xyz", "opacity", "scaling", "f_dc", "rotation"):
-        out["init_grad0_" + k] = rec.rows[0]["grad_" + k]
+    out["init_n_per_iter"] = np.array([r["n"] for r in rec.rows])
+    # an iteration that densifies replaces the parameters before the step (slam_backend.py:131-144): that step sees no
+    # gradients.  Keep the gradients of the first two iterations that do step.
+    stepping = [i for i, r in enumerate(rec.rows) if r["grad_xyz"] is not None]
+    out["init_stepping_iterations"] = np.array(stepping)
+    for n, it in enumerate(stepping[:2]):
+        for k in ("xyz", "opacity", "scaling", "f_dc", "rotation"):
+            out[f"init_grad{n}_{k}"] = rec.rows[it]["grad_" + k]
     for k, v in snapshot(be.gaussians).items():
         out["init_end_" + k] = v
     out["init_occ0"] = be.occ_aware_visibility[0].numpy()
@@ -127,7 +130,7 @@ def main():
 
     # ------------------------------------------------------------------ BackEnd.map (window of 4 + older keyframes)
     torch.manual_seed(1)
-    sc = build_scene("cpu")
+    sc = build_scene("cpu", RefCamera)
     be = backend_mod.BackEnd(cfg)
     be.gaussians, be.background, be.pipeline_params = sc["gaussians"], sc["background"], sc["pipe"]
     be.opt_params = types.SimpleNamespace(**cfg["opt_params"])
@@ -151,12 +154,15 @@ def main():
     be.map(window, iters=sc["map_iters"])
     backend_mod.torch.randperm = ref_randperm
     out["map_random_picks"] = np.array(picks)
-    out["map_n_per_iter"] = np.array([r["grad_xyz"].shape[0] for r in rec.rows])
-    for it in (0, 1):
+    out["map_n_per_iter"] = np.array([r["n"] for r in rec.rows])
+    stepping = [i for i, r in enumerate(rec.rows) if r["grad_xyz"] is not None]
+    out["map_stepping_iterations"] = np.array(stepping)
+    for n, it in enumerate(stepping[:2]):
         for k in ("xyz", "opacity", "scaling", "f_dc", "rotation"):
-            out[f"map_grad{it}_{k}"] = rec.rows[it]["grad_" + k]
+            out[f"map_grad{n}_{k}"] = rec.rows[it]["grad_" + k]
         for name, g in kf_rows[it].items():
-            out[f"map_kfgrad{it}_{name}"] = g
+            out[f"map_kfgrad{n}_{name}"] = g
+    out["map_losses"] = np.array(losses)
     for k, v in snapshot(be.gaussians).items():
         out["map_end_" + k] = v
     for i, cam in enumerate(sc["cameras"]):
@@ -175,7 +181,7 @@ def main():
 
     # ------------------------------------------------------------------ FrontEnd.tracking
     torch.manual_seed(2)
-    sc = build_scene("cpu")
+    sc = build_scene("cpu", RefCamera)
     cfg_t = json.loads(json.dumps(cfg))
     cfg_t["dynamic_filtering"] = {"enabled": False}
     fe = frontend_mod.FrontEnd(cfg_t, model=lambda img: sc["track_mono_depth"])

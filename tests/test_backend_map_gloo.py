@@ -1,0 +1,178 @@
+"""world_size-2 gloo test (CPU) of the sharded mapping loop ``lvdgs.backend_map.map_window``: four iterations on the
+toy scene (a densification in the third, an opacity reset of the non-visible in the fourth... see loop_scene.py), then the
+pruning pass -- on two ranks and in one process.
+
+Checked: (1) the two replicas end bit-identical (parameters, Adam moments, keyframe poses and exposures, bookkeeping),
+which is what lets the ranks go on without ever broadcasting parameters; (2) they agree with the single-process run
+(same random keyframes) to float rounding -- sums are formed in a different order; (3) the schedule of Gaussian counts
+(densify / prune) is identical.  The renderer is the dense CPU one (the HIP path needs a GPU; the collectives and the
+bookkeeping are what is under test)."""
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+ITERS = 4
+
+
+def _paths():
+    for p in (os.path.join(ROOT, "oracle"), ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import lvdgs  # noqa: F401
+
+
+def _run(group_world):
+    """One run of ITERS iterations + the pruning pass; returns a dict of numpy results."""
+    _paths()
+    import test_loop_golden as tl
+    from dense_render import dense_render
+    from loop_scene import build_scene, loop_config
+    from lvdgs import backend_map as bm
+    cfg = loop_config()
+    sc = build_scene("cpu")
+    be = tl._backend(sc, cfg)
+    be.initialized = True
+    for i, cam in enumerate(sc["cameras"]):
+        be.viewpoints[i] = cam
+    window = sc["window"]
+    be.current_window = window
+    be.keyframe_optimizers = sc["make_keyframe_optimizer"](be.viewpoints, window, cfg)
+    counts = []
+    sc["gaussians"].optimizer.register_step_pre_hook(lambda opt, a, k: counts.append(int(opt.param_groups[0]["params"][0].shape[0])))
+    if group_world == 1:
+        # single process: draw the random keyframes the way the ranks do, so that the runs are comparable
+        keyed = bm.random_view_indices
+        bm.random_view_indices = lambda n, k, it, world, seed=0: keyed(n, k, it, 2, seed)
+    stats = {}
+    try:
+        bm.map_window(be, window, iters=ITERS, render_fn=dense_render, view_loss_fn=tl._cpu_view_loss, stats=stats)
+        n_mid = be.gaussians.get_xyz.shape[0]
+        bm.map_window(be, window, prune=True, render_fn=dense_render, view_loss_fn=tl._cpu_view_loss)
+        # one more iteration after the pruning pass: its (unreduced) gradients must have been dropped with the
+        # replaced parameters, or carried consistently
+        bm.map_window(be, window, iters=1, render_fn=dense_render, view_loss_fn=tl._cpu_view_loss)
+    finally:
+        if group_world == 1:
+            bm.random_view_indices = keyed
+    G = be.gaussians
+    out = {k: v.detach().numpy().copy() for k, v in G._params_by_name().items()}
+    for gp in G.optimizer.param_groups:
+        st = G.optimizer.state.get(gp["params"][0], {})
+        if "exp_avg" in st:
+            out["m_" + gp["name"]] = st["exp_avg"].numpy().copy()
+            out["v_" + gp["name"]] = st["exp_avg_sq"].numpy().copy()
+    out.update(max_radii2D=G.max_radii2D.numpy().copy(), accum=G.xyz_gradient_accum.numpy().copy(), denom=G.denom.numpy().copy(),
+               n_obs=G.n_obs.numpy().copy(), kf_ids=G.unique_kfIDs.numpy().copy(), counts=np.array(counts), n_mid=np.array(n_mid))
+    for i, cam in enumerate(sc["cameras"]):
+        out[f"R{i}"], out[f"T{i}"] = cam.R.numpy().copy(), cam.T.numpy().copy()
+        out[f"exp{i}"] = np.array([float(cam.exposure_a.detach()), float(cam.exposure_b.detach())])
+    for kf in window:
+        out[f"occ{kf}"] = be.occ_aware_visibility[kf].numpy().copy()
+    out["views_per_iteration"] = np.array([len(r["views"]) for r in stats["iterations"]])
+    return out
+
+
+def _digest(res):
+    h = hashlib.sha256()
+    for k in sorted(res):
+        if k != "views_per_iteration":
+            h.update(k.encode())
+            h.update(np.ascontiguousarray(res[k]).tobytes())
+    return h.hexdigest()
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)   # the ranks' global generators differ on purpose: nothing may depend on them
+        res = _run(world)
+        q.put((rank, _digest(res), res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_stay_bit_identical_and_match_the_single_process_run():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=600) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, d0, r0), (_, d1, r1) = results
+    # (1) replicas: bit-identical, everything
+    for k in r0:
+        if k != "views_per_iteration":
+            np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)
+    assert d0 == d1
+    # the six views of an iteration (4 window + 2 random) split 3 + 3
+    assert r0["views_per_iteration"].tolist() == [3] * ITERS and r1["views_per_iteration"].tolist() == [3] * ITERS
+    # (2) single process, same random keyframes
+    torch.manual_seed(7)
+    ref = _run(1)
+    np.testing.assert_array_equal(ref["counts"], r0["counts"])
+    assert int(ref["n_mid"]) == int(r0["n_mid"]) and len(set(ref["counts"].tolist())) > 1   # a densification happened
+    for k in ref:
+        if k in ("views_per_iteration", "counts", "n_mid"):
+            continue
+        a, b = np.asarray(r0[k], np.float64), np.asarray(ref[k], np.float64)
+        assert a.shape == b.shape, k
+        if a.size:
+            tol = 5e-4 * np.abs(b) + 5e-5 * max(np.abs(b).max(), 1e-30)
+            assert (np.abs(a - b) <= tol).all(), (k, np.abs(a - b).max(), np.abs(b).max())
+
+
+def test_view_assignment_and_random_choice():
+    _paths()
+    from lvdgs import backend_map as bm
+    # window keyframe i -> rank i mod world; the two random views go to the least loaded ranks, rotating
+    assert bm.assign_views(8, 2, 8, 0)[:8] == list(range(8))
+    for it in range(8):
+        owners = bm.assign_views(8, 2, 8, it)
+        load = [owners.count(r) for r in range(8)]
+        assert max(load) == 2 and sum(load) == 10 and owners[8] != owners[9]
+    assert {bm.assign_views(8, 2, 8, it)[8] for it in range(8)} == set(range(8))   # no rank carries the extra view every time
+    assert sorted(bm.assign_views(8, 2, 10, 3)) == list(range(10))                 # ten ranks: one view each
+    assert bm.assign_views(8, 2, 1, 5) == [0] * 10
+    # all ranks draw the same random keyframes, different ones from iteration to iteration
+    assert bm.random_view_indices(7, 2, 11, 4) == bm.random_view_indices(7, 2, 11, 4)
+    assert len({tuple(bm.random_view_indices(7, 2, it, 4)) for it in range(20)}) > 5
+    assert bm.random_view_indices(0, 2, 3, 2) == [] and len(bm.random_view_indices(1, 2, 3, 2)) == 1
+
+
+def test_flat_reducer_repacks_and_handles_aliasing():
+    """ADVICE (round 1): a bucket that captured Parameter objects went on reducing stale tensors after densify / prune
+    replaced them, and a .grad left pointing into the flat buffer aliased the next pack.  The reducer takes the live
+    tensors at every call and copes with gradients that are views of its own buffer."""
+    _paths()
+    from lvdgs.backend_map import FlatReducer
+    red = FlatReducer()
+    a, b = torch.arange(6.0), torch.arange(4.0) + 10
+    out = red.sum_floats([a, None, b], [6, 3, 4], torch.device("cpu"))
+    assert torch.equal(out[0], a) and not out[1].any() and torch.equal(out[2], b)
+    # gradients now alias the bucket (as after map_window assigns p.grad = view); accumulate into them and re-reduce
+    ga, gb = out[0], out[2]
+    ga += 1.0
+    out2 = red.sum_floats([ga, None, gb], [6, 3, 4], torch.device("cpu"))
+    assert torch.equal(out2[0], a + 1.0) and torch.equal(out2[2], b)
+    # sizes change (densification): the bucket is re-planned, views of the old layout that overlap are copied out first
+    shifted = out2[2][:3]
+    out3 = red.sum_floats([shifted, torch.ones(5)], [3, 5], torch.device("cpu"))
+    assert torch.equal(out3[0], b[:3]) and torch.equal(out3[1], torch.ones(5))
+    ints = red.max_ints([torch.tensor([1, 5, 2], dtype=torch.int32), torch.tensor([7], dtype=torch.int32)], torch.device("cpu"))
+    assert ints[0].tolist() == [1, 5, 2] and ints[1].tolist() == [7]

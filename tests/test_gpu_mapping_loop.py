@@ -176,59 +176,3 @@ def test_masked_l1_dssim_mapping_step_drives_every_parameter():
     deep_inside = (u > 85) & (u < 115) & (v > 62) & (v < 78) & (pkg["radii"] < 8) & (pkg["radii"] > 0)
     assert int(deep_inside.sum()) > 0
     assert float(m._features_dc.grad[deep_inside].abs().max()) == 0.0
-
-
-def test_sharded_map_iteration_with_the_real_renderer_equals_the_plain_loop():
-    """window_shard.sharded_map_iteration (what each rank runs under torchrun) on one GPU, against the loop of
-    BackEnd.map written out: summed losses over the window + isotropic term, one backward, bookkeeping vectors."""
-    from lvdgs import window_shard as ws
-    from lvdgs.gaussian_model import GaussianModel
-    from lvdgs.gaussian_renderer import render
-    from lvdgs.pose_utils import SE3_exp
-    from lvdgs.slam_utils import get_loss_mapping
-    W, H = 200, 120
-    target, depth, opac, pipe, bg = _scene_and_target(W, H, n=2000)
-    seed_depth = torch.where(opac > 0.5, depth / opac.clamp(min=1e-3), torch.zeros_like(depth))
-    views = []
-    for k in range(3):
-        cam = _camera(W, H, target, pose=SE3_exp(torch.tensor([0.02 * k, -0.01 * k, 0.0, 0.0, 0.01 * k, 0.0])),
-                      mono_depth=seed_depth.cpu().numpy())
-        views.append(cam)
-    m = GaussianModel(0, config=CONFIG)
-    m.init_lr(6.0)
-    m.training_setup(OPT)
-    m.extend_from_pcd_seq(views[0], kf_id=0, init=True, scale=2.0, depthmap=seed_depth.cpu().numpy())
-    render_fn = lambda v: render(v, m, pipe, bg)
-    loss_fn = lambda v, pkg: get_loss_mapping(CONFIG, pkg["render"], v, depth=pkg["depth"])
-    iso = lambda: 10 * torch.abs(m.get_scaling - m.get_scaling.mean(dim=1).view(-1, 1)).mean()
-
-    # the plain loop (utils/slam_backend.py:180-306, 311-357)
-    total = 0
-    pkgs = []
-    for v in views:
-        pkg = render_fn(v)
-        pkgs.append(pkg)
-        total = total + loss_fn(v, pkg)
-    total = total + iso()
-    total.backward()
-    want = {n: p.grad.clone() for n, p in zip("abcdef", m.parameters()) if p.grad is not None}
-    want_radii = torch.stack([torch.where(p["visibility_filter"], p["radii"], torch.zeros_like(p["radii"])) for p in pkgs]).max(0).values
-    want_touched = torch.stack([p["n_touched"] > 0 for p in pkgs])
-    want_norm = sum(torch.where(p["visibility_filter"], p["viewspace_points"].grad[:, :2].norm(dim=-1),
-                                torch.zeros_like(p["viewspace_points"].grad[:, 0])) for p in pkgs)
-    for p in m.parameters():
-        p.grad = None
-    for v in views:
-        for t in (v.cam_rot_delta, v.cam_trans_delta, v.exposure_a, v.exposure_b):
-            t.grad = None
-
-    out = ws.sharded_map_iteration(render_fn, loss_fn, views, m, ws.GradientBucket(m.parameters()), extra_loss_fn=iso, window_size=3)
-    assert abs(float(out["loss"]) - float(total.detach())) < 1e-6 * max(1.0, abs(float(total.detach())))
-    for n, p in zip("abcdef", m.parameters()):
-        if n in want:
-            assert torch.equal(p.grad, want[n]), n  # same kernels, same order: bit-identical
-    assert torch.equal(out["radii_max"], want_radii.to(torch.int32))
-    assert torch.equal(out["n_touched_gt0"], want_touched)
-    assert torch.allclose(out["viewspace_grad_norm_sum"], want_norm, rtol=1e-6, atol=0)
-    assert torch.equal(out["visibility_count"], torch.stack([p["visibility_filter"] for p in pkgs]).sum(0).float())
-    assert out["my_views"] == [0, 1, 2]

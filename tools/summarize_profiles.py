@@ -61,6 +61,8 @@ def main(tag, workload="cfg3_500k_1920x1080"):
             f, w = sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"]), sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])
             entry[k] = {"FETCH_SIZE_KB_raw": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
                         "hbm_bytes_per_launch": int((2 * f + w) * 1024), "note": note}
+            if "SQ_INSTS_VALU" in c:
+                entry[k]["valu_wave_instructions_per_launch"] = int(sum(c["SQ_INSTS_VALU"]) / len(c["SQ_INSTS_VALU"]))
     if entry:
         entry["_source"] = f"gpurun_out/{tag} (tools/profile_round.sh), summarised by tools/summarize_profiles.py"
         traffic[workload] = entry
