@@ -217,6 +217,33 @@ size_t lvdgs_loss_scratch_bytes(int32_t width, int32_t height);
 int lvdgs_photometric_loss_forward(const lvdgs_loss_args *a, void *stream);
 int lvdgs_photometric_loss_backward(const lvdgs_loss_args *a, void *stream);
 
+/* ---- per-frame pose optimiser step (reference utils/slam_frontend.py:1518-1521, utils/pose_utils.py:70-87) ----
+ * One launch = `pose_optimizer.step()` (torch.optim.Adam: betas, eps, one learning rate per group) on the frame's
+ * cam_rot_delta, cam_trans_delta, exposure_a, exposure_b, then `update_pose`: T_w2c <- SE3_exp([trans, rot]) @ [R T],
+ * deltas zeroed, and the matrices the next render reads (Camera.world_view_transform / full_proj_transform /
+ * camera_center, utils/camera_utils.py:106-120).  `state` = 19 floats owned by the caller and zeroed before the first
+ * step of a frame: Adam's (exp_avg, exp_avg_sq) of the 8 scalars, the step count, a STICKY converged flag
+ * (||tau|| < converged_threshold at some step) and the number of steps applied.  Once the flag is set further calls
+ * change nothing, so the host may enqueue iterations ahead and read the flag late. */
+typedef struct lvdgs_pose_step_args {
+    float *R;                      /* 9, row-major world-to-camera rotation (in / out)                */
+    float *T;                      /* 3 (in / out)                                                    */
+    float *cam_rot_delta;          /* 3 parameter values (in / out: stepped, consumed, zeroed)        */
+    float *cam_trans_delta;        /* 3                                                               */
+    float *exposure_a;             /* 1 or NULL                                                       */
+    float *exposure_b;             /* 1 or NULL                                                       */
+    const float *grad_tau;         /* 6: dL/d(trans, rot), as lvdgs_backward writes dL_dtau; NULL = 0 */
+    const float *grad_exposure_a;  /* 1 or NULL                                                       */
+    const float *grad_exposure_b;  /* 1 or NULL                                                       */
+    float *state;                  /* 19 floats, see above                                            */
+    float lr_rot, lr_trans, lr_exposure, beta1, beta2, eps, converged_threshold;
+    const float *projmatrix_raw;   /* 16: the camera's projection_matrix (row-vector layout) or NULL  */
+    float *viewmatrix;             /* out 16 or NULL                                                  */
+    float *projmatrix;             /* out 16 or NULL: viewmatrix @ projmatrix_raw                     */
+    float *campos;                 /* out 3 or NULL                                                   */
+} lvdgs_pose_step_args;
+int lvdgs_pose_step(const lvdgs_pose_step_args *a, void *stream);
+
 /* ---- depth term of the static-mask mapping loss (reference utils/slam_backend.py:216-261) ----
  *   M    = static_mask & (mono_depth > 0) & (rendered depth > 0)          (static_mask NULL = every pixel)
  *   loss = depth_lambda-free mean over M of |D_p - Z_p|;  0 when M is empty (the reference then adds nothing)

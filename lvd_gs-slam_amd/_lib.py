@@ -61,6 +61,17 @@ class MaskedDepthArgs(C.Structure):
     ]
 
 
+class PoseStepArgs(C.Structure):
+    """struct lvdgs_pose_step_args (include/lvdgs.h)."""
+    _fields_ = [
+        ("R", _fp), ("T", _fp), ("cam_rot_delta", _fp), ("cam_trans_delta", _fp), ("exposure_a", _fp), ("exposure_b", _fp),
+        ("grad_tau", _fp), ("grad_exposure_a", _fp), ("grad_exposure_b", _fp), ("state", _fp),
+        ("lr_rot", C.c_float), ("lr_trans", C.c_float), ("lr_exposure", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+        ("eps", C.c_float), ("converged_threshold", C.c_float),
+        ("projmatrix_raw", _fp), ("viewmatrix", _fp), ("projmatrix", _fp), ("campos", _fp),
+    ]
+
+
 class SsimArgs(C.Structure):
     """struct lvdgs_ssim_args (include/lvdgs.h)."""
     _fields_ = [
@@ -90,7 +101,7 @@ EXPORTS = (
     "lvdgs_backward", "lvdgs_mark_visible", "lvdgs_state_layout_query", "lvdgs_knn_scratch_bytes",
     "lvdgs_dist2_knn3", "lvdgs_rope2d", "lvdgs_rope2d_strided", "lvdgs_loss_scratch_bytes", "lvdgs_photometric_loss_forward",
     "lvdgs_photometric_loss_backward", "lvdgs_masked_depth_scratch_bytes", "lvdgs_masked_depth_l1_forward",
-    "lvdgs_masked_depth_l1_backward", "lvdgs_ssim_scratch_bytes", "lvdgs_ssim_l1", "lvdgs_last_error", "lvdgs_version", "lvdgs_profile_enable",
+    "lvdgs_masked_depth_l1_backward", "lvdgs_pose_step", "lvdgs_ssim_scratch_bytes", "lvdgs_ssim_l1", "lvdgs_last_error", "lvdgs_version", "lvdgs_profile_enable",
     "lvdgs_profile_reset", "lvdgs_profile_read",
 )
 
@@ -143,6 +154,7 @@ def lib():
         L.lvdgs_masked_depth_scratch_bytes.argtypes = [C.c_int32, C.c_int32]
         L.lvdgs_masked_depth_l1_forward.argtypes = [C.POINTER(MaskedDepthArgs), C.c_void_p]
         L.lvdgs_masked_depth_l1_backward.argtypes = [C.POINTER(MaskedDepthArgs), C.c_void_p]
+        L.lvdgs_pose_step.argtypes = [C.POINTER(PoseStepArgs), C.c_void_p]
         L.lvdgs_ssim_scratch_bytes.restype = C.c_size_t
         L.lvdgs_ssim_scratch_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
         L.lvdgs_ssim_l1.argtypes = [C.POINTER(SsimArgs), C.c_void_p]

@@ -578,13 +578,14 @@ int launch_blend_fwd(const lvdgs_args &a, const GeomView &g, const BinView &b, c
     return LVDGS_OK;
 }
 
-// LVDGS_BLEND_BWD selects the backward kernel: "1" single pass, "2" two passes with batches of 8 (default),
-// "3" two passes with batches of 16.  Read once per process.
+// LVDGS_BLEND_BWD selects the backward kernel: "2" two passes with batches of 8 (default), "1" the single-pass kernel
+// (kept for A/B measurements in one process tree; batches of 16 were measured too: 50 KB LDS, 3 waves/SIMD, 437 us).
+// Read once per process.
 static int blend_bwd_variant() {
     static const int v = [] {
         const char *e = getenv("LVDGS_BLEND_BWD");
         const int x = e ? atoi(e) : 2;
-        return (x >= 1 && x <= 3) ? x : 2;
+        return (x >= 1 && x <= 2) ? x : 2;
     }();
     return v;
 }
@@ -597,7 +598,6 @@ int launch_blend_bwd(const lvdgs_args &a, const GeomView &g, const BinView &b, c
     ProfScope ps("blend_bwd", s);
     switch (blend_bwd_variant()) {
         case 1: hipLaunchKernelGGL(blend_bwd_kernel, dim3(p.num_tiles), dim3(256), 0, s, p); break;
-        case 3: hipLaunchKernelGGL(blend_bwd2_kernel<16>, dim3(p.num_tiles), dim3(256), 0, s, p); break;
         default: hipLaunchKernelGGL(blend_bwd2_kernel<8>, dim3(p.num_tiles), dim3(256), 0, s, p); break;
     }
     LVDGS_LAUNCH_CHECK("blend_bwd", a.debug, s);

@@ -58,12 +58,33 @@ def make_pose_optimizer(viewpoint, config):
     ])
 
 
+def _can_fuse(viewpoint, gaussians, pipeline_params):
+    dev = gaussians.get_xyz.device
+    if dev.type != "cuda" or getattr(pipeline_params, "compute_cov3D_python", False) or getattr(pipeline_params, "convert_SHs_python", False):
+        return False
+    for name in ("cam_rot_delta", "cam_trans_delta", "exposure_a", "exposure_b"):
+        p = getattr(viewpoint, name, None)
+        if not torch.is_tensor(p) or p.device != dev or p.dtype is not torch.float32 or not p.is_contiguous():
+            return False
+    return hasattr(viewpoint, "update_RT")
+
+
 def track_frame(viewpoint, gaussians, config, pipeline_params, background, tracking_itr_num=None, render_fn=render,
-                on_iteration=None):
+                on_iteration=None, fused="auto"):
     """Pose + exposure optimisation of one frame against the map (reference utils/slam_frontend.py:1467-1536): up to
     ``tracking_itr_num`` iterations of render -> get_loss_tracking -> backward -> Adam step -> ``update_pose``, stopping
     when the pose update falls under 1e-4 (utils/pose_utils.py:82).  The frame's initial ``R, T`` (MASt3R / PnP, out of
-    scope here) must already be set.  Returns (last render package, median depth :1535, iterations run)."""
+    scope here) must already be set.  Returns (last render package, median depth :1535, iterations run).
+
+    ``fused`` ("auto" / True / False): with the HIP renderer and everything on the GPU the loop runs on
+    ``fast_tracking.TrackingSession`` -- the same arithmetic as five C-ABI calls per iteration on buffers that live for
+    the frame, the Adam step / retraction / camera matrices in one device kernel, no autograd engine and no host
+    synchronisation inside the loop.  ``on_iteration`` then gets (iteration, loss as a 0-dim CPU tensor, None) after
+    the loop.  ``fused=False`` (or another ``render_fn``) is the PyTorch loop below, statement for statement the
+    reference's."""
+    if fused is True or (fused == "auto" and render_fn is render and _can_fuse(viewpoint, gaussians, pipeline_params)):
+        from .fast_tracking import track_frame_fused
+        return track_frame_fused(viewpoint, gaussians, config, pipeline_params, background, tracking_itr_num, on_iteration)
     n_iter = config["Training"]["tracking_itr_num"] if tracking_itr_num is None else tracking_itr_num
     pose_optimizer = make_pose_optimizer(viewpoint, config)
     render_pkg, it = None, 0

@@ -1,0 +1,134 @@
+"""The device-side pose optimiser step and the autograd-free tracking session against the PyTorch statements of the
+same loop (torch.optim.Adam + pose_utils.update_pose + Camera's derived matrices; slam_loops.track_frame(fused=False))."""
+import ctypes as C
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+pytestmark = pytest.mark.gpu
+
+
+def _camera(W=64, H=48):
+    from lvdgs.camera_utils import Camera
+    from lvdgs.graphics_utils import focal2fov, getProjectionMatrix2
+    proj = getProjectionMatrix2(znear=0.01, zfar=100.0, fx=70.0, fy=72.0, cx=31.0, cy=25.0, W=W, H=H).transpose(0, 1).cuda()
+    return Camera(3, torch.rand(3, H, W).cuda(), None, None, torch.eye(4), proj, 70.0, 72.0, 31.0, 25.0, focal2fov(70.0, W),
+                  focal2fov(72.0, H), H, W, device="cuda")
+
+
+@pytest.mark.parametrize("grad_scale", [1.0, 1e-3, 1e-9])
+def test_pose_step_equals_adam_plus_update_pose(grad_scale):
+    """Twelve steps with seeded gradients: parameters, Adam moments, R, T, the three derived matrices and the
+    converged flag follow torch.optim.Adam.step() + update_pose() (reference utils/slam_frontend.py:1518-1521,
+    utils/pose_utils.py:70-87).  grad_scale 1e-9 keeps the rotation below the 1e-5 rad series threshold and converges."""
+    from lvdgs import _lib
+    from lvdgs.pose_utils import SE3_exp, update_pose
+    g = torch.Generator().manual_seed(5)
+    cam_t, cam_k = _camera(), _camera()
+    pose0 = SE3_exp(torch.tensor([0.3, -0.1, 0.2, 0.2, -0.4, 0.1]))
+    for cam in (cam_t, cam_k):
+        cam.update_RT(pose0[:3, :3].cuda(), pose0[:3, 3].cuda())
+    opt = torch.optim.Adam([{"params": [cam_t.cam_rot_delta], "lr": 0.003}, {"params": [cam_t.cam_trans_delta], "lr": 0.001},
+                            {"params": [cam_t.exposure_a], "lr": 0.01}, {"params": [cam_t.exposure_b], "lr": 0.01}])
+    L = _lib.lib()
+    R, T = cam_k.R.clone().contiguous(), cam_k.T.clone().contiguous()
+    view, proj, campos = torch.empty(4, 4, device="cuda"), torch.empty(4, 4, device="cuda"), torch.empty(3, device="cuda")
+    state = torch.zeros(19, device="cuda")
+    gtau, ga, gb = torch.empty(6, device="cuda"), torch.empty(1, device="cuda"), torch.empty(1, device="cuda")
+    pa = _lib.PoseStepArgs()
+    P = lambda t: C.c_void_p(t.data_ptr())
+    pa.R, pa.T, pa.cam_rot_delta, pa.cam_trans_delta = P(R), P(T), P(cam_k.cam_rot_delta), P(cam_k.cam_trans_delta)
+    pa.exposure_a, pa.exposure_b, pa.grad_tau, pa.grad_exposure_a, pa.grad_exposure_b = P(cam_k.exposure_a), P(cam_k.exposure_b), P(gtau), P(ga), P(gb)
+    pa.state, pa.lr_rot, pa.lr_trans, pa.lr_exposure = P(state), 0.003, 0.001, 0.01
+    pa.beta1, pa.beta2, pa.eps, pa.converged_threshold = 0.9, 0.999, 1e-8, 1e-4
+    pa.projmatrix_raw, pa.viewmatrix, pa.projmatrix, pa.campos = P(cam_k.projection_matrix), P(view), P(proj), P(campos)
+    stream = _lib.raw_stream(torch.device("cuda", 0))
+    first_converged = None
+    for it in range(12):
+        grads = torch.randn(8, generator=g) * grad_scale * (1.0 if it < 8 else 0.0)   # later steps: Adam's momentum alone
+        cam_t.cam_trans_delta.grad, cam_t.cam_rot_delta.grad = grads[:3].cuda(), grads[3:6].cuda()
+        cam_t.exposure_a.grad, cam_t.exposure_b.grad = grads[6:7].cuda(), grads[7:8].cuda()
+        gtau.copy_(grads[:6]); ga.copy_(grads[6:7]); gb.copy_(grads[7:8])
+        if first_converged is None:
+            with torch.no_grad():
+                opt.step()
+                if bool(update_pose(cam_t)):
+                    first_converged = it
+        _lib.check(L.lvdgs_pose_step(C.byref(pa), stream), "lvdgs_pose_step")
+        torch.cuda.synchronize()
+        assert (float(state[17]) != 0.0) == (first_converged is not None), it
+        np.testing.assert_allclose(R.cpu().numpy(), cam_t.R.cpu().numpy(), atol=2e-6, err_msg=f"R at {it}")
+        np.testing.assert_allclose(T.cpu().numpy(), cam_t.T.cpu().numpy(), atol=2e-6, err_msg=f"T at {it}")
+        np.testing.assert_allclose(float(cam_k.exposure_a.detach()), float(cam_t.exposure_a.detach()), atol=1e-7, rtol=1e-5)
+        np.testing.assert_allclose(float(cam_k.exposure_b.detach()), float(cam_t.exposure_b.detach()), atol=1e-7, rtol=1e-5)
+        assert not cam_k.cam_rot_delta.detach().any() and not cam_k.cam_trans_delta.detach().any()
+        np.testing.assert_allclose(view.cpu().numpy(), cam_t.world_view_transform.cpu().numpy(), atol=2e-6)
+        np.testing.assert_allclose(proj.cpu().numpy(), cam_t.full_proj_transform.cpu().numpy(), rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(campos.cpu().numpy(), cam_t.camera_center.cpu().numpy(), atol=5e-6)
+    if grad_scale == 1e-9:
+        assert first_converged is not None and int(state[18]) == first_converged + 1   # steps after convergence are no-ops
+    else:
+        assert int(state[18]) == (12 if first_converged is None else first_converged + 1)
+    st = opt.state[cam_t.cam_rot_delta]
+    np.testing.assert_allclose(state[0:6:2].cpu().numpy(), st["exp_avg"].cpu().numpy(), rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(state[1:6:2].cpu().numpy(), st["exp_avg_sq"].cpu().numpy(), rtol=1e-5, atol=1e-20)
+
+
+def test_fused_tracking_equals_the_autograd_loop():
+    """slam_loops.track_frame on the TrackingSession against the same loop through render() / autograd /
+    torch.optim.Adam / update_pose: per-iteration losses, final pose, exposure, median depth, last images."""
+    sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
+    from loop_scene import build_scene, loop_config
+    from lvdgs.slam_loops import track_frame
+    cfg = loop_config()
+    out = {}
+    for fused in (False, True):
+        torch.manual_seed(2)
+        sc = build_scene("cuda")
+        cam, prev = sc["track_camera"], sc["cameras"][0]
+        cam.mono_depth = sc["track_mono_depth"]
+        cam.update_RT(prev.R, prev.T)
+        losses = []
+        pkg, med, n_it = track_frame(cam, sc["gaussians"], cfg, sc["pipe"], sc["background"], tracking_itr_num=25, fused=fused,
+                                     on_iteration=lambda i, loss, p: losses.append(float(loss.detach())))
+        out[fused] = dict(losses=np.array(losses), R=cam.R.cpu().numpy(), T=cam.T.cpu().numpy(), n_it=n_it, med=float(med),
+                          exp=[float(cam.exposure_a.detach()), float(cam.exposure_b.detach())],
+                          depth=pkg["depth"].detach().cpu().numpy(), image=pkg["render"].detach().cpu().numpy(),
+                          deltas=torch.cat([cam.cam_rot_delta.detach(), cam.cam_trans_delta.detach()]).cpu().numpy())
+        assert sc["gaussians"]._xyz.grad is None or not fused   # the session leaves the map's .grad fields alone
+    a, b = out[True], out[False]
+    assert a["n_it"] == b["n_it"] == 25 and len(a["losses"]) == 25
+    np.testing.assert_allclose(a["losses"], b["losses"], rtol=2e-5)
+    np.testing.assert_allclose(a["R"], b["R"], atol=2e-6)
+    np.testing.assert_allclose(a["T"], b["T"], atol=2e-6)
+    np.testing.assert_allclose(a["exp"], b["exp"], rtol=1e-4, atol=1e-7)
+    assert abs(a["med"] - b["med"]) <= 1e-5 * abs(b["med"])
+    np.testing.assert_allclose(a["depth"], b["depth"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(a["image"], b["image"], rtol=1e-4, atol=1e-6)
+    assert not a["deltas"].any() and not b["deltas"].any()
+
+
+def test_fused_tracking_stops_at_convergence_like_the_loop_that_breaks():
+    """Start at the optimum with a vanishing learning rate: the pose update is below 1e-4 at once.  The reference loop
+    breaks after its first iteration; the session, polled two iterations late, must report one applied iteration and the
+    same pose, however many iterations the host had already enqueued."""
+    sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
+    from loop_scene import build_scene, loop_config
+    from lvdgs.slam_loops import track_frame
+    cfg = loop_config()
+    cfg["Training"]["lr"] = {"cam_rot_delta": 1e-6, "cam_trans_delta": 1e-6}
+    res = {}
+    for fused in (False, True):
+        sc = build_scene("cuda")
+        cam = sc["track_camera"]          # already at its true pose
+        cam.mono_depth = sc["track_mono_depth"]
+        _, _, n_it = track_frame(cam, sc["gaussians"], cfg, sc["pipe"], sc["background"], tracking_itr_num=10, fused=fused)
+        res[fused] = (n_it, cam.R.cpu().numpy(), cam.T.cpu().numpy())
+    assert res[True][0] == res[False][0] == 1
+    np.testing.assert_allclose(res[True][1], res[False][1], atol=1e-7)
+    np.testing.assert_allclose(res[True][2], res[False][2], atol=1e-7)
