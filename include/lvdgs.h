@@ -236,7 +236,8 @@ typedef struct lvdgs_pose_step_args {
     const float *grad_exposure_a;  /* 1 or NULL                                                       */
     const float *grad_exposure_b;  /* 1 or NULL                                                       */
     float *state;                  /* 19 floats, see above                                            */
-    float lr_rot, lr_trans, lr_exposure, beta1, beta2, eps, converged_threshold;
+    double lr_rot, lr_trans, lr_exposure, beta1, beta2, eps;  /* doubles, like the Python floats torch.optim.Adam computes with */
+    float converged_threshold;
     const float *projmatrix_raw;   /* 16: the camera's projection_matrix (row-vector layout) or NULL  */
     float *viewmatrix;             /* out 16 or NULL                                                  */
     float *projmatrix;             /* out 16 or NULL: viewmatrix @ projmatrix_raw                     */

@@ -66,8 +66,8 @@ class PoseStepArgs(C.Structure):
     _fields_ = [
         ("R", _fp), ("T", _fp), ("cam_rot_delta", _fp), ("cam_trans_delta", _fp), ("exposure_a", _fp), ("exposure_b", _fp),
         ("grad_tau", _fp), ("grad_exposure_a", _fp), ("grad_exposure_b", _fp), ("state", _fp),
-        ("lr_rot", C.c_float), ("lr_trans", C.c_float), ("lr_exposure", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
-        ("eps", C.c_float), ("converged_threshold", C.c_float),
+        ("lr_rot", C.c_double), ("lr_trans", C.c_double), ("lr_exposure", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
+        ("eps", C.c_double), ("converged_threshold", C.c_float),
         ("projmatrix_raw", _fp), ("viewmatrix", _fp), ("projmatrix", _fp), ("campos", _fp),
     ]
 

@@ -34,13 +34,16 @@ __device__ void mat3_mul(const float *X, const float *Y, float *Z) {  // row-maj
         for (int j = 0; j < 3; j++) Z[3 * i + j] = X[3 * i] * Y[j] + X[3 * i + 1] * Y[3 + j] + X[3 * i + 2] * Y[6 + j];
 }
 
-__device__ float adam_update(float p, float g, float *m, float *v, float lr, float beta1, float beta2, float eps, double bc1, double bc2_sqrt) {
-    // torch.optim.Adam, single-tensor path: exp_avg.lerp_(grad, 1 - beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-    const float m1 = *m + (g - *m) * (1.f - beta1);
-    const float v1 = *v * beta2 + (1.f - beta2) * g * g;
+__device__ float adam_update(float p, float g, float *m, float *v, double lr, double beta1, double beta2, double eps, double bc1, double bc2_sqrt) {
+    // torch.optim.Adam, single-tensor path: exp_avg.lerp_(grad, 1 - beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2);
+    // denom = (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps); param.addcdiv_(exp_avg, denom, value=-lr / bias_correction1).
+    // The scalars are Python floats (doubles) rounded to float32 where they meet the tensors.
+    const float w1 = (float)(1.0 - beta1), b2 = (float)beta2, w2 = (float)(1.0 - beta2);
+    const float m1 = *m + w1 * (g - *m);
+    const float v1 = *v * b2 + w2 * (g * g);
     *m = m1; *v = v1;
-    const float step_size = (float)((double)lr / bc1);
-    const float denom = sqrtf(v1) / (float)bc2_sqrt + eps;
+    const float step_size = (float)(lr / bc1);
+    const float denom = sqrtf(v1) / (float)bc2_sqrt + (float)eps;
     return p - step_size * (m1 / denom);
 }
 
@@ -52,8 +55,8 @@ __global__ void pose_step_kernel(PoseStepParams pp) {
     const float step = st[16] + 1.f;
     st[16] = step;
     st[18] = step;
-    const double bc1 = 1.0 - pow((double)a.beta1, (double)step);
-    const double bc2_sqrt = sqrt(1.0 - pow((double)a.beta2, (double)step));
+    const double bc1 = 1.0 - pow(a.beta1, (double)step);
+    const double bc2_sqrt = sqrt(1.0 - pow(a.beta2, (double)step));
     // ---- Adam ----
     float rot[3], trans[3];
     for (int k = 0; k < 3; k++) {
@@ -120,7 +123,7 @@ extern "C" int lvdgs_pose_step(const lvdgs_pose_step_args *a, void *stream) {
         set_error("pose step: R / T / cam_rot_delta / cam_trans_delta / state is NULL");
         return LVDGS_E_INVALID;
     }
-    if (!(a->beta1 >= 0.f && a->beta1 < 1.f && a->beta2 >= 0.f && a->beta2 < 1.f)) { set_error("pose step: betas must lie in [0, 1)"); return LVDGS_E_INVALID; }
+    if (!(a->beta1 >= 0.0 && a->beta1 < 1.0 && a->beta2 >= 0.0 && a->beta2 < 1.0)) { set_error("pose step: betas must lie in [0, 1)"); return LVDGS_E_INVALID; }
     PoseStepParams pp{*a};
     ProfScope ps("pose_step", s);
     hipLaunchKernelGGL(pose_step_kernel, dim3(1), dim3(64), 0, s, pp);

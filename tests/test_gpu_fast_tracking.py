@@ -46,7 +46,8 @@ def test_pose_step_equals_adam_plus_update_pose(grad_scale):
     pa.exposure_a, pa.exposure_b, pa.grad_tau, pa.grad_exposure_a, pa.grad_exposure_b = P(cam_k.exposure_a), P(cam_k.exposure_b), P(gtau), P(ga), P(gb)
     pa.state, pa.lr_rot, pa.lr_trans, pa.lr_exposure = P(state), 0.003, 0.001, 0.01
     pa.beta1, pa.beta2, pa.eps, pa.converged_threshold = 0.9, 0.999, 1e-8, 1e-4
-    pa.projmatrix_raw, pa.viewmatrix, pa.projmatrix, pa.campos = P(cam_k.projection_matrix), P(view), P(proj), P(campos)
+    praw = cam_k.projection_matrix.contiguous()   # the Camera keeps the transposed VIEW it was given: make the memory row-major
+    pa.projmatrix_raw, pa.viewmatrix, pa.projmatrix, pa.campos = P(praw), P(view), P(proj), P(campos)
     stream = _lib.raw_stream(torch.device("cuda", 0))
     first_converged = None
     for it in range(12):
