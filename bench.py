@@ -65,21 +65,24 @@ def algorithmic_bytes(kernel, N, V, D, P, T):
 
 
 def build_scene(workload, rank, dev):
+    """The workload's Gaussians as a GaussianModel on `dev` and one Camera (seeded pose, target image, edge mask, mono depth)."""
+    from lvdgs.camera_utils import Camera
+    from lvdgs.graphics_utils import focal2fov, getProjectionMatrix2
+    from lvdgs.pose_utils import SE3_exp
     cfg = synthetic.CONFIGS[workload]
     N, W, H = cfg["N"], cfg["W"], cfg["H"]
     g = synthetic.make_gaussians(N, W, H, seed=0)
-    cam = synthetic.make_camera(W, H, pose_seed=None if rank == 0 else rank,
-                                **{k: cfg[k] for k in ("fx", "fy", "cx", "cy") if k in cfg})
-    for k in ("world_view_transform", "projection_matrix", "full_proj_transform", "camera_center"):
-        setattr(cam, k, getattr(cam, k).to(dev))
-    cam.cam_rot_delta = torch.nn.Parameter(torch.zeros(3, device=dev))
-    cam.cam_trans_delta = torch.nn.Parameter(torch.zeros(3, device=dev))
-    cam.exposure_a = torch.nn.Parameter(torch.zeros(1, device=dev))
-    cam.exposure_b = torch.nn.Parameter(torch.zeros(1, device=dev))
+    fx, fy = cfg.get("fx", float(W)), cfg.get("fy", float(W))
+    cx, cy = cfg.get("cx", W / 2.0), cfg.get("cy", H / 2.0)
+    proj = getProjectionMatrix2(znear=0.01, zfar=100.0, fx=fx, fy=fy, cx=cx, cy=cy, W=W, H=H).transpose(0, 1).contiguous().to(dev)
     gen = torch.Generator().manual_seed(4242 + rank)
-    cam.original_image = torch.rand(3, H, W, generator=gen).to(dev)
+    image = torch.rand(3, H, W, generator=gen).to(dev)
+    cam = Camera(rank + 1, image, None, (torch.rand(H, W, generator=gen) * 40 + 1).numpy(), torch.eye(4), proj, fx, fy, cx, cy,
+                 focal2fov(fx, W), focal2fov(fy, H), H, W, device=dev)
     cam.grad_mask = (torch.rand(1, H, W, generator=gen) > 0.5).to(dev)
-    cam.mono_depth = (torch.rand(H, W, generator=gen) * 40 + 1).to(dev)
+    if rank:
+        pose = SE3_exp(torch.randn(6, generator=torch.Generator().manual_seed(1000 + rank)) * 0.05)
+        cam.update_RT(pose[:3, :3], pose[:3, 3])
     model = GaussianModel.from_activated(g["means3D"], g["scales"], g["rotations"], g["opacities"], shs=g["shs"],
                                          sh_degree=0, device=dev)
     return model, cam, g, (N, W, H)
@@ -134,8 +137,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("LVDGS_BENCH_WORKLOAD", "cfg3_500k_1920x1080"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--step", choices=["auto", "tracking", "mapping"], default="auto",
-                    help="auto: tracking iteration on 1 GPU, mapping-window iteration on N > 1")
+    ap.add_argument("--step", choices=["auto", "tracking", "tracking-autograd", "mapping"], default="auto",
+                    help="auto: tracking iteration on 1 GPU, mapping-window iteration on N > 1.  tracking: one iteration of "
+                         "the product's tracking loop (fast_tracking.TrackingSession: render, tracking loss, backward, pose "
+                         "optimiser step -- five C-ABI calls, no autograd); tracking-autograd: render() -> "
+                         "get_loss_tracking -> backward through the public autograd API, without the optimiser step")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -166,19 +172,29 @@ def main():
     bg = torch.zeros(3, device=dev)
     params = model.parameters()
     pose_params = [cam.cam_rot_delta, cam.cam_trans_delta, cam.exposure_a, cam.exposure_b]
-    tracking = (world == 1) if args.step == "auto" else args.step == "tracking"
+    tracking = (world == 1) if args.step == "auto" else args.step.startswith("tracking")
+    use_session = tracking and args.step != "tracking-autograd"
     stats = {}
-    backend = window = None
+    backend = window = session = None
     if not tracking:
         backend, window = build_window(args.workload, world, dev, model)
+    elif use_session:
+        from lvdgs.fast_tracking import TrackingSession
+        session = TrackingSession(cam, model, CONFIG, pipe, bg)
+
+    def autograd_step():
+        for p in params + pose_params:
+            p.grad = None
+        pkg = render(cam, model, pipe, bg)
+        slam_utils.get_loss_tracking(CONFIG, pkg["render"], pkg["depth"], pkg["opacity"], cam).backward()
+        return pkg["radii"]
 
     def step():
+        if session is not None:
+            session.step()
+            return session.radii
         if tracking:
-            for p in params + pose_params:
-                p.grad = None
-            pkg = render(cam, model, pipe, bg)
-            slam_utils.get_loss_tracking(CONFIG, pkg["render"], pkg["depth"], pkg["opacity"], cam).backward()
-            return pkg["radii"]
+            return autograd_step()
         backend_map.map_window(backend, window, iters=1)
         return None
 
@@ -191,7 +207,7 @@ def main():
     for _ in range(max(args.warmup, 1)):
         radii = step()
     sync()
-    stats["D"] = int(rasterizer._DEBUG_LAST.get("num_rendered", 0))
+    stats["D"] = int(session.num_rendered) if session is not None else int(rasterizer._DEBUG_LAST.get("num_rendered", 0))
     stats["V"] = int((radii > 0).sum().item()) if radii is not None else int((backend.gaussians.max_radii2D > 0).sum().item())
     rasterizer.KEEP_DEBUG_STATE = False
     rasterizer._DEBUG_LAST.clear()
@@ -254,6 +270,18 @@ def main():
                                     "frac_of_measured_ceiling": round(g_per_s / VALU_MEASURED_G, 4),
                                     "source": "SQ_INSTS_VALU of a separate rocprofv3 --pmc pass (profiles/traffic.json), not measured in this run"}
 
+    autograd_rate = None
+    if rank == 0 and session is not None:
+        # the same iteration through the public autograd API (render() / get_loss_tracking / backward), for comparison
+        for _ in range(3):
+            autograd_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            autograd_step()
+        torch.cuda.synchronize()
+        autograd_rate = round(args.steps / (time.perf_counter() - t1), 3)
+
     comm_us = None
     if world > 1 and not tracking:
         # the collectives' share, measured apart (the timers synchronise the device around them)
@@ -277,13 +305,16 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "gaussians": N, "width": W, "height": H, "visible": stats["V"],
                        "pairs": stats["D"], "sh_degree": 0,
-                       "step": ("tracking iteration: render + get_loss_tracking + backward (pose + all Gaussian grads)"
+                       "step": (("tracking iteration of slam_loops.track_frame on a TrackingSession: render + get_loss_tracking + backward "
+                                 "(pose + all Gaussian grads) + pose optimiser step (Adam, SE(3) retraction, camera matrices) -- five C-ABI calls"
+                                 if session is not None else
+                                 "tracking iteration through the autograd API: render() + get_loss_tracking + backward (pose + all Gaussian grads)")
                                 if tracking else
                                 "mapping iteration (backend_map.map_window): one keyframe per GPU -- render + get_loss_mapping + backward, "
                                 "2 RCCL collectives (gradients + statistics, radii + flags), bookkeeping, Adam over all Gaussians, "
                                 "keyframe Adam, pose retraction"),
                        "parallelism": f"keyframe-per-gpu x{world}" if world > 1 else "single",
-                       "comm_us_per_step": comm_us},
+                       "comm_us_per_step": comm_us, "autograd_api_iters_per_s": autograd_rate},
             **({"collective_backend": backend_name + " (functional check only, not a benchmark result)"} if world > 1 and backend_name != "nccl" else {}),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels_us_per_step": {k: round(v["us_per_step"], 2) for k, v in kernels.items()},
         }

@@ -245,6 +245,16 @@ typedef struct lvdgs_pose_step_args {
 } lvdgs_pose_step_args;
 int lvdgs_pose_step(const lvdgs_pose_step_args *a, void *stream);
 
+/* ---- Adam step of the Gaussian map (reference utils/slam_backend.py:144, :378, :458: gaussians.optimizer.step()) ----
+ * All parameter tensors in one launch, one pass over (grad, exp_avg, exp_avg_sq, param); torch.optim.Adam's arithmetic
+ * (no weight decay, no amsgrad), `step` = that tensor's step count INCLUDING this step (bias corrections). */
+#define LVDGS_ADAM_MAX_TENSORS 8
+typedef struct lvdgs_adam_tensor {
+    float *param; const float *grad; float *exp_avg; float *exp_avg_sq;
+    int64_t numel; int64_t step; double lr;
+} lvdgs_adam_tensor;
+int lvdgs_adam_step(const lvdgs_adam_tensor *tensors, int32_t count, double beta1, double beta2, double eps, void *stream);
+
 /* ---- depth term of the static-mask mapping loss (reference utils/slam_backend.py:216-261) ----
  *   M    = static_mask & (mono_depth > 0) & (rendered depth > 0)          (static_mask NULL = every pixel)
  *   loss = depth_lambda-free mean over M of |D_p - Z_p|;  0 when M is empty (the reference then adds nothing)

@@ -72,6 +72,12 @@ class PoseStepArgs(C.Structure):
     ]
 
 
+class AdamTensor(C.Structure):
+    """struct lvdgs_adam_tensor (include/lvdgs.h)."""
+    _fields_ = [("param", _fp), ("grad", _fp), ("exp_avg", _fp), ("exp_avg_sq", _fp), ("numel", C.c_int64), ("step", C.c_int64),
+                ("lr", C.c_double)]
+
+
 class SsimArgs(C.Structure):
     """struct lvdgs_ssim_args (include/lvdgs.h)."""
     _fields_ = [
@@ -101,7 +107,7 @@ EXPORTS = (
     "lvdgs_backward", "lvdgs_mark_visible", "lvdgs_state_layout_query", "lvdgs_knn_scratch_bytes",
     "lvdgs_dist2_knn3", "lvdgs_rope2d", "lvdgs_rope2d_strided", "lvdgs_loss_scratch_bytes", "lvdgs_photometric_loss_forward",
     "lvdgs_photometric_loss_backward", "lvdgs_masked_depth_scratch_bytes", "lvdgs_masked_depth_l1_forward",
-    "lvdgs_masked_depth_l1_backward", "lvdgs_pose_step", "lvdgs_ssim_scratch_bytes", "lvdgs_ssim_l1", "lvdgs_last_error", "lvdgs_version", "lvdgs_profile_enable",
+    "lvdgs_masked_depth_l1_backward", "lvdgs_pose_step", "lvdgs_adam_step", "lvdgs_ssim_scratch_bytes", "lvdgs_ssim_l1", "lvdgs_last_error", "lvdgs_version", "lvdgs_profile_enable",
     "lvdgs_profile_reset", "lvdgs_profile_read",
 )
 
@@ -155,6 +161,7 @@ def lib():
         L.lvdgs_masked_depth_l1_forward.argtypes = [C.POINTER(MaskedDepthArgs), C.c_void_p]
         L.lvdgs_masked_depth_l1_backward.argtypes = [C.POINTER(MaskedDepthArgs), C.c_void_p]
         L.lvdgs_pose_step.argtypes = [C.POINTER(PoseStepArgs), C.c_void_p]
+        L.lvdgs_adam_step.argtypes = [C.POINTER(AdamTensor), C.c_int32, C.c_double, C.c_double, C.c_double, C.c_void_p]
         L.lvdgs_ssim_scratch_bytes.restype = C.c_size_t
         L.lvdgs_ssim_scratch_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
         L.lvdgs_ssim_l1.argtypes = [C.POINTER(SsimArgs), C.c_void_p]

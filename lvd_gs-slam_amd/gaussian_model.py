@@ -63,6 +63,64 @@ def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, ma
 UPSTREAM_NONVISIBLE_RESET = True  # see GaussianModel.reset_opacity_nonvisible
 
 
+class FusedAdam(torch.optim.Adam):
+    """``torch.optim.Adam`` whose ``step()`` updates every parameter of every group in ONE HIP launch (lvdgs_adam_step):
+    one pass over grad / exp_avg / exp_avg_sq / parameter instead of PyTorch's ~60 multi-tensor launches per step.
+    Same state layout (``exp_avg``, ``exp_avg_sq``, ``step``), same ``param_groups``, so the densification code that
+    edits the state (and anything written against torch.optim.Adam) keeps working; float32 parameters on the GPU, no
+    weight decay / amsgrad / maximize -- anything else goes to the parent class."""
+
+    def _fusable(self):
+        for group in self.param_groups:
+            if group.get("weight_decay", 0) or group.get("amsgrad", False) or group.get("maximize", False):
+                return False
+            for p in group["params"]:
+                if p.grad is not None and (not p.is_cuda or p.dtype is not torch.float32 or not p.is_contiguous()
+                                           or p.grad.is_sparse or not p.grad.is_contiguous() or p.grad.dtype is not torch.float32):
+                    return False
+        return True
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None or not self._fusable():
+            # the parent's step, without its hook wrapper (this method already ran the optimizer's step hooks once)
+            parent = torch.optim.Adam.step
+            return getattr(parent, "__wrapped__", parent)(self, closure)
+        import ctypes as C
+        from . import _lib
+        items = []
+        for group in self.param_groups:
+            beta1, beta2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None or p.numel() == 0:
+                    continue
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] = st["step"] + 1 if torch.is_tensor(st["step"]) else st["step"] + 1
+                items.append((p, st, float(group["lr"]), float(beta1), float(beta2), float(group["eps"])))
+        dev = None
+        i = 0
+        while i < len(items):
+            # one launch per run of up to 8 tensors that share betas / eps / device (the map has one such run)
+            b1, b2, eps, dev = items[i][3], items[i][4], items[i][5], items[i][0].device
+            arr = (_lib.AdamTensor * 8)()
+            n = 0
+            while i < len(items) and n < 8 and items[i][3:6] == (b1, b2, eps) and items[i][0].device == dev:
+                p, st, lr = items[i][0], items[i][1], items[i][2]
+                t = arr[n]
+                t.param, t.grad = C.c_void_p(p.data_ptr()), C.c_void_p(p.grad.data_ptr())
+                t.exp_avg, t.exp_avg_sq = C.c_void_p(st["exp_avg"].data_ptr()), C.c_void_p(st["exp_avg_sq"].data_ptr())
+                t.numel, t.step, t.lr = p.numel(), int(st["step"]), lr
+                n += 1
+                i += 1
+            with _lib.on_device(dev):
+                _lib.check(_lib.lib().lvdgs_adam_step(arr, n, b1, b2, eps, _lib.raw_stream(dev)), "lvdgs_adam_step")
+        return None
+
+
 class GaussianModel:
     standard_activations = True  # exp / normalize / sigmoid, as published: render() may fuse them into the kernels
 
@@ -174,7 +232,8 @@ class GaussianModel:
             {"params": [self._scaling], "lr": g("scaling_lr") * self.spatial_lr_scale, "name": "scaling"},
             {"params": [self._rotation], "lr": g("rotation_lr"), "name": "rotation"},
         ]
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        # FusedAdam is torch.optim.Adam with a one-launch step() on the GPU (and the parent's step() anywhere else)
+        self.optimizer = FusedAdam(groups, lr=0.0, eps=1e-15)
         self.lr_init = g("position_lr_init") * self.spatial_lr_scale
         self.lr_final = g("position_lr_final") * self.spatial_lr_scale
         self.lr_delay_mult = g("position_lr_delay_mult")

@@ -133,3 +133,46 @@ def test_fused_tracking_stops_at_convergence_like_the_loop_that_breaks():
     assert res[True][0] == res[False][0] == 1
     np.testing.assert_allclose(res[True][1], res[False][1], atol=1e-7)
     np.testing.assert_allclose(res[True][2], res[False][2], atol=1e-7)
+
+
+def test_fused_adam_equals_torch_adam_through_densification_style_state_edits():
+    """gaussian_model.FusedAdam (one HIP launch per step) against torch.optim.Adam on the map's six groups: ten steps, a
+    parameter replaced with its moments kept (what prune / densify do), a group whose gradient is missing, sizes that are
+    not multiples of four."""
+    from lvdgs.gaussian_model import FusedAdam
+    g = torch.Generator().manual_seed(3)
+    N = 10_007
+    shapes = [(N, 3), (N, 1, 3), (N, 0, 3), (N, 1), (N, 3), (N, 4)]
+    lrs = [1.6e-3 * 6, 2.5e-3, 2.5e-3 / 20, 0.05, 1e-3 * 6, 1e-3]
+    init = [torch.randn(*s, generator=g) for s in shapes]
+    opts = {}
+    for kind, cls in (("fused", FusedAdam), ("torch", torch.optim.Adam)):
+        ps = [torch.nn.Parameter(t.clone().cuda()) for t in init]
+        opts[kind] = (cls([{"params": [p], "lr": lr, "name": str(i)} for i, (p, lr) in enumerate(zip(ps, lrs))], lr=0.0, eps=1e-15), ps)
+    for it in range(10):
+        grads = [torch.randn(*s, generator=g) * (10.0 ** -(it % 4)) for s in shapes]
+        for kind, (opt, ps) in opts.items():
+            for i, (p, gr) in enumerate(zip([gp["params"][0] for gp in opt.param_groups], grads)):
+                p.grad = None if (i == 3 and it == 4) else gr.cuda()       # one group without a gradient once
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            if it == 5:   # keep the first 9000 rows of group 0 with their moments (prune_points does this to every group)
+                gp = opt.param_groups[0]
+                old = gp["params"][0]
+                st = opt.state.pop(old)
+                new = torch.nn.Parameter(old.data[:9000].clone())
+                st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"][:9000].clone(), st["exp_avg_sq"][:9000].clone()
+                opt.state[new] = st
+                gp["params"][0] = new
+                shapes[0] = (9000, 3) if kind == "torch" else shapes[0]
+        a = [gp["params"][0].detach().cpu().numpy() for gp in opts["fused"][0].param_groups]
+        b = [gp["params"][0].detach().cpu().numpy() for gp in opts["torch"][0].param_groups]
+        for i, (x, y) in enumerate(zip(a, b)):
+            np.testing.assert_allclose(x, y, rtol=2e-6, atol=1e-7, err_msg=f"group {i} after step {it}")
+    fo, to = opts["fused"][0], opts["torch"][0]
+    for gf, gt in zip(fo.param_groups, to.param_groups):
+        sf, st = fo.state[gf["params"][0]], to.state[gt["params"][0]]
+        if "exp_avg" in st:
+            assert int(sf["step"]) == int(st["step"])
+            np.testing.assert_allclose(sf["exp_avg"].cpu().numpy(), st["exp_avg"].cpu().numpy(), rtol=1e-5, atol=1e-12)
+            np.testing.assert_allclose(sf["exp_avg_sq"].cpu().numpy(), st["exp_avg_sq"].cpu().numpy(), rtol=1e-5, atol=1e-20)
