@@ -92,7 +92,7 @@ class FusedAdam(torch.optim.Adam):
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
             for p in group["params"]:
-                if p.grad is None or p.numel() == 0:
+                if p.grad is None:
                     continue
                 st = self.state[p]
                 if len(st) == 0:
