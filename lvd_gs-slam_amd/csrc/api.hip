@@ -99,10 +99,12 @@ ProfScope::~ProfScope() {
 int allow_dynamic_lds(const void *kernel, int bytes, unsigned char (&done)[16]) {
     int dev = 0;
     if (int e = check_hip(hipGetDevice(&dev), "hipGetDevice")) return e;
+    // Two host threads may get here together (one stream each): the flag is read and written atomically, and setting the
+    // attribute twice is harmless, so the worst case is one redundant call.
     unsigned char &flag = done[dev & 15];
-    if (!flag) {
+    if (!__atomic_load_n(&flag, __ATOMIC_ACQUIRE)) {
         if (int e = check_hip(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), "reserve dynamic LDS")) return e;
-        flag = 1;
+        __atomic_store_n(&flag, (unsigned char)1, __ATOMIC_RELEASE);
     }
     return LVDGS_OK;
 }

@@ -19,9 +19,14 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+# kernel symbol -> the name its launch is timed under in bench.py (ProfScope), where they differ
+ALIASES = {"blend_bwd2": "blend_bwd"}
+
+
 def short(name):
     m = re.search(r"(\w+)_kernel", name)
-    return m.group(1) if m else name
+    n = m.group(1) if m else name
+    return ALIASES.get(n, n)
 
 
 def main(tag, workload="cfg3_500k_1920x1080"):
