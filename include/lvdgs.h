@@ -242,6 +242,12 @@ typedef struct lvdgs_pose_step_args {
     float *viewmatrix;             /* out 16 or NULL                                                  */
     float *projmatrix;             /* out 16 or NULL: viewmatrix @ projmatrix_raw                     */
     float *campos;                 /* out 3 or NULL                                                   */
+    /* The mapping loop's keyframes (utils/slam_backend.py:381-389) hold their gradients in separate tensors and may
+     * lack some: when grad_tau is NULL these are read instead, and a parameter whose gradient pointer is NULL is left
+     * untouched, moments included -- torch.optim.Adam skips parameters without a gradient.  R == NULL (with T NULL)
+     * steps the exposure only (keyframes outside the pose window).  converged_threshold < 0 never raises the flag. */
+    const float *grad_rot;         /* 3 or NULL */
+    const float *grad_trans;       /* 3 or NULL */
 } lvdgs_pose_step_args;
 int lvdgs_pose_step(const lvdgs_pose_step_args *a, void *stream);
 
@@ -254,6 +260,18 @@ typedef struct lvdgs_adam_tensor {
     int64_t numel; int64_t step; double lr;
 } lvdgs_adam_tensor;
 int lvdgs_adam_step(const lvdgs_adam_tensor *tensors, int32_t count, double beta1, double beta2, double eps, void *stream);
+
+/* Isotropic regulariser of the mapping loss (reference utils/slam_backend.py:303-305):
+ *   loss = weight * mean_{i,k} | s_ik - mean_k s_ik |,  s = exp(raw_scales)   (the model's scaling activation)
+ * writes the value to *loss and ADDS its gradient w.r.t. the raw (log) scales to grad_raw_scales (NULL: value only). */
+size_t lvdgs_isotropic_scratch_bytes(int32_t num_gaussians);
+int lvdgs_isotropic_reg(int32_t num_gaussians, const float *raw_scales /* N*3 */, float *grad_raw_scales /* N*3 or NULL */,
+                        float weight, void *scratch, size_t scratch_bytes, float *loss, void *stream);
+/* What the back end derives from one view's render package (utils/slam_backend.py:311-315, :350-357), accumulated over
+ * the views rendered so far: radii_max = max(radii_max, radii); for visible Gaussians (radii > 0) norm_sum += |viewspace
+ * gradient xy|, vis_count += 1, seen = 1; touched_row[i] = n_touched[i] > 0 (NULL for views outside the window). */
+int lvdgs_view_stats(int32_t num_gaussians, const int32_t *radii, const int32_t *n_touched, const float *viewspace_grad /* N*3 or NULL */,
+                     int32_t *radii_max, float *norm_sum, float *vis_count, uint8_t *seen, uint8_t *touched_row, void *stream);
 
 /* ---- depth term of the static-mask mapping loss (reference utils/slam_backend.py:216-261) ----
  *   M    = static_mask & (mono_depth > 0) & (rendered depth > 0)          (static_mask NULL = every pixel)

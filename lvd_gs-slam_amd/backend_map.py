@@ -23,10 +23,13 @@ bit-identical without parameter broadcasts; densification draws its samples from
 Not sharded (one view per iteration, reference :95-149, :393-468): ``initialize_map``, ``color_refinement`` --
 replicas only.
 """
+import ctypes as C
 from typing import Dict, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
+
+from . import _lib
 
 from .gaussian_renderer import render
 from .loss_utils import masked_mapping_loss
@@ -147,6 +150,147 @@ def _flag_words(rows: int, n: int, device):
     return torch.zeros(rows, n4, dtype=torch.uint8, device=device)
 
 
+_P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _on_gpu_f32(*tensors):
+    return all(t is not None and t.is_cuda and t.dtype is torch.float32 and t.is_contiguous() for t in tensors)
+
+
+class KeyframeStepper:
+    """``keyframe_optimizers.step()`` + ``update_pose`` of the window's keyframes (reference utils/slam_backend.py:381-389)
+    as ONE launch per keyframe (``lvdgs_pose_step``): Adam on the keyframe's pose deltas and exposure with the learning
+    rates of the optimiser's groups, the SE(3) retraction, deltas zeroed -- no ``if angle < 1e-5`` / ``converged``
+    round trips to the host.  Built from the ``torch.optim.Adam`` the back end made for the window (:545-598): the
+    parameters stay the viewpoints' own tensors, the Adam moments live here (the torch optimiser's state is not used)."""
+
+    def __init__(self, optimizer, viewpoints: Sequence, pose_window: int):
+        self.optimizer = optimizer
+        self.signature = self._sig(optimizer)
+        lr_of = {}
+        for gp in optimizer.param_groups:
+            for p in gp["params"]:
+                lr_of[id(p)] = (float(gp["lr"]), gp.get("betas", (0.9, 0.999)), float(gp.get("eps", 1e-8)))
+        self.items = []
+        for idx, vp in enumerate(viewpoints):
+            has = {n: id(getattr(vp, n, None)) in lr_of for n in _POSE_FIELDS}
+            if not any(has.values()):
+                continue
+            pose = has["cam_rot_delta"] and has["cam_trans_delta"] and idx < pose_window and vp.uid != 0
+            if (has["cam_rot_delta"] or has["cam_trans_delta"]) and not pose:
+                raise NotImplementedError("pose deltas in the optimiser of a keyframe that update_pose skips")
+            dev = vp.exposure_a.device
+            a = _lib.PoseStepArgs()
+            state = torch.zeros(19, dtype=torch.float32, device=dev)
+            keep = [state]
+            if pose:
+                R = vp.R.detach().to(device=dev, dtype=torch.float32).contiguous().clone()
+                T = vp.T.detach().to(device=dev, dtype=torch.float32).contiguous().clone()
+                vp.update_RT(R, T)     # the viewpoint's R, T ARE the buffers the kernel advances in place
+                keep += [R, T]
+                a.R, a.T, a.cam_rot_delta, a.cam_trans_delta = _P(R), _P(T), _P(vp.cam_rot_delta), _P(vp.cam_trans_delta)
+                a.lr_rot, a.lr_trans = lr_of[id(vp.cam_rot_delta)][0], lr_of[id(vp.cam_trans_delta)][0]
+            if has["exposure_a"]:
+                a.exposure_a, a.lr_exposure = _P(vp.exposure_a), lr_of[id(vp.exposure_a)][0]
+            if has["exposure_b"]:
+                a.exposure_b, a.lr_exposure = _P(vp.exposure_b), lr_of[id(vp.exposure_b)][0]
+            any_p = next(getattr(vp, n) for n in _POSE_FIELDS if has[n])
+            (a.beta1, a.beta2), a.eps = lr_of[id(any_p)][1], lr_of[id(any_p)][2]
+            a.state, a.converged_threshold = _P(state), -1.0
+            self.items.append((vp, a, pose, has, keep))
+
+    @staticmethod
+    def _sig(optimizer):
+        return tuple((id(p), float(gp["lr"])) for gp in optimizer.param_groups for p in gp["params"])
+
+    @staticmethod
+    def usable(optimizer, viewpoints) -> bool:
+        if type(optimizer) is not torch.optim.Adam:
+            return False
+        for gp in optimizer.param_groups:
+            if gp.get("weight_decay", 0) or gp.get("amsgrad", False) or gp.get("maximize", False):
+                return False
+            if not _on_gpu_f32(*gp["params"]):
+                return False
+        owned = {id(getattr(vp, n, None)) for vp in viewpoints for n in _POSE_FIELDS}
+        return all(id(p) in owned for gp in optimizer.param_groups for p in gp["params"]) and all(hasattr(vp, "update_RT") for vp in viewpoints)
+
+    def step(self):
+        L = _lib.lib()
+        for vp, a, pose, has, _ in self.items:
+            g = lambda n: getattr(vp, n).grad if has[n] else None
+            gr, gt, ga, gb = g("cam_rot_delta"), g("cam_trans_delta"), g("exposure_a"), g("exposure_b")
+            for t in (gr, gt, ga, gb):
+                if t is not None and not _on_gpu_f32(t):
+                    raise ValueError("KeyframeStepper: gradients must be contiguous float32 GPU tensors")
+            a.grad_rot, a.grad_trans, a.grad_exposure_a, a.grad_exposure_b = _P(gr), _P(gt), _P(ga), _P(gb)
+            dev = vp.exposure_a.device
+            with _lib.on_device(dev):
+                _lib.check(L.lvdgs_pose_step(C.byref(a), _lib.raw_stream(dev)), "lvdgs_pose_step")
+            if pose and hasattr(vp, "_derived_key"):
+                vp._derived_key = None   # R / T were advanced in place: the camera's cached matrices are stale
+
+
+class _ViewStats:
+    """radii_max / norm_sum / vis_count / flags of the views a rank rendered, filled by one ``lvdgs_view_stats`` launch per
+    view on the GPU (the PyTorch statements otherwise)."""
+
+    def __init__(self, N, n_window, dev):
+        self.N, self.n_window, self.dev = N, n_window, dev
+        self.radii_max = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.norm_sum = torch.zeros(N, dtype=torch.float32, device=dev)
+        self.vis_count = torch.zeros(N, dtype=torch.float32, device=dev)
+        self.flags = _flag_words(n_window + 1, N, dev)   # rows 0..n_window-1: n_touched > 0 ; last row: seen by any view
+
+    def add(self, i, pkg):
+        N, n_window = self.N, self.n_window
+        radii, nt, vg = pkg["radii"], pkg["n_touched"], pkg["viewspace_points"].grad
+        fast = (self.dev.type == "cuda" and radii.dtype is torch.int32 and nt.dtype is torch.int32 and radii.is_contiguous()
+                and nt.is_contiguous() and (vg is None or _on_gpu_f32(vg)))
+        if fast:
+            row = self.flags[i] if i < n_window else None
+            with _lib.on_device(self.dev):
+                _lib.check(_lib.lib().lvdgs_view_stats(N, _P(radii), _P(nt), _P(vg), _P(self.radii_max), _P(self.norm_sum),
+                                                       _P(self.vis_count), _P(self.flags[n_window]), _P(row),
+                                                       _lib.raw_stream(self.dev)), "lvdgs_view_stats")
+            return
+        vis = pkg["visibility_filter"]
+        self.radii_max = torch.maximum(self.radii_max, radii.to(torch.int32))
+        if vg is not None:
+            self.norm_sum += torch.where(vis, torch.norm(vg[:, :2], dim=-1), torch.zeros_like(self.norm_sum))
+        self.vis_count += vis.to(torch.float32)
+        self.flags[n_window, :N] |= vis.to(torch.uint8)
+        if i < n_window:
+            self.flags[i, :N] = (nt > 0).to(torch.uint8)
+
+
+def _isotropic_term(G, weight=10.0):
+    """``weight * mean |s - mean_k s|`` over the activated scales (reference utils/slam_backend.py:303-305) as an
+    autograd expression -- the statement the reference makes."""
+    scaling = G.get_scaling
+    return weight * torch.abs(scaling - scaling.mean(dim=1).view(-1, 1)).mean()
+
+
+def _isotropic_fused(G, weight=10.0):
+    """The same term through ``lvdgs_isotropic_reg``: value returned, gradient ADDED to ``G._scaling.grad`` (two
+    launches instead of a dozen).  None when the model is not the standard one on the GPU."""
+    raw = getattr(G, "_scaling", None)
+    if not (getattr(G, "standard_activations", False) and torch.is_tensor(raw) and _on_gpu_f32(raw) and raw.dim() == 2 and raw.shape[1] == 3):
+        return None
+    N, dev = raw.shape[0], raw.device
+    if raw.grad is None:
+        raw.grad = torch.zeros_like(raw)
+    elif not _on_gpu_f32(raw.grad):
+        return None
+    L = _lib.lib()
+    scratch = torch.empty(int(L.lvdgs_isotropic_scratch_bytes(N)), dtype=torch.uint8, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    with _lib.on_device(dev):
+        _lib.check(L.lvdgs_isotropic_reg(N, _P(raw), _P(raw.grad), float(weight), _P(scratch), scratch.numel(), _P(loss),
+                                         _lib.raw_stream(dev)), "lvdgs_isotropic_reg")
+    return loss
+
+
 def view_loss(backend, viewpoint, pkg):
     """Loss of one window keyframe: the static-mask branch when the keyframe carries a mask (:196-261), else
     ``get_loss_mapping`` (:263-266)."""
@@ -158,12 +302,14 @@ def view_loss(backend, viewpoint, pkg):
 
 
 def map_window(backend, current_window, prune=False, iters=1, up_pose=True, group=None, reducer: Optional[FlatReducer] = None,
-               render_fn=render, view_loss_fn=None, stats: Optional[Dict] = None):
+               render_fn=render, view_loss_fn=None, stats: Optional[Dict] = None, fused=True):
     """``BackEnd.map(current_window, prune, iters, up_pose)`` (reference utils/slam_backend.py:153-390) with the
     iteration's views sharded over ``group``.  Returns ``gaussian_split`` of the last iteration like the reference.
     ``stats`` (optional dict) receives per-iteration records: loss, views of this rank, collective time.
     ``render_fn`` / ``view_loss_fn`` default to the HIP renderer and the fused losses; the CPU tests of the loop logic
-    pass the dense renderer and the float64 loss statements instead."""
+    pass the dense renderer and the float64 loss statements instead.  ``fused`` (GPU only): the isotropic regulariser,
+    the per-view statistics and the keyframes' Adam + ``update_pose`` run as single launches (``lvdgs_isotropic_reg``,
+    ``lvdgs_view_stats``, ``lvdgs_pose_step``) instead of PyTorch statements; ``fused=False`` keeps the statements."""
     if len(current_window) == 0:
         return
     view_loss_fn = view_loss if view_loss_fn is None else view_loss_fn
@@ -205,32 +351,27 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
                 loss_mapping = loss_mapping + view_loss_fn(backend, views[i], pkg)
             else:
                 loss_mapping = loss_mapping + get_loss_mapping(cfg, pkg["render"], views[i], depth=pkg["depth"], monodepth=True)
-        if rank == 0:
-            scaling = G.get_scaling
-            isotropic_loss = torch.abs(scaling - scaling.mean(dim=1).view(-1, 1))
-            loss_mapping = loss_mapping + 10 * isotropic_loss.mean()
+        # isotropic regulariser (:303-305), rank 0 only: fused kernel after the backward where it applies, else in the graph
+        fuse_iso = rank == 0 and fused and G.get_xyz.is_cuda and getattr(G, "standard_activations", False)
+        if rank == 0 and not fuse_iso:
+            loss_mapping = loss_mapping + _isotropic_term(G)
         if torch.is_tensor(loss_mapping):
             loss_mapping.backward()
+        if fuse_iso:
+            iso = _isotropic_fused(G)
+            if iso is None:          # not the standard model after all: the autograd statement
+                iso = _isotropic_term(G)
+                iso.backward()
+            loss_mapping = (loss_mapping.detach() if torch.is_tensor(loss_mapping) else 0) + iso.detach()
 
         with torch.no_grad():
             N = G.get_xyz.shape[0]
             dev = G.get_xyz.device
             # ---- what this rank's views say, in view order ----
-            radii_max = torch.zeros(N, dtype=torch.int32, device=dev)
-            norm_sum = torch.zeros(N, dtype=torch.float32, device=dev)
-            vis_count = torch.zeros(N, dtype=torch.float32, device=dev)
-            flags = _flag_words(n_window + 1, N, dev)   # rows 0..n_window-1: n_touched > 0 ; last row: seen by any view
+            vs = _ViewStats(N, n_window, dev)
             for i in mine:
-                pkg = pkgs[i]
-                vis = pkg["visibility_filter"]
-                radii_max = torch.maximum(radii_max, pkg["radii"].to(torch.int32))
-                vg = pkg["viewspace_points"].grad
-                if vg is not None:
-                    norm_sum += torch.where(vis, torch.norm(vg[:, :2], dim=-1), torch.zeros_like(norm_sum))
-                vis_count += vis.to(torch.float32)
-                flags[n_window, :N] |= vis.to(torch.uint8)
-                if i < n_window:
-                    flags[i, :N] = (pkg["n_touched"] > 0).to(torch.uint8)
+                vs.add(i, pkgs[i])
+            radii_max, norm_sum, vis_count, flags = vs.radii_max, vs.norm_sum, vs.vis_count, vs.flags
             # ---- two collectives (a pruning pass reduces the flags only, see below) ----
             params = G.parameters()
             t0 = _now(dev) if stats is not None else None
@@ -307,8 +448,13 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
             G.optimizer.step()
             G.optimizer.zero_grad(set_to_none=True)
             G.update_learning_rate(backend.iteration_count)
+            stepper = None
             if backend.keyframe_optimizers is not None:
-                backend.keyframe_optimizers.step()
+                stepper = _keyframe_stepper(backend, viewpoint_stack, frames_to_optimize) if (fused and up_pose) else None
+                if stepper is not None:
+                    stepper.step()       # Adam + update_pose of every window keyframe, one launch each
+                else:
+                    backend.keyframe_optimizers.step()
                 backend.keyframe_optimizers.zero_grad(set_to_none=True)
             for v in views:   # exposure gradients of the random views are never stepped; do not let them pile up
                 for name in _POSE_FIELDS:
@@ -316,13 +462,30 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
                     if p is not None and p.grad is not None and not any(p is q for q in kf_params):
                         p.grad = None
             # Pose update (:383-389): every rank holds the same reduced gradients, so every rank moves every keyframe
-            if up_pose:
+            if up_pose and stepper is None:
                 for cam_idx in range(min(frames_to_optimize, n_window)):
                     viewpoint = viewpoint_stack[cam_idx]
                     if viewpoint.uid == 0:
                         continue
                     update_pose(viewpoint)
     return gaussian_split
+
+
+def _keyframe_stepper(backend, viewpoint_stack, pose_window):
+    """The KeyframeStepper of the back end's current keyframe optimiser (rebuilt when the optimiser or its groups change);
+    None when that optimiser is not a plain torch.optim.Adam over GPU float32 parameters of the window's viewpoints."""
+    opt = backend.keyframe_optimizers
+    st = getattr(opt, "_lvdgs_stepper", None)
+    if st is not None and st.signature == KeyframeStepper._sig(opt):
+        return st
+    if not KeyframeStepper.usable(opt, viewpoint_stack):
+        return None
+    try:
+        st = KeyframeStepper(opt, viewpoint_stack, pose_window)
+    except NotImplementedError:
+        return None
+    opt._lvdgs_stepper = st
+    return st
 
 
 def _now(dev):

@@ -87,3 +87,104 @@ extern "C" int lvdgs_adam_step(const lvdgs_adam_tensor *tensors, int32_t count, 
     LVDGS_LAUNCH_CHECK("adam_step", 0, s);
     return LVDGS_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Two small fusions for the mapping iteration (reference utils/slam_backend.py:303-305, :350-357).
+namespace lvdgs {
+namespace {
+
+// Isotropic regulariser  L = weight * mean_{i,k} | s_ik - mean_k s_ik |,  s = exp(raw log-scale)  (slam_backend.py:303-305):
+// the value (per-workgroup partial sums, finished in a fixed order by the last launch below) and its gradient w.r.t. the
+// RAW scales, ADDED to the gradient the render's backward left there.  PyTorch: exp, mean, sub, abs, mean, mul and
+// their six backward kernels over N x 3.
+__global__ void __launch_bounds__(256) isotropic_kernel(int N, const float *__restrict__ raw, float *__restrict__ grad, float scale,
+                                                        float *__restrict__ partial) {
+    __shared__ float s_red[4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float acc = 0.f;
+    if (i < N) {
+        const float s0 = __expf(raw[3 * (size_t)i]), s1 = __expf(raw[3 * (size_t)i + 1]), s2 = __expf(raw[3 * (size_t)i + 2]);
+        const float m = (s0 + s1 + s2) / 3.f;
+        const float d0 = s0 - m, d1 = s1 - m, d2 = s2 - m;
+        acc = fabsf(d0) + fabsf(d1) + fabsf(d2);
+        auto sgn = [](float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); };
+        const float g0 = sgn(d0), g1 = sgn(d1), g2 = sgn(d2), gm = (g0 + g1 + g2) / 3.f;
+        if (grad) {
+            grad[3 * (size_t)i] += scale * (g0 - gm) * s0;
+            grad[3 * (size_t)i + 1] += scale * (g1 - gm) * s1;
+            grad[3 * (size_t)i + 2] += scale * (g2 - gm) * s2;
+        }
+    }
+    // block sum in a fixed order
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+}
+
+__global__ void __launch_bounds__(256) isotropic_finish_kernel(int nblk, const float *__restrict__ partial, float scale, float *__restrict__ loss) {
+    __shared__ float s[256];
+    float a = 0.f;
+    for (int b = threadIdx.x; b < nblk; b += 256) a += partial[b];
+    s[threadIdx.x] = a;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = scale * s[0];
+}
+
+// What the back end derives from one view's render package (slam_backend.py:311-315, :350-357), accumulated over the
+// views a rank rendered: element-wise max of the radii, sum of the screen-space gradient norms and count of the views that
+// saw each Gaussian, "seen by any view", and the view's own (n_touched > 0) row.  One launch per view instead of ~10.
+__global__ void __launch_bounds__(256) view_stats_kernel(int N, const int32_t *__restrict__ radii, const int32_t *__restrict__ n_touched,
+                                                         const float *__restrict__ viewspace_grad, int32_t *__restrict__ radii_max,
+                                                         float *__restrict__ norm_sum, float *__restrict__ vis_count,
+                                                         uint8_t *__restrict__ seen, uint8_t *__restrict__ touched_row) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int r = radii[i];
+    const bool vis = r > 0;
+    if (r > radii_max[i]) radii_max[i] = r;
+    if (vis) {
+        if (viewspace_grad) {
+            const float gx = viewspace_grad[3 * (size_t)i], gy = viewspace_grad[3 * (size_t)i + 1];
+            norm_sum[i] += sqrtf(gx * gx + gy * gy);
+        }
+        vis_count[i] += 1.f;
+        seen[i] = 1;
+    }
+    if (touched_row) touched_row[i] = n_touched[i] > 0 ? 1 : 0;
+}
+
+}  // namespace
+}  // namespace lvdgs
+
+extern "C" size_t lvdgs_isotropic_scratch_bytes(int32_t num_gaussians) { return align256((size_t)cdiv(num_gaussians > 0 ? num_gaussians : 1, 256) * sizeof(float) + 256); }
+
+extern "C" int lvdgs_isotropic_reg(int32_t N, const float *raw_scales, float *grad_raw_scales, float weight, void *scratch, size_t scratch_bytes,
+                                   float *loss, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (N < 0 || !loss || (N > 0 && (!raw_scales || !scratch))) { set_error("isotropic reg: bad arguments"); return LVDGS_E_INVALID; }
+    if (N == 0) return check_hip(hipMemsetAsync(loss, 0, sizeof(float), s), "memset loss");
+    if (scratch_bytes < lvdgs_isotropic_scratch_bytes(N)) { set_error("isotropic reg: scratch too small"); return LVDGS_E_INVALID; }
+    const int nblk = cdiv(N, 256);
+    const float scale = weight / (3.f * (float)N);
+    { ProfScope ps("isotropic_reg", s); hipLaunchKernelGGL(isotropic_kernel, dim3(nblk), dim3(256), 0, s, N, raw_scales, grad_raw_scales, scale, (float *)scratch); LVDGS_LAUNCH_CHECK("isotropic_reg", 0, s); }
+    { ProfScope ps("isotropic_finish", s); hipLaunchKernelGGL(isotropic_finish_kernel, dim3(1), dim3(256), 0, s, nblk, (const float *)scratch, scale, loss); LVDGS_LAUNCH_CHECK("isotropic_finish", 0, s); }
+    return LVDGS_OK;
+}
+
+extern "C" int lvdgs_view_stats(int32_t N, const int32_t *radii, const int32_t *n_touched, const float *viewspace_grad, int32_t *radii_max,
+                                float *norm_sum, float *vis_count, uint8_t *seen, uint8_t *touched_row, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (N < 0 || (N > 0 && (!radii || !radii_max || !norm_sum || !vis_count || !seen || (touched_row && !n_touched)))) {
+        set_error("view stats: a required pointer is NULL"); return LVDGS_E_INVALID;
+    }
+    if (N == 0) return LVDGS_OK;
+    ProfScope ps("view_stats", s);
+    hipLaunchKernelGGL(view_stats_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, N, radii, n_touched, viewspace_grad, radii_max, norm_sum, vis_count, seen, touched_row);
+    LVDGS_LAUNCH_CHECK("view_stats", 0, s);
+    return LVDGS_OK;
+}

@@ -57,14 +57,20 @@ __global__ void pose_step_kernel(PoseStepParams pp) {
     st[18] = step;
     const double bc1 = 1.0 - pow(a.beta1, (double)step);
     const double bc2_sqrt = sqrt(1.0 - pow(a.beta2, (double)step));
-    // ---- Adam ----
-    float rot[3], trans[3];
-    for (int k = 0; k < 3; k++) {
-        rot[k] = adam_update(a.cam_rot_delta[k], a.grad_tau ? a.grad_tau[3 + k] : 0.f, st + 2 * k, st + 2 * k + 1, a.lr_rot, a.beta1, a.beta2, a.eps, bc1, bc2_sqrt);
-        trans[k] = adam_update(a.cam_trans_delta[k], a.grad_tau ? a.grad_tau[k] : 0.f, st + 6 + 2 * k, st + 6 + 2 * k + 1, a.lr_trans, a.beta1, a.beta2, a.eps, bc1, bc2_sqrt);
+    // ---- Adam (a parameter without a gradient is skipped, moments included, as torch.optim.Adam does) ----
+    const float *g_rot = a.grad_tau ? a.grad_tau + 3 : a.grad_rot, *g_trans = a.grad_tau ? a.grad_tau : a.grad_trans;
+    float rot[3] = {0.f, 0.f, 0.f}, trans[3] = {0.f, 0.f, 0.f};
+    if (a.R) {
+        for (int k = 0; k < 3; k++) {
+            rot[k] = g_rot ? adam_update(a.cam_rot_delta[k], g_rot[k], st + 2 * k, st + 2 * k + 1, a.lr_rot, a.beta1, a.beta2, a.eps, bc1, bc2_sqrt)
+                           : a.cam_rot_delta[k];
+            trans[k] = g_trans ? adam_update(a.cam_trans_delta[k], g_trans[k], st + 6 + 2 * k, st + 6 + 2 * k + 1, a.lr_trans, a.beta1, a.beta2, a.eps, bc1, bc2_sqrt)
+                               : a.cam_trans_delta[k];
+        }
     }
-    if (a.exposure_a) *a.exposure_a = adam_update(*a.exposure_a, a.grad_exposure_a ? *a.grad_exposure_a : 0.f, st + 12, st + 13, a.lr_exposure, a.beta1, a.beta2, a.eps, bc1, bc2_sqrt);
-    if (a.exposure_b) *a.exposure_b = adam_update(*a.exposure_b, a.grad_exposure_b ? *a.grad_exposure_b : 0.f, st + 14, st + 15, a.lr_exposure, a.beta1, a.beta2, a.eps, bc1, bc2_sqrt);
+    if (a.exposure_a && a.grad_exposure_a) *a.exposure_a = adam_update(*a.exposure_a, *a.grad_exposure_a, st + 12, st + 13, a.lr_exposure, a.beta1, a.beta2, a.eps, bc1, bc2_sqrt);
+    if (a.exposure_b && a.grad_exposure_b) *a.exposure_b = adam_update(*a.exposure_b, *a.grad_exposure_b, st + 14, st + 15, a.lr_exposure, a.beta1, a.beta2, a.eps, bc1, bc2_sqrt);
+    if (!a.R) return;  // exposure only
     // ---- update_pose: T_w2c <- SE3_exp([trans, rot]) @ [R T] ----
     const float angle = sqrtf(rot[0] * rot[0] + rot[1] * rot[1] + rot[2] * rot[2]);
     float A, B, C;
@@ -119,8 +125,8 @@ using namespace lvdgs;
 
 extern "C" int lvdgs_pose_step(const lvdgs_pose_step_args *a, void *stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (!a || !a->R || !a->T || !a->cam_rot_delta || !a->cam_trans_delta || !a->state) {
-        set_error("pose step: R / T / cam_rot_delta / cam_trans_delta / state is NULL");
+    if (!a || !a->state || (a->R ? (!a->T || !a->cam_rot_delta || !a->cam_trans_delta) : (a->T != nullptr))) {
+        set_error("pose step: state is NULL, or R is given without T / cam_rot_delta / cam_trans_delta (R and T both NULL = exposure only)");
         return LVDGS_E_INVALID;
     }
     if (!(a->beta1 >= 0.0 && a->beta1 < 1.0 && a->beta2 >= 0.0 && a->beta2 < 1.0)) { set_error("pose step: betas must lie in [0, 1)"); return LVDGS_E_INVALID; }

@@ -48,6 +48,41 @@ def test_ctypes_struct_matches_c_layout(tmp_path):
     assert int(out["ktime"]) == C.sizeof(_lib.KernelTime)
 
 
+@pytest.mark.parametrize("ctype,cname", [("LossArgs", "lvdgs_loss_args"), ("MaskedDepthArgs", "lvdgs_masked_depth_args"),
+                                         ("SsimArgs", "lvdgs_ssim_args"), ("PoseStepArgs", "lvdgs_pose_step_args"),
+                                         ("AdamTensor", "lvdgs_adam_tensor")])
+def test_every_other_ctypes_struct_matches_its_c_layout(tmp_path, ctype, cname):
+    """Field offsets and sizes of the ctypes mirrors against a C probe compiled from include/lvdgs.h."""
+    cls = getattr(_lib, ctype)
+    fields = [f for f, _ in cls._fields_]
+    lines = "\n".join(f'    printf("{f} %zu\\n", offsetof({cname}, {f}));' for f in fields)
+    src = tmp_path / "probe.c"
+    src.write_text(f'#include <stdio.h>\n#include <stddef.h>\n#include "{HEADER}"\nint main(void) {{\n'
+                   f'    printf("sizeof %zu\\n", sizeof({cname}));\n{lines}\n    return 0;\n}}\n')
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-std=c11", "-o", str(exe), str(src)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)]).decode().splitlines())
+    assert int(out["sizeof"]) == C.sizeof(cls), ctype
+    for f in fields:
+        assert int(out[f]) == getattr(cls, f).offset, (ctype, f)
+
+
+def test_pose_and_adam_argument_validation_without_gpu():
+    L = _lib.lib()
+    pa = _lib.PoseStepArgs()
+    assert L.lvdgs_pose_step(C.byref(pa), None) == _lib.E_INVALID and b"NULL" in L.lvdgs_last_error()
+    arr = (_lib.AdamTensor * 8)()
+    assert L.lvdgs_adam_step(arr, 9, 0.9, 0.999, 1e-15, None) == _lib.E_INVALID
+    assert L.lvdgs_adam_step(arr, 1, 1.0, 0.999, 1e-15, None) == _lib.E_INVALID and b"betas" in L.lvdgs_last_error()
+    arr[0].numel, arr[0].step = 4, 0
+    assert L.lvdgs_adam_step(arr, 1, 0.9, 0.999, 1e-15, None) == _lib.E_INVALID      # step counts start at 1
+    arr[0].step = 1
+    assert L.lvdgs_adam_step(arr, 1, 0.9, 0.999, 1e-15, None) == _lib.E_INVALID and b"NULL" in L.lvdgs_last_error()
+    assert L.lvdgs_adam_step(arr, 0, 0.9, 0.999, 1e-15, None) == _lib.OK             # nothing to do
+    md = _lib.MaskedDepthArgs()
+    assert L.lvdgs_masked_depth_l1_forward(C.byref(md), None) == _lib.E_INVALID
+
+
 def test_sizes_are_monotone_and_aligned():
     L = _lib.lib()
     assert L.lvdgs_geom_bytes(0) > 0

@@ -176,3 +176,55 @@ def test_fused_adam_equals_torch_adam_through_densification_style_state_edits():
             assert int(sf["step"]) == int(st["step"])
             np.testing.assert_allclose(sf["exp_avg"].cpu().numpy(), st["exp_avg"].cpu().numpy(), rtol=1e-5, atol=1e-7)
             np.testing.assert_allclose(sf["exp_avg_sq"].cpu().numpy(), st["exp_avg_sq"].cpu().numpy(), rtol=1e-5, atol=1e-9)
+
+
+def test_map_window_with_fused_steps_equals_the_pytorch_statements():
+    """backend_map.map_window(fused=True) -- isotropic regulariser, per-view statistics and the keyframes' Adam +
+    update_pose as single launches -- against fused=False (autograd term, PyTorch bookkeeping, torch.optim.Adam +
+    pose_utils.update_pose) on the toy scene: six iterations through a densification and an opacity reset."""
+    sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
+    import test_loop_golden as tl
+    from loop_scene import build_scene, loop_config
+    from lvdgs.backend_map import map_window
+    cfg = loop_config()
+    res = {}
+    for fused in (False, True):
+        torch.manual_seed(1)
+        sc = build_scene("cuda")
+        be = tl._backend(sc, cfg)
+        be.initialized = True
+        for i, cam in enumerate(sc["cameras"]):
+            be.viewpoints[i] = cam
+        window = sc["window"]
+        be.current_window = window
+        be.keyframe_optimizers = sc["make_keyframe_optimizer"](be.viewpoints, window, cfg)
+        counts = []
+        tl._record_steps(sc["gaussians"].optimizer, counts, [])
+        stats = {}
+        map_window(be, window, iters=sc["map_iters"], stats=stats, fused=fused)
+        G = be.gaussians
+        res[fused] = dict(counts=counts, losses=[float(x) for x in stats["losses"]],
+                          params={k: v.detach().cpu().numpy() for k, v in G._params_by_name().items()},
+                          radii=G.max_radii2D.cpu().numpy(), accum=G.xyz_gradient_accum.cpu().numpy(), denom=G.denom.cpu().numpy(),
+                          poses=[(c.R.cpu().numpy(), c.T.cpu().numpy(), float(c.exposure_a.detach()), float(c.exposure_b.detach()))
+                                 for c in sc["cameras"]],
+                          occ={kf: be.occ_aware_visibility[kf].cpu().numpy() for kf in window},
+                          deltas=[torch.cat([c.cam_rot_delta.detach(), c.cam_trans_delta.detach()]).cpu().numpy() for c in sc["cameras"]])
+        assert hasattr(be.keyframe_optimizers, "_lvdgs_stepper") == fused
+    a, b = res[True], res[False]
+    assert a["counts"] == b["counts"] and len(set(a["counts"])) > 1
+    np.testing.assert_allclose(a["losses"], b["losses"], rtol=2e-5)
+    for k in a["params"]:
+        if a["params"][k].size:
+            np.testing.assert_allclose(a["params"][k], b["params"][k], rtol=2e-4, atol=2e-5, err_msg=k)
+    np.testing.assert_array_equal(a["radii"], b["radii"])
+    np.testing.assert_array_equal(a["denom"], b["denom"])
+    np.testing.assert_allclose(a["accum"], b["accum"], rtol=1e-4, atol=1e-7)
+    for (Ra, Ta, ea, fa), (Rb, Tb, eb, fb) in zip(a["poses"], b["poses"]):
+        np.testing.assert_allclose(Ra, Rb, atol=5e-6)
+        np.testing.assert_allclose(Ta, Tb, atol=5e-6)
+        assert abs(ea - eb) < 1e-5 and abs(fa - fb) < 1e-5
+    for kf in a["occ"]:
+        np.testing.assert_array_equal(a["occ"][kf], b["occ"][kf])
+    # the three keyframes of the pose window were retracted (deltas zero), the others never moved
+    assert all(not d.any() for d in a["deltas"])
