@@ -445,6 +445,8 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
                 G.reset_opacity_nonvisible([seen_by_any])
                 gaussian_split = True
 
+            if stats is not None and callable(stats.get("before_steps")):
+                stats["before_steps"](backend)   # tests look at the (reduced) gradients here
             G.optimizer.step()
             G.optimizer.zero_grad(set_to_none=True)
             G.update_learning_rate(backend.iteration_count)
