@@ -451,7 +451,8 @@ __global__ void __launch_bounds__(256, 4) blend_bwd2_kernel(BlendParams p) {
                 // ---------------- pixel pass: up to NB entries with at least one hit ----------------
                 uint64_t batch = 0ull;
                 int nb = 0;
-                while (live && nb < NB) {
+                const uint32_t rel_last = my_last > (uint32_t)base ? my_last - (uint32_t)base : 0u;  // entries below this position composited
+                do {   // scalar loop control kept minimal: one test of `live` per entry, one of the batch size per hit
                     const int j = 63 - __builtin_clzll(live);
                     live = mask_clear_bit(live, j);
                     const float4 A = sh.a[j];
@@ -462,7 +463,7 @@ __global__ void __launch_bounds__(256, 4) blend_bwd2_kernel(BlendParams p) {
                     const float pw2 = fmaf(dx, fmaf(B.w, dx, Cc.w * dy), (-0.5f * LOG2E * B.x) * dy * dy);
                     const float G = __builtin_amdgcn_exp2f(pw2);
                     const float alpha = fminf(ALPHA_MAX, B.y * G);
-                    const bool hit = ((uint32_t)(base + j) < my_last) && (pw2 <= 0.f) && (alpha >= ALPHA_MIN);
+                    const bool hit = ((uint32_t)j < rel_last) && (pw2 <= 0.f) && (alpha >= ALPHA_MIN);
                     if (__ballot(hit) == 0ull) continue;
                     float u = 0.f, w = 0.f;
                     if (hit) {
@@ -476,8 +477,8 @@ __global__ void __launch_bounds__(256, 4) blend_bwd2_kernel(BlendParams p) {
                     }
                     sh.M[wave][nb][lane] = make_float2(u, w);
                     batch = mask_set_bit(batch, j);
-                    nb++;
-                }
+                    if (++nb == NB) break;
+                } while (live);
                 if (nb == 0) break;
                 wrote |= batch;
                 // slot table: the entry at bit position `lane` of the batch was given slot = number of batch bits above it
