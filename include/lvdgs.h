@@ -216,6 +216,10 @@ typedef struct lvdgs_loss_args {
 size_t lvdgs_loss_scratch_bytes(int32_t width, int32_t height);
 int lvdgs_photometric_loss_forward(const lvdgs_loss_args *a, void *stream);
 int lvdgs_photometric_loss_backward(const lvdgs_loss_args *a, void *stream);
+/* Value and every gradient in ONE pass over the images (for callers whose objective is this loss, so that
+ * d objective / d loss is known up front): grad_loss may be NULL (= 1) or a device scalar.  Same results as the two
+ * calls above. */
+int lvdgs_photometric_loss_value_and_grad(const lvdgs_loss_args *a, void *stream);
 
 /* ---- per-frame pose optimiser step (reference utils/slam_frontend.py:1518-1521, utils/pose_utils.py:70-87) ----
  * One launch = `pose_optimizer.step()` (torch.optim.Adam: betas, eps, one learning rate per group) on the frame's

@@ -217,13 +217,18 @@ class KeyframeStepper:
 
     def step(self):
         L = _lib.lib()
-        for vp, a, pose, has, _ in self.items:
+        for vp, a, pose, has, keep in self.items:
             g = lambda n: getattr(vp, n).grad if has[n] else None
             gr, gt, ga, gb = g("cam_rot_delta"), g("cam_trans_delta"), g("exposure_a"), g("exposure_b")
             for t in (gr, gt, ga, gb):
                 if t is not None and not _on_gpu_f32(t):
                     raise ValueError("KeyframeStepper: gradients must be contiguous float32 GPU tensors")
             a.grad_rot, a.grad_trans, a.grad_exposure_a, a.grad_exposure_b = _P(gr), _P(gt), _P(ga), _P(gb)
+            if pose and (vp.R is not keep[1] or vp.T is not keep[2]):
+                # somebody gave the keyframe a new pose since the last step (update_RT): adopt it into the buffers
+                keep[1].copy_(vp.R.detach().to(keep[1]))
+                keep[2].copy_(vp.T.detach().to(keep[2]))
+                vp.update_RT(keep[1], keep[2])
             dev = vp.exposure_a.device
             with _lib.on_device(dev):
                 _lib.check(L.lvdgs_pose_step(C.byref(a), _lib.raw_stream(dev)), "lvdgs_pose_step")

@@ -49,14 +49,18 @@ __device__ __forceinline__ float block_sum(float v, float *s /* [4] */) {
 }
 
 // 4 consecutive pixels per lane: 16-byte loads / stores on every plane when P % 4 == 0 (VEC), scalar otherwise.
-template <bool BACKWARD, bool VEC>
+// MODE 0: the loss value; 1: every gradient; 2: both in ONE pass over the images (the tracking session's case: the
+// objective IS the loss, d objective / d loss is known -- 1, or a device scalar -- before the pixels are read).
+template <int MODE, bool VEC>
 __global__ void __launch_bounds__(LOSS_THREADS) photometric_kernel(LossParams p) {
+    constexpr bool BACKWARD = MODE != 0, VALUE = MODE != 1;
     __shared__ float s_red[4];
     const float ea = p.exposure_a ? __expf(p.exposure_a[0]) : 1.f;
     const float eb = p.exposure_b ? p.exposure_b[0] : 0.f;
-    const float g = BACKWARD ? p.grad_out[0] : 0.f;
+    const float g = BACKWARD ? (p.grad_out ? p.grad_out[0] : 1.f) : 0.f;
     const float Wr = p.w_rgb / (3.f * (float)p.P) * g, Wd = p.w_d / (float)p.P * g;
-    float acc0 = 0.f, acc1 = 0.f;  // fwd: rgb sum, depth sum ; bwd: d_a sum, d_b sum
+    float acc0 = 0.f, acc1 = 0.f;  // rgb sum, depth sum (value)
+    float acc2 = 0.f, acc3 = 0.f;  // d_a sum, d_b sum (gradients)
     const int base = (blockIdx.x * LOSS_THREADS + threadIdx.x) * LOSS_PIX_PER_THREAD;
     const size_t P = (size_t)p.P;
     const bool has_d = p.depth && p.gt_depth;
@@ -101,17 +105,18 @@ __global__ void __launch_bounds__(LOSS_THREADS) photometric_kernel(LossParams p)
                 if (p.depth_needs_opaque) kd *= op[k] > 0.95f ? 1.f : 0.f;
                 rd = Dv[k] * kd - Z[k] * kd;
             }
-            if (!BACKWARD) {
+            if (VALUE) {
                 acc0 += om * (fabsf(r0) + fabsf(r1) + fabsf(r2));
                 acc1 += fabsf(rd);
-            } else {
+            }
+            if (BACKWARD) {
                 auto sgn = [](float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); };
                 const float q0 = Wr * om * sgn(r0) * m, q1 = Wr * om * sgn(r1) * m, q2 = Wr * om * sgn(r2) * m;
                 dI[0][k] = ea * q0; dI[1][k] = ea * q1; dI[2][k] = ea * q2;
                 dO[k] = p.weight_by_opacity ? Wr * (fabsf(r0) + fabsf(r1) + fabsf(r2)) : 0.f;
                 dD[k] = Wd * sgn(rd) * kd;
-                acc0 += ea * (q0 * I[0][k] + q1 * I[1][k] + q2 * I[2][k]);
-                acc1 += q0 + q1 + q2;
+                acc2 += ea * (q0 * I[0][k] + q1 * I[1][k] + q2 * I[2][k]);
+                acc3 += q0 + q1 + q2;
             }
         }
         if (BACKWARD) {
@@ -128,28 +133,40 @@ __global__ void __launch_bounds__(LOSS_THREADS) photometric_kernel(LossParams p)
             if (p.d_depth) store4(p.d_depth, dD);
         }
     }
-    const float s0 = block_sum(acc0, s_red);
-    const float s1 = block_sum(acc1, s_red);
-    if (threadIdx.x == 0) { p.partial[2 * blockIdx.x] = s0; p.partial[2 * blockIdx.x + 1] = s1; }
+    // partial sums of a block: [0], [1] value (rgb, depth), [2], [3] gradients (d_a, d_b)
+    if (VALUE) {
+        const float s0 = block_sum(acc0, s_red);
+        const float s1 = block_sum(acc1, s_red);
+        if (threadIdx.x == 0) { p.partial[4 * blockIdx.x] = s0; p.partial[4 * blockIdx.x + 1] = s1; }
+    }
+    if (BACKWARD) {
+        const float s2 = block_sum(acc2, s_red);
+        const float s3 = block_sum(acc3, s_red);
+        if (threadIdx.x == 0) { p.partial[4 * blockIdx.x + 2] = s2; p.partial[4 * blockIdx.x + 3] = s3; }
+    }
 }
 
-template <bool BACKWARD>
+template <int MODE>
 __global__ void __launch_bounds__(256) photometric_finish_kernel(LossParams p, int nblk) {
-    __shared__ float s[2][256];
-    float a0 = 0.f, a1 = 0.f;
-    for (int b = threadIdx.x; b < nblk; b += 256) { a0 += p.partial[2 * b]; a1 += p.partial[2 * b + 1]; }
-    s[0][threadIdx.x] = a0; s[1][threadIdx.x] = a1;
+    constexpr bool BACKWARD = MODE != 0, VALUE = MODE != 1;
+    __shared__ float s[4][256];
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+        if (VALUE) { a[0] += p.partial[4 * b]; a[1] += p.partial[4 * b + 1]; }
+        if (BACKWARD) { a[2] += p.partial[4 * b + 2]; a[3] += p.partial[4 * b + 3]; }
+    }
+    for (int k = 0; k < 4; k++) s[k][threadIdx.x] = a[k];
     __syncthreads();
     for (int st = 128; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) { s[0][threadIdx.x] += s[0][threadIdx.x + st]; s[1][threadIdx.x] += s[1][threadIdx.x + st]; }
+        if ((int)threadIdx.x < st)
+            for (int k = 0; k < 4; k++) s[k][threadIdx.x] += s[k][threadIdx.x + st];
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        if (!BACKWARD) {
-            p.loss[0] = p.w_rgb * (s[0][0] / (3.f * (float)p.P)) + p.w_d * (s[1][0] / (float)p.P);
-        } else {
-            if (p.d_a) p.d_a[0] = s[0][0];
-            if (p.d_b) p.d_b[0] = s[1][0];
+        if (VALUE) p.loss[0] = p.w_rgb * (s[0][0] / (3.f * (float)p.P)) + p.w_d * (s[1][0] / (float)p.P);
+        if (BACKWARD) {
+            if (p.d_a) p.d_a[0] = s[2][0];
+            if (p.d_b) p.d_b[0] = s[3][0];
         }
     }
 }
@@ -251,7 +268,7 @@ extern "C" {
 
 size_t lvdgs_loss_scratch_bytes(int32_t width, int32_t height) {
     const int64_t P = (int64_t)width * height;
-    return align256((size_t)cdiv(P, LOSS_THREADS * LOSS_PIX_PER_THREAD) * 2 * sizeof(float) + 256);
+    return align256((size_t)cdiv(P, LOSS_THREADS * LOSS_PIX_PER_THREAD) * 4 * sizeof(float) + 256);
 }
 
 static int loss_common(const lvdgs_loss_args *a, LossParams &p, int &nblk) {
@@ -276,8 +293,8 @@ int lvdgs_photometric_loss_forward(const lvdgs_loss_args *a, void *stream) {
     if (int e = loss_common(a, p, nblk)) return e;
     if (!a->loss) { set_error("loss: output is NULL"); return LVDGS_E_INVALID; }
     p.loss = a->loss;
-    { ProfScope ps("loss_fwd", s); if (p.P % 4 == 0) hipLaunchKernelGGL((photometric_kernel<false, true>), dim3(nblk), dim3(LOSS_THREADS), 0, s, p); else hipLaunchKernelGGL((photometric_kernel<false, false>), dim3(nblk), dim3(LOSS_THREADS), 0, s, p); LVDGS_LAUNCH_CHECK("loss_fwd", 0, s); }
-    { ProfScope ps("loss_fwd_finish", s); hipLaunchKernelGGL(photometric_finish_kernel<false>, dim3(1), dim3(256), 0, s, p, nblk); LVDGS_LAUNCH_CHECK("loss_fwd_finish", 0, s); }
+    { ProfScope ps("loss_fwd", s); if (p.P % 4 == 0) hipLaunchKernelGGL((photometric_kernel<0, true>), dim3(nblk), dim3(LOSS_THREADS), 0, s, p); else hipLaunchKernelGGL((photometric_kernel<0, false>), dim3(nblk), dim3(LOSS_THREADS), 0, s, p); LVDGS_LAUNCH_CHECK("loss_fwd", 0, s); }
+    { ProfScope ps("loss_fwd_finish", s); hipLaunchKernelGGL(photometric_finish_kernel<0>, dim3(1), dim3(256), 0, s, p, nblk); LVDGS_LAUNCH_CHECK("loss_fwd_finish", 0, s); }
     return LVDGS_OK;
 }
 
@@ -288,8 +305,21 @@ int lvdgs_photometric_loss_backward(const lvdgs_loss_args *a, void *stream) {
     if (!a->grad_loss || !a->d_image) { set_error("loss backward: grad_loss / d_image is NULL"); return LVDGS_E_INVALID; }
     p.grad_out = a->grad_loss; p.d_image = a->d_image; p.d_depth = a->d_depth; p.d_opacity = a->d_opacity;
     p.d_a = a->d_exposure_a; p.d_b = a->d_exposure_b;
-    { ProfScope ps("loss_bwd", s); if (p.P % 4 == 0) hipLaunchKernelGGL((photometric_kernel<true, true>), dim3(nblk), dim3(LOSS_THREADS), 0, s, p); else hipLaunchKernelGGL((photometric_kernel<true, false>), dim3(nblk), dim3(LOSS_THREADS), 0, s, p); LVDGS_LAUNCH_CHECK("loss_bwd", 0, s); }
-    { ProfScope ps("loss_bwd_finish", s); hipLaunchKernelGGL(photometric_finish_kernel<true>, dim3(1), dim3(256), 0, s, p, nblk); LVDGS_LAUNCH_CHECK("loss_bwd_finish", 0, s); }
+    { ProfScope ps("loss_bwd", s); if (p.P % 4 == 0) hipLaunchKernelGGL((photometric_kernel<1, true>), dim3(nblk), dim3(LOSS_THREADS), 0, s, p); else hipLaunchKernelGGL((photometric_kernel<1, false>), dim3(nblk), dim3(LOSS_THREADS), 0, s, p); LVDGS_LAUNCH_CHECK("loss_bwd", 0, s); }
+    { ProfScope ps("loss_bwd_finish", s); hipLaunchKernelGGL(photometric_finish_kernel<1>, dim3(1), dim3(256), 0, s, p, nblk); LVDGS_LAUNCH_CHECK("loss_bwd_finish", 0, s); }
+    return LVDGS_OK;
+}
+
+int lvdgs_photometric_loss_value_and_grad(const lvdgs_loss_args *a, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    LossParams p; int nblk;
+    if (int e = loss_common(a, p, nblk)) return e;
+    if (!a->loss || !a->d_image) { set_error("loss value_and_grad: loss / d_image is NULL"); return LVDGS_E_INVALID; }
+    p.loss = a->loss;
+    p.grad_out = a->grad_loss;  // NULL: d objective / d loss = 1
+    p.d_image = a->d_image; p.d_depth = a->d_depth; p.d_opacity = a->d_opacity; p.d_a = a->d_exposure_a; p.d_b = a->d_exposure_b;
+    { ProfScope ps("loss_both", s); if (p.P % 4 == 0) hipLaunchKernelGGL((photometric_kernel<2, true>), dim3(nblk), dim3(LOSS_THREADS), 0, s, p); else hipLaunchKernelGGL((photometric_kernel<2, false>), dim3(nblk), dim3(LOSS_THREADS), 0, s, p); LVDGS_LAUNCH_CHECK("loss_both", 0, s); }
+    { ProfScope ps("loss_both_finish", s); hipLaunchKernelGGL(photometric_finish_kernel<2>, dim3(1), dim3(256), 0, s, p, nblk); LVDGS_LAUNCH_CHECK("loss_both_finish", 0, s); }
     return LVDGS_OK;
 }
 

@@ -9,10 +9,10 @@ Driven through PyTorch that is two ``autograd.Function`` round trips, the autogr
 matrices, with three host synchronisations (``if angle < 1e-5`` twice, ``if converged``): 0.5 ms of host time per
 iteration whatever the scene, which is what bounds tracking at SLAM-sized maps (1e5 Gaussians, KITTI frames).
 
-The session does the same arithmetic as five calls into the C ABI on pre-filled argument blocks and buffers that
+The session does the same arithmetic as four calls into the C ABI on pre-filled argument blocks and buffers that
 live for the frame:
 
-    lvdgs_forward -> lvdgs_photometric_loss_forward / _backward -> lvdgs_backward -> lvdgs_pose_step
+    lvdgs_forward -> lvdgs_photometric_loss_value_and_grad -> lvdgs_backward -> lvdgs_pose_step
 
 and nothing comes back to the host inside the loop except the pair count ``lvdgs_forward`` has always read (the GPU has
 the rest of the iteration queued behind it).  Convergence (``||tau|| < 1e-4``, utils/pose_utils.py:82) is a sticky
@@ -182,10 +182,10 @@ class TrackingSession:
             else:
                 _lib.check(status, "lvdgs_forward")
             self.num_rendered = a.num_rendered = D
-            _lib.check(L.lvdgs_photometric_loss_forward(C.byref(self.la), stream), "lvdgs_photometric_loss_forward")
+            # loss value and all its gradients in one pass over the images (the objective is the loss: d/d loss = 1)
+            _lib.check(L.lvdgs_photometric_loss_value_and_grad(C.byref(self.la), stream), "lvdgs_photometric_loss_value_and_grad")
             if record_loss is not None:
                 record_loss.copy_(self.loss)
-            _lib.check(L.lvdgs_photometric_loss_backward(C.byref(self.la), stream), "lvdgs_photometric_loss_backward")
             _lib.check(L.lvdgs_backward(C.byref(a), stream), "lvdgs_backward")
             _lib.check(L.lvdgs_pose_step(C.byref(self.pa), stream), "lvdgs_pose_step")
         self.iterations_enqueued += 1

@@ -91,6 +91,9 @@ CONFIGS = {
     "cfg3_500k_1920x1080": dict(N=500_000, W=1920, H=1080),
     # KITTI-07 geometry (configs/mono/KITTI/07.yaml:8-18)
     "kitti07_geom": dict(N=200_000, W=1226, H=370, fx=707.0912, fy=707.0912, cx=601.8873, cy=183.1104),
+    # the same pair density per tile as kitti07_geom on four times the area (diagnostic: is a 1848-tile frame slow per
+    # pair because it leaves compute units idle?)
+    "kitti07_x4": dict(N=800_000, W=2452, H=740, fx=1414.1824, fy=1414.1824, cx=1203.7746, cy=366.2208),
     # BASELINE.json configs[4] shape: 2 M Gaussians, waymo-sized frames (configs/mono/waymo/405841.yaml:15-16)
     "cfg5_2m_1920x1280": dict(N=2_000_000, W=1920, H=1280),
 }

@@ -63,3 +63,47 @@ def test_fused_loss_matches_torch_formulas(case, H, W):
     np.testing.assert_allclose(l_f, l_t, rtol=2e-5)
     for a, b, name in zip(g_f, g_t, ("image", "depth", "opacity", "a", "b")):
         np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-9 + 2e-5 * np.abs(b).max(), err_msg=name)
+
+
+def test_value_and_grad_in_one_pass_equals_the_two_passes():
+    """lvdgs_photometric_loss_value_and_grad (what the tracking session calls) against forward + backward: loss, image /
+    depth / opacity / exposure gradients, with and without a device scalar for d objective / d loss."""
+    import ctypes as C
+    from lvdgs import _lib
+    H, W = 67, 130   # P = 8710, not a multiple of 4: the scalar path; and a multiple-of-4 size below
+    for (H, W) in ((67, 130), (64, 96)):
+        g = torch.Generator().manual_seed(H)
+        dev = torch.device("cuda", 0)
+        mk = lambda *s: torch.rand(*s, generator=g).to(dev)
+        image, gt, depth, gtd, opac = mk(3, H, W), mk(3, H, W), mk(1, H, W) * 5, mk(1, H, W) * 5, mk(1, H, W)
+        gm = (torch.rand(H * W, generator=g) > 0.4).to(torch.uint8).to(dev)
+        ea, eb = torch.tensor([0.1], device=dev), torch.tensor([-0.02], device=dev)
+        L = _lib.lib()
+        P = lambda t: C.c_void_p(t.data_ptr())
+        outs = {}
+        for mode, scale in (("two", None), ("one", None), ("one_scaled", 0.37), ("two_scaled", 0.37)):
+            a = _lib.LossArgs()
+            a.width, a.height = W, H
+            a.image, a.depth, a.opacity, a.gt_image, a.gt_depth, a.grad_mask = P(image), P(depth), P(opac), P(gt), P(gtd), P(gm)
+            a.exposure_a, a.exposure_b = P(ea), P(eb)
+            a.rgb_boundary_threshold, a.weight_rgb, a.weight_depth, a.weight_by_opacity, a.depth_needs_opaque = 0.01, 0.9, 0.1, 1, 1
+            scratch = torch.empty(int(L.lvdgs_loss_scratch_bytes(W, H)), dtype=torch.uint8, device=dev)
+            loss, gl = torch.zeros((), device=dev), torch.full((), 1.0 if scale is None else scale, device=dev)
+            d = [torch.empty(3, H, W, device=dev), torch.empty(1, H, W, device=dev), torch.empty(1, H, W, device=dev),
+                 torch.empty(1, device=dev), torch.empty(1, device=dev)]
+            a.scratch, a.scratch_bytes, a.loss = P(scratch), scratch.numel(), P(loss)
+            a.d_image, a.d_depth, a.d_opacity, a.d_exposure_a, a.d_exposure_b = (P(t) for t in d)
+            stream = _lib.raw_stream(dev)
+            if mode.startswith("two"):
+                a.grad_loss = P(gl)
+                _lib.check(L.lvdgs_photometric_loss_forward(C.byref(a), stream), "fwd")
+                _lib.check(L.lvdgs_photometric_loss_backward(C.byref(a), stream), "bwd")
+            else:
+                a.grad_loss = None if scale is None else P(gl)
+                _lib.check(L.lvdgs_photometric_loss_value_and_grad(C.byref(a), stream), "both")
+            torch.cuda.synchronize()
+            outs[mode] = [float(loss)] + [t.cpu().numpy() for t in d]
+        for x, y in (("one", "two"), ("one_scaled", "two_scaled")):
+            assert outs[x][0] == outs[y][0]
+            for u, v in zip(outs[x][1:], outs[y][1:]):
+                np.testing.assert_array_equal(u, v)
