@@ -63,7 +63,7 @@ def dump(root):
     rows = [(t, w, s) for t, d in REPORT.items() for w, s in d.items()]
     rows.sort(key=lambda r: -r[2]["max_rel_sig"])
     with open(os.path.join(out, "parity_report.txt"), "w") as f:
-        f.write(f"{'test':110s} {'tensor':22s} {'rel_l2':>10s} {'max_rel_sig':>12s} {'max_abs/scale':>14s} {'frac<=1e-4':>10s}\n")
+        f.write(f"{'test':110s} {'tensor':52s} {'rel_l2':>10s} {'max_rel_sig':>12s} {'max_abs/scale':>14s} {'frac<=1e-4':>10s}\n")
         for t, w, s in rows:
-            f.write(f"{t[:110]:110s} {w[:22]:22s} {s['rel_l2']:10.2e} {s['max_rel_sig']:12.2e} "
+            f.write(f"{t[:110]:110s} {w[:52]:52s} {s['rel_l2']:10.2e} {s['max_rel_sig']:12.2e} "
                     f"{s['max_abs'] / max(s['scale'], 1e-300):14.2e} {s['frac_1e-4']:10.4f}\n")
