@@ -1,7 +1,8 @@
-"""The two single-view optimisation loops around ``render()``: map initialisation and per-frame pose tracking.
+"""The single-view optimisation loops around ``render()``: map initialisation, colour refinement, per-frame pose tracking.
 
-Statements of the loop bodies of the reference's ``BackEnd.initialize_map`` (utils/slam_backend.py:95-149) and
-``FrontEnd.tracking`` (utils/slam_frontend.py:1467-1536, everything after the MASt3R pose initialisation), written
+Statements of the loop bodies of the reference's ``BackEnd.initialize_map`` (utils/slam_backend.py:95-149),
+``BackEnd.color_refinement`` (:393-468) and ``FrontEnd.tracking`` (utils/slam_frontend.py:1467-1536, everything after the
+MASt3R pose initialisation), written
 against duck-typed ``backend`` / ``viewpoint`` objects so that the reference's own classes can be passed in.  One view
 per iteration: nothing to shard (on several GPUs these run as replicas); the sharded loop is
 ``backend_map.map_window``.
@@ -45,6 +46,36 @@ def initialize_map(backend, cur_frame_idx, viewpoint, render_fn=render, on_itera
             G.optimizer.zero_grad(set_to_none=True)
     backend.occ_aware_visibility[cur_frame_idx] = (n_touched > 0).long()
     return render_pkg
+
+
+def color_refinement(backend, iteration_total=26000, render_fn=render, loss_fn=None, on_iteration=None):
+    """The post-SLAM colour refinement (reference utils/slam_backend.py:393-468): ``iteration_total`` iterations of one
+    random keyframe (``random.randint`` on the keyframe list, as the reference draws it) -> render ->
+    ``(1 - l) L1 + l (1 - SSIM)``, on the static pixels only when the keyframe carries a ``static_mask`` -> backward ->
+    ``max_radii2D`` -> Adam step -> position learning-rate schedule.  One view per iteration: replicas only.
+    ``loss_fn(image, gt_image, lambda_dssim, static_mask, background)`` defaults to the fused HIP kernel
+    (``loss_utils.l1_dssim_loss``: both means and the gradient image in one launch)."""
+    import random
+    if loss_fn is None:
+        from .loss_utils import l1_dssim_loss as loss_fn
+    G = backend.gaussians
+    for iteration in range(1, iteration_total + 1):
+        viewpoint_idx_stack = list(backend.viewpoints.keys())
+        viewpoint_cam_idx = viewpoint_idx_stack.pop(random.randint(0, len(viewpoint_idx_stack) - 1))
+        viewpoint_cam = backend.viewpoints[viewpoint_cam_idx]
+        render_pkg = render_fn(viewpoint_cam, G, backend.pipeline_params, backend.background)
+        image, visibility_filter, radii = render_pkg["render"], render_pkg["visibility_filter"], render_pkg["radii"]
+        gt_image = viewpoint_cam.original_image.to(image.device)
+        static_mask = getattr(viewpoint_cam, "static_mask", None)
+        loss = loss_fn(image, gt_image, backend.opt_params.lambda_dssim, static_mask, backend.background if static_mask is not None else None)
+        loss.backward()
+        if on_iteration is not None:
+            on_iteration(iteration, viewpoint_cam_idx, loss)
+        with torch.no_grad():
+            G.max_radii2D[visibility_filter] = torch.max(G.max_radii2D[visibility_filter], radii[visibility_filter])
+            G.optimizer.step()
+            G.optimizer.zero_grad(set_to_none=True)
+            G.update_learning_rate(iteration)
 
 
 def make_pose_optimizer(viewpoint, config):

@@ -179,6 +179,32 @@ def main():
     out["prune_end_xyz"] = be.gaussians.get_xyz.detach().clone().numpy()
     backend_mod.get_loss_mapping = ref_loss
 
+    # ------------------------------------------------------------------ BackEnd.color_refinement (first 8 of its 26000 iterations)
+    import itertools
+    import random
+    torch.manual_seed(3)
+    random.seed(3)
+    sc = build_scene("cpu", RefCamera)
+    be = backend_mod.BackEnd(cfg)
+    be.gaussians, be.background, be.pipeline_params = sc["gaussians"], sc["background"], sc["pipe"]
+    be.opt_params = types.SimpleNamespace(**cfg["opt_params"])
+    for i, cam in enumerate(sc["cameras"]):
+        be.viewpoints[i] = cam
+    backend_mod.tqdm = lambda it: itertools.islice(it, 8)   # the reference hard-codes iteration_total = 26000 (:399)
+    rec = Recorder()
+    rec.hook_optimizer(be.gaussians.optimizer, "refine")
+    ref_render = backend_mod.render
+    seen = []
+    backend_mod.render = lambda vp, *a, **k: (seen.append(int(vp.uid)) or ref_render(vp, *a, **k))
+    be.color_refinement()
+    backend_mod.render = ref_render
+    out["refine_keyframes"] = np.array(seen)
+    for k in ("xyz", "opacity", "scaling", "f_dc", "rotation"):
+        out["refine_grad0_" + k] = rec.rows[0]["grad_" + k]
+    for k, v in snapshot(be.gaussians).items():
+        out["refine_end_" + k] = v
+    out["refine_end_lr_xyz"] = np.array([gp["lr"] for gp in be.gaussians.optimizer.param_groups if gp["name"] == "xyz"])
+
     # ------------------------------------------------------------------ FrontEnd.tracking
     torch.manual_seed(2)
     sc = build_scene("cpu", RefCamera)

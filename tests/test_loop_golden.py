@@ -185,3 +185,37 @@ def test_track_frame_replays_the_reference_tracking_loop(gold):
     _close([float(cam.exposure_a.detach()), float(cam.exposure_b.detach())], gold["track_end_exposure"], "exposure", rtol=1e-3, atol_scale=1e-3)
     assert abs(float(median_depth) - float(gold["track_median_depth"])) < 1e-4 * float(gold["track_median_depth"])
     _close(pkg["depth"].detach().numpy(), gold["track_last_depth"], "last rendered depth")
+
+
+def _cpu_refine_loss(image, gt_image, lambda_dssim, static_mask, background):
+    import loss_oracle as lo
+    return lo.l1_dssim_loss(image, gt_image, lambda_dssim, static_mask, background).to(image.dtype)
+
+
+def test_color_refinement_replays_the_reference_loop(gold):
+    """BackEnd.color_refinement (utils/slam_backend.py:393-468), first 8 iterations: which keyframes random.randint
+    picks, the masked / unmasked L1 + SSIM loss, the Adam steps and the learning-rate schedule."""
+    import random
+    from dense_render import dense_render
+    from loop_scene import build_scene, loop_config
+    from lvdgs.slam_loops import color_refinement
+    cfg = loop_config()
+    torch.manual_seed(3)
+    random.seed(3)
+    sc = build_scene("cpu")
+    be = _backend(sc, cfg)
+    for i, cam in enumerate(sc["cameras"]):
+        be.viewpoints[i] = cam
+    counts, grads, seen = [], [], []
+    _record_steps(sc["gaussians"].optimizer, counts, grads)
+    color_refinement(be, iteration_total=8, render_fn=dense_render, loss_fn=_cpu_refine_loss,
+                     on_iteration=lambda it, kf, loss: seen.append(kf))
+    np.testing.assert_array_equal(seen, gold["refine_keyframes"])
+    assert 4 in seen   # the keyframe with a static mask was drawn: both branches of the loss ran
+    for k in ("xyz", "opacity", "scaling", "f_dc", "rotation"):
+        _close(grads[0][k], gold["refine_grad0_" + k], "first gradient of " + k)
+    for k, v in _snap(be.gaussians).items():
+        _close(v, gold["refine_end_" + k], "final " + k, rtol=1e-3, atol_scale=1e-4)
+    _close(be.gaussians.max_radii2D.numpy(), gold["refine_end_max_radii2D"], "max_radii2D")
+    lr = [gp["lr"] for gp in be.gaussians.optimizer.param_groups if gp["name"] == "xyz"]
+    np.testing.assert_allclose(lr, gold["refine_end_lr_xyz"], rtol=1e-12)
