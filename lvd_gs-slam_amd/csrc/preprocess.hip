@@ -273,6 +273,8 @@ struct BwdParams {
     float *tau_part;
 };
 
+constexpr int PAIR_CHUNK = 256;  // pair records staged per round: 12 KB of LDS
+
 __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
     __shared__ float s_tau[4][6];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -290,20 +292,39 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
         if (p.dcolors) { for (int k = 0; k < 3; k++) p.dcolors[3 * (size_t)i + k] = 0.f; }
         if (p.dshs) { for (int k = 0; k < 3 * c.M; k++) p.dshs[(size_t)i * 3 * c.M + k] = 0.f; }
     }
-    if (live) {
-        // ---- sum this Gaussian's per-tile partial gradients (contiguous run, fixed order) ----
-        const float4 *r4 = reinterpret_cast<const float4 *>(p.rec + (size_t)i * REC_FLOATS);
-        const uint32_t first = p.slot_base[i], cnt = p.tiles_touched[i];
-        float A[10];
+    // ---- sum every Gaussian's per-tile partial gradients (a contiguous run of 48-byte records, fixed order) ----
+    // The runs of a workgroup's 256 Gaussians follow each other in memory (slots are in id order), so the workgroup
+    // streams that region through LDS in chunks with coalesced 16-byte loads and every lane picks its own records out
+    // of the chunk -- instead of 64 lanes walking 64 different runs with one 48-byte gather each per step, which moved
+    // 2.2x the bytes (r01 / r02_a counters).  Same additions in the same order as before.
+    __shared__ float4 s_pg[3 * PAIR_CHUNK];
+    __shared__ uint32_t s_region[2];
+    float A[10];
 #pragma unroll
-        for (int k = 0; k < 10; k++) A[k] = 0.f;
-        const float4 *pg = reinterpret_cast<const float4 *>(p.pair_grads) + (size_t)first * 3;
-        for (uint32_t t = 0; t < cnt; t++) {
-            const float4 a0 = pg[3 * t], a1 = pg[3 * t + 1], a2 = pg[3 * t + 2];
-            A[0] += a0.x; A[1] += a0.y; A[2] += a0.z; A[3] += a0.w;
-            A[4] += a1.x; A[5] += a1.y; A[6] += a1.z; A[7] += a1.w;
-            A[8] += a2.x; A[9] += a2.y;
+    for (int k = 0; k < 10; k++) A[k] = 0.f;
+    {
+        const int blk_first = blockIdx.x * blockDim.x, blk_last = min(p.N, blk_first + (int)blockDim.x) - 1;
+        if (threadIdx.x == 0) { s_region[0] = p.slot_base[blk_first]; s_region[1] = p.slot_base[blk_last] + p.tiles_touched[blk_last]; }
+        const uint32_t first = live ? p.slot_base[i] : 0u, last = live ? first + p.tiles_touched[i] : 0u;
+        __syncthreads();
+        const uint32_t r_lo = s_region[0], r_hi = s_region[1];
+        const float4 *pg_all = reinterpret_cast<const float4 *>(p.pair_grads);
+        for (uint32_t c0 = r_lo; c0 < r_hi; c0 += PAIR_CHUNK) {
+            const uint32_t n = min((uint32_t)PAIR_CHUNK, r_hi - c0);
+            for (uint32_t k = threadIdx.x; k < 3 * n; k += blockDim.x) s_pg[k] = pg_all[(size_t)3 * c0 + k];
+            __syncthreads();
+            const uint32_t lo = max(first, c0), hi = min(last, c0 + n);
+            for (uint32_t t = lo; t < hi; t++) {
+                const float4 a0 = s_pg[3 * (t - c0)], a1 = s_pg[3 * (t - c0) + 1], a2 = s_pg[3 * (t - c0) + 2];
+                A[0] += a0.x; A[1] += a0.y; A[2] += a0.z; A[3] += a0.w;
+                A[4] += a1.x; A[5] += a1.y; A[6] += a1.z; A[7] += a1.w;
+                A[8] += a2.x; A[9] += a2.y;
+            }
+            __syncthreads();
         }
+    }
+    if (live) {
+        const float4 *r4 = reinterpret_cast<const float4 *>(p.rec + (size_t)i * REC_FLOATS);
         // A: [0,1] d/d pixel mean, [2..4] d/d conic a,b,c, [5] d/d opacity, [6..8] d/d rgb, [9] d/d view depth
         const float pos[3] = {p.means3D[3 * i], p.means3D[3 * i + 1], p.means3D[3 * i + 2]};
         float pv[3], ph[3];
