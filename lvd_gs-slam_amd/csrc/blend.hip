@@ -78,10 +78,12 @@ __device__ __forceinline__ bool reaches_rect(float mx, float my, float a, float 
 
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendParams p) {
-    __shared__ float4 s_a[256];  // x, y, -a/2*log2e, -b*log2e
-    __shared__ float4 s_b[256];  // -c/2*log2e, opacity, depth, id bits
-    __shared__ float4 s_c[256];  // r, g, b, a (raw conic a, for the quadrant test)
-    __shared__ float2 s_d[256];  // raw conic b, c
+    // one shared object, so that the three reads of a survivor share one address register
+    __shared__ struct { float4 a[256], b[256], c[256]; float2 d[256]; } s_recs;
+    float4 *const s_a = s_recs.a;  // x, y, -a/2*log2e, -b*log2e
+    float4 *const s_b = s_recs.b;  // -c/2*log2e, opacity, depth, id bits
+    float4 *const s_c = s_recs.c;  // r, g, b, a (raw conic a, for the quadrant test)
+    float2 *const s_d = s_recs.d;  // raw conic b, c
     __shared__ int s_touch[256]; // pixels of this tile each staged Gaussian "touched" (T after it > 0.5)
 
     const int tile = tile_of_workgroup(blockIdx.x, p.num_tiles);
