@@ -138,7 +138,7 @@ size_t geom_layout(int N, GeomView *v, void *base) {
     return off;
 }
 
-static size_t scan_blocks(int N) { return (size_t)cdiv(N > 0 ? N : 1, 2048) + 1; }
+static size_t scan_blocks(int N) { return (size_t)cdiv(N > 0 ? N : 1, 256) + 1; }  // one sum per preprocess_fwd workgroup
 
 size_t prep_scratch_layout(int N, PrepScratch *v, void *base) {
     PrepScratch tmp;
@@ -293,7 +293,7 @@ int enqueue_prepare(const lvdgs_args *a, const GeomView &g, hipStream_t s) {
     const int N = a->num_gaussians;
     PrepScratch w;
     prep_scratch_layout(N, &w, a->scratch);
-    if (int e = launch_preprocess_fwd(*a, g, s)) return e;
+    if (int e = launch_preprocess_fwd(*a, g, w.blocksums, s)) return e;
     return launch_slot_scan(g.tiles_touched, g.slot_base, w.blocksums, g.total, N, a->debug, s);
 }
 

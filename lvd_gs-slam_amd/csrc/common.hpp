@@ -101,7 +101,7 @@ size_t bwd_scratch_layout(int N, int64_t D, BwdScratch *v, void *base);
 int tile_sort_bits(int W, int H);  // number of key bits to sort for the tile id
 
 // ---- launchers (one per kernel family; all enqueue on `stream` and return a status) ----
-int launch_preprocess_fwd(const lvdgs_args &a, const GeomView &g, hipStream_t s);
+int launch_preprocess_fwd(const lvdgs_args &a, const GeomView &g, uint32_t *blocksums /* one per 256 Gaussians */, hipStream_t s);
 int launch_preprocess_bwd(const lvdgs_args &a, const GeomView &g, const BwdScratch &b, hipStream_t s);
 int launch_mark_visible(int N, const float *means3D, const float *view, uint8_t *present, hipStream_t s);
 

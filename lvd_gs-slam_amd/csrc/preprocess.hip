@@ -170,11 +170,25 @@ struct FwdParams {
     uint32_t *tiles_touched, *depth_bits;
     uint2 *rect;
     int32_t *radii;
+    uint32_t *blocksums;   // per workgroup: sum of tiles_touched (first level of the slot scan, sortscan.hip)
 };
 
+__device__ __forceinline__ void preprocess_one(const FwdParams &p, int i, uint32_t &tiles_out);
+
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(FwdParams p) {
+    __shared__ uint32_t s_sum[4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= p.N) return;
+    uint32_t tiles = 0;
+    if (i < p.N) preprocess_one(p, i, tiles);
+    // the workgroup's pair count: the slot scan starts from these sums instead of re-reading tiles_touched in a launch of its own
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tiles += (uint32_t)__shfl_xor((int)tiles, off, 64);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = tiles;
+    __syncthreads();
+    if (threadIdx.x == 0) p.blocksums[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+}
+
+__device__ __forceinline__ void preprocess_one(const FwdParams &p, int i, uint32_t &tiles_out) {
     const Cam &c = p.cam;
     // culled unless proven visible
     int radius = 0;
@@ -258,6 +272,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(FwdParams p) {
     p.tiles_touched[i] = tiles;
     p.rect[i] = rect;
     p.depth_bits[i] = depth_bits;
+    tiles_out = tiles;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -565,9 +580,10 @@ Cam make_cam(const lvdgs_args &a) {
 
 }  // namespace
 
-int launch_preprocess_fwd(const lvdgs_args &a, const GeomView &g, hipStream_t s) {
+int launch_preprocess_fwd(const lvdgs_args &a, const GeomView &g, uint32_t *blocksums, hipStream_t s) {
     if (a.num_gaussians == 0) return LVDGS_OK;
     FwdParams p;
+    p.blocksums = blocksums;
     p.cam = make_cam(a); p.N = a.num_gaussians; p.act = a.activations;
     p.means3D = a.means3D; p.opacities = a.opacities; p.scales = a.scales; p.rotations = a.rotations;
     p.cov3D_precomp = a.cov3D_precomp; p.shs = a.shs; p.colors_precomp = a.colors_precomp;

@@ -198,27 +198,15 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
 
 // slot_base[i] = exclusive scan over i of tiles_touched[i]: where Gaussian i's pairs (and, in the backward pass, its
 // per-pair partial gradients) start in the unsorted pair list.
-__global__ void __launch_bounds__(SCAN_THREADS) scan_reduce_kernel(const uint32_t *__restrict__ tt, int N,
-                                                                   uint32_t *__restrict__ blocksums) {
-    __shared__ uint32_t s[SCAN_THREADS];
-    uint32_t sum = 0;
-    const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_IPT;
-#pragma unroll
-    for (int k = 0; k < SCAN_IPT; k++)
-        if (base + k < N) sum += tt[base + k];
-    uint32_t total;
-    block_exclusive_scan(sum, s, &total);
-    if (threadIdx.x == 0) blocksums[blockIdx.x] = total;
-}
-
-// Second of two launches: every workgroup first adds up the sums of the workgroups before it (a few hundred
-// values: cheaper than a third launch for a one-workgroup scan of them), then scans its own chunk.
+// One launch: preprocess_fwd left the pair count of every 256 Gaussians in `blocksums`; every workgroup here first
+// adds up the sums in front of its chunk (at most a few thousand values: cheaper than a launch for a scan of them),
+// then scans its own chunk of SCAN_CHUNK = 8 x 256 Gaussians.
 __global__ void __launch_bounds__(SCAN_THREADS) scan_apply_kernel(const uint32_t *__restrict__ tt, int N,
                                                                   const uint32_t *__restrict__ blocksums,
                                                                   uint32_t *__restrict__ slot_base, uint32_t *__restrict__ total_out) {
     __shared__ uint32_t s[SCAN_THREADS];
     uint32_t before = 0;
-    for (int b = threadIdx.x; b < (int)blockIdx.x; b += SCAN_THREADS) before += blocksums[b];
+    for (int b = threadIdx.x; b < (int)blockIdx.x * (SCAN_CHUNK / 256); b += SCAN_THREADS) before += blocksums[b];
     uint32_t prefix;
     block_exclusive_scan(before, s, &prefix);  // only the total is of interest
     uint32_t v[SCAN_IPT];
@@ -290,11 +278,6 @@ int launch_slot_scan(const uint32_t *tiles_touched, uint32_t *slot_base, uint32_
         return check_hip(hipMemsetAsync(total_dev, 0, sizeof(uint32_t), s), "memset total");
     }
     const int nblk = cdiv(N, SCAN_CHUNK);
-    {
-        ProfScope ps("scan_reduce", s);
-        hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblk), dim3(SCAN_THREADS), 0, s, tiles_touched, N, blocksums);
-        LVDGS_LAUNCH_CHECK("scan_reduce", dbg, s);
-    }
     {
         ProfScope ps("scan_apply", s);
         hipLaunchKernelGGL(scan_apply_kernel, dim3(nblk), dim3(SCAN_THREADS), 0, s, tiles_touched, N, (const uint32_t *)blocksums, slot_base,
