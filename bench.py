@@ -282,6 +282,26 @@ def main():
         torch.cuda.synchronize()
         autograd_rate = round(args.steps / (time.perf_counter() - t1), 3)
 
+    same_step_single = None
+    if world > 1 and not tracking:
+        # The same step on ONE GPU, measured inside this job (every rank alone in a group of its own: no collective),
+        # so that the N-GPU number can be read against the right single-GPU number: bench.py's N = 1 default is the
+        # tracking iteration of BASELINE configs[2], a different (lighter) step than the mapping iteration timed here.
+        solo_groups = [dist.new_group(ranks=[r]) for r in range(world)]
+        solo_backend, solo_window = build_window(args.workload, 1, dev, GaussianModel.from_activated(
+            g_cpu["means3D"], g_cpu["scales"], g_cpu["rotations"], g_cpu["opacities"], shs=g_cpu["shs"], sh_degree=0, device=dev))
+        for _ in range(3):
+            backend_map.map_window(solo_backend, solo_window, iters=1, group=solo_groups[rank])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            backend_map.map_window(solo_backend, solo_window, iters=1, group=solo_groups[rank])
+        torch.cuda.synchronize()
+        solo = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        dist.all_reduce(solo, op=dist.ReduceOp.MAX)
+        same_step_single = round(args.steps / float(solo.item()), 3)
+        del solo_backend
+
     comm_us = None
     if world > 1 and not tracking:
         # the collectives' share, measured apart (the timers synchronise the device around them)
@@ -314,7 +334,8 @@ def main():
                                 "2 RCCL collectives (gradients + statistics, radii + flags), bookkeeping, Adam over all Gaussians, "
                                 "keyframe Adam, pose retraction"),
                        "parallelism": f"keyframe-per-gpu x{world}" if world > 1 else "single",
-                       "comm_us_per_step": comm_us, "autograd_api_iters_per_s": autograd_rate},
+                       "comm_us_per_step": comm_us, "autograd_api_iters_per_s": autograd_rate,
+                       "same_step_on_one_gpu_iters_per_s": same_step_single},
             **({"collective_backend": backend_name + " (functional check only, not a benchmark result)"} if world > 1 and backend_name != "nccl" else {}),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels_us_per_step": {k: round(v["us_per_step"], 2) for k, v in kernels.items()},
         }
