@@ -18,6 +18,8 @@
 // whole cache lines.  Gradients are therefore bitwise reproducible.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 #include "device_utils.hpp"
 
@@ -78,12 +80,13 @@ __device__ __forceinline__ bool reaches_rect(float mx, float my, float a, float 
 
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendParams p) {
-    // one shared object, so that the three reads of a survivor share one address register
-    __shared__ struct { float4 a[256], b[256], c[256]; float2 d[256]; } s_recs;
+    // one shared object, so that the three reads of a survivor share one address register; laid out so that they are
+    // a 16-, an 8- and a 16-byte read (4 + 2 + 4 LDS cycles per wave; a 12-byte read alone costs 8)
+    __shared__ struct { float4 a[256], b[256], c[256]; float d[256]; } s_recs;
     float4 *const s_a = s_recs.a;  // x, y, -a/2*log2e, -b*log2e
-    float4 *const s_b = s_recs.b;  // -c/2*log2e, opacity, depth, id bits
-    float4 *const s_c = s_recs.c;  // r, g, b, a (raw conic a, for the quadrant test)
-    float2 *const s_d = s_recs.d;  // raw conic b, c
+    float4 *const s_b = s_recs.b;  // -c/2*log2e, opacity | raw conic a, b (for the quadrant test; survivors read the first half only)
+    float4 *const s_c = s_recs.c;  // r, g, b, depth
+    float *const s_d = s_recs.d;   // raw conic c
     __shared__ int s_touch[256]; // pixels of this tile each staged Gaussian "touched" (T after it > 0.5)
 
     const int tile = tile_of_workgroup(blockIdx.x, p.num_tiles);
@@ -115,9 +118,9 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendParams p) {
             const float4 *r4 = reinterpret_cast<const float4 *>(p.rec + (size_t)my_id * REC_FLOATS);
             const float4 r0 = r4[0], r1 = r4[1], r2 = r4[2];
             s_a[tid] = make_float4(r0.x, r0.y, -0.5f * LOG2E * r0.z, -LOG2E * r0.w);
-            s_b[tid] = make_float4(-0.5f * LOG2E * r1.x, r1.y, r2.y, 0.f);
-            s_c[tid] = make_float4(r1.z, r1.w, r2.x, r0.z);
-            s_d[tid] = make_float2(r0.w, r1.x);
+            s_b[tid] = make_float4(-0.5f * LOG2E * r1.x, r1.y, r0.z, r0.w);
+            s_c[tid] = make_float4(r1.z, r1.w, r2.x, r2.y);
+            s_d[tid] = r1.x;
         }
         s_touch[tid] = 0;
         __syncthreads();
@@ -128,9 +131,8 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendParams p) {
                 bool keep = false;
                 if (jl < cnt) {
                     const float4 A = s_a[jl];
-                    const float4 Cc = s_c[jl];
-                    const float2 Dd = s_d[jl];
-                    keep = reaches_rect(A.x, A.y, Cc.w, Dd.x, Dd.y, s_b[jl].y, rx0, ry0, rx1, ry1);
+                    const float4 B = s_b[jl];
+                    keep = reaches_rect(A.x, A.y, B.z, B.w, s_d[jl], B.y, rx0, ry0, rx1, ry1);
                 }
                 uint64_t live = __ballot(keep);
                 // n_touched only counts pixels whose transmittance is still above 1/2: once no pixel of the quadrant
@@ -142,7 +144,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendParams p) {
                     const int jj = c0 + jb;
                     live = mask_clear_bit(live, jb);
                     const float4 A = s_a[jj];
-                    const float4 B = s_b[jj];
+                    const float2 B = *reinterpret_cast<const float2 *>(&s_b[jj]);
                     const float dx = A.x - pxe, dy = A.y - pyf;
                     const float pw2 = fmaf(dx, fmaf(A.z, dx, A.w * dy), B.x * dy * dy);  // log2 of the falloff (backward repeats this exactly)
                     const float alpha = fminf(ALPHA_MAX, B.y * __builtin_amdgcn_exp2f(pw2));
@@ -155,7 +157,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendParams p) {
                     const float4 Cc = s_c[jj];
                     const float w = hit ? alpha * T : 0.f;
                     C0 = fmaf(Cc.x, w, C0); C1 = fmaf(Cc.y, w, C1); C2 = fmaf(Cc.z, w, C2);
-                    Dp = fmaf(B.z, w, Dp);
+                    Dp = fmaf(Cc.w, w, Dp);
                     T = hit ? test_T : T;
                     last = hit ? (uint32_t)(base + jj + 1) : last;
                     if (wave_touching) {
@@ -559,6 +561,224 @@ __global__ void __launch_bounds__(256, 4) blend_bwd2_kernel(BlendParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Third form of the backward pass: the two passes above with the per-entry control flow taken out.
+//
+// At 4-5 waves per SIMD the pixel pass is bound by the LENGTH of one wave's instruction stream per entry, not by any
+// pipe (tools/scalar_rec.hip: a 32-instruction dependent stream with its record from LDS runs at 80 cycles per entry
+// per SIMD; the pixel pass of blend_bwd2 needed 137): per entry it spent ~21 scalar instructions, four branches and an
+// EXEC save/restore on `if (hit)`, "any lane hit?", the batch counter and the two loop exits.  Here a batch is the next
+// NB SURVIVORS of the quadrant test (hit or not), so its size is known before it starts: full batches are straight-line
+// code (no branch, no counter, slot offsets immediate), the lanes that miss go through the same arithmetic with
+// alpha = G = 0 (T, R unchanged, (u, w) = 0 -- same values as before for every lane), and the compiler is free to
+// start an entry's reads and exponent while the previous entry's T/R chain finishes.
+// The splat pass takes the pixel's coordinates and image gradients from the lane that owns the pixel inside the
+// instruction that uses them (DPP row_ror:s on the subtract / multiply-add), instead of rotating two registers per step
+// and reading the four gradients from LDS: no per-step moves, half the LDS reads, 4 KB less LDS (5 workgroups per CU).
+template <int S>
+__device__ __forceinline__ float sub_rotated(float a, float p) {  // a - (p of lane (i - S) mod 16 of the row)
+    if constexpr (S == 0) return a - p;
+    float d;
+    asm("v_subrev_f32_dpp %0, %1, %2 row_ror:%3 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(p), "v"(a), "n"(S));
+    return d;
+}
+template <int S>
+__device__ __forceinline__ float fma_rotated(float g, float w, float acc) {  // acc + (g of lane (i - S) mod 16) * w
+    if constexpr (S == 0) return fmaf(g, w, acc);
+    asm("v_fmac_f32_dpp %0, %1, %2 row_ror:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(g), "v"(w), "n"(S));
+    return acc;
+}
+
+struct Bwd3Shared {
+    static constexpr int NB = 8;
+    float4 a[BR];                        // x, y, a, b
+    float4 b[BR];                        // -c/2*log2e, opacity, depth, -a/2*log2e
+    float4 c[BR];                        // r, g, b, -b*log2e
+    float craw[BR];                      // c
+    uint32_t slot[BR];
+    float acc[4][BR * ACC_STRIDE];       // per wave: Sx Sy Sxx Sxy Syy Su C0 C1 C2 CD of every entry it accumulated
+    unsigned long long mask[4];
+    uint32_t wmax[4];
+    float2 M[4][NB][64];                 // per wave: (u, w) of [batch slot][pixel]
+    uint32_t bj[4][NB];                  // per wave: entry (position in the round) of every batch slot
+};
+
+__global__ void __launch_bounds__(256, 5) blend_bwd3_kernel(BlendParams p) {
+    constexpr int NB = Bwd3Shared::NB;
+    __shared__ Bwd3Shared sh;
+
+    const int tile = tile_of_workgroup(blockIdx.x, p.num_tiles);
+    const int tx = tile % p.gx, ty = tile / p.gx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool inside = px < p.W && py < p.H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float rx0 = (float)qx0, ry0 = (float)qy0, rx1 = (float)(qx0 + 7), ry1 = (float)(qy0 + 7);
+    const size_t pix = (size_t)py * p.W + px, P = (size_t)p.W * p.H;
+
+    const uint2 range = p.ranges[tile];
+    const float T_final = inside ? p.final_T[pix] : 0.f;
+    const uint32_t my_last = inside ? p.n_contrib[pix] : 0u;
+    float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gD = 0.f, gO = 0.f;
+    if (inside) {
+        gC0 = p.dL_dcolor[pix]; gC1 = p.dL_dcolor[P + pix]; gC2 = p.dL_dcolor[2 * P + pix];
+        if (p.dL_ddepth) gD = p.dL_ddepth[pix];
+        if (p.dL_dopacity) gO = p.dL_dopacity[pix];
+    }
+    const float tail = T_final * (p.bg[0] * gC0 + p.bg[1] * gC1 + p.bg[2] * gC2 - gO);
+
+    uint32_t m = my_last;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+    if (lane == 0) sh.wmax[wave] = m;
+    const int wave_last = (int)m;
+    __syncthreads();
+    const int depth_max = (int)max(max(sh.wmax[0], sh.wmax[1]), max(sh.wmax[2], sh.wmax[3]));
+    const int todo = (int)(range.y - range.x);
+
+    float T = T_final, R = tail;  // see the single-pass kernel for the scalar recurrence
+    // splat pass: this lane's slot in the batch and its 16-lane row; at step s it looks at the pixel of lane (col - s) mod 16
+    const int row = lane >> 4, col = lane & 15;
+    const int my_slot = col & (NB - 1);
+    const float2 *Mrow = &sh.M[wave][my_slot][row * 16];
+    float2 *const Mmine = &sh.M[wave][0][lane];
+
+    const int rounds = (todo + BR - 1) / BR;
+    for (int r = rounds - 1; r >= 0; r--) {
+        const int base = r * BR;
+        const int cnt = min(BR, todo - base);
+        if (tid < cnt) {
+            const uint32_t id = p.point_list[range.x + base + tid];
+            const float4 *r4 = reinterpret_cast<const float4 *>(p.rec + (size_t)id * REC_FLOATS);
+            const float4 r0 = r4[0], r1 = r4[1], r2 = r4[2];
+            sh.a[tid] = r0;
+            sh.b[tid] = make_float4(-0.5f * LOG2E * r1.x, r1.y, r2.y, -0.5f * LOG2E * r0.z);
+            sh.c[tid] = make_float4(r1.z, r1.w, r2.x, -LOG2E * r0.w);
+            sh.craw[tid] = r1.x;
+            const int rad = __float_as_int(r2.w);
+            int x0 = (int)((r0.x - (float)rad) / (float)TILE), y0 = (int)((r0.y - (float)rad) / (float)TILE);
+            int x1 = (int)((r0.x + (float)rad + (float)(TILE - 1)) / (float)TILE);
+            x0 = min(p.gx, max(0, x0)); x1 = min(p.gx, max(0, x1)); y0 = min(p.gy, max(0, y0));
+            sh.slot[tid] = p.slot_base[id] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+        }
+        __syncthreads();
+        uint64_t wrote = 0ull;
+        if (base < depth_max) {
+            bool keep = false;
+            if (lane < cnt && base + lane < wave_last) {
+                const float4 A = sh.a[lane];
+                keep = reaches_rect(A.x, A.y, A.z, A.w, sh.craw[lane], sh.b[lane].y, rx0, ry0, rx1, ry1);
+            }
+            uint64_t live = __ballot(keep);
+            const uint32_t rel_last = my_last > (uint32_t)base ? my_last - (uint32_t)base : 0u;  // entries below this position composited
+            wrote = live;
+            while (live) {
+                // ---------------- pixel pass: the next NB survivors, back to front ----------------
+                const uint64_t before = live;
+                const int nb = min(NB, (int)__popcll(live));
+                auto entry = [&](auto slot) {
+                    const int j = 63 - __builtin_clzll(live);
+                    live = mask_clear_bit(live, j);
+                    const float4 A = sh.a[j];
+                    const float4 B = sh.b[j];
+                    const float4 Cc = sh.c[j];
+                    const float dx = A.x - pxf, dy = A.y - pyf;
+                    // the same expression, operand for operand, as the forward pass: identical hit set
+                    const float pw2 = fmaf(dx, fmaf(B.w, dx, Cc.w * dy), B.x * dy * dy);
+                    const float G = __builtin_amdgcn_exp2f(pw2);
+                    const float alpha = fminf(ALPHA_MAX, B.y * G);
+                    const bool hit = ((uint32_t)j < rel_last) && (pw2 <= 0.f) && (alpha >= ALPHA_MIN);
+                    // lanes that miss run the same arithmetic with alpha = G = 0: 1 / (1 - 0) is exactly 1, so T and R
+                    // keep their values and (u, w) = (0, 0)
+                    const float alpha_h = hit ? alpha : 0.f, G_h = hit ? G : 0.f;
+                    const float k = fmaf(B.z, gD, fmaf(Cc.z, gC2, fmaf(Cc.y, gC1, Cc.x * gC0)));
+                    const float inv = __builtin_amdgcn_rcpf(1.f - alpha_h);
+                    T *= inv;
+                    const float w = alpha_h * T;
+                    const float dL_dalpha = fmaf(k, T, -(R * inv));
+                    R = fmaf(k, w, R);
+                    Mmine[(int)slot * 64] = make_float2(G_h * dL_dalpha, w);
+                };
+                if (nb == NB) {
+                    entry(std::integral_constant<int, 0>{}); entry(std::integral_constant<int, 1>{});
+                    entry(std::integral_constant<int, 2>{}); entry(std::integral_constant<int, 3>{});
+                    entry(std::integral_constant<int, 4>{}); entry(std::integral_constant<int, 5>{});
+                    entry(std::integral_constant<int, 6>{}); entry(std::integral_constant<int, 7>{});
+                } else {
+                    for (int s = 0; s < nb; s++) entry(s);
+                }
+                const uint64_t batch = before ^ live;
+                // slot table: the entry at bit position `lane` of the batch was given slot = number of batch bits above it
+                if ((batch >> lane) & 1ull) sh.bj[wave][__popcll(batch >> lane) - 1] = (uint32_t)lane;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // ---------------- splat pass: lane -> (slot, 8 pixels of its row) ----------------
+                const bool valid = my_slot < nb;
+                const int jj = valid ? (int)sh.bj[wave][my_slot] : 0;
+                const float2 Aj = *reinterpret_cast<const float2 *>(&sh.a[jj]);
+                float Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Su = 0.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, CD = 0.f;
+#define LVDGS_SPLAT_STEP(S)                                                                          \
+                {                                                                                    \
+                    const float2 uw = Mrow[(col - S) & 15];                                          \
+                    const float dx = sub_rotated<S>(Aj.x, pxf), dy = sub_rotated<S>(Aj.y, pyf);      \
+                    const float t1 = uw.x * dx, t2 = uw.x * dy;                                      \
+                    Sx += t1; Sy += t2;                                                              \
+                    Sxx = fmaf(t1, dx, Sxx); Sxy = fmaf(t1, dy, Sxy); Syy = fmaf(t2, dy, Syy);       \
+                    Su += uw.x;                                                                      \
+                    C0 = fma_rotated<S>(gC0, uw.y, C0); C1 = fma_rotated<S>(gC1, uw.y, C1);          \
+                    C2 = fma_rotated<S>(gC2, uw.y, C2); CD = fma_rotated<S>(gD, uw.y, CD);           \
+                }
+                LVDGS_SPLAT_STEP(0) LVDGS_SPLAT_STEP(1) LVDGS_SPLAT_STEP(2) LVDGS_SPLAT_STEP(3)
+                LVDGS_SPLAT_STEP(4) LVDGS_SPLAT_STEP(5) LVDGS_SPLAT_STEP(6) LVDGS_SPLAT_STEP(7)
+#undef LVDGS_SPLAT_STEP
+                // fold the 8 partial sums of every slot: rows first (two pairwise folds, ten registers -> three) ...
+                float q0 = fold16(fold32(Sx, Sy), fold32(Sxx, Sxy));   // rows: Sx Sxx Sy Sxy
+                float q1 = fold16(fold32(Syy, Su), fold32(C0, C1));    // rows: Syy C0 Su C1
+                float q2 = fold16(fold32(C2, CD), C1);                  // rows: C2 x CD x
+                q0 += row_rotate<8>(q0);  // ... then the two half-rows that share a slot
+                q1 += row_rotate<8>(q1);
+                q2 += row_rotate<8>(q2);
+                if (valid && col < NB) {
+                    // value index held by this row: q0 -> {Sx, Sxx, Sy, Sxy}, q1 -> {Syy, C0, Su, C1}, q2 -> {C2, -, CD, -}
+                    const int i0 = row == 0 ? 0 : (row == 1 ? 2 : (row == 2 ? 1 : 3));
+                    const int i1 = row == 0 ? 4 : (row == 1 ? 6 : (row == 2 ? 5 : 7));
+                    float *o = &sh.acc[wave][jj * ACC_STRIDE];
+                    o[i0] = q0; o[i1] = q1;
+                    if ((row & 1) == 0) o[row == 0 ? 8 : 9] = q2;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (lane == 0) sh.mask[wave] = wrote;
+        __syncthreads();
+        if (tid < cnt) {
+            float acc[ACC_STRIDE];
+#pragma unroll
+            for (int k = 0; k < ACC_STRIDE; k++) acc[k] = 0.f;
+            const unsigned long long bit = 1ull << tid;
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+                if (sh.mask[w] & bit) {
+                    const float2 *o = reinterpret_cast<const float2 *>(&sh.acc[w][tid * ACC_STRIDE]);
+#pragma unroll
+                    for (int k = 0; k < 5; k++) { const float2 t = o[k]; acc[2 * k] += t.x; acc[2 * k + 1] += t.y; }
+                }
+            // acc: Sx Sy Sxx Sxy Syy Su C0 C1 C2 CD (sums of u, not yet of h = opacity * u)
+            const float4 A = sh.a[tid];
+            const float op = sh.b[tid].y;
+            const float sx = op * acc[0], sy = op * acc[1];
+            float4 *dst = reinterpret_cast<float4 *>(p.pair_grads + (size_t)sh.slot[tid] * PAIR_FLOATS);
+            dst[0] = make_float4(-fmaf(A.z, sx, A.w * sy), -fmaf(sh.craw[tid], sy, A.w * sx), -0.5f * (op * acc[2]), -(op * acc[3]));
+            dst[1] = make_float4(-0.5f * (op * acc[4]), acc[5], acc[6], acc[7]);
+            dst[2] = make_float4(acc[8], acc[9], 0.f, 0.f);
+        }
+        __syncthreads();
+    }
+}
+
 BlendParams make_params(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im) {
     BlendParams p{};
     p.W = a.image_width; p.H = a.image_height;
@@ -587,8 +807,8 @@ int launch_blend_fwd(const lvdgs_args &a, const GeomView &g, const BinView &b, c
 static int blend_bwd_variant() {
     static const int v = [] {
         const char *e = getenv("LVDGS_BLEND_BWD");
-        const int x = e ? atoi(e) : 2;
-        return (x >= 1 && x <= 2) ? x : 2;
+        const int x = e ? atoi(e) : 3;
+        return (x >= 1 && x <= 3) ? x : 3;
     }();
     return v;
 }
@@ -601,7 +821,8 @@ int launch_blend_bwd(const lvdgs_args &a, const GeomView &g, const BinView &b, c
     ProfScope ps("blend_bwd", s);
     switch (blend_bwd_variant()) {
         case 1: hipLaunchKernelGGL(blend_bwd_kernel, dim3(p.num_tiles), dim3(256), 0, s, p); break;
-        default: hipLaunchKernelGGL(blend_bwd2_kernel<8>, dim3(p.num_tiles), dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL(blend_bwd2_kernel<8>, dim3(p.num_tiles), dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL(blend_bwd3_kernel, dim3(p.num_tiles), dim3(256), 0, s, p); break;
     }
     LVDGS_LAUNCH_CHECK("blend_bwd", a.debug, s);
     return LVDGS_OK;
