@@ -45,12 +45,20 @@ struct BlendParams {
     float *pair_grads;
 };
 
-// Workgroup -> tile.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), so
-// give every XCD one contiguous run of row-major tiles: neighbouring tiles share most of their
-// Gaussians and then find each other's record lines in the same 4 MiB L2.  Bijective for any count.
+// Workgroup -> tile.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one) and an XCD takes its
+// workgroups in order.  Runs of TILE_RUN row-major tiles go to the XCDs in turn: neighbouring tiles share most of their
+// Gaussians and find each other's record lines in the same 4 MiB L2, while every XCD sees every part of the image (one
+// contiguous run per XCD gave the XCD holding the densest image rows 1.5 x its share of the work at KITTI's 1226x370;
+// tools/tile_schedule_model.py).  Bijective for any count: whole groups of 8 runs are permuted, the rest is identity.
+#ifndef LVDGS_TILE_RUN
+#define LVDGS_TILE_RUN 16
+#endif
+constexpr int TILE_RUN = LVDGS_TILE_RUN;
 __device__ __forceinline__ int tile_of_workgroup(int b, int n) {
-    const int xcd = b & 7, k = b >> 3, q = n >> 3, r = n & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    const int grouped = n - n % (8 * TILE_RUN);
+    if (b >= grouped) return b;
+    const int xcd = b & 7, k = b >> 3;
+    return ((k / TILE_RUN) * 8 + xcd) * TILE_RUN + k % TILE_RUN;
 }
 
 // Can a Gaussian (mean m, conic a,b,c, opacity op) reach alpha >= 1/255 anywhere in the pixel
@@ -677,12 +685,15 @@ __global__ void __launch_bounds__(256, 5) blend_bwd3_kernel(BlendParams p) {
                 // ---------------- pixel pass: the next NB survivors, back to front ----------------
                 const uint64_t before = live;
                 const int nb = min(NB, (int)__popcll(live));
-                auto entry = [&](auto slot) {
+                struct Rec { float4 A, B, Cc; };
+                auto next_entry = [&]() {
                     const int j = 63 - __builtin_clzll(live);
                     live = mask_clear_bit(live, j);
-                    const float4 A = sh.a[j];
-                    const float4 B = sh.b[j];
-                    const float4 Cc = sh.c[j];
+                    return j;
+                };
+                auto fetch = [&](int j) { return Rec{sh.a[j], sh.b[j], sh.c[j]}; };
+                auto entry = [&](auto slot, int j, const Rec &rc) {
+                    const float4 A = rc.A, B = rc.B, Cc = rc.Cc;
                     const float dx = A.x - pxf, dy = A.y - pyf;
                     // the same expression, operand for operand, as the forward pass: identical hit set
                     const float pw2 = fmaf(dx, fmaf(B.w, dx, Cc.w * dy), B.x * dy * dy);
@@ -701,12 +712,24 @@ __global__ void __launch_bounds__(256, 5) blend_bwd3_kernel(BlendParams p) {
                     Mmine[(int)slot * 64] = make_float2(G_h * dL_dalpha, w);
                 };
                 if (nb == NB) {
-                    entry(std::integral_constant<int, 0>{}); entry(std::integral_constant<int, 1>{});
-                    entry(std::integral_constant<int, 2>{}); entry(std::integral_constant<int, 3>{});
-                    entry(std::integral_constant<int, 4>{}); entry(std::integral_constant<int, 5>{});
-                    entry(std::integral_constant<int, 6>{}); entry(std::integral_constant<int, 7>{});
+                    // straight-line; the records of entries s + 1 and s + 2 are on their way while entry s is evaluated
+                    int js[NB];
+#pragma unroll
+                    for (int s = 0; s < NB; s++) js[s] = next_entry();
+                    Rec r0 = fetch(js[0]), r1 = fetch(js[1]), r2 = fetch(js[2]);
+                    entry(std::integral_constant<int, 0>{}, js[0], r0); r0 = fetch(js[3]);
+                    entry(std::integral_constant<int, 1>{}, js[1], r1); r1 = fetch(js[4]);
+                    entry(std::integral_constant<int, 2>{}, js[2], r2); r2 = fetch(js[5]);
+                    entry(std::integral_constant<int, 3>{}, js[3], r0); r0 = fetch(js[6]);
+                    entry(std::integral_constant<int, 4>{}, js[4], r1); r1 = fetch(js[7]);
+                    entry(std::integral_constant<int, 5>{}, js[5], r2);
+                    entry(std::integral_constant<int, 6>{}, js[6], r0);
+                    entry(std::integral_constant<int, 7>{}, js[7], r1);
                 } else {
-                    for (int s = 0; s < nb; s++) entry(s);
+                    for (int s = 0; s < nb; s++) {
+                        const int j = next_entry();
+                        entry(s, j, fetch(j));
+                    }
                 }
                 const uint64_t batch = before ^ live;
                 // slot table: the entry at bit position `lane` of the batch was given slot = number of batch bits above it
@@ -719,9 +742,14 @@ __global__ void __launch_bounds__(256, 5) blend_bwd3_kernel(BlendParams p) {
                 const int jj = valid ? (int)sh.bj[wave][my_slot] : 0;
                 const float2 Aj = *reinterpret_cast<const float2 *>(&sh.a[jj]);
                 float Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Su = 0.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, CD = 0.f;
+                // all eight (u, w) reads go out first: their addresses are known, and at 5 waves per SIMD a read issued
+                // one step ahead is still on its way when it is needed
+                float2 uw8[8];
+#pragma unroll
+                for (int s8 = 0; s8 < 8; s8++) uw8[s8] = Mrow[(col - s8) & 15];
 #define LVDGS_SPLAT_STEP(S)                                                                          \
                 {                                                                                    \
-                    const float2 uw = Mrow[(col - S) & 15];                                          \
+                    const float2 uw = uw8[S];                                                        \
                     const float dx = sub_rotated<S>(Aj.x, pxf), dy = sub_rotated<S>(Aj.y, pyf);      \
                     const float t1 = uw.x * dx, t2 = uw.x * dy;                                      \
                     Sx += t1; Sy += t2;                                                              \

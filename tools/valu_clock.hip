@@ -19,6 +19,7 @@ template <int MODE>
 __global__ void __launch_bounds__(256) k(float *out, unsigned long long *stamps, int iters) {
     float a0 = threadIdx.x + 1.f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
     const float m = 1.0001f, c = 0.5f;
+    unsigned s0 = blockIdx.x, s1 = 3, s2 = 1, s3 = 0xff;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int i = 0; i < iters; i++) {
         if (MODE == 0) {
@@ -40,8 +41,23 @@ __global__ void __launch_bounds__(256) k(float *out, unsigned long long *stamps,
 #define S(n) "v_mov_b32_dpp %" #n ", %" #n " wave_ror:1 row_mask:0xf bank_mask:0xf\n"
             asm volatile(REP8(S) OPERANDS);
 #undef S
+        } else if (MODE >= 5 && MODE <= 7) {  // scalar instructions beside (5: four, 6: eight) or instead of (7) the eight v_fma_f32
+#define S(n) "v_fma_f32 %" #n ", %" #n ", %8, %9\n"
+            if (MODE != 7) asm volatile(REP8(S) OPERANDS);
+#undef S
+            asm volatile("s_add_u32 %0, %0, 1\n s_xor_b32 %1, %1, 5\n s_lshl_b32 %2, %2, 1\n s_and_b32 %3, %3, 7\n" : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");
+            if (MODE != 5) asm volatile("s_add_u32 %0, %0, 1\n s_xor_b32 %1, %1, 5\n s_lshl_b32 %2, %2, 1\n s_and_b32 %3, %3, 7\n" : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");
+        } else if (MODE == 8) {  // two taken branches beside the eight v_fma_f32
+#define S(n) "v_fma_f32 %" #n ", %" #n ", %8, %9\n"
+            asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n s_branch 1f\n s_nop 0\n 1:\n"
+                         "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n s_branch 2f\n s_nop 0\n 2:\n" OPERANDS);
+#undef S
+        } else if (MODE == 9) {  // a compare, its mask combined on the scalar unit, and a select, four times (the blend loops' hit tests)
+            asm volatile("v_cmp_lt_f32 vcc, %0, %8\n s_and_b64 vcc, vcc, exec\n v_cndmask_b32 %1, %1, %0, vcc\n v_cmp_lt_f32 vcc, %2, %8\n s_and_b64 vcc, vcc, exec\n v_cndmask_b32 %3, %3, %2, vcc\n"
+                         "v_cmp_lt_f32 vcc, %4, %8\n s_and_b64 vcc, vcc, exec\n v_cndmask_b32 %5, %5, %4, vcc\n v_cmp_lt_f32 vcc, %6, %8\n s_and_b64 vcc, vcc, exec\n v_cndmask_b32 %7, %7, %6, vcc\n" OPERANDS : "vcc", "scc");
         }
     }
+    out[0] = (float)(s0 + s1 + s2 + s3);
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
     if ((threadIdx.x & 63) == 0) {
@@ -80,6 +96,13 @@ int main(int argc, char **argv) {
     run<2>("v_add_f32_dpp row_shr", out, stamps, 8, iters);
     run<3>("blend-like mix", out, stamps, 8, iters);
     run<4>("v_mov_dpp wave_ror:1", out, stamps, 8, iters);
+    for (int wps : {4, 8}) {
+        run<5>("8 v_fma + 4 scalar", out, stamps, wps, iters);
+        run<6>("8 v_fma + 8 scalar", out, stamps, wps, iters);
+        run<7>("8 scalar only", out, stamps, wps, iters);
+        run<8>("8 v_fma + 2 taken branches", out, stamps, wps, iters);
+        run<9>("4 x (cmp, s_and, cndmask)", out, stamps, wps, iters);
+    }
     run<0>("v_fma_f32 (short)", out, stamps, 8, 20000);  // the 1.7 ms launch tools/instr_cost.hip times
     return 0;
 }
