@@ -7,8 +7,9 @@ the window's keyframes (<= 8, ``Training.window_size``) plus two random older on
 path is what ``tests/golden/map_loop.npz`` (produced by running the reference's own ``BackEnd.map``) pins.
 
 Per iteration and rank:
-  1. render + loss of the rank's own views (HIP rasterizer, fused losses), the isotropic regulariser on rank 0
-     (:303-305), ONE backward;
+  1. render + loss + backward of the rank's own views -- three C-ABI calls per view on the GPU (fast_mapping.MapViewPass:
+     no autograd engine, gradients written where autograd would have put them), the autograd path for views with a
+     static mask and off the GPU -- and the isotropic regulariser on rank 0 (:303-305);
   2. ONE float32 SUM all-reduce (RCCL) of a flat bucket
         [ Gaussian parameter gradients (N x 14 at SH degree 0) | pose / exposure gradients of the window keyframes
           | sum over views of the screen-space gradient norms (N) | visibility counts (N) | loss ]
@@ -31,6 +32,7 @@ import torch.distributed as dist
 
 from . import _lib
 
+from .fast_mapping import MapViewPass
 from .gaussian_renderer import render
 from .loss_utils import masked_mapping_loss
 from .pose_utils import update_pose
@@ -190,6 +192,14 @@ class KeyframeStepper:
                 keep += [R, T]
                 a.R, a.T, a.cam_rot_delta, a.cam_trans_delta = _P(R), _P(T), _P(vp.cam_rot_delta), _P(vp.cam_trans_delta)
                 a.lr_rot, a.lr_trans = lr_of[id(vp.cam_rot_delta)][0], lr_of[id(vp.cam_trans_delta)][0]
+                # the launch also leaves the matrices the next render reads (Camera._matrices: getWorld2View2, a bmm and
+                # torch.inverse -- whose error check waits for the GPU -- per keyframe and iteration otherwise)
+                if hasattr(vp, "_derived_key") and torch.is_tensor(getattr(vp, "projection_matrix", None)):
+                    P = vp.projection_matrix
+                    Pc = P.detach().to(device=dev, dtype=torch.float32).contiguous()
+                    view, full, centre = (torch.empty(4, 4, device=dev), torch.empty(4, 4, device=dev), torch.empty(3, device=dev))
+                    a.projmatrix_raw, a.viewmatrix, a.projmatrix, a.campos = _P(Pc), _P(view), _P(full), _P(centre)
+                    keep += [P, Pc, view, full, centre]
             if has["exposure_a"]:
                 a.exposure_a, a.lr_exposure = _P(vp.exposure_a), lr_of[id(vp.exposure_a)][0]
             if has["exposure_b"]:
@@ -233,7 +243,13 @@ class KeyframeStepper:
             with _lib.on_device(dev):
                 _lib.check(L.lvdgs_pose_step(C.byref(a), _lib.raw_stream(dev)), "lvdgs_pose_step")
             if pose and hasattr(vp, "_derived_key"):
-                vp._derived_key = None   # R / T were advanced in place: the camera's cached matrices are stale
+                # R / T were advanced in place (their version counters did not move): install the matrices the launch
+                # wrote as the camera's cache for exactly these tensors, or drop the stale cache
+                if len(keep) > 3 and vp.projection_matrix is keep[3]:
+                    R, T, P = keep[1], keep[2], keep[3]
+                    vp._derived, vp._derived_key = (keep[5], keep[6], keep[7]), (R, R._version, T, T._version, P, P._version)
+                else:
+                    vp._derived_key = None
 
 
 class _ViewStats:
@@ -347,9 +363,15 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
         owners = assign_views(n_window, len(picks), world, backend.iteration_count)
         mine = [i for i, o in enumerate(owners) if o == rank]
 
-        loss_mapping = 0
+        loss_mapping = 0      # views that go through autograd (a graph)
+        loss_direct = None    # views rendered, scored and differentiated by MapViewPass (values only)
         pkgs = {}
+        vpass = _view_pass(backend) if (fused and render_fn is render and view_loss_fn is view_loss) else None
         for i in mine:
+            if vpass is not None and MapViewPass.usable(backend, views[i]):
+                pkgs[i], l = vpass.run(backend, views[i])
+                loss_direct = l if loss_direct is None else loss_direct + l
+                continue
             pkg = render_fn(views[i], G, backend.pipeline_params, backend.background)
             pkgs[i] = pkg
             if i < n_window:
@@ -362,12 +384,15 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
             loss_mapping = loss_mapping + _isotropic_term(G)
         if torch.is_tensor(loss_mapping):
             loss_mapping.backward()
+            loss_mapping = loss_mapping.detach()
+        if loss_direct is not None:
+            loss_mapping = loss_mapping + loss_direct
         if fuse_iso:
             iso = _isotropic_fused(G)
             if iso is None:          # not the standard model after all: the autograd statement
                 iso = _isotropic_term(G)
                 iso.backward()
-            loss_mapping = (loss_mapping.detach() if torch.is_tensor(loss_mapping) else 0) + iso.detach()
+            loss_mapping = loss_mapping + iso.detach()
 
         with torch.no_grad():
             N = G.get_xyz.shape[0]
@@ -476,6 +501,21 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
                         continue
                     update_pose(viewpoint)
     return gaussian_split
+
+
+def _view_pass(backend):
+    """The back end's MapViewPass (its buffers live as long as the back end); None off the GPU."""
+    dev = backend.gaussians.get_xyz.device
+    if dev.type != "cuda":
+        return None
+    vp = getattr(backend, "_lvdgs_view_pass", None)
+    if vp is None or vp.dev != dev:
+        vp = MapViewPass(dev)
+        try:
+            backend._lvdgs_view_pass = vp
+        except Exception:
+            pass
+    return vp
 
 
 def _keyframe_stepper(backend, viewpoint_stack, pose_window):

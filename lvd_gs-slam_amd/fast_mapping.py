@@ -1,0 +1,223 @@
+"""One mapping view without the autograd engine: ``MapViewPass``.
+
+Per window keyframe the reference's mapping iteration (utils/slam_backend.py:175-266) does
+
+    render(viewpoint, gaussians, ...)  ->  get_loss_mapping(...)  ->  (summed over the views)  loss.backward()
+
+Through PyTorch that is two ``autograd.Function`` round trips per view, the concatenation of the SH features, the
+engine's thread hand-over and a dozen accumulation kernels: ~0.3 ms of host time per view, which is what bounds a
+mapping iteration once the kernels are fast (one view per GPU in the sharded window, ten on a single GPU).
+
+The pass does the same arithmetic as three calls into the C ABI on argument blocks and buffers that live as long as the
+back end:
+
+    lvdgs_forward -> lvdgs_photometric_loss_value_and_grad -> lvdgs_backward
+
+with the activations fused into the rasterizer (``lvdgs_args.activations``), so ``lvdgs_backward`` writes the gradients
+w.r.t. the model's RAW parameters: they go straight into the ``.grad`` fields autograd would have filled (the first view
+of an iteration writes them, later views are added with one ``_foreach_add_``), the pose / exposure gradients into the
+viewpoint's ``cam_rot_delta.grad`` ... ``exposure_b.grad``.  Views with a static mask (L1 + SSIM, masked depth) and
+models with non-standard activations keep the autograd path (``usable``).
+"""
+import ctypes as C
+import math
+from types import SimpleNamespace
+
+import torch
+
+from . import _lib
+from . import rasterizer as _rz
+from .gaussian_renderer import _raw_parameters
+from .slam_utils import _gt_image, _mono_depth
+
+_P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+_PARAM_FIELDS = ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")
+_VIEW_FIELDS = ("cam_rot_delta", "cam_trans_delta", "exposure_a", "exposure_b")
+
+
+def _gpu_f32c(t, dev):
+    return torch.is_tensor(t) and t.device == dev and t.dtype is torch.float32 and t.is_contiguous()
+
+
+class MapViewPass:
+    """Buffers and argument blocks for render + ``get_loss_mapping`` + backward of one view; re-pointed at every call
+    (the model's tensors are replaced by densification, the viewpoint changes from call to call)."""
+
+    def __init__(self, device):
+        if device.type != "cuda":
+            raise _lib.LvdgsError("MapViewPass needs the map on the GPU (there is no CPU path)")
+        self.dev = device
+        self.L = _lib.lib()
+        self.a, self.la = _lib.Args(), _lib.LossArgs()
+        self.N = self.W = self.H = -1
+        self.cap = 0
+        self.one = torch.ones((), dtype=torch.float32, device=device)
+        self._keep = []
+
+    # ---- eligibility -------------------------------------------------------------------------------------------------
+    @staticmethod
+    def usable(backend, viewpoint) -> bool:
+        G = backend.gaussians
+        dev = G.get_xyz.device
+        pp = backend.pipeline_params
+        if dev.type != "cuda" or getattr(pp, "compute_cov3D_python", False) or getattr(pp, "convert_SHs_python", False):
+            return False
+        if getattr(viewpoint, "static_mask", None) is not None or _raw_parameters(G) is None:
+            return False
+        if not all(_gpu_f32c(getattr(G, n, None), dev) and getattr(G, n).requires_grad for n in _PARAM_FIELDS):
+            return False
+        if G._features_dc.dim() != 3 or G._features_dc.shape[1] != 1 or G._opacity.numel() != G._xyz.shape[0]:
+            return False
+        return all(_gpu_f32c(getattr(viewpoint, n, None), dev) for n in _VIEW_FIELDS)
+
+    # ---- buffers -----------------------------------------------------------------------------------------------------
+    def _bytes(self, n):
+        return torch.empty(max(int(n), 256), dtype=torch.uint8, device=self.dev)
+
+    def _size_for_model(self, N, K):
+        e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=self.dev)
+        self.N, self.K = N, K
+        self.geom = self._bytes(self.L.lvdgs_geom_bytes(N))
+        # two sets of gradient buffers: `first` becomes the parameters' .grad, `more` receives the later views
+        mk = lambda: dict(_xyz=e(N, 3), _features_dc=e(N, 1, 3), _features_rest=e(N, K - 1, 3), _scaling=e(N, 3),
+                          _rotation=e(N, 4), _opacity=e(N, 1), sh=(e(N, K, 3) if K > 1 else None))
+        self.first, self.more = mk(), mk()
+        self.shs = e(N, K, 3) if K > 1 else None
+        a = self.a
+        a.num_gaussians, a.sh_coeffs = N, K
+        a.geom_state, a.geom_bytes = _P(self.geom), self.geom.numel()
+        self._size_for_pairs(max(self.cap, _rz._MIN_PAIR_CAPACITY, _rz._PAIRS_PER_GAUSSIAN_GUESS * N, 1))
+
+    def _size_for_image(self, W, H):
+        e = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.dev)
+        self.W, self.H = W, H
+        self.image = self._bytes(self.L.lvdgs_image_bytes(W, H))
+        self.d_image, self.d_depth = e(3, H, W), e(1, H, W)
+        self.loss_scratch = self._bytes(self.L.lvdgs_loss_scratch_bytes(W, H))
+        a, la = self.a, self.la
+        a.image_height, a.image_width = H, W
+        a.image_state, a.image_bytes = _P(self.image), self.image.numel()
+        a.dL_dout_color, a.dL_dout_opacity = _P(self.d_image), None
+        la.width, la.height = W, H
+        la.scratch, la.scratch_bytes, la.grad_loss = _P(self.loss_scratch), self.loss_scratch.numel(), _P(self.one)
+        la.d_image, la.d_opacity, la.opacity, la.grad_mask = _P(self.d_image), None, None, None
+        la.weight_by_opacity = la.depth_needs_opaque = 0
+        if self.N >= 0:
+            self._size_for_pairs(self.cap)
+
+    def _size_for_pairs(self, pairs):
+        L, a = self.L, self.a
+        self.cap = int(pairs)
+        self.binning = self._bytes(L.lvdgs_binning_bytes(self.cap))
+        need = max(L.lvdgs_prepare_scratch_bytes(self.N), L.lvdgs_backward_scratch_bytes(self.N, self.cap),
+                   L.lvdgs_render_scratch_bytes(self.N, self.cap, self.W, self.H) if self.W > 0 else 0)
+        self.scratch = self._bytes(need)
+        a.pair_capacity = self.cap
+        a.binning_state, a.binning_bytes = _P(self.binning), self.binning.numel()
+        a.scratch, a.scratch_bytes = _P(self.scratch), self.scratch.numel()
+
+    # ---- one view ----------------------------------------------------------------------------------------------------
+    def run(self, backend, viewpoint, initialization=False):
+        """Render ``viewpoint``, evaluate ``get_loss_mapping`` and add its gradients to the model's and the viewpoint's
+        ``.grad`` fields.  Returns the render package (fresh tensors, ``viewspace_points`` carries ``.grad``) and the
+        loss (0-dim tensor)."""
+        G, cfg, dev, L = backend.gaussians, backend.config, self.dev, self.L
+        T = cfg["Training"]
+        N, K = int(G._xyz.shape[0]), 1 + int(G._features_rest.shape[1])
+        H, W = int(viewpoint.image_height), int(viewpoint.image_width)
+        if N != self.N or K != getattr(self, "K", -1):
+            self._size_for_model(N, K)
+        if (W, H) != (self.W, self.H):
+            self._size_for_image(W, H)
+        a, la = self.a, self.la
+        e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=dev)
+        keep = self._keep = []
+        f32c = lambda t: t.detach() if _gpu_f32c(t, dev) else t.detach().to(device=dev, dtype=torch.float32).contiguous()
+
+        # ---- inputs ----
+        a.tanfovx, a.tanfovy = math.tan(viewpoint.FoVx * 0.5), math.tan(viewpoint.FoVy * 0.5)
+        a.scale_modifier, a.sh_degree, a.prefiltered, a.debug = 1.0, int(G.active_sh_degree), 0, 0
+        cam = [f32c(t) for t in (backend.background, viewpoint.world_view_transform, viewpoint.full_proj_transform,
+                                 viewpoint.projection_matrix, viewpoint.camera_center)]
+        keep += cam
+        a.bg, a.viewmatrix, a.projmatrix, a.projmatrix_raw, a.campos = (_P(t) for t in cam)
+        a.activations = _rz.ACT_EXP_SCALES | _rz.ACT_NORMALIZE_ROTATIONS | _rz.ACT_SIGMOID_OPACITIES
+        if K > 1:
+            torch.cat((G._features_dc.detach(), G._features_rest.detach()), dim=1, out=self.shs)
+            shs = self.shs
+        else:
+            shs = G._features_dc.detach()
+        a.means3D, a.opacities, a.scales, a.rotations, a.shs = _P(G._xyz), _P(G._opacity), _P(G._scaling), _P(G._rotation), _P(shs)
+        color, depth, opacity = e(3, H, W), e(1, H, W), e(1, H, W)
+        radii, n_touched = e(N, dt=torch.int32), e(N, dt=torch.int32)
+        a.radii, a.n_touched, a.out_color, a.out_depth, a.out_opacity = _P(radii), _P(n_touched), _P(color), _P(depth), _P(opacity)
+
+        # ---- where the gradients go ----
+        # (an empty _features_rest -- SH degree 0 -- gets no gradient from autograd either)
+        fields = [n for n in _PARAM_FIELDS if getattr(G, n).numel() > 0]
+        has = [getattr(G, n).grad is not None for n in fields]
+        if any(has) and not all(has):
+            raise _lib.LvdgsError("MapViewPass: some of the model's parameters carry a gradient and some do not")
+        into = self.more if has[0] else self.first
+        if has[0] and any(not _gpu_f32c(getattr(G, n).grad, dev) for n in fields):
+            raise _lib.LvdgsError("MapViewPass: the model's existing gradients are not contiguous float32 tensors on the GPU")
+        d_sh = into["sh"] if K > 1 else into["_features_dc"]
+        a.dL_dmeans3D, a.dL_dopacities, a.dL_dscales = _P(into["_xyz"]), _P(into["_opacity"]), _P(into["_scaling"])
+        a.dL_drotations, a.dL_dshs = _P(into["_rotation"]), _P(d_sh)
+        d_tau, d_a, d_b, d_m2 = e(6), e(1), e(1), e(N, 3)
+        a.dL_dtau, a.dL_dmeans2D = _P(d_tau), _P(d_m2)
+
+        # ---- get_loss_mapping (reference utils/slam_utils.py:82-121) ----
+        # (monodepth=True at every call site of the mapping loop, so the loss is the rgb-d one whatever Training.monocular says)
+        gt = f32c(_gt_image(viewpoint, color))
+        keep.append(gt)
+        la.image, la.gt_image = _P(color), _P(gt)
+        la.rgb_boundary_threshold = float(T["rgb_boundary_threshold"])
+        if initialization:
+            la.exposure_a = la.exposure_b = la.d_exposure_a = la.d_exposure_b = None
+        else:
+            la.exposure_a, la.exposure_b, la.d_exposure_a, la.d_exposure_b = _P(viewpoint.exposure_a), _P(viewpoint.exposure_b), _P(d_a), _P(d_b)
+        alpha = T.get("alpha", 0.95)
+        md = f32c(_mono_depth(viewpoint, color))
+        keep.append(md)
+        la.depth, la.gt_depth, la.d_depth = _P(depth), _P(md), _P(self.d_depth)
+        la.weight_rgb, la.weight_depth = float(alpha), float(1 - alpha)
+        a.dL_dout_depth = _P(self.d_depth)
+        loss = e(())
+        la.loss = _P(loss)
+
+        with _lib.on_device(dev):
+            stream = _lib.raw_stream(dev)
+            num = C.c_int64(0)
+            status = L.lvdgs_forward(C.byref(a), C.byref(num), stream)
+            D = int(num.value)
+            if status == _lib.E_CAPACITY:   # more pairs than the buffers hold: grow them and redo binning + blend
+                self._size_for_pairs(D + D // 2)
+                a.num_rendered = D
+                _lib.check(L.lvdgs_forward_render(C.byref(a), stream), "lvdgs_forward_render")
+            else:
+                _lib.check(status, "lvdgs_forward")
+            a.num_rendered = D
+            _lib.check(L.lvdgs_photometric_loss_value_and_grad(C.byref(la), stream), "lvdgs_photometric_loss_value_and_grad")
+            _lib.check(L.lvdgs_backward(C.byref(a), stream), "lvdgs_backward")
+
+        # ---- hand the gradients over exactly where autograd would have put them ----
+        if K > 1:
+            into["_features_dc"].copy_(d_sh[:, :1])
+            into["_features_rest"].copy_(d_sh[:, 1:])
+        if has[0]:
+            torch._foreach_add_([getattr(G, n).grad for n in fields], [into[n] for n in fields])
+        else:
+            for n in fields:
+                getattr(G, n).grad = into[n]
+        pose = (("cam_trans_delta", d_tau[:3]), ("cam_rot_delta", d_tau[3:]))
+        expo = () if initialization else (("exposure_a", d_a), ("exposure_b", d_b))
+        for name, g in pose + expo:
+            p = getattr(viewpoint, name)
+            if p.requires_grad:
+                g = g.view_as(p)
+                p.grad = g if p.grad is None else p.grad + g
+        vsp = SimpleNamespace(grad=d_m2)   # stands in for the leaf autograd would have filled: only .grad is read
+        pkg = {"render": color, "viewspace_points": vsp, "visibility_filter": radii > 0, "radii": radii, "depth": depth,
+               "opacity": opacity, "n_touched": n_touched}
+        return pkg, loss

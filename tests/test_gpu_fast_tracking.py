@@ -241,3 +241,76 @@ def test_map_window_with_fused_steps_equals_the_pytorch_statements():
         np.testing.assert_array_equal(a["occ"][kf], b["occ"][kf])
     # the three keyframes of the pose window were retracted (deltas zero), the others never moved
     assert all(not d.any() for d in a["deltas"])
+
+
+def test_map_view_pass_equals_render_loss_backward_through_autograd():
+    """fast_mapping.MapViewPass.run against render() -> get_loss_mapping() -> backward() on the same view: the loss, the
+    images, the gradients of the six parameter tensors, of the pose deltas and of the exposure, and the screen-space
+    gradient -- first as the only view (gradients assigned), then as a second view (gradients added)."""
+    sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
+    import test_loop_golden as tl
+    from loop_scene import build_scene, loop_config
+    from lvdgs.fast_mapping import MapViewPass
+    from lvdgs.gaussian_renderer import render
+    from lvdgs.slam_utils import get_loss_mapping
+    cfg = loop_config()
+    torch.manual_seed(3)
+    sc = build_scene("cuda")
+    be = tl._backend(sc, cfg)
+    G = be.gaussians
+    cams = sc["cameras"]
+    names = ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")
+    view_names = ("cam_rot_delta", "cam_trans_delta", "exposure_a", "exposure_b")
+
+    def grad_of(c, n):
+        g = getattr(c, n).grad
+        return None if g is None else g.clone()
+
+    def clear():
+        for n in names:
+            getattr(G, n).grad = None
+        for c in cams:
+            for n in view_names:
+                getattr(c, n).grad = None
+
+    def through_autograd(views):
+        clear()
+        loss, pkgs = 0, []
+        for c in views:
+            pkg = render(c, G, be.pipeline_params, be.background)
+            loss = loss + get_loss_mapping(cfg, pkg["render"], c, depth=pkg["depth"], monodepth=True)
+            pkgs.append(pkg)
+        loss.backward()
+        return (float(loss.detach()), [grad_of(G, n) for n in names],
+                [[grad_of(c, n) for n in view_names] for c in views], pkgs)
+
+    def through_pass(views):
+        clear()
+        assert all(MapViewPass.usable(be, c) for c in views)
+        vp, loss, pkgs = MapViewPass(torch.device("cuda", torch.cuda.current_device())), 0.0, []
+        for c in views:
+            pkg, l = vp.run(be, c)
+            loss = loss + float(l)
+            pkgs.append(pkg)
+        return (loss, [grad_of(G, n) for n in names],
+                [[grad_of(c, n) for n in view_names] for c in views], pkgs)
+
+    for views in ([cams[1]], [cams[1], cams[2]]):
+        la, ga, va, pa = through_autograd(views)
+        lb, gb, vb, pb = through_pass(views)
+        assert abs(la - lb) <= 1e-6 * abs(la)
+        for n, x, y in zip(names, ga, gb):
+            assert (x is None) == (y is None), n
+            if x is not None:
+                assert x.shape == y.shape, n
+                # one view: the same kernels on the same inputs; two views: a sum of two terms in the other order
+                torch.testing.assert_close(y, x, rtol=0 if len(views) == 1 else 1e-6, atol=0 if len(views) == 1 else 1e-9, msg=n)
+        for xs, ys in zip(va, vb):
+            for n, x, y in zip(view_names, xs, ys):
+                assert (x is None) == (y is None), n   # a parameter autograd leaves without a gradient stays without one
+                if x is not None:
+                    torch.testing.assert_close(y, x, rtol=0, atol=0, msg=n)
+        for p, q in zip(pa, pb):
+            for k in ("render", "depth", "opacity", "radii", "n_touched"):
+                assert torch.equal(p[k], q[k]), k
+            assert torch.equal(p["viewspace_points"].grad, q["viewspace_points"].grad)
