@@ -207,7 +207,12 @@ def main():
     for _ in range(max(args.warmup, 1)):
         radii = step()
     sync()
-    stats["D"] = int(session.num_rendered) if session is not None else int(rasterizer._DEBUG_LAST.get("num_rendered", 0))
+    if session is not None:
+        stats["D"] = int(session.num_rendered)
+    elif backend is not None and getattr(backend, "_lvdgs_view_pass", None) is not None:
+        stats["D"] = int(backend._lvdgs_view_pass.a.num_rendered)   # the mapping views bypass the autograd rasterizer
+    else:
+        stats["D"] = int(rasterizer._DEBUG_LAST.get("num_rendered", 0))
     stats["V"] = int((radii > 0).sum().item()) if radii is not None else int((backend.gaussians.max_radii2D > 0).sum().item())
     rasterizer.KEEP_DEBUG_STATE = False
     rasterizer._DEBUG_LAST.clear()
