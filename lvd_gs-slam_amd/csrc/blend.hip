@@ -195,6 +195,117 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) blend_fwd2_kernel(BlendParams p) {
+    // one shared object, so that the three reads of a survivor share one address register; laid out so that they are
+    // a 16-, an 8- and a 16-byte read (4 + 2 + 4 LDS cycles per wave; a 12-byte read alone costs 8)
+    __shared__ struct { float4 a[256], b[256], c[256]; float d[256]; } s_recs;
+    float4 *const s_a = s_recs.a;  // x, y, -a/2*log2e, -b*log2e
+    float4 *const s_b = s_recs.b;  // -c/2*log2e, opacity | raw conic a, b (for the quadrant test; survivors read the first half only)
+    float4 *const s_c = s_recs.c;  // r, g, b, depth
+    float *const s_d = s_recs.d;   // raw conic c
+    __shared__ int s_touch[256]; // pixels of this tile each staged Gaussian "touched" (T after it > 0.5)
+
+    const int tile = tile_of_workgroup(blockIdx.x, p.num_tiles);
+    const int tx = tile % p.gx, ty = tile / p.gx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;
+    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+    const bool inside = px < p.W && py < p.H;
+    const float pxf = (float)px, pyf = (float)py;
+    const float rx0 = (float)qx0, ry0 = (float)qy0, rx1 = (float)(qx0 + 7), ry1 = (float)(qy0 + 7);
+
+    const uint2 range = p.ranges[tile];
+    const int todo = (int)(range.y - range.x);
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
+    uint32_t last = 0;
+    // A finished pixel (transmittance below 1e-4, or outside the image) is moved to x = 1e30: every later Gaussian
+    // then evaluates to alpha = 0 there and fails the 1/255 test by itself, so the per-Gaussian code carries no
+    // "done" mask (that mask cost five scalar instructions per Gaussian, on a scalar unit shared by four SIMDs).
+    constexpr float FAR_AWAY = 1e30f;
+    float pxe = inside ? pxf : FAR_AWAY;
+
+    for (int base = 0; base < todo; base += 256) {
+        const bool done = pxe == FAR_AWAY;
+        if (__syncthreads_and(done)) break;
+        const int cnt = min(256, todo - base);
+        uint32_t my_id = 0;
+        if (tid < cnt) {
+            my_id = p.point_list[range.x + base + tid];
+            const float4 *r4 = reinterpret_cast<const float4 *>(p.rec + (size_t)my_id * REC_FLOATS);
+            const float4 r0 = r4[0], r1 = r4[1], r2 = r4[2];
+            s_a[tid] = make_float4(r0.x, r0.y, -0.5f * LOG2E * r0.z, -LOG2E * r0.w);
+            s_b[tid] = make_float4(-0.5f * LOG2E * r1.x, r1.y, r0.z, r0.w);
+            s_c[tid] = make_float4(r1.z, r1.w, r2.x, r2.y);
+            s_d[tid] = r1.x;
+        }
+        s_touch[tid] = 0;
+        __syncthreads();
+        if (__ballot(!done) != 0ull) {
+            for (int c0 = 0; c0 < cnt; c0 += 64) {
+                // ---- lane -> Gaussian: which of these 64 can touch this wave's quadrant? ----
+                const int jl = c0 + lane;
+                bool keep = false;
+                if (jl < cnt) {
+                    const float4 A = s_a[jl];
+                    const float4 B = s_b[jl];
+                    keep = reaches_rect(A.x, A.y, B.z, B.w, s_d[jl], B.y, rx0, ry0, rx1, ry1);
+                }
+                uint64_t live = __ballot(keep);
+                // n_touched only counts pixels whose transmittance is still above 1/2: once no pixel of the quadrant
+                // is (transmittance never grows), the rest of the list skips that bookkeeping
+                const bool wave_touching = __ballot(T > T_TOUCH && pxe != FAR_AWAY) != 0ull;
+                // ---- lane -> pixel: composite the survivors in list order ----
+                while (live) {
+                    const int jb = __builtin_ctzll(live);
+                    const int jj = c0 + jb;
+                    live = mask_clear_bit(live, jb);
+                    const float4 A = s_a[jj];
+                    const float2 B = *reinterpret_cast<const float2 *>(&s_b[jj]);
+                    const float dx = A.x - pxe, dy = A.y - pyf;
+                    const float pw2 = fmaf(dx, fmaf(A.z, dx, A.w * dy), B.x * dy * dy);  // log2 of the falloff (backward repeats this exactly)
+                    const float alpha = fminf(ALPHA_MAX, B.y * __builtin_amdgcn_exp2f(pw2));
+                    const bool hit = (pw2 <= 0.f) && (alpha >= ALPHA_MIN);
+                    // the lanes that hit run the rest under EXEC (no selects); nobody hit: the branch skips it
+                    if (hit) {
+                        const float test_T = T * (1.f - alpha);
+                        if (test_T < T_STOP) {
+                            pxe = FAR_AWAY;
+                        } else {
+                            const float4 Cc = s_c[jj];
+                            const float w = alpha * T;
+                            C0 = fmaf(Cc.x, w, C0); C1 = fmaf(Cc.y, w, C1); C2 = fmaf(Cc.z, w, C2);
+                            Dp = fmaf(Cc.w, w, Dp);
+                            T = test_T;
+                            last = (uint32_t)(base + jj + 1);
+                            if (wave_touching) {
+                                const uint64_t touched = __ballot(test_T > T_TOUCH);
+                                if (touched != 0ull && lane == (int)__builtin_ctzll(touched)) atomicAdd(&s_touch[jj], (int)__popcll(touched));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // one integer atomic per (tile, Gaussian) that touched anything
+        if (tid < cnt) {
+            const int n = s_touch[tid];
+            if (n) atomicAdd(&p.n_touched[my_id], n);
+        }
+    }
+    if (inside) {
+        const size_t pix = (size_t)py * p.W + px, P = (size_t)p.W * p.H;
+        p.final_T[pix] = T;
+        p.n_contrib[pix] = last;
+        p.out_color[pix] = fmaf(T, p.bg[0], C0);
+        p.out_color[P + pix] = fmaf(T, p.bg[1], C1);
+        p.out_color[2 * P + pix] = fmaf(T, p.bg[2], C2);
+        p.out_depth[pix] = Dp;
+        p.out_opacity[pix] = 1.f - T;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 constexpr int ACC_STRIDE = 10;  // floats per (wave, entry) accumulator slot
 constexpr int BR = 64;          // list entries staged per round in the backward pass
 
@@ -820,34 +931,34 @@ BlendParams make_params(const lvdgs_args &a, const GeomView &g, const BinView &b
 
 }  // namespace
 
+// LVDGS_BLEND_FWD / LVDGS_BLEND_BWD select other forms of the kernels for A/B measurements in one process tree.
+static int blend_variant(const char *name, int count, int dflt) {
+    const char *e = getenv(name);
+    const int x = e ? atoi(e) : dflt;
+    return (x >= 1 && x <= count) ? x : dflt;
+}
+
 int launch_blend_fwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, hipStream_t s) {
     BlendParams p = make_params(a, g, b, im);
     if (p.num_tiles == 0) return LVDGS_OK;
     ProfScope ps("blend_fwd", s);
-    hipLaunchKernelGGL(blend_fwd_kernel, dim3(p.num_tiles), dim3(256), 0, s, p);
+    static const int variant = blend_variant("LVDGS_BLEND_FWD", 2, 1);
+    if (variant == 2) hipLaunchKernelGGL(blend_fwd2_kernel, dim3(p.num_tiles), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(blend_fwd_kernel, dim3(p.num_tiles), dim3(256), 0, s, p);
     LVDGS_LAUNCH_CHECK("blend_fwd", a.debug, s);
     return LVDGS_OK;
 }
 
-// LVDGS_BLEND_BWD selects the backward kernel: "2" two passes with batches of 8 (default), "1" the single-pass kernel
-// (kept for A/B measurements in one process tree; batches of 16 were measured too: 50 KB LDS, 3 waves/SIMD, 437 us).
-// Read once per process.
-static int blend_bwd_variant() {
-    static const int v = [] {
-        const char *e = getenv("LVDGS_BLEND_BWD");
-        const int x = e ? atoi(e) : 3;
-        return (x >= 1 && x <= 3) ? x : 3;
-    }();
-    return v;
-}
-
+// LVDGS_BLEND_BWD: "3" two passes with straight-line batches of 8 survivors (default), "2" two passes with per-entry
+// control flow, "1" the single-pass kernel (batches of 16 were measured too: 50 KB LDS, 3 waves/SIMD, 437 us).
 int launch_blend_bwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, const BwdScratch &w,
                      hipStream_t s) {
     BlendParams p = make_params(a, g, b, im);
     p.pair_grads = w.pair_grads;
     if (p.num_tiles == 0) return LVDGS_OK;
     ProfScope ps("blend_bwd", s);
-    switch (blend_bwd_variant()) {
+    static const int variant = blend_variant("LVDGS_BLEND_BWD", 3, 3);  // read once per process
+    switch (variant) {
         case 1: hipLaunchKernelGGL(blend_bwd_kernel, dim3(p.num_tiles), dim3(256), 0, s, p); break;
         case 2: hipLaunchKernelGGL(blend_bwd2_kernel<8>, dim3(p.num_tiles), dim3(256), 0, s, p); break;
         default: hipLaunchKernelGGL(blend_bwd3_kernel, dim3(p.num_tiles), dim3(256), 0, s, p); break;
