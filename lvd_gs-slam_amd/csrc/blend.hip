@@ -195,6 +195,58 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// One survivor of the quadrant test against the wave's 64 pixels, hand-scheduled: the hit lanes run the compositing
+// under EXEC instead of through selects (the compiler's form of the same statements is 31 vector + 17 scalar
+// instructions per survivor; this one 25 + 8, and both pipes are what blend_fwd is bound by).  Arithmetic, operand for
+// operand, as in blend_fwd_kernel.  Returns the number of pixels with transmittance still above 1/2 after this Gaussian.
+__device__ __forceinline__ int composite_one(const float4 A, const float2 B, const float4 Cc, float &pxe, const float pyf, float &T,
+                                             float &C0, float &C1, float &C2, float &Dp, uint32_t &last, const uint32_t index,
+                                             const float far_away) {
+    float dx, dy, t, u, a, tt;
+    unsigned long long saved, m;
+    int n;
+    asm("v_sub_f32 %[dx], %[ax], %[pxe]\n\t"
+        "v_sub_f32 %[dy], %[ay], %[pyf]\n\t"
+        "v_mul_f32 %[t], %[ab], %[dy]\n\t"                  // kb * dy
+        "v_mul_f32 %[u], %[bc], %[dy]\n\t"                  // kc * dy
+        "v_fmac_f32 %[t], %[aa], %[dx]\n\t"                 // ka * dx + kb * dy
+        "v_mul_f32 %[u], %[u], %[dy]\n\t"                   // (kc * dy) * dy
+        "v_fmac_f32 %[u], %[dx], %[t]\n\t"                  // log2 of the falloff
+        "v_exp_f32 %[t], %[u]\n\t"
+        "s_mov_b32 %[n], 0\n\t"
+        "v_cmp_ge_f32 vcc, 0, %[u]\n\t"
+        "v_mul_f32 %[a], %[op], %[t]\n\t"
+        "v_min_f32 %[a], %[amax], %[a]\n\t"
+        "v_cmp_le_f32 %[m], %[amin], %[a]\n\t"
+        "s_and_b64 vcc, vcc, %[m]\n\t"
+        "s_and_saveexec_b64 %[saved], vcc\n\t"               // EXEC = lanes that hit
+        "s_cbranch_execz 1f\n\t"
+        "v_sub_f32 %[t], 1.0, %[a]\n\t"
+        "v_mul_f32 %[tt], %[T], %[t]\n\t"                   // transmittance behind this Gaussian
+        "v_cmp_gt_f32 vcc, %[tstop], %[tt]\n\t"             // ... below 1e-4: the pixel is finished, this Gaussian not composited
+        "v_cndmask_b32 %[pxe], %[pxe], %[far], vcc\n\t"
+        "s_andn2_b64 exec, exec, vcc\n\t"
+        "v_mul_f32 %[t], %[a], %[T]\n\t"                    // weight
+        "v_fmac_f32 %[C0], %[cr], %[t]\n\t"
+        "v_fmac_f32 %[C1], %[cg], %[t]\n\t"
+        "v_fmac_f32 %[C2], %[cb], %[t]\n\t"
+        "v_fmac_f32 %[Dp], %[cd], %[t]\n\t"
+        "v_mov_b32 %[T], %[tt]\n\t"
+        "v_mov_b32 %[last], %[index]\n\t"
+        "v_cmp_lt_f32 vcc, 0.5, %[tt]\n\t"
+        "s_bcnt1_i32_b64 %[n], vcc\n"
+        "1:\n\t"
+        "s_mov_b64 exec, %[saved]"
+        : [dx] "=&v"(dx), [dy] "=&v"(dy), [t] "=&v"(t), [u] "=&v"(u), [a] "=&v"(a), [tt] "=&v"(tt), [saved] "=&s"(saved), [m] "=&s"(m),
+          [n] "=&s"(n), [pxe] "+v"(pxe), [T] "+v"(T), [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2), [Dp] "+v"(Dp), [last] "+v"(last)
+        : [ax] "v"(A.x), [ay] "v"(A.y), [aa] "v"(A.z), [ab] "v"(A.w), [bc] "v"(B.x), [op] "v"(B.y), [cr] "v"(Cc.x), [cg] "v"(Cc.y),
+          [cb] "v"(Cc.z), [cd] "v"(Cc.w), [pyf] "v"(pyf), [far] "v"(far_away), [index] "s"(index), [amax] "s"(ALPHA_MAX),
+          [amin] "s"(ALPHA_MIN), [tstop] "s"(T_STOP)
+        : "vcc", "scc");
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) blend_fwd2_kernel(BlendParams p) {
     // one shared object, so that the three reads of a survivor share one address register; laid out so that they are
     // a 16-, an 8- and a 16-byte read (4 + 2 + 4 LDS cycles per wave; a 12-byte read alone costs 8)
@@ -223,6 +275,7 @@ __global__ void __launch_bounds__(256) blend_fwd2_kernel(BlendParams p) {
     // "done" mask (that mask cost five scalar instructions per Gaussian, on a scalar unit shared by four SIMDs).
     constexpr float FAR_AWAY = 1e30f;
     float pxe = inside ? pxf : FAR_AWAY;
+    const float far_away = FAR_AWAY;
 
     for (int base = 0; base < todo; base += 256) {
         const bool done = pxe == FAR_AWAY;
@@ -251,39 +304,19 @@ __global__ void __launch_bounds__(256) blend_fwd2_kernel(BlendParams p) {
                     keep = reaches_rect(A.x, A.y, B.z, B.w, s_d[jl], B.y, rx0, ry0, rx1, ry1);
                 }
                 uint64_t live = __ballot(keep);
-                // n_touched only counts pixels whose transmittance is still above 1/2: once no pixel of the quadrant
-                // is (transmittance never grows), the rest of the list skips that bookkeeping
-                const bool wave_touching = __ballot(T > T_TOUCH && pxe != FAR_AWAY) != 0ull;
                 // ---- lane -> pixel: composite the survivors in list order ----
+                int vcnt = 0;  // lane -> staged Gaussian c0 + lane: pixels of this quadrant it "touched"
                 while (live) {
                     const int jb = __builtin_ctzll(live);
                     const int jj = c0 + jb;
                     live = mask_clear_bit(live, jb);
                     const float4 A = s_a[jj];
                     const float2 B = *reinterpret_cast<const float2 *>(&s_b[jj]);
-                    const float dx = A.x - pxe, dy = A.y - pyf;
-                    const float pw2 = fmaf(dx, fmaf(A.z, dx, A.w * dy), B.x * dy * dy);  // log2 of the falloff (backward repeats this exactly)
-                    const float alpha = fminf(ALPHA_MAX, B.y * __builtin_amdgcn_exp2f(pw2));
-                    const bool hit = (pw2 <= 0.f) && (alpha >= ALPHA_MIN);
-                    // the lanes that hit run the rest under EXEC (no selects); nobody hit: the branch skips it
-                    if (hit) {
-                        const float test_T = T * (1.f - alpha);
-                        if (test_T < T_STOP) {
-                            pxe = FAR_AWAY;
-                        } else {
-                            const float4 Cc = s_c[jj];
-                            const float w = alpha * T;
-                            C0 = fmaf(Cc.x, w, C0); C1 = fmaf(Cc.y, w, C1); C2 = fmaf(Cc.z, w, C2);
-                            Dp = fmaf(Cc.w, w, Dp);
-                            T = test_T;
-                            last = (uint32_t)(base + jj + 1);
-                            if (wave_touching) {
-                                const uint64_t touched = __ballot(test_T > T_TOUCH);
-                                if (touched != 0ull && lane == (int)__builtin_ctzll(touched)) atomicAdd(&s_touch[jj], (int)__popcll(touched));
-                            }
-                        }
-                    }
+                    const float4 Cc = s_c[jj];
+                    const int n = composite_one(A, B, Cc, pxe, pyf, T, C0, C1, C2, Dp, last, (uint32_t)(base + jj + 1), far_away);
+                    vcnt = write_lane(vcnt, n, jb);  // 0 by itself once no pixel of the quadrant has transmittance above 1/2
                 }
+                if (vcnt) atomicAdd(&s_touch[c0 + lane], vcnt);
             }
         }
         __syncthreads();
@@ -942,9 +975,10 @@ int launch_blend_fwd(const lvdgs_args &a, const GeomView &g, const BinView &b, c
     BlendParams p = make_params(a, g, b, im);
     if (p.num_tiles == 0) return LVDGS_OK;
     ProfScope ps("blend_fwd", s);
-    static const int variant = blend_variant("LVDGS_BLEND_FWD", 2, 1);
-    if (variant == 2) hipLaunchKernelGGL(blend_fwd2_kernel, dim3(p.num_tiles), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(blend_fwd_kernel, dim3(p.num_tiles), dim3(256), 0, s, p);
+    // LVDGS_BLEND_FWD: "2" the survivor step hand-scheduled under EXEC (default), "1" the compiler's form of the same statements
+    static const int variant = blend_variant("LVDGS_BLEND_FWD", 2, 2);
+    if (variant == 1) hipLaunchKernelGGL(blend_fwd_kernel, dim3(p.num_tiles), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(blend_fwd2_kernel, dim3(p.num_tiles), dim3(256), 0, s, p);
     LVDGS_LAUNCH_CHECK("blend_fwd", a.debug, s);
     return LVDGS_OK;
 }

@@ -74,6 +74,12 @@ __device__ __forceinline__ uint64_t mask_set_bit(uint64_t m, int bit) {
     return m;
 }
 
+// v with lane `lane` (wave-uniform) replaced by the wave-uniform value x (v_writelane_b32; clang has no builtin for
+// it, the intrinsic is reached by name; the compiler puts the lane select into M0 itself, as gfx9's one-SGPR-per-
+// instruction rule demands).
+extern "C" __device__ int lvdgs_writelane_i32(int x, int lane, int v) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ int write_lane(int v, int x, int lane) { return lvdgs_writelane_i32(x, lane, v); }
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 }  // namespace lvdgs
