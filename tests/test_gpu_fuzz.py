@@ -26,8 +26,19 @@ def _case(rng):
 
 @pytest.mark.parametrize("case_seed", list(range(int(os.environ.get("LVDGS_FUZZ_CASES", "24")))))  # more: set the variable
 def test_random_scene_matches_oracle(case_seed):
+    _check_case(_case(np.random.default_rng(1000 + case_seed)))
+
+
+@pytest.mark.parametrize("opacity_scale", [0.02, 1.0])
+def test_wide_faint_gaussians_keep_every_quadrant_busy(opacity_scale):
+    """Footprints of 25-70 px on a 112 x 90 image: every tile's list is long and nearly every entry reaches every 8 x 8
+    quadrant, so the backward pass's rounds exceed the per-wave accumulator slots and take the two-half path
+    (csrc/blend.hip, ACC_CAP); faint ones (nothing saturates, the lists are walked to the end) and opaque ones."""
+    _check_case(dict(N=700, W=112, H=90, r_min=25.0, r_max=70.0, z_min=1.0, z_max=10.0, pose=3, opacity_scale=opacity_scale, seed=77))
+
+
+def _check_case(c):
     orc, hr, syn = tp._mods()
-    c = _case(np.random.default_rng(1000 + case_seed))
     g = syn.make_gaussians(c["N"], c["W"], c["H"], seed=c["seed"], r_min=c["r_min"], r_max=c["r_max"], z_min=c["z_min"], z_max=c["z_max"])
     with torch.no_grad():
         g["opacities"].mul_(c["opacity_scale"])
