@@ -32,8 +32,8 @@ def test_random_scene_matches_oracle(case_seed):
 @pytest.mark.parametrize("opacity_scale", [0.02, 1.0])
 def test_wide_faint_gaussians_keep_every_quadrant_busy(opacity_scale):
     """Footprints of 25-70 px on a 112 x 90 image: every tile's list is long and nearly every entry reaches every 8 x 8
-    quadrant, so the backward pass's rounds exceed the per-wave accumulator slots and take the two-half path
-    (csrc/blend.hip, ACC_CAP); faint ones (nothing saturates, the lists are walked to the end) and opaque ones."""
+    quadrant (all 64 entries of a backward round survive the quadrant test, every batch of the splat pass is full) --
+    faint ones (nothing saturates, the lists are walked to the end) and opaque ones (early termination everywhere)."""
     _check_case(dict(N=700, W=112, H=90, r_min=25.0, r_max=70.0, z_min=1.0, z_max=10.0, pose=3, opacity_scale=opacity_scale, seed=77))
 
 
