@@ -140,15 +140,29 @@ __global__ void __launch_bounds__(1024) group_tilescan_kernel(int T, const uint3
         v[k] = t < T ? totals[t] : 0u;
         sum += v[k];
     }
-    s_scan[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const uint32_t x = (int)threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0u;
-        __syncthreads();
-        s_scan[threadIdx.x] += x;
-        __syncthreads();
+    // inclusive scan of the 1024 thread sums: inside every wave by lane shifts, then the 16 wave totals by wave 0
+    // (two barriers; the log-step scan over all 1024 threads it replaces needed twenty)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t x = (uint32_t)__shfl_up((int)inc, off, 64);
+        if (lane >= off) inc += x;
     }
-    uint32_t run = s_scan[threadIdx.x] - sum;
+    if (lane == 63) s_scan[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t w = lane < 16 ? s_scan[lane] : 0u;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            const uint32_t x = (uint32_t)__shfl_up((int)w, off, 64);
+            if (lane >= off) w += x;
+        }
+        if (lane < 16) s_scan[16 + lane] = w;   // inclusive over the waves
+    }
+    __syncthreads();
+    inc += wave ? s_scan[16 + wave - 1] : 0u;
+    uint32_t run = inc - sum;
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         const int t = (int)threadIdx.x * PER + k;

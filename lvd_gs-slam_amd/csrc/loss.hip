@@ -149,19 +149,21 @@ __global__ void __launch_bounds__(LOSS_THREADS) photometric_kernel(LossParams p)
 template <int MODE>
 __global__ void __launch_bounds__(256) photometric_finish_kernel(LossParams p, int nblk) {
     constexpr bool BACKWARD = MODE != 0, VALUE = MODE != 1;
-    __shared__ float s[4][256];
+    __shared__ float s[4][4];   // [value][wave]
     float a[4] = {0.f, 0.f, 0.f, 0.f};
     for (int b = threadIdx.x; b < nblk; b += 256) {
         if (VALUE) { a[0] += p.partial[4 * b]; a[1] += p.partial[4 * b + 1]; }
         if (BACKWARD) { a[2] += p.partial[4 * b + 2]; a[3] += p.partial[4 * b + 3]; }
     }
-    for (int k = 0; k < 4; k++) s[k][threadIdx.x] = a[k];
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st)
-            for (int k = 0; k < 4; k++) s[k][threadIdx.x] += s[k][threadIdx.x + st];
-        __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float v = wave_sum_to_lane63(a[k]);
+        if (lane == 63) s[k][wave] = v;
     }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 4; k++) s[k][0] = ((s[k][0] + s[k][1]) + s[k][2]) + s[k][3];
     if (threadIdx.x == 0) {
         if (VALUE) p.loss[0] = p.w_rgb * (s[0][0] / (3.f * (float)p.P)) + p.w_d * (s[1][0] / (float)p.P);
         if (BACKWARD) {

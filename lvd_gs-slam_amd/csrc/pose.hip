@@ -34,6 +34,13 @@ __device__ void mat3_mul(const float *X, const float *Y, float *Z) {  // row-maj
         for (int j = 0; j < 3; j++) Z[3 * i + j] = X[3 * i] * Y[j] + X[3 * i + 1] * Y[3 + j] + X[3 * i + 2] * Y[6 + j];
 }
 
+__device__ double int_pow(double x, unsigned n) {
+    double r = 1.0;
+    for (; n; n >>= 1, x *= x)
+        if (n & 1u) r *= x;
+    return r;
+}
+
 __device__ float adam_update(float p, float g, float *m, float *v, double lr, double beta1, double beta2, double eps, double bc1, double bc2_sqrt) {
     // torch.optim.Adam, single-tensor path: exp_avg.lerp_(grad, 1 - beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2);
     // denom = (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps); param.addcdiv_(exp_avg, denom, value=-lr / bias_correction1).
@@ -55,8 +62,11 @@ __global__ void pose_step_kernel(PoseStepParams pp) {
     const float step = st[16] + 1.f;
     st[16] = step;
     st[18] = step;
-    const double bc1 = 1.0 - pow(a.beta1, (double)step);
-    const double bc2_sqrt = sqrt(1.0 - pow(a.beta2, (double)step));
+    // beta^step by squaring (the step count is a small integer; the general pow() is several hundred dependent
+    // double-precision instructions on this one thread -- a third of the launch).  It can differ from Python's
+    // beta ** step in the last bits of the double, which the float32 step size and denominator never see.
+    const double bc1 = 1.0 - int_pow(a.beta1, (unsigned)step);
+    const double bc2_sqrt = sqrt(1.0 - int_pow(a.beta2, (unsigned)step));
     // ---- Adam (a parameter without a gradient is skipped, moments included, as torch.optim.Adam does) ----
     const float *g_rot = a.grad_tau ? a.grad_tau + 3 : a.grad_rot, *g_trans = a.grad_tau ? a.grad_tau : a.grad_trans;
     float rot[3] = {0.f, 0.f, 0.f}, trans[3] = {0.f, 0.f, 0.f};

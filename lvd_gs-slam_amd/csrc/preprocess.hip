@@ -538,23 +538,22 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
             ((s_tau[0][threadIdx.x] + s_tau[1][threadIdx.x]) + s_tau[2][threadIdx.x]) + s_tau[3][threadIdx.x];
 }
 
-// fixed-order reduction of the per-workgroup pose partials
+// fixed-order reduction of the per-workgroup pose partials (strided per-thread sums, then a wave fold and a four-term sum:
+// two barriers fewer than an LDS tree, the order of the additions fixed by the code either way)
 __global__ void __launch_bounds__(256) tau_reduce_kernel(const float *part, int nblk, float *out) {
-    __shared__ float s[256][6];
+    __shared__ float s[4][6];
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int b = threadIdx.x; b < nblk; b += 256)
 #pragma unroll
         for (int k = 0; k < 6; k++) acc[k] += part[(size_t)b * 6 + k];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < 6; k++) s[threadIdx.x][k] = acc[k];
-    __syncthreads();
-    for (int stride = 128; stride > 0; stride >>= 1) {
-        if ((int)threadIdx.x < stride)
-#pragma unroll
-            for (int k = 0; k < 6; k++) s[threadIdx.x][k] += s[threadIdx.x + stride][k];
-        __syncthreads();
+    for (int k = 0; k < 6; k++) {
+        const float v = wave_sum_to_lane63(acc[k]);
+        if (lane == 63) s[wave][k] = v;
     }
-    if (threadIdx.x < 6) out[threadIdx.x] = s[0][threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < 6) out[threadIdx.x] = ((s[0][threadIdx.x] + s[1][threadIdx.x]) + s[2][threadIdx.x]) + s[3][threadIdx.x];
 }
 
 __global__ void __launch_bounds__(256) mark_visible_kernel(int N, const float *means3D, const float *view, uint8_t *present) {
