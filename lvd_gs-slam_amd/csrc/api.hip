@@ -168,7 +168,7 @@ size_t image_layout(int W, int H, ImageView *v, void *base) {
     const size_t P = (size_t)W * H, T = (size_t)cdiv(W, TILE) * cdiv(H, TILE);
     carve(v->ranges, T ? T : 1, b, off);
     carve(v->long_count, 64, b, off);  // directly behind ranges: one memset clears both
-    carve(v->long_tiles, 2 * (T ? T : 1), b, off);  // two queues of up to T tile ids
+    carve(v->long_tiles, 2 * (T ? T : 1), b, off);  // queue of up to T tile ids (the second half is unused)
     carve(v->final_T, P ? P : 1, b, off);
     carve(v->n_contrib, P ? P : 1, b, off);
     return off;
@@ -181,6 +181,7 @@ size_t render_scratch_layout(int N, int64_t D, int W, int H, RenderScratch *v, v
     char *b = (char *)base;
     const size_t d = (size_t)(D > 0 ? D : 1);
     const int T = cdiv(W, TILE) * cdiv(H, TILE);
+    carve(v->blocksums, scan_blocks(N), b, off);  // as in prep_scratch_layout: left by preprocess_fwd, read by count_pairs
     carve(v->keys, d, b, off);
     carve(v->vals, d, b, off);
     v->hist = v->totals = v->group_hist = v->group_totals = nullptr;
@@ -289,17 +290,27 @@ int get_probe(PairProbe **out) {
 }
 
 // preprocess -> prefix sum of tiles touched; the pair count ends up in g.total (device)
-int enqueue_prepare(const lvdgs_args *a, const GeomView &g, hipStream_t s) {
+// (slot_scan = false: the counting path's first kernel does the prefix sum, enqueue_render is told so)
+int enqueue_prepare(const lvdgs_args *a, const GeomView &g, bool slot_scan, hipStream_t s) {
     const int N = a->num_gaussians;
     PrepScratch w;
     prep_scratch_layout(N, &w, a->scratch);
     if (int e = launch_preprocess_fwd(*a, g, w.blocksums, s)) return e;
+    if (!slot_scan) return LVDGS_OK;
     return launch_slot_scan(g.tiles_touched, g.slot_base, w.blocksums, g.total, N, a->debug, s);
+}
+
+int enqueue_count_probe(PairProbe *probe, const uint32_t *total, hipStream_t s) {
+    if (int e = check_hip(hipMemcpyAsync(probe->pinned, total, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read pair count")) return e;
+    return check_hip(hipEventRecord(probe->ready, s), "record pair count event");
 }
 
 // pair emission -> grouping by tile -> ranges -> depth order inside each tile -> blend.  `cap` sizes grids and buffers; when `count_on_device`
 // the kernels take the actual pair count from g.total (clamped to cap), otherwise cap IS the count.
-int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipStream_t s) {
+// probe (optional): the pair count is copied to the host as soon as it exists -- after the first grouping kernel when
+// that one makes it (fused_slot_scan), else the caller has done so already.
+int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipStream_t s, bool fused_slot_scan = false,
+                   PairProbe *probe = nullptr) {
     const int N = a->num_gaussians, W = a->image_width, H = a->image_height;
     GeomView g{}; BinView b{}; ImageView im; RenderScratch w{};
     image_layout(W, H, &im, a->image_state);
@@ -318,7 +329,10 @@ int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipSt
         render_scratch_layout(N, cap, W, H, &w, a->scratch);
         if (use_counting_path(num_tiles)) {
             // counting path: no pair list is materialised, the tile ranges fall out of the counts
-            if (int e = launch_group_pairs(*a, g, im, w, (unsigned long long *)w.keys, cap, s)) return e;
+            if (int e = launch_group_count(*a, g, im, w, fused_slot_scan, s)) return e;
+            if (fused_slot_scan && probe)
+                if (int e = enqueue_count_probe(probe, g.total, s)) return e;
+            if (int e = launch_group_scatter(*a, g, im, w, (unsigned long long *)w.keys, cap, s)) return e;
             grouped = true;
         } else {
             if (!w.hist) { set_error("internal: scratch was not laid out for the radix grouping"); return LVDGS_E_INVALID; }
@@ -370,7 +384,7 @@ int lvdgs_forward_prepare(const lvdgs_args *a, int64_t *num_rendered, void *stre
     }
     GeomView g;
     geom_layout(N, &g, a->geom_state);
-    if (int e = enqueue_prepare(a, g, s)) return e;
+    if (int e = enqueue_prepare(a, g, true, s)) return e;
     uint32_t total = 0;
     if (int e = check_hip(hipMemcpyAsync(&total, g.total, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read pair count")) return e;
     if (int e = check_hip(hipStreamSynchronize(s), "synchronize after prepare")) return e;
@@ -410,12 +424,17 @@ int lvdgs_forward(const lvdgs_args *a, int64_t *num_rendered, void *stream) {
     if (int e = get_probe(&probe)) return e;
     GeomView g;
     geom_layout(N, &g, a->geom_state);
-    if (int e = enqueue_prepare(a, g, s)) return e;
-    if (int e = check_hip(hipMemcpyAsync(probe->pinned, g.total, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read pair count")) return e;
-    if (int e = check_hip(hipEventRecord(probe->ready, s), "record pair count event")) return e;
+    // The counting path's first kernel can make the slot prefix sum and the pair count itself: one launch less (config 3:
+    // -5 us per frame), but the host then learns the count one kernel later, and on small frames (KITTI geometry, 200k
+    // Gaussians: 0.34 ms per tracking iteration) it is the host's enqueueing of the rest of the iteration that the GPU
+    // ends up waiting for (+12 us measured).  So only for large maps.
+    const bool fused = N >= (1 << 18) && use_counting_path(cdiv(a->image_width, TILE) * cdiv(a->image_height, TILE));
+    if (int e = enqueue_prepare(a, g, !fused, s)) return e;
+    if (!fused)
+        if (int e = enqueue_count_probe(probe, g.total, s)) return e;
     // Everything after the count is enqueued BEFORE the host waits for it: the GPU keeps working on
     // the tile sort and the blend while the host learns whether the capacity was enough.
-    if (int e = enqueue_render(a, cap, true, s)) return e;
+    if (int e = enqueue_render(a, cap, true, s, fused, probe)) return e;
     if (int e = check_hip(hipEventSynchronize(probe->ready), "wait for pair count")) return e;
     const uint32_t total = *probe->pinned;
     if (total > 0x7FFFFFFFu) { set_error("%u (Gaussian, tile) pairs exceed the 2^31 limit", total); return LVDGS_E_RANGE; }

@@ -75,12 +75,44 @@ __device__ __forceinline__ void for_each_pair_of_chunk(int N, int gx, const uint
     }
 }
 
-// (Also clears what the later kernels of the frame accumulate into: n_touched and the tile-sort queues -- two
-// memset launches less.)
+// Exclusive scan of one value per thread over a workgroup of 1024 threads (wave shifts, then the 16 wave totals by wave
+// 0: two barriers); *total = sum over the workgroup.  s_scan: 33 words.
+__device__ __forceinline__ uint32_t scan_1024(uint32_t v, uint32_t *s_scan, uint32_t *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t x = (uint32_t)__shfl_up((int)inc, off, 64);
+        if (lane >= off) inc += x;
+    }
+    if (lane == 63) s_scan[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t w = lane < 16 ? s_scan[lane] : 0u;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            const uint32_t x = (uint32_t)__shfl_up((int)w, off, 64);
+            if (lane >= off) w += x;
+        }
+        if (lane < 16) s_scan[16 + lane] = w;   // inclusive over the waves
+    }
+    __syncthreads();
+    *total = s_scan[31];
+    return inc - v + (wave ? s_scan[16 + wave - 1] : 0u);
+}
+
+// (Also clears what the later kernels of the frame accumulate into: n_touched and the tile-sort queue -- two memset
+// launches less -- and, when `tt` is given, makes slot_base[i] = exclusive scan of tiles_touched and the pair total from
+// the sums preprocess_fwd left per 256 Gaussians: the launch of the separate slot scan less.  Every workgroup adds up the
+// block sums in front of its chunk -- at most a few thousand values -- and scans its own 4096 Gaussians.)
 __global__ void __launch_bounds__(GROUP_THREADS) count_pairs_kernel(int N, int gx, int T, const uint2 *__restrict__ rect,
                                                                    uint32_t *__restrict__ hist, int32_t *__restrict__ n_touched,
-                                                                   uint32_t *__restrict__ queue_counts) {
+                                                                   uint32_t *__restrict__ queue_counts,
+                                                                   const uint32_t *__restrict__ tt, const uint32_t *__restrict__ blocksums,
+                                                                   uint32_t *__restrict__ slot_base, uint32_t *__restrict__ total_out) {
+    static_assert(GROUP_THREADS == 1024 && GROUP_PER_THREAD == 4, "scan_1024 over one uint4 per thread");
     extern __shared__ uint32_t s_tile[];
+    __shared__ uint32_t s_scan[33];
     for (int t = threadIdx.x; t < T; t += GROUP_THREADS) s_tile[t] = 0u;
 #pragma unroll
     for (int k = 0; k < GROUP_PER_THREAD; k++) {
@@ -88,6 +120,25 @@ __global__ void __launch_bounds__(GROUP_THREADS) count_pairs_kernel(int N, int g
         if (i < N) n_touched[i] = 0;
     }
     if (blockIdx.x == 0 && threadIdx.x < 64) queue_counts[threadIdx.x] = 0u;
+    if (tt) {
+        uint32_t before = 0;
+        for (int b = threadIdx.x; b < (int)blockIdx.x * (GROUP_CHUNK / 256); b += GROUP_THREADS) before += blocksums[b];
+        uint32_t prefix;
+        scan_1024(before, s_scan, &prefix);  // only the total is of interest
+        __syncthreads();                     // s_scan is used again
+        const int base = blockIdx.x * GROUP_CHUNK + (int)threadIdx.x * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = base + k < N ? tt[base + k] : 0u;
+        uint32_t total;
+        uint32_t run = scan_1024(v[0] + v[1] + v[2] + v[3], s_scan, &total) + prefix;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (base + k < N) slot_base[base + k] = run;
+            run += v[k];
+        }
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = prefix + total;
+    }
     __syncthreads();
     for_each_pair_of_chunk(N, gx, rect, [&](int tile, uint32_t) { atomicAdd(&s_tile[tile], 1u); });
     __syncthreads();
@@ -204,22 +255,31 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t *__rest
 int group_max_tiles() { return GROUP_MAX_TILES; }
 size_t group_hist_entries(int N, int num_tiles) { return (size_t)cdiv(N > 0 ? N : 1, GROUP_CHUNK) * (size_t)num_tiles; }
 
-int launch_group_pairs(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, unsigned long long *keys64,
-                       int64_t capacity, hipStream_t s) {
+int launch_group_count(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, bool slot_scan, hipStream_t s) {
     const int N = a.num_gaussians;
     const int gx = (a.image_width + TILE - 1) / TILE, gy = (a.image_height + TILE - 1) / TILE, T = gx * gy;
     if (N == 0 || T == 0) return LVDGS_OK;
     const int nchunks = cdiv(N, GROUP_CHUNK);
     const size_t lds = (size_t)T * sizeof(uint32_t);
-    static unsigned char count_done[16], scatter_done[16];
+    static unsigned char count_done[16];
     if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&count_pairs_kernel), GROUP_MAX_TILES * 4, count_done)) return e;
+    ProfScope ps("group_count", s);
+    hipLaunchKernelGGL(count_pairs_kernel, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint2 *)g.rect, w.group_hist,
+                       a.n_touched, im.long_count, slot_scan ? (const uint32_t *)g.tiles_touched : nullptr,
+                       (const uint32_t *)w.blocksums, g.slot_base, g.total);
+    LVDGS_LAUNCH_CHECK("group_count", a.debug, s);
+    return LVDGS_OK;
+}
+
+int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, unsigned long long *keys64,
+                         int64_t capacity, hipStream_t s) {
+    const int N = a.num_gaussians;
+    const int gx = (a.image_width + TILE - 1) / TILE, gy = (a.image_height + TILE - 1) / TILE, T = gx * gy;
+    if (N == 0 || T == 0) return LVDGS_OK;
+    const int nchunks = cdiv(N, GROUP_CHUNK);
+    const size_t lds = (size_t)T * sizeof(uint32_t);
+    static unsigned char scatter_done[16];
     if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&scatter_pairs_kernel), GROUP_MAX_TILES * 4, scatter_done)) return e;
-    {
-        ProfScope ps("group_count", s);
-        hipLaunchKernelGGL(count_pairs_kernel, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint2 *)g.rect, w.group_hist,
-                           a.n_touched, im.long_count);
-        LVDGS_LAUNCH_CHECK("group_count", a.debug, s);
-    }
     {
         ProfScope ps("group_scan", s);
         hipLaunchKernelGGL(group_colscan_kernel, dim3(cdiv(T, COLSCAN_TILES)), dim3(COLSCAN_TILES * COLSCAN_GROUPS), 0, s, T, nchunks, w.group_hist,

@@ -69,6 +69,7 @@ struct PrepScratch {
     uint32_t *blocksums; // scan block sums
 };
 struct RenderScratch {
+    uint32_t *blocksums; // same place as PrepScratch::blocksums: the counting path's first kernel still reads them
     uint32_t *keys;  // D (alternate tile-key buffer of the radix path; 64-bit keys of over-long tile segments)
     uint32_t *vals;  // D (alternate id buffer)
     uint32_t *hist;         // radix path only
@@ -82,8 +83,8 @@ struct BinView {
 };
 struct ImageView {
     uint2 *ranges;       // T
-    uint32_t *long_count; // 2 (+ padding): lengths of the two queues of over-long segments; zeroed with ranges
-    uint32_t *long_tiles; // 2 T: the queues (tile ids)
+    uint32_t *long_count; // 1 (+ padding): length of the queue of over-long segments; zeroed with ranges
+    uint32_t *long_tiles; // the queue (tile ids; room for 2 T)
     float *final_T;      // P
     uint32_t *n_contrib; // P
 };
@@ -122,8 +123,12 @@ int launch_slot_scan(const uint32_t *tiles_touched, uint32_t *slot_base, uint32_
 // the tile sort makes it canonical.  Only for images of at most group_max_tiles() tiles (LDS counters).
 int group_max_tiles();
 size_t group_hist_entries(int N, int num_tiles);
-int launch_group_pairs(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, unsigned long long *keys64,
-                       int64_t capacity, hipStream_t s);
+// Grouping by counting in two calls, so that the caller can enqueue the read-back of the pair count between them.
+// slot_scan: the first kernel also makes slot_base / the pair total from tiles_touched and w.blocksums (the separate
+// launch_slot_scan is then not needed).
+int launch_group_count(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, bool slot_scan, hipStream_t s);
+int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, unsigned long long *keys64,
+                         int64_t capacity, hipStream_t s);
 int launch_emit_pairs(const lvdgs_args &a, const GeomView &g, uint32_t *tile_keys, uint32_t *ids, int64_t capacity, hipStream_t s);
 // Sorts every tile's segment by (view-depth bits, id) and leaves the ids in point_list.  keys64 holds D 64-bit
 // keys: already filled per segment (counting path, keys_ready), or scratch for over-long segments whose keys are

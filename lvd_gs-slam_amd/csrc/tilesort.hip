@@ -12,10 +12,11 @@
 //      compare-exchanges, strides across lanes one 64-bit lane shuffle per key; no LDS array, no barrier.  This
 //      is the common case by far (a few hundred entries per tile) and ~8x fewer instructions than a
 //      workgroup-wide LDS network, whose threads mostly wait at barriers;
-//   <= 2048 entries: queued, then one 256-thread workgroup per segment on 16 KiB of LDS;
-//   <= 16384 entries: queued again, 1024 threads on 128 KiB of LDS;
+//   <= 16384 entries: queued, then one 1024-thread workgroup per segment on 128 KiB of LDS;
 //   longer: the same network in place on global memory (64-bit key scratch).
-// The queues are filled with one atomic per over-long segment and cleared together with the tile ranges.
+// The queue is filled with one atomic per over-long segment and cleared together with the tile ranges.  (A middle
+// class -- 256 threads on 16 KiB for up to 2048 entries, fed by the first queue and feeding a second -- was one more
+// launch on every frame's critical path, ~6 us whether or not a single segment was that long.)
 #include "common.hpp"
 #include "device_utils.hpp"
 
@@ -176,32 +177,7 @@ __global__ void __launch_bounds__(256) tile_depth_sort_wave_kernel(const uint2 *
     else if (lane == 0) queue[atomicAdd(queue_count, 1u)] = (uint32_t)tile;
 }
 
-constexpr int CLASS_A = 2048, CLASS_B = 16384;
-
-// queued segments up to CLASS_A entries: one workgroup each on LDS; longer ones are queued once more
-__global__ void __launch_bounds__(256) tile_depth_sort_kernel(const uint2 *__restrict__ ranges, KeySource src,
-                                                              uint32_t *__restrict__ point_list, const uint32_t *queue_count,
-                                                              const uint32_t *__restrict__ queue, uint32_t *long_count,
-                                                              uint32_t *__restrict__ long_tiles) {
-    __shared__ u64 s_keys[CLASS_A];
-    const int tid = threadIdx.x;
-    const int count = (int)*queue_count;
-    for (int q = blockIdx.x; q < count; q += gridDim.x) {
-        const uint32_t tile = queue[q];
-        const uint2 r = ranges[tile];
-        const int n = (int)(r.y - r.x);
-        if (n > CLASS_A) {
-            if (tid == 0) long_tiles[atomicAdd(long_count, 1u)] = tile;
-            continue;
-        }
-        for (int i = tid; i < n; i += 256) s_keys[i] = src.load(r.x + i);
-        __syncthreads();
-        bitonic_sort_ascending<false>(s_keys, n, tid, 256);
-        __syncthreads();
-        for (int i = tid; i < n; i += 256) point_list[r.x + i] = (uint32_t)s_keys[i];
-        __syncthreads();
-    }
-}
+constexpr int CLASS_B = 16384;
 
 // queued segments: in 128 KiB of LDS up to CLASS_B entries, in place on global memory beyond
 __global__ void __launch_bounds__(1024) tile_depth_sort_long_kernel(const uint2 *__restrict__ ranges, KeySource src,
@@ -247,18 +223,10 @@ int launch_tile_depth_sort(const ImageView &im, int num_tiles, const float *rec,
                            point_list, im.long_count, im.long_tiles);
         LVDGS_LAUNCH_CHECK("tile_sort", dbg, s);
     }
-    // queue 1 (count at long_count[0], entries long_tiles[0 .. T)) -> queue 2 (long_count[1], long_tiles[T .. 2T))
-    uint32_t *q2 = im.long_tiles + num_tiles;
-    {
-        ProfScope ps("tile_sort_mid", s);
-        hipLaunchKernelGGL(tile_depth_sort_kernel, dim3(2048), dim3(256), 0, s, (const uint2 *)im.ranges, src, point_list,
-                           (const uint32_t *)im.long_count, (const uint32_t *)im.long_tiles, im.long_count + 1, q2);
-        LVDGS_LAUNCH_CHECK("tile_sort_mid", dbg, s);
-    }
     {
         ProfScope ps("tile_sort_long", s);
-        hipLaunchKernelGGL(tile_depth_sort_long_kernel, dim3(64), dim3(1024), CLASS_B * 8, s, (const uint2 *)im.ranges, src, point_list,
-                           (const uint32_t *)(im.long_count + 1), (const uint32_t *)q2, (unsigned long long *)keys64);
+        hipLaunchKernelGGL(tile_depth_sort_long_kernel, dim3(256), dim3(1024), CLASS_B * 8, s, (const uint2 *)im.ranges, src, point_list,
+                           (const uint32_t *)im.long_count, (const uint32_t *)im.long_tiles, (unsigned long long *)keys64);
         LVDGS_LAUNCH_CHECK("tile_sort_long", dbg, s);
     }
     return LVDGS_OK;
