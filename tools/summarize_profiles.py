@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 # kernel symbol -> the name its launch is timed under in bench.py (ProfScope), where they differ
-ALIASES = {"blend_bwd2": "blend_bwd", "blend_bwd3": "blend_bwd"}
+ALIASES = {"blend_bwd2": "blend_bwd", "blend_bwd3": "blend_bwd", "blend_fwd2": "blend_fwd"}
 
 
 def short(name):
