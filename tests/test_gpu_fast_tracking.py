@@ -314,3 +314,48 @@ def test_map_view_pass_equals_render_loss_backward_through_autograd():
             for k in ("render", "depth", "opacity", "radii", "n_touched"):
                 assert torch.equal(p[k], q[k]), k
             assert torch.equal(p["viewspace_points"].grad, q["viewspace_points"].grad)
+
+
+def test_map_view_pass_with_higher_order_sh_splits_the_colour_gradient():
+    """SH degree 1 (four coefficients per channel): MapViewPass concatenates _features_dc / _features_rest for the
+    rasterizer and splits the SH gradient back into the two parameters; against autograd's cat / backward."""
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    import bench
+    from lvdgs import synthetic
+    from lvdgs.fast_mapping import MapViewPass
+    from lvdgs.gaussian_model import GaussianModel
+    from lvdgs.gaussian_renderer import render
+    from lvdgs.slam_utils import get_loss_mapping
+    dev = torch.device("cuda", torch.cuda.current_device())
+    cfg = synthetic.CONFIGS["cfg1_10k_640x480"]
+    g = synthetic.make_gaussians(cfg["N"], cfg["W"], cfg["H"], seed=5, sh_degree=1)
+    model = GaussianModel.from_activated(g["means3D"], g["scales"], g["rotations"], g["opacities"], shs=g["shs"], sh_degree=1, device=dev)
+    be, window = bench.build_window("cfg1_10k_640x480", 2, dev, model)
+    G = be.gaussians
+    assert G._features_rest.shape[1] == 3
+    names = ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")
+    views = [be.viewpoints[k] for k in window]
+
+    def clear():
+        for n in names:
+            getattr(G, n).grad = None
+
+    clear()
+    loss = 0
+    for c in views:
+        pkg = render(c, G, be.pipeline_params, be.background)
+        loss = loss + get_loss_mapping(be.config, pkg["render"], c, depth=pkg["depth"], monodepth=True)
+    loss.backward()
+    ref = [getattr(G, n).grad.clone() for n in names]
+    clear()
+    vp = MapViewPass(dev)
+    total = 0.0
+    for c in views:
+        assert MapViewPass.usable(be, c)
+        _, l = vp.run(be, c)
+        total += float(l)
+    assert abs(total - float(loss.detach())) <= 1e-6 * abs(total)
+    for n, r in zip(names, ref):
+        got = getattr(G, n).grad
+        assert got.shape == r.shape and got.is_contiguous(), n
+        torch.testing.assert_close(got, r, rtol=1e-6, atol=1e-9, msg=n)
