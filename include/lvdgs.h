@@ -107,7 +107,8 @@ typedef struct lvdgs_args {
     float *dL_dshs;       /* N*M*3 or NULL with colors_precomp */
     float *dL_dcolors;    /* N*3 or NULL with shs */
     float *dL_dtau;       /* 6: [d/d rho (3), d/d theta (3)] of T_w2c <- Exp(tau) T_w2c
-                             (reference utils/pose_utils.py:70-87) */
+                             (reference utils/pose_utils.py:70-87).  NULL: the per-workgroup partial sums stay in
+                             `scratch` and lvdgs_tracking_tail reduces them (one launch less) */
 
     /* ---- single-call forward only ---- */
     int64_t pair_capacity; /* pairs binning_state / scratch were sized for (lvdgs_forward) */
@@ -220,6 +221,10 @@ int lvdgs_photometric_loss_backward(const lvdgs_loss_args *a, void *stream);
  * d objective / d loss is known up front): grad_loss may be NULL (= 1) or a device scalar.  Same results as the two
  * calls above. */
 int lvdgs_photometric_loss_value_and_grad(const lvdgs_loss_args *a, void *stream);
+/* The same pass WITHOUT the final reduction: d_image / d_depth / d_opacity are written, the per-workgroup partial sums
+ * of the loss value and of the exposure gradients stay in `scratch` for lvdgs_tracking_tail (`loss`, `d_exposure_a/b`
+ * are not written yet).  One launch. */
+int lvdgs_photometric_loss_partials(const lvdgs_loss_args *a, void *stream);
 
 /* ---- per-frame pose optimiser step (reference utils/slam_frontend.py:1518-1521, utils/pose_utils.py:70-87) ----
  * One launch = `pose_optimizer.step()` (torch.optim.Adam: betas, eps, one learning rate per group) on the frame's
@@ -254,6 +259,15 @@ typedef struct lvdgs_pose_step_args {
     const float *grad_trans;       /* 3 or NULL */
 } lvdgs_pose_step_args;
 int lvdgs_pose_step(const lvdgs_pose_step_args *a, void *stream);
+
+/* The end of a tracking iteration in ONE launch (instead of three at ~6 us each on the iteration's critical path):
+ *   - finishes lvdgs_photometric_loss_partials(loss): writes loss->loss, loss->d_exposure_a / _b;
+ *   - reduces the pose-gradient partials lvdgs_backward(bwd) left in bwd->scratch when called with bwd->dL_dtau == NULL
+ *     (same `bwd` block, untouched in between: num_gaussians, num_rendered, scratch) and writes dL_dtau (6 floats);
+ *   - applies lvdgs_pose_step(pose) with those gradients (pose->grad_* are ignored: the pose deltas take dL_dtau, the
+ *     exposure parameters that `pose` names take loss->d_exposure_a / _b).
+ * Same additions in the same order as the three separate launches: bit-identical results. */
+int lvdgs_tracking_tail(const lvdgs_loss_args *loss, const lvdgs_args *bwd, const lvdgs_pose_step_args *pose, float *dL_dtau, void *stream);
 
 /* ---- Adam step of the Gaussian map (reference utils/slam_backend.py:144, :378, :458: gaussians.optimizer.step()) ----
  * All parameter tensors in one launch, one pass over (grad, exp_avg, exp_avg_sq, param); torch.optim.Adam's arithmetic

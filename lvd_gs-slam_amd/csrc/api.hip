@@ -451,8 +451,7 @@ int lvdgs_backward(const lvdgs_args *a, void *stream) {
     if (int e = check_common(a)) return e;
     if (int e = check_gaussians(a)) return e;
     const int N = a->num_gaussians, W = a->image_width, H = a->image_height;
-    if (!a->dL_dtau) { set_error("dL_dtau is NULL"); return LVDGS_E_INVALID; }
-    if (N == 0) return check_hip(hipMemsetAsync(a->dL_dtau, 0, 6 * sizeof(float), s), "memset tau");
+    if (N == 0) return a->dL_dtau ? check_hip(hipMemsetAsync(a->dL_dtau, 0, 6 * sizeof(float), s), "memset tau") : LVDGS_OK;
     const int64_t D = a->num_rendered;
     if (D < 0) { set_error("negative num_rendered"); return LVDGS_E_INVALID; }
     if (!a->dL_dout_color || !a->dL_dmeans3D || !a->dL_dmeans2D || !a->dL_dopacities || !a->projmatrix_raw || !a->radii) {

@@ -115,6 +115,12 @@ int radix_num_passes(int total_bits);
 size_t radix_hist_entries(int64_t n);
 
 // slot_base[i] = exclusive scan over i of tiles_touched[i]; *total_dev = the sum (pair count D)
+// Pieces lvdgs_tracking_tail (pose.hip) puts into one launch.
+struct LossTail {            // what photometric_finish_kernel<2> reads and writes (loss.hip)
+    const float *partial; int nblk; int P; float w_rgb, w_d; float *loss, *d_a, *d_b;
+};
+int loss_tail_params(const lvdgs_loss_args *a, LossTail *out);   // validates like lvdgs_photometric_loss_value_and_grad
+
 int launch_slot_scan(const uint32_t *tiles_touched, uint32_t *slot_base, uint32_t *blocksums, uint32_t *total_dev, int N, int dbg,
                      hipStream_t s);
 

@@ -312,18 +312,52 @@ int lvdgs_photometric_loss_backward(const lvdgs_loss_args *a, void *stream) {
     return LVDGS_OK;
 }
 
-int lvdgs_photometric_loss_value_and_grad(const lvdgs_loss_args *a, void *stream) {
-    hipStream_t s = (hipStream_t)stream;
-    LossParams p; int nblk;
+static int value_and_grad_params(const lvdgs_loss_args *a, LossParams &p, int &nblk, bool need_loss) {
     if (int e = loss_common(a, p, nblk)) return e;
-    if (!a->loss || !a->d_image) { set_error("loss value_and_grad: loss / d_image is NULL"); return LVDGS_E_INVALID; }
+    if ((need_loss && !a->loss) || !a->d_image) { set_error("loss value_and_grad: loss / d_image is NULL"); return LVDGS_E_INVALID; }
     p.loss = a->loss;
     p.grad_out = a->grad_loss;  // NULL: d objective / d loss = 1
     p.d_image = a->d_image; p.d_depth = a->d_depth; p.d_opacity = a->d_opacity; p.d_a = a->d_exposure_a; p.d_b = a->d_exposure_b;
-    { ProfScope ps("loss_both", s); if (p.P % 4 == 0) hipLaunchKernelGGL((photometric_kernel<2, true>), dim3(nblk), dim3(LOSS_THREADS), 0, s, p); else hipLaunchKernelGGL((photometric_kernel<2, false>), dim3(nblk), dim3(LOSS_THREADS), 0, s, p); LVDGS_LAUNCH_CHECK("loss_both", 0, s); }
+    return LVDGS_OK;
+}
+
+static void launch_value_and_grad_pass(const LossParams &p, int nblk, hipStream_t s) {
+    ProfScope ps("loss_both", s);
+    if (p.P % 4 == 0) hipLaunchKernelGGL((photometric_kernel<2, true>), dim3(nblk), dim3(LOSS_THREADS), 0, s, p);
+    else hipLaunchKernelGGL((photometric_kernel<2, false>), dim3(nblk), dim3(LOSS_THREADS), 0, s, p);
+}
+
+int lvdgs_photometric_loss_value_and_grad(const lvdgs_loss_args *a, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    LossParams p; int nblk;
+    if (int e = value_and_grad_params(a, p, nblk, true)) return e;
+    launch_value_and_grad_pass(p, nblk, s);
+    LVDGS_LAUNCH_CHECK("loss_both", 0, s);
     { ProfScope ps("loss_both_finish", s); hipLaunchKernelGGL(photometric_finish_kernel<2>, dim3(1), dim3(256), 0, s, p, nblk); LVDGS_LAUNCH_CHECK("loss_both_finish", 0, s); }
     return LVDGS_OK;
 }
+
+int lvdgs_photometric_loss_partials(const lvdgs_loss_args *a, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    LossParams p; int nblk;
+    if (int e = value_and_grad_params(a, p, nblk, false)) return e;
+    launch_value_and_grad_pass(p, nblk, s);
+    LVDGS_LAUNCH_CHECK("loss_both", 0, s);
+    return LVDGS_OK;
+}
+
+}  // extern "C"
+
+namespace lvdgs {
+int loss_tail_params(const lvdgs_loss_args *a, LossTail *out) {
+    LossParams p; int nblk;
+    if (int e = value_and_grad_params(a, p, nblk, true)) return e;
+    *out = LossTail{p.partial, nblk, p.P, p.w_rgb, p.w_d, p.loss, p.d_a, p.d_b};
+    return LVDGS_OK;
+}
+}  // namespace lvdgs
+
+extern "C" {
 
 size_t lvdgs_masked_depth_scratch_bytes(int32_t width, int32_t height) {
     const int64_t P = (int64_t)width * height;

@@ -13,6 +13,7 @@
 //
 // Arithmetic mirrors the PyTorch statements in float32 (Adam's bias corrections in double, like Python floats).
 #include "common.hpp"
+#include "device_utils.hpp"
 
 namespace lvdgs {
 namespace {
@@ -54,9 +55,7 @@ __device__ float adam_update(float p, float g, float *m, float *v, double lr, do
     return p - step_size * (m1 / denom);
 }
 
-__global__ void pose_step_kernel(PoseStepParams pp) {
-    const lvdgs_pose_step_args &a = pp.a;
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void pose_step_body(const lvdgs_pose_step_args &a) {   // one thread
     float *st = a.state;  // [0..15]: (m, v) of rot xyz, trans xyz, a, b ; [16]: step count ; [17]: converged (sticky) ; [18]: iterations applied
     if (st[17] != 0.f) return;  // already converged: the host may have run ahead
     const float step = st[16] + 1.f;
@@ -128,21 +127,106 @@ __global__ void pose_step_kernel(PoseStepParams pp) {
         for (int i = 0; i < 3; i++) a.campos[i] = -(R1[i] * T1[0] + R1[3 + i] * T1[1] + R1[6 + i] * T1[2]);
 }
 
+__global__ void pose_step_kernel(PoseStepParams pp) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    pose_step_body(pp.a);
+}
+
+// The end of a tracking iteration in one launch (lvdgs_tracking_tail): what photometric_finish_kernel<2>, tau_reduce_kernel
+// and pose_step_kernel do one after the other -- the same additions in the same order, so the same bits -- without two
+// launches of ~6 us each on the iteration's critical path.
+struct TailParams {
+    LossTail loss;
+    const float *tau_part; int tau_blocks; float *dL_dtau;
+    lvdgs_pose_step_args pose;   // grad_tau / grad_exposure_* already point at dL_dtau and loss.d_a / d_b
+};
+
+__global__ void __launch_bounds__(256) tracking_tail_kernel(TailParams t) {
+    __shared__ float s[10][4];   // [value][wave]: loss sums 0..3, pose gradient 4..9
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int b = threadIdx.x; b < t.loss.nblk; b += 256) {
+        a[0] += t.loss.partial[4 * b]; a[1] += t.loss.partial[4 * b + 1];
+        a[2] += t.loss.partial[4 * b + 2]; a[3] += t.loss.partial[4 * b + 3];
+    }
+    float g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = threadIdx.x; b < t.tau_blocks; b += 256)
+#pragma unroll
+        for (int k = 0; k < 6; k++) g[k] += t.tau_part[(size_t)b * 6 + k];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const float v = wave_sum_to_lane63(a[k]);
+        if (lane == 63) s[k][wave] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const float v = wave_sum_to_lane63(g[k]);
+        if (lane == 63) s[4 + k][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) {
+        const float v = ((s[threadIdx.x][0] + s[threadIdx.x][1]) + s[threadIdx.x][2]) + s[threadIdx.x][3];
+        s[threadIdx.x][0] = v;
+        if (threadIdx.x >= 4) t.dL_dtau[threadIdx.x - 4] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    t.loss.loss[0] = t.loss.w_rgb * (s[0][0] / (3.f * (float)t.loss.P)) + t.loss.w_d * (s[1][0] / (float)t.loss.P);
+    if (t.loss.d_a) t.loss.d_a[0] = s[2][0];
+    if (t.loss.d_b) t.loss.d_b[0] = s[3][0];
+    __threadfence_block();   // this thread reads dL_dtau (written by threads 4..9 before the barrier) and d_a / d_b back
+    pose_step_body(t.pose);
+}
+
 }  // namespace
 }  // namespace lvdgs
 
 using namespace lvdgs;
 
+static int check_pose_args(const lvdgs_pose_step_args *a);
+
 extern "C" int lvdgs_pose_step(const lvdgs_pose_step_args *a, void *stream) {
     hipStream_t s = (hipStream_t)stream;
+    if (int e = check_pose_args(a)) return e;
+    PoseStepParams pp{*a};
+    ProfScope ps("pose_step", s);
+    hipLaunchKernelGGL(pose_step_kernel, dim3(1), dim3(64), 0, s, pp);
+    LVDGS_LAUNCH_CHECK("pose_step", 0, s);
+    return LVDGS_OK;
+}
+
+static int check_pose_args(const lvdgs_pose_step_args *a) {
     if (!a || !a->state || (a->R ? (!a->T || !a->cam_rot_delta || !a->cam_trans_delta) : (a->T != nullptr))) {
         set_error("pose step: state is NULL, or R is given without T / cam_rot_delta / cam_trans_delta (R and T both NULL = exposure only)");
         return LVDGS_E_INVALID;
     }
     if (!(a->beta1 >= 0.0 && a->beta1 < 1.0 && a->beta2 >= 0.0 && a->beta2 < 1.0)) { set_error("pose step: betas must lie in [0, 1)"); return LVDGS_E_INVALID; }
-    PoseStepParams pp{*a};
-    ProfScope ps("pose_step", s);
-    hipLaunchKernelGGL(pose_step_kernel, dim3(1), dim3(64), 0, s, pp);
-    LVDGS_LAUNCH_CHECK("pose_step", 0, s);
+    return LVDGS_OK;
+}
+
+extern "C" int lvdgs_tracking_tail(const lvdgs_loss_args *loss, const lvdgs_args *bwd, const lvdgs_pose_step_args *pose, float *dL_dtau,
+                                   void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!bwd || !dL_dtau) { set_error("tracking tail: backward arguments / dL_dtau is NULL"); return LVDGS_E_INVALID; }
+    if (int e = check_pose_args(pose)) return e;
+    TailParams t{};
+    if (int e = loss_tail_params(loss, &t.loss)) return e;
+    const int N = bwd->num_gaussians;
+    if (N < 0 || bwd->num_rendered < 0 || (N > 0 && !bwd->scratch)) { set_error("tracking tail: bad backward arguments"); return LVDGS_E_INVALID; }
+    if (N > 0) {
+        if (bwd->scratch_bytes < lvdgs_backward_scratch_bytes(N, bwd->num_rendered)) { set_error("tracking tail: scratch too small"); return LVDGS_E_INVALID; }
+        BwdScratch w;
+        bwd_scratch_layout(N, bwd->num_rendered, &w, bwd->scratch);
+        t.tau_part = w.tau_part;
+        t.tau_blocks = cdiv(N, 256);
+    }
+    t.dL_dtau = dL_dtau;
+    t.pose = *pose;
+    t.pose.grad_tau = dL_dtau; t.pose.grad_rot = t.pose.grad_trans = nullptr;
+    t.pose.grad_exposure_a = pose->exposure_a ? loss->d_exposure_a : nullptr;
+    t.pose.grad_exposure_b = pose->exposure_b ? loss->d_exposure_b : nullptr;
+    ProfScope ps("tracking_tail", s);
+    hipLaunchKernelGGL(tracking_tail_kernel, dim3(1), dim3(256), 0, s, t);
+    LVDGS_LAUNCH_CHECK("tracking_tail", 0, s);
     return LVDGS_OK;
 }

@@ -609,7 +609,7 @@ int launch_preprocess_bwd(const lvdgs_args &a, const GeomView &g, const BwdScrat
         hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(256), 0, s, p);
         LVDGS_LAUNCH_CHECK("preprocess_bwd", a.debug, s);
     }
-    {
+    if (a.dL_dtau) {   // NULL: the partials stay in the scratch for lvdgs_tracking_tail
         ProfScope ps("tau_reduce", s);
         hipLaunchKernelGGL(tau_reduce_kernel, dim3(1), dim3(256), 0, s, b.tau_part, nblk, a.dL_dtau);
         LVDGS_LAUNCH_CHECK("tau_reduce", a.debug, s);

@@ -12,7 +12,10 @@ iteration whatever the scene, which is what bounds tracking at SLAM-sized maps (
 The session does the same arithmetic as four calls into the C ABI on pre-filled argument blocks and buffers that
 live for the frame:
 
-    lvdgs_forward -> lvdgs_photometric_loss_value_and_grad -> lvdgs_backward -> lvdgs_pose_step
+    lvdgs_forward -> lvdgs_photometric_loss_partials -> lvdgs_backward -> lvdgs_tracking_tail
+
+(the last one finishes the loss, reduces the pose gradient and applies the pose step in one launch; the same arithmetic as
+lvdgs_photometric_loss_value_and_grad / lvdgs_backward with dL_dtau / lvdgs_pose_step, two launches fewer)
 
 and nothing comes back to the host inside the loop except the pair count ``lvdgs_forward`` has always read (the GPU has
 the rest of the iteration queued behind it).  Convergence (``||tau|| < 1e-4``, utils/pose_utils.py:82) is a sticky
@@ -110,7 +113,8 @@ class TrackingSession:
         self.d_m3, self.d_m2, self.d_op = e(N, 3), e(N, 3), e(*op.shape)
         self.d_sc, self.d_rot, self.d_sh, self.d_tau = e(N, 3), e(N, 4), e(*shs.shape), e(6)
         a.dL_dmeans3D, a.dL_dmeans2D, a.dL_dopacities = _P(self.d_m3), _P(self.d_m2), _P(self.d_op)
-        a.dL_dscales, a.dL_drotations, a.dL_dshs, a.dL_dtau = _P(self.d_sc), _P(self.d_rot), _P(self.d_sh), _P(self.d_tau)
+        a.dL_dscales, a.dL_drotations, a.dL_dshs = _P(self.d_sc), _P(self.d_rot), _P(self.d_sh)
+        a.dL_dtau = None   # the backward leaves its partial sums, lvdgs_tracking_tail reduces them into self.d_tau
 
         # ---- tracking loss (reference utils/slam_utils.py:42-79; include/lvdgs.h: lvdgs_loss_args) ----
         la = self.la = _lib.LossArgs()
@@ -182,12 +186,13 @@ class TrackingSession:
             else:
                 _lib.check(status, "lvdgs_forward")
             self.num_rendered = a.num_rendered = D
-            # loss value and all its gradients in one pass over the images (the objective is the loss: d/d loss = 1)
-            _lib.check(L.lvdgs_photometric_loss_value_and_grad(C.byref(self.la), stream), "lvdgs_photometric_loss_value_and_grad")
+            # loss and all its image gradients in one pass over the images (the objective is the loss: d/d loss = 1); its
+            # final reduction, the pose gradient's and the pose step share the iteration's last launch
+            _lib.check(L.lvdgs_photometric_loss_partials(C.byref(self.la), stream), "lvdgs_photometric_loss_partials")
+            _lib.check(L.lvdgs_backward(C.byref(a), stream), "lvdgs_backward")
+            _lib.check(L.lvdgs_tracking_tail(C.byref(self.la), C.byref(a), C.byref(self.pa), _P(self.d_tau), stream), "lvdgs_tracking_tail")
             if record_loss is not None:
                 record_loss.copy_(self.loss)
-            _lib.check(L.lvdgs_backward(C.byref(a), stream), "lvdgs_backward")
-            _lib.check(L.lvdgs_pose_step(C.byref(self.pa), stream), "lvdgs_pose_step")
         self.iterations_enqueued += 1
 
     def converged_lagging(self, lag=2):

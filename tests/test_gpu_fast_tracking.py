@@ -359,3 +359,58 @@ def test_map_view_pass_with_higher_order_sh_splits_the_colour_gradient():
         got = getattr(G, n).grad
         assert got.shape == r.shape and got.is_contiguous(), n
         torch.testing.assert_close(got, r, rtol=1e-6, atol=1e-9, msg=n)
+
+
+def test_tracking_tail_equals_loss_finish_plus_tau_reduce_plus_pose_step_bit_for_bit():
+    """lvdgs_photometric_loss_partials -> lvdgs_backward(dL_dtau = NULL) -> lvdgs_tracking_tail against
+    lvdgs_photometric_loss_value_and_grad -> lvdgs_backward -> lvdgs_pose_step from the same state: loss, exposure and pose
+    gradients, pose, deltas, exposure, Adam state and the derived matrices must be the same BITS (same additions in the
+    same order)."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    import bench
+    from lvdgs import _lib
+    from lvdgs.fast_tracking import TrackingSession, _P
+    dev = torch.device("cuda", torch.cuda.current_device())
+    model, cam, g, (N, W, H) = bench.build_scene("cfg1_10k_640x480", 3, dev)
+    cfg = {k: (dict(v) if isinstance(v, dict) else v) for k, v in bench.CONFIG.items()}
+    cfg["Training"]["monocular"] = False   # depth term on: all four partial sums are in play
+    pipe = type("P", (), dict(convert_SHs_python=False, compute_cov3D_python=False))()
+    sess = TrackingSession(cam, model, cfg, pipe, torch.zeros(3, device=dev))
+    sess.step(); sess.step()   # a state with non-zero Adam moments
+    torch.cuda.synchronize()
+    L, a, la, pa = sess.L, sess.a, sess.la, sess.pa
+    state = [sess.R, sess.T, cam.cam_rot_delta, cam.cam_trans_delta, cam.exposure_a, cam.exposure_b, sess.pose_state, sess.view, sess.proj, sess.campos]
+    outs = [sess.loss, sess.d_a, sess.d_b, sess.d_tau]
+    snap = [t.detach().clone() for t in state]
+
+    def run(fused):
+        with torch.no_grad():
+            for t, s0 in zip(state, snap):
+                t.copy_(s0)
+            for t in outs:
+                t.fill_(float("nan"))
+        with _lib.on_device(dev):
+            stream = _lib.raw_stream(dev)
+            num = C.c_int64(0)
+            _lib.check(L.lvdgs_forward(C.byref(a), C.byref(num), stream), "forward")
+            a.num_rendered = int(num.value)
+            if fused:
+                a.dL_dtau = None
+                _lib.check(L.lvdgs_photometric_loss_partials(C.byref(la), stream), "partials")
+                _lib.check(L.lvdgs_backward(C.byref(a), stream), "backward")
+                _lib.check(L.lvdgs_tracking_tail(C.byref(la), C.byref(a), C.byref(pa), _P(sess.d_tau), stream), "tail")
+            else:
+                a.dL_dtau = _P(sess.d_tau)
+                _lib.check(L.lvdgs_photometric_loss_value_and_grad(C.byref(la), stream), "value_and_grad")
+                _lib.check(L.lvdgs_backward(C.byref(a), stream), "backward")
+                _lib.check(L.lvdgs_pose_step(C.byref(pa), stream), "pose_step")
+        torch.cuda.synchronize()
+        return [t.detach().clone() for t in state + outs]
+
+    ra, rb = run(False), run(True)
+    names = "R T rot_delta trans_delta exposure_a exposure_b adam_state view proj campos loss d_a d_b d_tau".split()
+    for n, x, y in zip(names, ra, rb):
+        assert torch.isfinite(x).all(), n
+        assert torch.equal(x, y), (n, x, y)
+    assert not torch.equal(ra[0], snap[0])   # the step moved the pose
