@@ -265,7 +265,8 @@ int lvdgs_pose_step(const lvdgs_pose_step_args *a, void *stream);
  *   - reduces the pose-gradient partials lvdgs_backward(bwd) left in bwd->scratch when called with bwd->dL_dtau == NULL
  *     (same `bwd` block, untouched in between: num_gaussians, num_rendered, scratch) and writes dL_dtau (6 floats);
  *   - applies lvdgs_pose_step(pose) with those gradients (pose->grad_* are ignored: the pose deltas take dL_dtau, the
- *     exposure parameters that `pose` names take loss->d_exposure_a / _b).
+ *     exposure parameters that `pose` names take loss->d_exposure_a / _b).  pose == NULL: the two reductions only (a
+ *     view of the mapping iteration, whose keyframe is stepped after all views).
  * Same additions in the same order as the three separate launches: bit-identical results. */
 int lvdgs_tracking_tail(const lvdgs_loss_args *loss, const lvdgs_args *bwd, const lvdgs_pose_step_args *pose, float *dL_dtau, void *stream);
 

@@ -139,6 +139,7 @@ struct TailParams {
     LossTail loss;
     const float *tau_part; int tau_blocks; float *dL_dtau;
     lvdgs_pose_step_args pose;   // grad_tau / grad_exposure_* already point at dL_dtau and loss.d_a / d_b
+    int has_pose;                // 0: the two reductions only (a mapping view: its keyframe is stepped later)
 };
 
 __global__ void __launch_bounds__(256) tracking_tail_kernel(TailParams t) {
@@ -174,6 +175,7 @@ __global__ void __launch_bounds__(256) tracking_tail_kernel(TailParams t) {
     t.loss.loss[0] = t.loss.w_rgb * (s[0][0] / (3.f * (float)t.loss.P)) + t.loss.w_d * (s[1][0] / (float)t.loss.P);
     if (t.loss.d_a) t.loss.d_a[0] = s[2][0];
     if (t.loss.d_b) t.loss.d_b[0] = s[3][0];
+    if (!t.has_pose) return;
     __threadfence_block();   // this thread reads dL_dtau (written by threads 4..9 before the barrier) and d_a / d_b back
     pose_step_body(t.pose);
 }
@@ -208,7 +210,8 @@ extern "C" int lvdgs_tracking_tail(const lvdgs_loss_args *loss, const lvdgs_args
                                    void *stream) {
     hipStream_t s = (hipStream_t)stream;
     if (!bwd || !dL_dtau) { set_error("tracking tail: backward arguments / dL_dtau is NULL"); return LVDGS_E_INVALID; }
-    if (int e = check_pose_args(pose)) return e;
+    if (pose)
+        if (int e = check_pose_args(pose)) return e;
     TailParams t{};
     if (int e = loss_tail_params(loss, &t.loss)) return e;
     const int N = bwd->num_gaussians;
@@ -221,10 +224,13 @@ extern "C" int lvdgs_tracking_tail(const lvdgs_loss_args *loss, const lvdgs_args
         t.tau_blocks = cdiv(N, 256);
     }
     t.dL_dtau = dL_dtau;
-    t.pose = *pose;
-    t.pose.grad_tau = dL_dtau; t.pose.grad_rot = t.pose.grad_trans = nullptr;
-    t.pose.grad_exposure_a = pose->exposure_a ? loss->d_exposure_a : nullptr;
-    t.pose.grad_exposure_b = pose->exposure_b ? loss->d_exposure_b : nullptr;
+    t.has_pose = pose != nullptr;
+    if (pose) {
+        t.pose = *pose;
+        t.pose.grad_tau = dL_dtau; t.pose.grad_rot = t.pose.grad_trans = nullptr;
+        t.pose.grad_exposure_a = pose->exposure_a ? loss->d_exposure_a : nullptr;
+        t.pose.grad_exposure_b = pose->exposure_b ? loss->d_exposure_b : nullptr;
+    }
     ProfScope ps("tracking_tail", s);
     hipLaunchKernelGGL(tracking_tail_kernel, dim3(1), dim3(256), 0, s, t);
     LVDGS_LAUNCH_CHECK("tracking_tail", 0, s);

@@ -8,10 +8,10 @@ Through PyTorch that is two ``autograd.Function`` round trips per view, the conc
 engine's thread hand-over and a dozen accumulation kernels: ~0.3 ms of host time per view, which is what bounds a
 mapping iteration once the kernels are fast (one view per GPU in the sharded window, ten on a single GPU).
 
-The pass does the same arithmetic as three calls into the C ABI on argument blocks and buffers that live as long as the
+The pass does the same arithmetic as four calls into the C ABI on argument blocks and buffers that live as long as the
 back end:
 
-    lvdgs_forward -> lvdgs_photometric_loss_value_and_grad -> lvdgs_backward
+    lvdgs_forward -> lvdgs_photometric_loss_partials -> lvdgs_backward -> lvdgs_tracking_tail (reductions only)
 
 with the activations fused into the rasterizer (``lvdgs_args.activations``), so ``lvdgs_backward`` writes the gradients
 w.r.t. the model's RAW parameters: they go straight into the ``.grad`` fields autograd would have filled (the first view
@@ -165,7 +165,7 @@ class MapViewPass:
         a.dL_dmeans3D, a.dL_dopacities, a.dL_dscales = _P(into["_xyz"]), _P(into["_opacity"]), _P(into["_scaling"])
         a.dL_drotations, a.dL_dshs = _P(into["_rotation"]), _P(d_sh)
         d_tau, d_a, d_b, d_m2 = e(6), e(1), e(1), e(N, 3)
-        a.dL_dtau, a.dL_dmeans2D = _P(d_tau), _P(d_m2)
+        a.dL_dtau, a.dL_dmeans2D = None, _P(d_m2)   # the pose gradient's partial sums are reduced together with the loss's
 
         # ---- get_loss_mapping (reference utils/slam_utils.py:82-121) ----
         # (monodepth=True at every call site of the mapping loop, so the loss is the rgb-d one whatever Training.monocular says)
@@ -198,8 +198,9 @@ class MapViewPass:
             else:
                 _lib.check(status, "lvdgs_forward")
             a.num_rendered = D
-            _lib.check(L.lvdgs_photometric_loss_value_and_grad(C.byref(la), stream), "lvdgs_photometric_loss_value_and_grad")
+            _lib.check(L.lvdgs_photometric_loss_partials(C.byref(la), stream), "lvdgs_photometric_loss_partials")
             _lib.check(L.lvdgs_backward(C.byref(a), stream), "lvdgs_backward")
+            _lib.check(L.lvdgs_tracking_tail(C.byref(la), C.byref(a), None, _P(d_tau), stream), "lvdgs_tracking_tail")
 
         # ---- hand the gradients over exactly where autograd would have put them ----
         if K > 1:
