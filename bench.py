@@ -133,8 +133,8 @@ def build_window(workload, world, dev, model):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default=os.environ.get("LVDGS_BENCH_WORKLOAD", "cfg3_500k_1920x1080"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--step", choices=["auto", "tracking", "tracking-autograd", "mapping"], default="auto",
