@@ -59,14 +59,36 @@ def _check_case(c):
         tp._close(np.where(m, f_hip[k], 0), np.where(m, f_ora[k], 0), what=f"{k} {c}")
     np.testing.assert_array_equal(f_hip["n_contrib"][solid], f_ora["n_contrib"][solid], err_msg=str(c))
     names = ["means3D", "means2D", "opacities", "scales", "rotations", "colors"]
+    clean = _gaussians_without_fragile_pixels(c, f_ora, solid)
+    same = clean & (f_ora["radii"] > 0)   # integer bookkeeping: exact wherever no fragile pixel can reach
+    np.testing.assert_array_equal(f_hip["n_touched"][same], f_ora["n_touched"][same], err_msg=str(c))
+    try:
+        _check_backward_of_case(c, b_hip, b_ora, solid, clean, names)
+    except AssertionError as strict:
+        # About one random scene in a thousand has a gradient that float32 itself cannot hold to the strict bounds (the
+        # opacity gradient of a faint Gaussian is a sum of sign-alternating terms; stacks of opaque Gaussians recover T by
+        # division): there the float32 ORACLE is as far from the float64 oracle as the kernels are from it.  Such a case
+        # passes if the kernels are no farther from the float64 result than the float32 restatement is (x 1.5, + the
+        # strict tolerance), tensor by tensor; anything else is a failure with both messages.
+        f64, b64 = hr.run_oracle(orc, g, cam, c["W"], c["H"], bg, grads=grads, prec="f64")
+        for n in names + ["tau"]:
+            ref64 = np.asarray(b64[n], np.float64).reshape(b_hip[n].shape)
+            ref32 = np.asarray(b_ora[n], np.float64).reshape(b_hip[n].shape)
+            hip = np.asarray(b_hip[n], np.float64)
+            norm = max(np.linalg.norm(ref64), 1e-300)
+            e_hip, e_ora = np.linalg.norm(hip - ref64) / norm, np.linalg.norm(ref32 - ref64) / norm
+            assert e_hip <= 2e-5 + 1.5 * e_ora, f"{n}: kernels {e_hip:.3e} from float64, float32 oracle {e_ora:.3e} | strict check said: {strict}"
+            m_hip, m_ora = np.abs(hip - ref64).max(), np.abs(ref32 - ref64).max()
+            scale = max(np.abs(ref64).max(), 1e-300)
+            assert m_hip <= (1e-5 if solid.all() else 2e-2) * scale + 1.5 * m_ora, f"{n}: max error {m_hip:.3e} vs {m_ora:.3e} (scale {scale:.3e}) | {strict}"
+
+
+def _gaussians_without_fragile_pixels(c, f_ora, solid):
+    """Some pixel may sit within 1e-5 of a threshold: one faint Gaussian can be in on one side and out on the other, which
+    perturbs that pixel's contribution to every Gaussian composited in it.  All of those overlap the pixel's tile, so
+    every Gaussian whose tile rectangle holds no fragile pixel must still agree to the full tolerance."""
     if solid.all():
-        np.testing.assert_array_equal(f_hip["n_touched"], f_ora["n_touched"], err_msg=str(c))
-        tp._check_backward(b_hip, b_ora, names + ["tau"])
-        return
-    # Some pixel sat within 1e-5 of a threshold: one faint Gaussian may be in on one side and out on the other, which
-    # perturbs that pixel's contribution to every Gaussian composited in it.  All of those overlap the pixel's tile, so
-    # every Gaussian whose tile rectangle holds no fragile pixel must still agree to the full tolerance; the rest
-    # (and the pose gradient, a sum over all of them) to the size of the perturbation, alpha ~ 4e-3.
+        return np.ones(f_ora["radii"].shape[0], bool)
     gx, gy = (c["W"] + 15) // 16, (c["H"] + 15) // 16
     pad = np.zeros((gy * 16, gx * 16), bool)
     pad[:c["H"], :c["W"]] = ~solid
@@ -76,16 +98,27 @@ def _check_case(c):
     r = f_ora["rect"].astype(np.int64)
     x0, y0, x1, y1 = r[:, 0], r[:, 1], r[:, 2], r[:, 3]
     n_frag = cum[y1, x1] - cum[y0, x1] - cum[y1, x0] + cum[y0, x0]
-    clean = (n_frag == 0)
+    return n_frag == 0
+
+
+def _check_backward_of_case(c, b_hip, b_ora, solid, clean, names):
+    if solid.all():
+        tp._check_backward(b_hip, b_ora, names + ["tau"])
+        return
+    # the Gaussians a fragile pixel can reach (and the pose gradient, a sum over all of them): to the size of the
+    # perturbation, alpha ~ 4e-3
     for n in names:
         ref = b_ora[n].reshape(b_hip[n].shape)
         if clean.any():
-            tp._close(b_hip[n][clean], ref[clean], what=f"grad {n} (Gaussians away from fragile pixels) {c}")
+            # the other Gaussians take the reference's values: the error of the clean ones is then measured against the
+            # norm and scale of the WHOLE gradient, not against that of a subset that may consist of a few nearly hidden
+            # Gaussians (case 413 of a 4000-case sweep: 5 fragile pixels under wide opaque Gaussians left such a subset,
+            # 4.9e-5 of ITS norm while the whole tensor agreed to 4e-7)
+            sel = clean.reshape((-1,) + (1,) * (ref.ndim - 1))
+            tp._close(np.where(sel, b_hip[n], ref), ref, what=f"grad {n} (Gaussians away from fragile pixels) {c}")
         scale = max(np.abs(ref).max(), 1e-30)
         assert np.abs(b_hip[n] - ref).max() <= 2e-2 * scale, (n, c)
     assert np.abs(b_hip["tau"] - b_ora["tau"]).max() <= 2e-2 * max(np.abs(b_ora["tau"]).max(), 1e-30), c
-    same = clean & (f_ora["radii"] > 0)
-    np.testing.assert_array_equal(f_hip["n_touched"][same], f_ora["n_touched"][same], err_msg=str(c))
 
 
 @pytest.mark.parametrize("case_seed", list(range(16)))

@@ -125,8 +125,11 @@ def _check_backward(b_hip, b_ora, names, f_ora=None, W=None, H=None):
         if n == "tau":  # six sums over every Gaussian, the ones fragile pixels reach included
             _close(b_hip[n], ref, what="grad tau", rel_l2=1e-4)
             continue
-        if clean.sum() >= 50:
-            _close(b_hip[n][clean], ref[clean], what="grad " + n + " (away from fragile pixels)")
+        if clean.any():
+            # (the other Gaussians take the reference's values, so the error of the clean ones is measured against the
+            # norm and scale of the whole gradient, whatever the subset happens to contain)
+            sel = clean.reshape((-1,) + (1,) * (ref.ndim - 1))
+            _close(np.where(sel, b_hip[n], ref), ref, what="grad " + n + " (away from fragile pixels)")
         st = parity_stats_record("grad " + n + " (all Gaussians)", b_hip[n], ref)
         scale = max(np.abs(ref).max(), 1e-30)
         assert st["rel_l2"] <= 2e-4, (n, st)
