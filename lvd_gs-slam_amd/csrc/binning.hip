@@ -223,35 +223,6 @@ __global__ void __launch_bounds__(1024) group_tilescan_kernel(int T, const uint3
     }
 }
 
-// Small images (T <= 2048 tiles: KITTI's 1226x370 has 1848): both scans in ONE workgroup -- per tile the exclusive prefix
-// of hist over the chunks, then the scan of the totals -- one launch instead of two on a path where a launch costs more
-// than this much work (~50 chunks x 2048 tiles).
-constexpr int SMALL_SCAN_TILES = 2048;
-__global__ void __launch_bounds__(1024) group_scan_small_kernel(int T, int nchunks, uint32_t *__restrict__ hist, uint32_t capacity,
-                                                                uint2 *__restrict__ ranges) {
-    __shared__ uint32_t s_scan[33];
-    const int t0 = 2 * (int)threadIdx.x;   // this thread's two neighbouring tiles
-    uint32_t run[2] = {0u, 0u};
-    for (int c = 0; c < nchunks; c++) {
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            if (t0 + k < T) {
-                const uint32_t v = hist[(size_t)c * T + t0 + k];
-                hist[(size_t)c * T + t0 + k] = run[k];
-                run[k] += v;
-            }
-        }
-    }
-    uint32_t total;
-    uint32_t before = scan_1024(run[0] + run[1], s_scan, &total);
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        // empty tiles keep (0, 0), as after the radix path's memset
-        if (t0 + k < T) ranges[t0 + k] = run[k] ? make_uint2(min(before, capacity), min(before + run[k], capacity)) : make_uint2(0u, 0u);
-        before += run[k];
-    }
-}
-
 __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int gx, int T, const uint2 *__restrict__ rect,
                                                                      const uint32_t *__restrict__ hist,
                                                                      const uint2 *__restrict__ ranges, uint32_t capacity,
@@ -311,16 +282,11 @@ int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView
     if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&scatter_pairs_kernel), GROUP_MAX_TILES * 4, scatter_done)) return e;
     {
         ProfScope ps("group_scan", s);
-        if (T <= SMALL_SCAN_TILES) {
-            hipLaunchKernelGGL(group_scan_small_kernel, dim3(1), dim3(1024), 0, s, T, nchunks, w.group_hist, (uint32_t)capacity, im.ranges);
-            LVDGS_LAUNCH_CHECK("group_scan", a.debug, s);
-        } else {
         hipLaunchKernelGGL(group_colscan_kernel, dim3(cdiv(T, COLSCAN_TILES)), dim3(COLSCAN_TILES * COLSCAN_GROUPS), 0, s, T, nchunks, w.group_hist,
                            w.group_totals);
         hipLaunchKernelGGL(group_tilescan_kernel, dim3(1), dim3(1024), 0, s, T, (const uint32_t *)w.group_totals, (uint32_t)capacity,
                            im.ranges);
         LVDGS_LAUNCH_CHECK("group_scan", a.debug, s);
-        }
     }
     {
         ProfScope ps("group_scatter", s);
