@@ -250,7 +250,9 @@ def main():
         nbytes = algorithmic_bytes(dom, N, stats["V"], stats["D"], P, T)
         traffic = valu_insts = source = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        # (the PMC passes were taken on the tracking iteration; the mapping iteration's scene moves under Adam, its pair
+        # count differs: no traffic / instruction figures are attached to it)
+        if os.path.exists(tpath) and session is not None:
             tj = json.load(open(tpath))
             ent = tj.get(args.workload, {}).get(dom)
             if ent:
