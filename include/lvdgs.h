@@ -260,15 +260,28 @@ typedef struct lvdgs_pose_step_args {
 } lvdgs_pose_step_args;
 int lvdgs_pose_step(const lvdgs_pose_step_args *a, void *stream);
 
+/* lvdgs_backward with the photometric loss evaluated INSIDE the backward blend pass: every pixel's dL/d(colour, depth,
+ * opacity) is computed from `loss` (the formulas and parameters of lvdgs_photometric_loss_value_and_grad; d objective /
+ * d loss = *grad_loss, or 1 when NULL) as the pass reads its pixels -- no gradient images are written or read, and there
+ * is no separate pass over the frame (at 1080p: one launch and ~80 MB of traffic less per iteration).  a->dL_dout_* and
+ * loss->d_image / d_depth / d_opacity are ignored; the opacity image's gradient feeds the blend iff
+ * propagate_opacity_grad.  The loss's four partial sums are left per TILE in loss->scratch
+ * (lvdgs_loss_scratch_bytes covers that layout too) for lvdgs_tracking_tail(..., partials_per_tile = 1), which writes
+ * loss->loss and loss->d_exposure_a / _b.  Needs a non-empty map (num_gaussians, num_rendered > 0). */
+int lvdgs_backward_fused_loss(const lvdgs_args *a, const lvdgs_loss_args *loss, int32_t propagate_opacity_grad, void *stream);
+
 /* The end of a tracking iteration in ONE launch (instead of three at ~6 us each on the iteration's critical path):
- *   - finishes lvdgs_photometric_loss_partials(loss): writes loss->loss, loss->d_exposure_a / _b;
- *   - reduces the pose-gradient partials lvdgs_backward(bwd) left in bwd->scratch when called with bwd->dL_dtau == NULL
- *     (same `bwd` block, untouched in between: num_gaussians, num_rendered, scratch) and writes dL_dtau (6 floats);
+ *   - finishes the loss: sums the partial sums lvdgs_photometric_loss_partials(loss) left per 1024 pixels
+ *     (partials_per_tile = 0) or lvdgs_backward_fused_loss left per tile (1), writes loss->loss, loss->d_exposure_a / _b;
+ *   - reduces the pose-gradient partials lvdgs_backward(bwd) / lvdgs_backward_fused_loss(bwd, ...) left in bwd->scratch
+ *     when called with bwd->dL_dtau == NULL (same `bwd` block, untouched in between: num_gaussians, num_rendered,
+ *     scratch) and writes dL_dtau (6 floats);
  *   - applies lvdgs_pose_step(pose) with those gradients (pose->grad_* are ignored: the pose deltas take dL_dtau, the
  *     exposure parameters that `pose` names take loss->d_exposure_a / _b).  pose == NULL: the two reductions only (a
  *     view of the mapping iteration, whose keyframe is stepped after all views).
- * Same additions in the same order as the three separate launches: bit-identical results. */
-int lvdgs_tracking_tail(const lvdgs_loss_args *loss, const lvdgs_args *bwd, const lvdgs_pose_step_args *pose, float *dL_dtau, void *stream);
+ * Same additions in the same order as the separate launches: bit-identical results. */
+int lvdgs_tracking_tail(const lvdgs_loss_args *loss, const lvdgs_args *bwd, const lvdgs_pose_step_args *pose, float *dL_dtau,
+                        int32_t partials_per_tile, void *stream);
 
 /* ---- Adam step of the Gaussian map (reference utils/slam_backend.py:144, :378, :458: gaussians.optimizer.step()) ----
  * All parameter tensors in one launch, one pass over (grad, exp_avg, exp_avg_sq, param); torch.optim.Adam's arithmetic

@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "photometric.hpp"
 
 namespace lvdgs {
 
@@ -446,15 +447,14 @@ int lvdgs_forward(const lvdgs_args *a, int64_t *num_rendered, void *stream) {
     return LVDGS_OK;
 }
 
-int lvdgs_backward(const lvdgs_args *a, void *stream) {
-    hipStream_t s = (hipStream_t)stream;
+static int backward_impl(const lvdgs_args *a, const LossParams *fused, int propagate_opacity, hipStream_t s) {
     if (int e = check_common(a)) return e;
     if (int e = check_gaussians(a)) return e;
     const int N = a->num_gaussians, W = a->image_width, H = a->image_height;
     if (N == 0) return a->dL_dtau ? check_hip(hipMemsetAsync(a->dL_dtau, 0, 6 * sizeof(float), s), "memset tau") : LVDGS_OK;
     const int64_t D = a->num_rendered;
     if (D < 0) { set_error("negative num_rendered"); return LVDGS_E_INVALID; }
-    if (!a->dL_dout_color || !a->dL_dmeans3D || !a->dL_dmeans2D || !a->dL_dopacities || !a->projmatrix_raw || !a->radii) {
+    if ((!fused && !a->dL_dout_color) || !a->dL_dmeans3D || !a->dL_dmeans2D || !a->dL_dopacities || !a->projmatrix_raw || !a->radii) {
         set_error("a required backward pointer is NULL"); return LVDGS_E_INVALID;
     }
     if (a->cov3D_precomp ? !a->dL_dcov3D : (!a->dL_dscales || !a->dL_drotations)) { set_error("covariance gradient output is NULL"); return LVDGS_E_INVALID; }
@@ -470,9 +470,26 @@ int lvdgs_backward(const lvdgs_args *a, void *stream) {
     bwd_scratch_layout(N, D, &w, a->scratch);
     if (D > 0) {
         bin_layout(D, &b, a->binning_state);
-        if (int e = launch_blend_bwd(*a, g, b, im, w, s)) return e;
+        if (fused) {
+            if (int e = launch_blend_bwd_fused_loss(*a, g, b, im, w, *fused, propagate_opacity, s)) return e;
+        } else if (int e = launch_blend_bwd(*a, g, b, im, w, s)) return e;
     }
     return launch_preprocess_bwd(*a, g, w, s);
+}
+
+int lvdgs_backward(const lvdgs_args *a, void *stream) { return backward_impl(a, nullptr, 0, (hipStream_t)stream); }
+
+int lvdgs_backward_fused_loss(const lvdgs_args *a, const lvdgs_loss_args *loss, int32_t propagate_opacity_grad, void *stream) {
+    if (!a) { set_error("backward: args is NULL"); return LVDGS_E_INVALID; }
+    LossParams lp;
+    if (int e = loss_fused_params(loss, &lp)) return e;
+    if (loss->width != a->image_width || loss->height != a->image_height) { set_error("fused loss: image size differs from the rasterizer's"); return LVDGS_E_INVALID; }
+    if (a->num_gaussians == 0 || a->num_rendered == 0) {
+        // nothing was composited: the loss of the (background) image has no gradient to push anywhere, but its value is
+        // still wanted: zero partial sums are not it -- callers with an empty map use the separate loss kernels
+        set_error("fused loss: empty map (use lvdgs_photometric_loss_value_and_grad + lvdgs_backward)"); return LVDGS_E_INVALID;
+    }
+    return backward_impl(a, &lp, propagate_opacity_grad != 0, (hipStream_t)stream);
 }
 
 int lvdgs_mark_visible(int32_t N, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present,

@@ -22,6 +22,7 @@
 
 #include "common.hpp"
 #include "device_utils.hpp"
+#include "photometric.hpp"
 
 namespace lvdgs {
 
@@ -43,6 +44,9 @@ struct BlendParams {
     // backward
     const float *dL_dcolor, *dL_ddepth, *dL_dopacity;
     float *pair_grads;
+    // backward with the photometric loss evaluated in place of reading dL_d* (lvdgs_backward_fused_loss)
+    LossParams loss;             // loss.partial: 4 sums per TILE
+    int loss_propagate_opacity;  // dL/d(opacity image) feeds the blend (rasterizer.PROPAGATE_OPACITY_GRAD)
 };
 
 // Workgroup -> tile.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one) and an XCD takes its
@@ -751,10 +755,12 @@ struct Bwd3Shared {
     float acc[4][BR * ACC_STRIDE];       // per wave: Sx Sy Sxx Sxy Syy Su C0 C1 C2 CD of every entry it accumulated
     unsigned long long mask[4];
     uint32_t wmax[4];
+    float loss_sum[4][4];                // fused loss: [sum][wave]
     float2 M[4][NB][64];                 // per wave: (u, w) of [batch slot][pixel]
     uint32_t bj[4][NB];                  // per wave: entry (position in the round) of every batch slot
 };
 
+template <bool FUSED_LOSS>
 __global__ void __launch_bounds__(256, 5) blend_bwd3_kernel(BlendParams p) {
     constexpr int NB = Bwd3Shared::NB;
     __shared__ Bwd3Shared sh;
@@ -773,7 +779,30 @@ __global__ void __launch_bounds__(256, 5) blend_bwd3_kernel(BlendParams p) {
     const float T_final = inside ? p.final_T[pix] : 0.f;
     const uint32_t my_last = inside ? p.n_contrib[pix] : 0u;
     float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gD = 0.f, gO = 0.f;
-    if (inside) {
+    if constexpr (FUSED_LOSS) {
+        // the loss's gradient w.r.t. this pixel's colour / depth / opacity, from the rendered images and the targets:
+        // what photometric_kernel<2> would have written into three to five gradient images for this pass to read back
+        const LossParams &lp = p.loss;
+        const LossConsts lc(lp, true);
+        float G[3] = {0.f, 0.f, 0.f}, I[3] = {0.f, 0.f, 0.f}, op = 1.f, Z = 0.f, Dv = 0.f, gm = 1.f;
+        if (inside) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) { G[c] = lp.gt_image[c * P + pix]; I[c] = lp.image[c * P + pix]; }
+            if (lp.opacity) op = lp.opacity[pix];
+            if (lc.has_d) { Z = lp.gt_depth[pix]; Dv = lp.depth[pix]; }
+            if (lp.grad_mask) gm = lp.grad_mask[pix] ? 1.f : 0.f;
+        }
+        const PixelLoss px_loss = photometric_pixel<true, true>(lp, lc, G, I, op, Z, Dv, gm, inside);
+        gC0 = px_loss.dI[0]; gC1 = px_loss.dI[1]; gC2 = px_loss.dI[2]; gD = px_loss.dD;
+        gO = p.loss_propagate_opacity ? px_loss.dO : 0.f;
+        // the tile's four partial sums (loss value: colour, depth; exposure gradients: a, b), wave by wave
+        const float sums[4] = {px_loss.v_rgb, px_loss.v_d, px_loss.s_a, px_loss.s_b};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float v = wave_sum_to_lane63(sums[q]);
+            if (lane == 63) sh.loss_sum[q][wave] = v;
+        }
+    } else if (inside) {
         gC0 = p.dL_dcolor[pix]; gC1 = p.dL_dcolor[P + pix]; gC2 = p.dL_dcolor[2 * P + pix];
         if (p.dL_ddepth) gD = p.dL_ddepth[pix];
         if (p.dL_dopacity) gO = p.dL_dopacity[pix];
@@ -786,6 +815,9 @@ __global__ void __launch_bounds__(256, 5) blend_bwd3_kernel(BlendParams p) {
     if (lane == 0) sh.wmax[wave] = m;
     const int wave_last = (int)m;
     __syncthreads();
+    if constexpr (FUSED_LOSS) {
+        if (tid < 4) p.loss.partial[4 * (size_t)tile + tid] = ((sh.loss_sum[tid][0] + sh.loss_sum[tid][1]) + sh.loss_sum[tid][2]) + sh.loss_sum[tid][3];
+    }
     const int depth_max = (int)max(max(sh.wmax[0], sh.wmax[1]), max(sh.wmax[2], sh.wmax[3]));
     const int todo = (int)(range.y - range.x);
 
@@ -999,10 +1031,24 @@ int launch_blend_bwd(const lvdgs_args &a, const GeomView &g, const BinView &b, c
             // LVDGS_BWD3_LDS_PAD (experiments): unused dynamic LDS lowers the workgroups a CU holds (30.4 KB static: 5;
             // + 2560: 4).  Measured: config 3 302 us with five, 328 with four; KITTI geometry 136 / 132; 1200 tiles 83 / 96.
             static const int pad = [] { const char *e = getenv("LVDGS_BWD3_LDS_PAD"); return e ? atoi(e) : 0; }();
-            hipLaunchKernelGGL(blend_bwd3_kernel, dim3(p.num_tiles), dim3(256), pad, s, p);
+            hipLaunchKernelGGL(blend_bwd3_kernel<false>, dim3(p.num_tiles), dim3(256), pad, s, p);
             break;
         }
     }
+    LVDGS_LAUNCH_CHECK("blend_bwd", a.debug, s);
+    return LVDGS_OK;
+}
+
+
+int launch_blend_bwd_fused_loss(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, const BwdScratch &w,
+                                const LossParams &loss, int propagate_opacity, hipStream_t s) {
+    BlendParams p = make_params(a, g, b, im);
+    p.pair_grads = w.pair_grads;
+    p.loss = loss;
+    p.loss_propagate_opacity = propagate_opacity;
+    if (p.num_tiles == 0) return LVDGS_OK;
+    ProfScope ps("blend_bwd", s);
+    hipLaunchKernelGGL(blend_bwd3_kernel<true>, dim3(p.num_tiles), dim3(256), 0, s, p);
     LVDGS_LAUNCH_CHECK("blend_bwd", a.debug, s);
     return LVDGS_OK;
 }

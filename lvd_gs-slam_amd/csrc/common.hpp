@@ -119,7 +119,11 @@ size_t radix_hist_entries(int64_t n);
 struct LossTail {            // what photometric_finish_kernel<2> reads and writes (loss.hip)
     const float *partial; int nblk; int P; float w_rgb, w_d; float *loss, *d_a, *d_b;
 };
-int loss_tail_params(const lvdgs_loss_args *a, LossTail *out);   // validates like lvdgs_photometric_loss_value_and_grad
+int loss_tail_params(const lvdgs_loss_args *a, bool partials_per_tile, LossTail *out);   // validates like lvdgs_photometric_loss_value_and_grad
+struct LossParams;           // photometric.hpp
+int loss_fused_params(const lvdgs_loss_args *a, LossParams *out);   // for the backward blend pass: partial = a->scratch, 4 per tile
+int launch_blend_bwd_fused_loss(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, const BwdScratch &w,
+                                const LossParams &loss, int propagate_opacity, hipStream_t s);
 
 int launch_slot_scan(const uint32_t *tiles_touched, uint32_t *slot_base, uint32_t *blocksums, uint32_t *total_dev, int N, int dbg,
                      hipStream_t s);

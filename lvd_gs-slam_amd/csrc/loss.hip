@@ -12,29 +12,10 @@
 //   k_p = (Z_p > 0.01) [* (opacity_p > 0.95)]
 #include "common.hpp"
 #include "device_utils.hpp"
+#include "photometric.hpp"
 
 namespace lvdgs {
 namespace {
-
-struct LossParams {
-    int P;                       // pixels
-    const float *image;          // 3*P
-    const float *depth;          // P or null
-    const float *opacity;        // P or null
-    const float *gt_image;       // 3*P
-    const float *gt_depth;       // P or null
-    const uint8_t *grad_mask;    // P or null
-    const float *exposure_a, *exposure_b;  // 1 each or null (identity)
-    float rgb_thr, w_rgb, w_d;
-    int weight_by_opacity, depth_needs_opaque;
-    // forward
-    float *partial;              // nblk * 2 (rgb sum, depth sum)
-    float *loss;                 // 1
-    // backward
-    const float *grad_out;       // 1
-    float *d_image, *d_depth, *d_opacity;  // 3*P, P or null, P or null
-    float *d_a, *d_b;            // 1 each or null
-};
 
 constexpr int LOSS_THREADS = 256;
 constexpr int LOSS_PIX_PER_THREAD = 4;
@@ -55,15 +36,12 @@ template <int MODE, bool VEC>
 __global__ void __launch_bounds__(LOSS_THREADS) photometric_kernel(LossParams p) {
     constexpr bool BACKWARD = MODE != 0, VALUE = MODE != 1;
     __shared__ float s_red[4];
-    const float ea = p.exposure_a ? __expf(p.exposure_a[0]) : 1.f;
-    const float eb = p.exposure_b ? p.exposure_b[0] : 0.f;
-    const float g = BACKWARD ? (p.grad_out ? p.grad_out[0] : 1.f) : 0.f;
-    const float Wr = p.w_rgb / (3.f * (float)p.P) * g, Wd = p.w_d / (float)p.P * g;
+    const LossConsts lc(p, BACKWARD);
     float acc0 = 0.f, acc1 = 0.f;  // rgb sum, depth sum (value)
     float acc2 = 0.f, acc3 = 0.f;  // d_a sum, d_b sum (gradients)
     const int base = (blockIdx.x * LOSS_THREADS + threadIdx.x) * LOSS_PIX_PER_THREAD;
     const size_t P = (size_t)p.P;
-    const bool has_d = p.depth && p.gt_depth;
+    const bool has_d = lc.has_d;
     if (base < p.P) {
         float G[3][4], I[3][4], op[4], Z[4], Dv[4], gm[4];
         const int n = VEC ? 4 : min(4, p.P - base);
@@ -94,29 +72,13 @@ __global__ void __launch_bounds__(LOSS_THREADS) photometric_kernel(LossParams p)
         float dI[3][4], dO[4], dD[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const bool live = VEC || k < n;
-            const float m = ((G[0][k] + G[1][k] + G[2][k] > p.rgb_thr) ? 1.f : 0.f) * gm[k] * (live ? 1.f : 0.f);
-            const float om = p.weight_by_opacity ? op[k] : 1.f;
-            const float r0 = (ea * I[0][k] + eb) * m - G[0][k] * m, r1 = (ea * I[1][k] + eb) * m - G[1][k] * m,
-                        r2 = (ea * I[2][k] + eb) * m - G[2][k] * m;
-            float kd = 0.f, rd = 0.f;
-            if (has_d) {
-                kd = (Z[k] > 0.01f && live) ? 1.f : 0.f;
-                if (p.depth_needs_opaque) kd *= op[k] > 0.95f ? 1.f : 0.f;
-                rd = Dv[k] * kd - Z[k] * kd;
-            }
-            if (VALUE) {
-                acc0 += om * (fabsf(r0) + fabsf(r1) + fabsf(r2));
-                acc1 += fabsf(rd);
-            }
+            const float Gk[3] = {G[0][k], G[1][k], G[2][k]}, Ik[3] = {I[0][k], I[1][k], I[2][k]};
+            const PixelLoss px = photometric_pixel<VALUE, BACKWARD>(p, lc, Gk, Ik, op[k], has_d ? Z[k] : 0.f, has_d ? Dv[k] : 0.f, gm[k], VEC || k < n);
+            if (VALUE) { acc0 += px.v_rgb; acc1 += px.v_d; }
             if (BACKWARD) {
-                auto sgn = [](float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); };
-                const float q0 = Wr * om * sgn(r0) * m, q1 = Wr * om * sgn(r1) * m, q2 = Wr * om * sgn(r2) * m;
-                dI[0][k] = ea * q0; dI[1][k] = ea * q1; dI[2][k] = ea * q2;
-                dO[k] = p.weight_by_opacity ? Wr * (fabsf(r0) + fabsf(r1) + fabsf(r2)) : 0.f;
-                dD[k] = Wd * sgn(rd) * kd;
-                acc2 += ea * (q0 * I[0][k] + q1 * I[1][k] + q2 * I[2][k]);
-                acc3 += q0 + q1 + q2;
+                dI[0][k] = px.dI[0]; dI[1][k] = px.dI[1]; dI[2][k] = px.dI[2];
+                dO[k] = px.dO; dD[k] = px.dD;
+                acc2 += px.s_a; acc3 += px.s_b;
             }
         }
         if (BACKWARD) {
@@ -269,8 +231,12 @@ using namespace lvdgs;
 extern "C" {
 
 size_t lvdgs_loss_scratch_bytes(int32_t width, int32_t height) {
+    // 4 partial sums per workgroup of the loss kernels (1024 pixels each) or, when the backward blend pass evaluates the
+    // loss (lvdgs_backward_fused_loss), per 16x16 tile: room for the larger of the two
     const int64_t P = (int64_t)width * height;
-    return align256((size_t)cdiv(P, LOSS_THREADS * LOSS_PIX_PER_THREAD) * 4 * sizeof(float) + 256);
+    const int64_t tiles = (int64_t)cdiv(width, TILE) * cdiv(height, TILE);
+    const int64_t blocks = cdiv(P, LOSS_THREADS * LOSS_PIX_PER_THREAD);
+    return align256((size_t)(blocks > tiles ? blocks : tiles) * 4 * sizeof(float) + 256);
 }
 
 static int loss_common(const lvdgs_loss_args *a, LossParams &p, int &nblk) {
@@ -312,9 +278,9 @@ int lvdgs_photometric_loss_backward(const lvdgs_loss_args *a, void *stream) {
     return LVDGS_OK;
 }
 
-static int value_and_grad_params(const lvdgs_loss_args *a, LossParams &p, int &nblk, bool need_loss) {
+static int value_and_grad_params(const lvdgs_loss_args *a, LossParams &p, int &nblk, bool need_loss, bool need_images = true) {
     if (int e = loss_common(a, p, nblk)) return e;
-    if ((need_loss && !a->loss) || !a->d_image) { set_error("loss value_and_grad: loss / d_image is NULL"); return LVDGS_E_INVALID; }
+    if ((need_loss && !a->loss) || (need_images && !a->d_image)) { set_error("loss value_and_grad: loss / d_image is NULL"); return LVDGS_E_INVALID; }
     p.loss = a->loss;
     p.grad_out = a->grad_loss;  // NULL: d objective / d loss = 1
     p.d_image = a->d_image; p.d_depth = a->d_depth; p.d_opacity = a->d_opacity; p.d_a = a->d_exposure_a; p.d_b = a->d_exposure_b;
@@ -349,11 +315,17 @@ int lvdgs_photometric_loss_partials(const lvdgs_loss_args *a, void *stream) {
 }  // extern "C"
 
 namespace lvdgs {
-int loss_tail_params(const lvdgs_loss_args *a, LossTail *out) {
+int loss_tail_params(const lvdgs_loss_args *a, bool partials_per_tile, LossTail *out) {
     LossParams p; int nblk;
-    if (int e = value_and_grad_params(a, p, nblk, true)) return e;
+    if (int e = value_and_grad_params(a, p, nblk, true, !partials_per_tile)) return e;
+    if (partials_per_tile) nblk = cdiv(a->width, TILE) * cdiv(a->height, TILE);
     *out = LossTail{p.partial, nblk, p.P, p.w_rgb, p.w_d, p.loss, p.d_a, p.d_b};
     return LVDGS_OK;
+}
+
+int loss_fused_params(const lvdgs_loss_args *a, LossParams *out) {
+    int nblk;
+    return value_and_grad_params(a, *out, nblk, false, false);
 }
 }  // namespace lvdgs
 

@@ -142,16 +142,20 @@ struct TailParams {
     int has_pose;                // 0: the two reductions only (a mapping view: its keyframe is stepped later)
 };
 
-__global__ void __launch_bounds__(256) tracking_tail_kernel(TailParams t) {
-    __shared__ float s[10][4];   // [value][wave]: loss sums 0..3, pose gradient 4..9
+// THREADS = 256: the order of photometric_finish_kernel / tau_reduce_kernel (bit-identical to them); 1024: for the four
+// times as many per-tile partial sums lvdgs_backward_fused_loss leaves (a fixed order of its own).
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) tracking_tail_kernel(TailParams t) {
+    constexpr int WAVES = THREADS / 64;
+    __shared__ float s[10][WAVES];   // [value][wave]: loss sums 0..3, pose gradient 4..9
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float a[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int b = threadIdx.x; b < t.loss.nblk; b += 256) {
+    for (int b = threadIdx.x; b < t.loss.nblk; b += THREADS) {
         a[0] += t.loss.partial[4 * b]; a[1] += t.loss.partial[4 * b + 1];
         a[2] += t.loss.partial[4 * b + 2]; a[3] += t.loss.partial[4 * b + 3];
     }
     float g[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int b = threadIdx.x; b < t.tau_blocks; b += 256)
+    for (int b = threadIdx.x; b < t.tau_blocks; b += THREADS)
 #pragma unroll
         for (int k = 0; k < 6; k++) g[k] += t.tau_part[(size_t)b * 6 + k];
 #pragma unroll
@@ -166,7 +170,9 @@ __global__ void __launch_bounds__(256) tracking_tail_kernel(TailParams t) {
     }
     __syncthreads();
     if (threadIdx.x < 10) {
-        const float v = ((s[threadIdx.x][0] + s[threadIdx.x][1]) + s[threadIdx.x][2]) + s[threadIdx.x][3];
+        float v = s[threadIdx.x][0];
+#pragma unroll
+        for (int w = 1; w < WAVES; w++) v += s[threadIdx.x][w];   // ((s0 + s1) + s2) + s3 ...
         s[threadIdx.x][0] = v;
         if (threadIdx.x >= 4) t.dL_dtau[threadIdx.x - 4] = v;
     }
@@ -207,13 +213,13 @@ static int check_pose_args(const lvdgs_pose_step_args *a) {
 }
 
 extern "C" int lvdgs_tracking_tail(const lvdgs_loss_args *loss, const lvdgs_args *bwd, const lvdgs_pose_step_args *pose, float *dL_dtau,
-                                   void *stream) {
+                                   int32_t partials_per_tile, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     if (!bwd || !dL_dtau) { set_error("tracking tail: backward arguments / dL_dtau is NULL"); return LVDGS_E_INVALID; }
     if (pose)
         if (int e = check_pose_args(pose)) return e;
     TailParams t{};
-    if (int e = loss_tail_params(loss, &t.loss)) return e;
+    if (int e = loss_tail_params(loss, partials_per_tile != 0, &t.loss)) return e;
     const int N = bwd->num_gaussians;
     if (N < 0 || bwd->num_rendered < 0 || (N > 0 && !bwd->scratch)) { set_error("tracking tail: bad backward arguments"); return LVDGS_E_INVALID; }
     if (N > 0) {
@@ -232,7 +238,8 @@ extern "C" int lvdgs_tracking_tail(const lvdgs_loss_args *loss, const lvdgs_args
         t.pose.grad_exposure_b = pose->exposure_b ? loss->d_exposure_b : nullptr;
     }
     ProfScope ps("tracking_tail", s);
-    hipLaunchKernelGGL(tracking_tail_kernel, dim3(1), dim3(256), 0, s, t);
+    if (partials_per_tile) hipLaunchKernelGGL(tracking_tail_kernel<1024>, dim3(1), dim3(1024), 0, s, t);
+    else hipLaunchKernelGGL(tracking_tail_kernel<256>, dim3(1), dim3(256), 0, s, t);
     LVDGS_LAUNCH_CHECK("tracking_tail", 0, s);
     return LVDGS_OK;
 }

@@ -8,10 +8,12 @@ Through PyTorch that is two ``autograd.Function`` round trips per view, the conc
 engine's thread hand-over and a dozen accumulation kernels: ~0.3 ms of host time per view, which is what bounds a
 mapping iteration once the kernels are fast (one view per GPU in the sharded window, ten on a single GPU).
 
-The pass does the same arithmetic as four calls into the C ABI on argument blocks and buffers that live as long as the
+The pass does the same arithmetic as three calls into the C ABI on argument blocks and buffers that live as long as the
 back end:
 
-    lvdgs_forward -> lvdgs_photometric_loss_partials -> lvdgs_backward -> lvdgs_tracking_tail (reductions only)
+    lvdgs_forward -> lvdgs_backward_fused_loss -> lvdgs_tracking_tail (reductions only)
+
+(the backward evaluates the mapping loss's image gradients itself as it reads its pixels)
 
 with the activations fused into the rasterizer (``lvdgs_args.activations``), so ``lvdgs_backward`` writes the gradients
 w.r.t. the model's RAW parameters: they go straight into the ``.grad`` fields autograd would have filled (the first view
@@ -92,15 +94,14 @@ class MapViewPass:
         e = lambda *s: torch.empty(*s, dtype=torch.float32, device=self.dev)
         self.W, self.H = W, H
         self.image = self._bytes(self.L.lvdgs_image_bytes(W, H))
-        self.d_image, self.d_depth = e(3, H, W), e(1, H, W)
         self.loss_scratch = self._bytes(self.L.lvdgs_loss_scratch_bytes(W, H))
         a, la = self.a, self.la
         a.image_height, a.image_width = H, W
         a.image_state, a.image_bytes = _P(self.image), self.image.numel()
-        a.dL_dout_color, a.dL_dout_opacity = _P(self.d_image), None
+        a.dL_dout_color = a.dL_dout_depth = a.dL_dout_opacity = None   # the backward evaluates the loss per pixel
         la.width, la.height = W, H
         la.scratch, la.scratch_bytes, la.grad_loss = _P(self.loss_scratch), self.loss_scratch.numel(), _P(self.one)
-        la.d_image, la.d_opacity, la.opacity, la.grad_mask = _P(self.d_image), None, None, None
+        la.d_image = la.d_depth = la.d_opacity = la.opacity = la.grad_mask = None
         la.weight_by_opacity = la.depth_needs_opaque = 0
         if self.N >= 0:
             self._size_for_pairs(self.cap)
@@ -180,9 +181,8 @@ class MapViewPass:
         alpha = T.get("alpha", 0.95)
         md = f32c(_mono_depth(viewpoint, color))
         keep.append(md)
-        la.depth, la.gt_depth, la.d_depth = _P(depth), _P(md), _P(self.d_depth)
+        la.depth, la.gt_depth = _P(depth), _P(md)
         la.weight_rgb, la.weight_depth = float(alpha), float(1 - alpha)
-        a.dL_dout_depth = _P(self.d_depth)
         loss = e(())
         la.loss = _P(loss)
 
@@ -198,9 +198,8 @@ class MapViewPass:
             else:
                 _lib.check(status, "lvdgs_forward")
             a.num_rendered = D
-            _lib.check(L.lvdgs_photometric_loss_partials(C.byref(la), stream), "lvdgs_photometric_loss_partials")
-            _lib.check(L.lvdgs_backward(C.byref(a), stream), "lvdgs_backward")
-            _lib.check(L.lvdgs_tracking_tail(C.byref(la), C.byref(a), None, _P(d_tau), stream), "lvdgs_tracking_tail")
+            _lib.check(L.lvdgs_backward_fused_loss(C.byref(a), C.byref(la), 0, stream), "lvdgs_backward_fused_loss")
+            _lib.check(L.lvdgs_tracking_tail(C.byref(la), C.byref(a), None, _P(d_tau), 1, stream), "lvdgs_tracking_tail")
 
         # ---- hand the gradients over exactly where autograd would have put them ----
         if K > 1:

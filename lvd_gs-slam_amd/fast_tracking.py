@@ -12,10 +12,12 @@ iteration whatever the scene, which is what bounds tracking at SLAM-sized maps (
 The session does the same arithmetic as four calls into the C ABI on pre-filled argument blocks and buffers that
 live for the frame:
 
-    lvdgs_forward -> lvdgs_photometric_loss_partials -> lvdgs_backward -> lvdgs_tracking_tail
+    lvdgs_forward -> lvdgs_backward_fused_loss -> lvdgs_tracking_tail
 
-(the last one finishes the loss, reduces the pose gradient and applies the pose step in one launch; the same arithmetic as
-lvdgs_photometric_loss_value_and_grad / lvdgs_backward with dL_dtau / lvdgs_pose_step, two launches fewer)
+(the backward evaluates the tracking loss's image gradients itself, pixel by pixel, instead of reading gradient images a
+separate pass would have written; the tail finishes the loss value and the exposure gradients, reduces the pose gradient
+and applies the pose step in one launch: the arithmetic of lvdgs_photometric_loss_value_and_grad / lvdgs_backward /
+lvdgs_pose_step, three launches and ~80 MB of traffic per 1080p iteration fewer)
 
 and nothing comes back to the host inside the loop except the pair count ``lvdgs_forward`` has always read (the GPU has
 the rest of the iteration queued behind it).  Convergence (``||tau|| < 1e-4``, utils/pose_utils.py:82) is a sticky
@@ -138,12 +140,11 @@ class TrackingSession:
             la.weight_rgb, la.weight_depth, la.depth_needs_opaque = float(alpha), float(1 - alpha), 1
         self.loss_scratch = bytes_(L.lvdgs_loss_scratch_bytes(W, H))
         self.loss, self.one = e(()), torch.ones((), dtype=torch.float32, device=dev)
-        self.d_image, self.d_depth, self.d_opac = e(3, H, W), (None if T["monocular"] else e(1, H, W)), e(1, H, W)
         self.d_a, self.d_b = e(1), e(1)
         la.scratch, la.scratch_bytes, la.loss, la.grad_loss = _P(self.loss_scratch), self.loss_scratch.numel(), _P(self.loss), _P(self.one)
-        la.d_image, la.d_depth, la.d_opacity, la.d_exposure_a, la.d_exposure_b = _P(self.d_image), _P(self.d_depth), _P(self.d_opac), _P(self.d_a), _P(self.d_b)
-        a.dL_dout_color, a.dL_dout_depth = _P(self.d_image), _P(self.d_depth)
-        a.dL_dout_opacity = _P(self.d_opac) if _rz.PROPAGATE_OPACITY_GRAD else None
+        la.d_image = la.d_depth = la.d_opacity = None   # never materialised: the backward computes them per pixel
+        la.d_exposure_a, la.d_exposure_b = _P(self.d_a), _P(self.d_b)
+        a.dL_dout_color = a.dL_dout_depth = a.dL_dout_opacity = None
 
         # ---- pose step (include/lvdgs.h: lvdgs_pose_step_args): torch.optim.Adam defaults, the front end's learning rates ----
         pa = self.pa = _lib.PoseStepArgs()
@@ -186,11 +187,10 @@ class TrackingSession:
             else:
                 _lib.check(status, "lvdgs_forward")
             self.num_rendered = a.num_rendered = D
-            # loss and all its image gradients in one pass over the images (the objective is the loss: d/d loss = 1); its
-            # final reduction, the pose gradient's and the pose step share the iteration's last launch
-            _lib.check(L.lvdgs_photometric_loss_partials(C.byref(self.la), stream), "lvdgs_photometric_loss_partials")
-            _lib.check(L.lvdgs_backward(C.byref(a), stream), "lvdgs_backward")
-            _lib.check(L.lvdgs_tracking_tail(C.byref(self.la), C.byref(a), C.byref(self.pa), _P(self.d_tau), stream), "lvdgs_tracking_tail")
+            # the backward evaluates the loss's image gradients as it reads its pixels (the objective is the loss: d/d loss
+            # = 1); the loss's final reduction, the pose gradient's and the pose step share the iteration's last launch
+            _lib.check(L.lvdgs_backward_fused_loss(C.byref(a), C.byref(self.la), int(_rz.PROPAGATE_OPACITY_GRAD), stream), "lvdgs_backward_fused_loss")
+            _lib.check(L.lvdgs_tracking_tail(C.byref(self.la), C.byref(a), C.byref(self.pa), _P(self.d_tau), 1, stream), "lvdgs_tracking_tail")
             if record_loss is not None:
                 record_loss.copy_(self.loss)
         self.iterations_enqueued += 1
