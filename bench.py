@@ -140,7 +140,7 @@ def main():
     ap.add_argument("--step", choices=["auto", "tracking", "tracking-autograd", "mapping"], default="auto",
                     help="auto: tracking iteration on 1 GPU, mapping-window iteration on N > 1.  tracking: one iteration of "
                          "the product's tracking loop (fast_tracking.TrackingSession: render, tracking loss, backward, pose "
-                         "optimiser step -- four C-ABI calls, no autograd); tracking-autograd: render() -> "
+                         "optimiser step -- three C-ABI calls, no autograd); tracking-autograd: render() -> "
                          "get_loss_tracking -> backward through the public autograd API, without the optimiser step")
     args = ap.parse_args()
 
@@ -333,7 +333,7 @@ def main():
             "config": {"workload": args.workload, "gaussians": N, "width": W, "height": H, "visible": stats["V"],
                        "pairs": stats["D"], "sh_degree": 0,
                        "step": (("tracking iteration of slam_loops.track_frame on a TrackingSession: render + get_loss_tracking + backward "
-                                 "(pose + all Gaussian grads) + pose optimiser step (Adam, SE(3) retraction, camera matrices) -- four C-ABI calls"
+                                 "(pose + all Gaussian grads) + pose optimiser step (Adam, SE(3) retraction, camera matrices) -- three C-ABI calls: lvdgs_forward, lvdgs_backward_fused_loss, lvdgs_tracking_tail"
                                  if session is not None else
                                  "tracking iteration through the autograd API: render() + get_loss_tracking + backward (pose + all Gaussian grads)")
                                 if tracking else

@@ -9,7 +9,7 @@ Driven through PyTorch that is two ``autograd.Function`` round trips, the autogr
 matrices, with three host synchronisations (``if angle < 1e-5`` twice, ``if converged``): 0.5 ms of host time per
 iteration whatever the scene, which is what bounds tracking at SLAM-sized maps (1e5 Gaussians, KITTI frames).
 
-The session does the same arithmetic as four calls into the C ABI on pre-filled argument blocks and buffers that
+The session does the same arithmetic as three calls into the C ABI on pre-filled argument blocks and buffers that
 live for the frame:
 
     lvdgs_forward -> lvdgs_backward_fused_loss -> lvdgs_tracking_tail

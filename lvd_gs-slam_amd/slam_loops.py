@@ -108,7 +108,7 @@ def track_frame(viewpoint, gaussians, config, pipeline_params, background, track
     scope here) must already be set.  Returns (last render package, median depth :1535, iterations run).
 
     ``fused`` ("auto" / True / False): with the HIP renderer and everything on the GPU the loop runs on
-    ``fast_tracking.TrackingSession`` -- the same arithmetic as four C-ABI calls per iteration on buffers that live for
+    ``fast_tracking.TrackingSession`` -- the same arithmetic as three C-ABI calls per iteration on buffers that live for
     the frame, the Adam step / retraction / camera matrices in one device kernel, no autograd engine and no host
     synchronisation inside the loop.  ``on_iteration`` then gets (iteration, loss as a 0-dim CPU tensor, None) after
     the loop.  ``fused=False`` (or another ``render_fn``) is the PyTorch loop below, statement for statement the
