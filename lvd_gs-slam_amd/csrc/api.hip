@@ -425,11 +425,11 @@ int lvdgs_forward(const lvdgs_args *a, int64_t *num_rendered, void *stream) {
     if (int e = get_probe(&probe)) return e;
     GeomView g;
     geom_layout(N, &g, a->geom_state);
-    // The counting path's first kernel can make the slot prefix sum and the pair count itself: one launch less (config 3:
-    // -5 us per frame), but the host then learns the count one kernel later, and on small frames (KITTI geometry, 200k
-    // Gaussians: 0.34 ms per tracking iteration) it is the host's enqueueing of the rest of the iteration that the GPU
-    // ends up waiting for (+12 us measured).  So only for large maps.
-    const bool fused = N >= (1 << 18) && use_counting_path(cdiv(a->image_width, TILE) * cdiv(a->image_height, TILE));
+    // The counting path's first kernel makes the slot prefix sum and the pair count itself: one launch less (-5 us per frame
+    // at config 3, -2 us at KITTI geometry and at 100k / 640x480, same-box A/B; LVDGS_FUSE_SLOT_SCAN_MIN_N sets a lower
+    // bound on the map size for experiments).
+    static const int fuse_min_n = [] { const char *e = getenv("LVDGS_FUSE_SLOT_SCAN_MIN_N"); return e ? atoi(e) : 0; }();
+    const bool fused = N >= fuse_min_n && use_counting_path(cdiv(a->image_width, TILE) * cdiv(a->image_height, TILE));
     if (int e = enqueue_prepare(a, g, !fused, s)) return e;
     if (!fused)
         if (int e = enqueue_count_probe(probe, g.total, s)) return e;
