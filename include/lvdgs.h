@@ -259,6 +259,8 @@ typedef struct lvdgs_pose_step_args {
     const float *grad_trans;       /* 3 or NULL */
 } lvdgs_pose_step_args;
 int lvdgs_pose_step(const lvdgs_pose_step_args *a, void *stream);
+/* `count` independent steps (distinct cameras: the keyframes of a mapping window) in one launch instead of `count`. */
+int lvdgs_pose_step_batch(const lvdgs_pose_step_args *steps, int32_t count, void *stream);
 
 /* lvdgs_backward with the photometric loss evaluated INSIDE the backward blend pass: every pixel's dL/d(colour, depth,
  * opacity) is computed from `loss` (the formulas and parameters of lvdgs_photometric_loss_value_and_grad; d objective /

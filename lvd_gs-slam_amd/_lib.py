@@ -108,7 +108,7 @@ EXPORTS = (
     "lvdgs_backward", "lvdgs_mark_visible", "lvdgs_state_layout_query", "lvdgs_knn_scratch_bytes",
     "lvdgs_dist2_knn3", "lvdgs_rope2d", "lvdgs_rope2d_strided", "lvdgs_loss_scratch_bytes", "lvdgs_photometric_loss_forward",
     "lvdgs_photometric_loss_backward", "lvdgs_photometric_loss_value_and_grad", "lvdgs_photometric_loss_partials", "lvdgs_tracking_tail", "lvdgs_backward_fused_loss", "lvdgs_masked_depth_scratch_bytes", "lvdgs_masked_depth_l1_forward",
-    "lvdgs_masked_depth_l1_backward", "lvdgs_pose_step", "lvdgs_adam_step", "lvdgs_isotropic_scratch_bytes", "lvdgs_isotropic_reg", "lvdgs_view_stats", "lvdgs_ssim_scratch_bytes", "lvdgs_ssim_l1", "lvdgs_last_error", "lvdgs_version", "lvdgs_profile_enable",
+    "lvdgs_masked_depth_l1_backward", "lvdgs_pose_step", "lvdgs_pose_step_batch", "lvdgs_adam_step", "lvdgs_isotropic_scratch_bytes", "lvdgs_isotropic_reg", "lvdgs_view_stats", "lvdgs_ssim_scratch_bytes", "lvdgs_ssim_l1", "lvdgs_last_error", "lvdgs_version", "lvdgs_profile_enable",
     "lvdgs_profile_reset", "lvdgs_profile_read",
 )
 
@@ -163,6 +163,7 @@ def lib():
         L.lvdgs_masked_depth_l1_forward.argtypes = [C.POINTER(MaskedDepthArgs), C.c_void_p]
         L.lvdgs_masked_depth_l1_backward.argtypes = [C.POINTER(MaskedDepthArgs), C.c_void_p]
         L.lvdgs_pose_step.argtypes = [C.POINTER(PoseStepArgs), C.c_void_p]
+        L.lvdgs_pose_step_batch.argtypes = [C.POINTER(PoseStepArgs), C.c_int32, C.c_void_p]
         L.lvdgs_photometric_loss_partials.argtypes = [C.POINTER(LossArgs), C.c_void_p]
         L.lvdgs_tracking_tail.argtypes = [C.POINTER(LossArgs), C.POINTER(Args), C.POINTER(PoseStepArgs), C.c_void_p, C.c_int32, C.c_void_p]
         L.lvdgs_backward_fused_loss.argtypes = [C.POINTER(Args), C.POINTER(LossArgs), C.c_int32, C.c_void_p]

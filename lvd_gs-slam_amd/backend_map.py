@@ -226,8 +226,14 @@ class KeyframeStepper:
         return all(id(p) in owned for gp in optimizer.param_groups for p in gp["params"]) and all(hasattr(vp, "update_RT") for vp in viewpoints)
 
     def step(self):
+        """All keyframes' steps in ONE launch (``lvdgs_pose_step_batch``; they touch disjoint cameras)."""
         L = _lib.lib()
-        for vp, a, pose, has, keep in self.items:
+        if not self.items:
+            return
+        if getattr(self, "_batch", None) is None or len(self._batch) != len(self.items):
+            self._batch = (_lib.PoseStepArgs * len(self.items))()
+        dev = self.items[0][0].exposure_a.device
+        for i, (vp, a, pose, has, keep) in enumerate(self.items):
             g = lambda n: getattr(vp, n).grad if has[n] else None
             gr, gt, ga, gb = g("cam_rot_delta"), g("cam_trans_delta"), g("exposure_a"), g("exposure_b")
             for t in (gr, gt, ga, gb):
@@ -239,9 +245,12 @@ class KeyframeStepper:
                 keep[1].copy_(vp.R.detach().to(keep[1]))
                 keep[2].copy_(vp.T.detach().to(keep[2]))
                 vp.update_RT(keep[1], keep[2])
-            dev = vp.exposure_a.device
-            with _lib.on_device(dev):
-                _lib.check(L.lvdgs_pose_step(C.byref(a), _lib.raw_stream(dev)), "lvdgs_pose_step")
+            if vp.exposure_a.device != dev:
+                raise ValueError("KeyframeStepper: keyframes on different devices")
+            C.memmove(C.byref(self._batch, i * C.sizeof(_lib.PoseStepArgs)), C.byref(a), C.sizeof(_lib.PoseStepArgs))
+        with _lib.on_device(dev):
+            _lib.check(L.lvdgs_pose_step_batch(self._batch, len(self.items), _lib.raw_stream(dev)), "lvdgs_pose_step_batch")
+        for vp, a, pose, has, keep in self.items:
             if pose and hasattr(vp, "_derived_key"):
                 # R / T were advanced in place (their version counters did not move): install the matrices the launch
                 # wrote as the camera's cache for exactly these tensors, or drop the stale cache
@@ -258,10 +267,13 @@ class _ViewStats:
 
     def __init__(self, N, n_window, dev):
         self.N, self.n_window, self.dev = N, n_window, dev
-        self.radii_max = torch.zeros(N, dtype=torch.int32, device=dev)
-        self.norm_sum = torch.zeros(N, dtype=torch.float32, device=dev)
-        self.vis_count = torch.zeros(N, dtype=torch.float32, device=dev)
-        self.flags = _flag_words(n_window + 1, N, dev)   # rows 0..n_window-1: n_touched > 0 ; last row: seen by any view
+        # one zero-filled buffer (one launch) cut into the four pieces
+        n4 = (N + 3) // 4 * 4
+        raw = torch.zeros(12 * N + (n_window + 1) * n4, dtype=torch.uint8, device=dev)
+        self.radii_max = raw[:4 * N].view(torch.int32)
+        self.norm_sum = raw[4 * N:8 * N].view(torch.float32)
+        self.vis_count = raw[8 * N:12 * N].view(torch.float32)
+        self.flags = raw[12 * N:].view(n_window + 1, n4)   # rows 0..n_window-1: n_touched > 0 ; last row: seen by any view
 
     def add(self, i, pkg):
         N, n_window = self.N, self.n_window
@@ -428,8 +440,9 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
 
             # ---- bookkeeping of reference :309-389 on the reduced values ----
             backend.occ_aware_visibility = {}
+            touched = flags[:n_window].long()   # one conversion for the window; the dict holds its rows
             for idx in range(n_window):
-                backend.occ_aware_visibility[current_window[idx]] = flags[idx].long()
+                backend.occ_aware_visibility[current_window[idx]] = touched[idx]
 
             # Only prune on the last iteration and when we have full window (:318-348).  The reference returns from here
             # without an optimizer step and without clearing the gradients, so (unless pruning replaces the parameters)
@@ -461,9 +474,8 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
                         backend.initialized = True
                 return False
 
-            G.max_radii2D = torch.max(G.max_radii2D, radii_max.to(G.max_radii2D.dtype))
-            G.xyz_gradient_accum += norm_sum[:, None]
-            G.denom += vis_count[:, None]
+            G.max_radii2D = torch.maximum(G.max_radii2D, radii_max)   # (int32 promotes to the float32 of max_radii2D)
+            torch._foreach_add_([G.xyz_gradient_accum, G.denom], [norm_sum[:, None], vis_count[:, None]])
 
             update_gaussian = backend.iteration_count % backend.gaussian_update_every == backend.gaussian_update_offset
             gaussian_split = False

@@ -132,6 +132,16 @@ __global__ void pose_step_kernel(PoseStepParams pp) {
     pose_step_body(pp.a);
 }
 
+// Several independent pose steps (the window's keyframes after a mapping iteration) in one launch: one workgroup each.
+constexpr int POSE_BATCH_MAX = 16;
+struct PoseBatchParams {
+    lvdgs_pose_step_args a[POSE_BATCH_MAX];
+};
+__global__ void pose_step_batch_kernel(PoseBatchParams pp) {
+    if (threadIdx.x != 0) return;
+    pose_step_body(pp.a[blockIdx.x]);
+}
+
 // The end of a tracking iteration in one launch (lvdgs_tracking_tail): what photometric_finish_kernel<2>, tau_reduce_kernel
 // and pose_step_kernel do one after the other -- the same additions in the same order, so the same bits -- without two
 // launches of ~6 us each on the iteration's critical path.
@@ -241,5 +251,22 @@ extern "C" int lvdgs_tracking_tail(const lvdgs_loss_args *loss, const lvdgs_args
     if (partials_per_tile) hipLaunchKernelGGL(tracking_tail_kernel<1024>, dim3(1), dim3(1024), 0, s, t);
     else hipLaunchKernelGGL(tracking_tail_kernel<256>, dim3(1), dim3(256), 0, s, t);
     LVDGS_LAUNCH_CHECK("tracking_tail", 0, s);
+    return LVDGS_OK;
+}
+
+extern "C" int lvdgs_pose_step_batch(const lvdgs_pose_step_args *steps, int32_t count, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (count < 0 || (count > 0 && !steps)) { set_error("pose step batch: bad arguments"); return LVDGS_E_INVALID; }
+    for (int32_t first = 0; first < count; first += POSE_BATCH_MAX) {
+        const int n = count - first < POSE_BATCH_MAX ? count - first : POSE_BATCH_MAX;
+        PoseBatchParams pp{};
+        for (int i = 0; i < n; i++) {
+            if (int e = check_pose_args(steps + first + i)) return e;
+            pp.a[i] = steps[first + i];
+        }
+        ProfScope ps("pose_step", s);
+        hipLaunchKernelGGL(pose_step_batch_kernel, dim3(n), dim3(64), 0, s, pp);
+        LVDGS_LAUNCH_CHECK("pose_step", 0, s);
+    }
     return LVDGS_OK;
 }
