@@ -32,7 +32,7 @@ import torch.distributed as dist
 
 from . import _lib
 
-from .fast_mapping import MapViewPass
+from .fast_mapping import MapViewPass, _PARAM_FIELDS
 from .gaussian_renderer import render
 from .loss_utils import masked_mapping_loss
 from .pose_utils import update_pose
@@ -90,6 +90,18 @@ class FlatReducer:
             return torch.empty(max(n, 1), dtype=dtype, device=device)
         return buf
 
+    def plan_floats(self, sizes: Sequence[int], device):
+        """Views of the float bucket laid out for ``sizes``: whoever produces a piece can write it where ``sum_floats``
+        will look for it (a piece found in place is not copied)."""
+        total = int(sum(sizes))
+        self.fbuf = self._fit(self.fbuf, total, torch.float32, device)
+        return list(self.fbuf[:total].split([int(n) for n in sizes]))
+
+    def plan_ints(self, total: int, device):
+        """The first ``total`` int32 words of the int bucket (uninitialised), for a producer to lay its pieces out in."""
+        self.ibuf = self._fit(self.ibuf, int(total), torch.int32, device)
+        return self.ibuf[:int(total)]
+
     def sum_floats(self, tensors: Sequence[Optional[torch.Tensor]], sizes: Sequence[int], device, group=None):
         """Pack (None counts as zeros), all-reduce SUM, return views of the reduced pieces in order.
 
@@ -138,7 +150,9 @@ class FlatReducer:
         total = int(sum(sizes))
         self.ibuf = self._fit(self.ibuf, total, torch.int32, device)
         flat = self.ibuf[:total]
-        if tensors:
+        offs = [sum(sizes[:i]) for i in range(len(sizes))]
+        in_place = bool(tensors) and all(t.is_contiguous() and t.data_ptr() == flat.data_ptr() + 4 * o for t, o in zip(tensors, offs))
+        if tensors and not in_place:   # (pieces a producer laid out with plan_ints are where they belong already)
             torch.cat([t.reshape(-1) for t in tensors], out=flat)
         _, world = _world(group)
         if world > 1:
@@ -265,15 +279,25 @@ class _ViewStats:
     """radii_max / norm_sum / vis_count / flags of the views a rank rendered, filled by one ``lvdgs_view_stats`` launch per
     view on the GPU (the PyTorch statements otherwise)."""
 
-    def __init__(self, N, n_window, dev):
+    def __init__(self, N, n_window, dev, reducer=None, float_pieces=None):
+        """``reducer`` / ``float_pieces`` (sharded runs): the integer pieces are laid out in the reducer's int bucket and the
+        two float pieces are the given slices of its float bucket, so neither collective has anything to pack."""
         self.N, self.n_window, self.dev = N, n_window, dev
-        # one zero-filled buffer (one launch) cut into the four pieces
         n4 = (N + 3) // 4 * 4
-        raw = torch.zeros(12 * N + (n_window + 1) * n4, dtype=torch.uint8, device=dev)
-        self.radii_max = raw[:4 * N].view(torch.int32)
-        self.norm_sum = raw[4 * N:8 * N].view(torch.float32)
-        self.vis_count = raw[8 * N:12 * N].view(torch.float32)
-        self.flags = raw[12 * N:].view(n_window + 1, n4)   # rows 0..n_window-1: n_touched > 0 ; last row: seen by any view
+        words = N + (n_window + 1) * (n4 // 4)
+        if reducer is not None:
+            ints = reducer.plan_ints(words, dev)
+            ints.zero_()
+        else:
+            ints = torch.zeros(words, dtype=torch.int32, device=dev)
+        self.radii_max = ints[:N]
+        self.flags = ints[N:].view(torch.uint8).view(n_window + 1, n4)   # rows 0..n_window-1: n_touched > 0 ; last row: seen by any view
+        if float_pieces is not None:
+            self.norm_sum, self.vis_count = float_pieces
+            self.norm_sum.zero_(); self.vis_count.zero_()
+        else:
+            both = torch.zeros(2 * N, dtype=torch.float32, device=dev)
+            self.norm_sum, self.vis_count = both[:N], both[N:]
 
     def add(self, i, pkg):
         N, n_window = self.N, self.n_window
@@ -379,9 +403,17 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
         loss_direct = None    # views rendered, scored and differentiated by MapViewPass (values only)
         pkgs = {}
         vpass = _view_pass(backend) if (fused and render_fn is render and view_loss_fn is view_loss) else None
+        # sharded: the first view's backward writes the parameter gradients straight into their slices of the float
+        # bucket the all-reduce works on (no packing copy); the statistics' float pieces live there too
+        plan = first = None
+        if vpass is not None and world > 1:
+            live = G.parameters()
+            plan = reducer.plan_floats([p.numel() for p in live] + [p.numel() for p in kf_params] + [live[0].shape[0]] * 2 + [1],
+                                       live[0].device)
+            first = {n: plan[k].view_as(p) for k, (n, p) in enumerate(zip(_PARAM_FIELDS, live))}
         for i in mine:
             if vpass is not None and MapViewPass.usable(backend, views[i]):
-                pkgs[i], l = vpass.run(backend, views[i])
+                pkgs[i], l = vpass.run(backend, views[i], first=first)
                 loss_direct = l if loss_direct is None else loss_direct + l
                 continue
             pkg = render_fn(views[i], G, backend.pipeline_params, backend.background)
@@ -410,7 +442,8 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
             N = G.get_xyz.shape[0]
             dev = G.get_xyz.device
             # ---- what this rank's views say, in view order ----
-            vs = _ViewStats(N, n_window, dev)
+            vs = _ViewStats(N, n_window, dev, reducer if (plan is not None and dev.type == "cuda") else None,
+                            (plan[-3], plan[-2]) if plan is not None else None)
             for i in mine:
                 vs.add(i, pkgs[i])
             radii_max, norm_sum, vis_count, flags = vs.radii_max, vs.norm_sum, vs.vis_count, vs.flags

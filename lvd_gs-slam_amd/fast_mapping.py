@@ -118,9 +118,10 @@ class MapViewPass:
         a.scratch, a.scratch_bytes = _P(self.scratch), self.scratch.numel()
 
     # ---- one view ----------------------------------------------------------------------------------------------------
-    def run(self, backend, viewpoint, initialization=False):
+    def run(self, backend, viewpoint, initialization=False, first=None):
         """Render ``viewpoint``, evaluate ``get_loss_mapping`` and add its gradients to the model's and the viewpoint's
-        ``.grad`` fields.  Returns the render package (fresh tensors, ``viewspace_points`` carries ``.grad``) and the
+        ``.grad`` fields (``first``: buffers, by parameter field, for a view that finds no gradients yet to write into --
+        the sharded loop passes slices of its all-reduce bucket -- instead of the pass's own).  Returns the render package (fresh tensors, ``viewspace_points`` carries ``.grad``) and the
         loss (0-dim tensor)."""
         G, cfg, dev, L = backend.gaussians, backend.config, self.dev, self.L
         T = cfg["Training"]
@@ -159,7 +160,7 @@ class MapViewPass:
         has = [getattr(G, n).grad is not None for n in fields]
         if any(has) and not all(has):
             raise _lib.LvdgsError("MapViewPass: some of the model's parameters carry a gradient and some do not")
-        into = self.more if has[0] else self.first
+        into = self.more if has[0] else (self.first if first is None or K > 1 else first)
         if has[0] and any(not _gpu_f32c(getattr(G, n).grad, dev) for n in fields):
             raise _lib.LvdgsError("MapViewPass: the model's existing gradients are not contiguous float32 tensors on the GPU")
         d_sh = into["sh"] if K > 1 else into["_features_dc"]
