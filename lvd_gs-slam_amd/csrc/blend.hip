@@ -11,11 +11,19 @@
 // so results are unchanged; a typical scene discards well over half of the (pixel, Gaussian) work.
 //
 // Backward walks the same list back to front (as published: T is recovered by dividing out
-// 1-alpha).  The per-Gaussian sums over pixels are done without atomics: a DPP wave reduction,
-// per-wave LDS slots, a fixed-order 4-wave sum, and one 48-byte record per (Gaussian, tile) pair
+// 1-alpha).  The per-Gaussian sums over pixels are done without atomics: in the current kernel (blend_bwd3) a
+// "pixel pass" leaves the two state-dependent numbers of every (pixel, Gaussian) in an LDS matrix and a "splat pass"
+// (lane -> Gaussian of a batch of eight) accumulates the ten sums in registers, one fold per batch; then per-wave
+// LDS slots, a fixed-order 4-wave sum, and one 48-byte record per (Gaussian, tile) pair
 // stored at slot_base[id] + (ty - y0) * width + (tx - x0): a Gaussian's records form one contiguous
 // run, and the runs follow each other in id order, so the per-Gaussian kernel (one lane per id) reads
 // whole cache lines.  Gradients are therefore bitwise reproducible.
+//
+// Kernels in this file: blend_fwd2_kernel (default; its survivor step is the hand-scheduled composite_one) and
+// blend_fwd_kernel (the compiler's form, LVDGS_BLEND_FWD=1); blend_bwd3_kernel<FUSED_LOSS> (default; with the
+// photometric loss evaluated in its prologue for lvdgs_backward_fused_loss), blend_bwd2_kernel and blend_bwd_kernel
+// (earlier forms, LVDGS_BLEND_BWD=2 / 1, kept for A/B measurements).  What bounds them and what was tried:
+// DESIGN.md section 2, profiles/experiments/README.md.
 #include <stdlib.h>
 
 #include <type_traits>
