@@ -117,6 +117,14 @@ static bool use_counting_path(int num_tiles) {
     return !forced && num_tiles <= group_max_tiles();
 }
 
+// Small grids (a KITTI frame: 1848 tiles for 2048 places) are resident all at once, so nothing rebalances the CUs while
+// they run: the blend kernels then take their tiles longest list first, dealt round-robin (binning.hip writes the order
+// into the second half of long_tiles).  LVDGS_TILE_ORDER_MAX_TILES overrides the bound (0: never).
+bool tile_order_in_use(int num_tiles) {
+    static const int max_tiles = [] { const char *e = getenv("LVDGS_TILE_ORDER_MAX_TILES"); return e ? atoi(e) : 4096; }();
+    return use_counting_path(num_tiles) && num_tiles <= max_tiles && num_tiles > 0;
+}
+
 // ---------------------------------------------------------------- layouts
 template <typename T>
 static void carve(T *&ptr, size_t count, char *base, size_t &off) {

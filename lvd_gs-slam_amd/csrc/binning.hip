@@ -180,8 +180,11 @@ __global__ void __launch_bounds__(COLSCAN_TILES * COLSCAN_GROUPS) group_colscan_
 }
 
 // one workgroup: ranges[t] = [sum of totals before t, + totals[t]), clamped to the pair capacity
+// tile_order (optional, T entries): the tiles by descending list length (in steps of 8 entries; ties in arrival order --
+// it only decides which workgroup of a blend kernel takes which tile, never a result).
 __global__ void __launch_bounds__(1024) group_tilescan_kernel(int T, const uint32_t *__restrict__ totals, uint32_t capacity,
-                                                              uint2 *__restrict__ ranges) {
+                                                              uint2 *__restrict__ ranges, uint32_t *__restrict__ tile_order,
+                                                              uint32_t *__restrict__ order_valid) {
     __shared__ uint32_t s_scan[1024];
     constexpr int PER = GROUP_MAX_TILES / 1024;
     uint32_t v[PER], sum = 0;
@@ -221,6 +224,44 @@ __global__ void __launch_bounds__(1024) group_tilescan_kernel(int T, const uint3
         if (t < T) ranges[t] = v[k] ? make_uint2(min(run, capacity), min(run + v[k], capacity)) : make_uint2(0u, 0u);
         run += v[k];
     }
+    if (!tile_order) return;
+    // counting sort of the tiles by bucket 1023 - min(length / 8, 1023): bucket 0 holds the longest lists
+    auto bucket = [](uint32_t len) { return 1023u - min(len >> 3, 1023u); };
+    __syncthreads();
+    s_scan[threadIdx.x] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; k++)
+        if ((int)threadIdx.x * PER + k < T) atomicAdd(&s_scan[bucket(v[k])], 1u);
+    __syncthreads();
+    const uint32_t mine = s_scan[threadIdx.x];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t x = (uint32_t)__shfl_up((int)incl, off, 64);
+        if (lane >= off) incl += x;
+    }
+    __shared__ uint32_t s_wave[32];
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t w = lane < 16 ? s_wave[lane] : 0u;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            const uint32_t x = (uint32_t)__shfl_up((int)w, off, 64);
+            if (lane >= off) w += x;
+        }
+        if (lane < 16) s_wave[16 + lane] = w;
+    }
+    __syncthreads();
+    s_scan[threadIdx.x] = incl - mine + (wave ? s_wave[16 + wave - 1] : 0u);   // first position of this bucket
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int t = (int)threadIdx.x * PER + k;
+        if (t < T) tile_order[atomicAdd(&s_scan[bucket(v[k])], 1u)] = (uint32_t)t;
+    }
+    if (threadIdx.x == 0) *order_valid = 1u;   // (cleared with the tile-sort queue at the start of every frame)
 }
 
 __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int gx, int T, const uint2 *__restrict__ rect,
@@ -285,7 +326,7 @@ int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView
         hipLaunchKernelGGL(group_colscan_kernel, dim3(cdiv(T, COLSCAN_TILES)), dim3(COLSCAN_TILES * COLSCAN_GROUPS), 0, s, T, nchunks, w.group_hist,
                            w.group_totals);
         hipLaunchKernelGGL(group_tilescan_kernel, dim3(1), dim3(1024), 0, s, T, (const uint32_t *)w.group_totals, (uint32_t)capacity,
-                           im.ranges);
+                           im.ranges, tile_order_in_use(T) ? im.long_tiles + T : nullptr, im.long_count + 1);
         LVDGS_LAUNCH_CHECK("group_scan", a.debug, s);
     }
     {

@@ -41,6 +41,8 @@ constexpr float LOG2E = 1.4426950408889634f;
 struct BlendParams {
     int W, H, gx, gy, num_tiles;
     const uint2 *ranges;
+    const uint32_t *tile_order;  // tiles by descending list length, or null (tile_of_workgroup)
+    const uint32_t *order_valid; // 1 once this frame's grouping has written tile_order
     const uint32_t *point_list;
     const float *rec;
     const uint32_t *slot_base;
@@ -109,7 +111,7 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendParams p) {
     float *const s_d = s_recs.d;   // raw conic c
     __shared__ int s_touch[256]; // pixels of this tile each staged Gaussian "touched" (T after it > 0.5)
 
-    const int tile = tile_of_workgroup(blockIdx.x, p.num_tiles);
+    const int tile = (p.tile_order && *p.order_valid) ? (int)p.tile_order[blockIdx.x] : tile_of_workgroup(blockIdx.x, p.num_tiles);
     const int tx = tile % p.gx, ty = tile / p.gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;
@@ -269,7 +271,7 @@ __global__ void __launch_bounds__(256) blend_fwd2_kernel(BlendParams p) {
     float *const s_d = s_recs.d;   // raw conic c
     __shared__ int s_touch[256]; // pixels of this tile each staged Gaussian "touched" (T after it > 0.5)
 
-    const int tile = tile_of_workgroup(blockIdx.x, p.num_tiles);
+    const int tile = (p.tile_order && *p.order_valid) ? (int)p.tile_order[blockIdx.x] : tile_of_workgroup(blockIdx.x, p.num_tiles);
     const int tx = tile % p.gx, ty = tile / p.gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;
@@ -363,7 +365,7 @@ __global__ void __launch_bounds__(256, 8) blend_bwd_kernel(BlendParams p) {
     __shared__ unsigned long long s_mask[4][BR / 64];  // [wave][chunk]: entries this wave accumulated
     __shared__ uint32_t s_max[4];
 
-    const int tile = tile_of_workgroup(blockIdx.x, p.num_tiles);
+    const int tile = (p.tile_order && *p.order_valid) ? (int)p.tile_order[blockIdx.x] : tile_of_workgroup(blockIdx.x, p.num_tiles);
     const int tx = tile % p.gx, ty = tile / p.gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;
@@ -550,7 +552,7 @@ __global__ void __launch_bounds__(256, 4) blend_bwd2_kernel(BlendParams p) {
     constexpr int STEPS = NB;            // pixels a lane visits per batch (16-pixel row / lanes per slot in the row)
     __shared__ Bwd2Shared<NB> sh;
 
-    const int tile = tile_of_workgroup(blockIdx.x, p.num_tiles);
+    const int tile = (p.tile_order && *p.order_valid) ? (int)p.tile_order[blockIdx.x] : tile_of_workgroup(blockIdx.x, p.num_tiles);
     const int tx = tile % p.gx, ty = tile / p.gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;
@@ -773,7 +775,7 @@ __global__ void __launch_bounds__(256, 5) blend_bwd3_kernel(BlendParams p) {
     constexpr int NB = Bwd3Shared::NB;
     __shared__ Bwd3Shared sh;
 
-    const int tile = tile_of_workgroup(blockIdx.x, p.num_tiles);
+    const int tile = (p.tile_order && *p.order_valid) ? (int)p.tile_order[blockIdx.x] : tile_of_workgroup(blockIdx.x, p.num_tiles);
     const int tx = tile % p.gx, ty = tile / p.gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;
@@ -995,7 +997,7 @@ BlendParams make_params(const lvdgs_args &a, const GeomView &g, const BinView &b
     BlendParams p{};
     p.W = a.image_width; p.H = a.image_height;
     p.gx = (p.W + TILE - 1) / TILE; p.gy = (p.H + TILE - 1) / TILE; p.num_tiles = p.gx * p.gy;
-    p.ranges = im.ranges; p.point_list = b.point_list; p.rec = g.rec; p.slot_base = g.slot_base; p.bg = a.bg;
+    p.ranges = im.ranges; p.tile_order = tile_order_in_use(p.num_tiles) ? im.long_tiles + p.num_tiles : nullptr; p.order_valid = im.long_count + 1; p.point_list = b.point_list; p.rec = g.rec; p.slot_base = g.slot_base; p.bg = a.bg;
     p.out_color = a.out_color; p.out_depth = a.out_depth; p.out_opacity = a.out_opacity;
     p.final_T = im.final_T; p.n_contrib = im.n_contrib; p.n_touched = a.n_touched;
     p.dL_dcolor = a.dL_dout_color; p.dL_ddepth = a.dL_dout_depth; p.dL_dopacity = a.dL_dout_opacity;

@@ -83,8 +83,8 @@ struct BinView {
 };
 struct ImageView {
     uint2 *ranges;       // T
-    uint32_t *long_count; // 1 (+ padding): length of the queue of over-long segments; zeroed with ranges
-    uint32_t *long_tiles; // the queue (tile ids; room for 2 T)
+    uint32_t *long_count; // [0]: length of the queue of over-long segments, [1]: tile order valid; zeroed with ranges
+    uint32_t *long_tiles; // T: the queue (tile ids); T more: the tiles by descending list length (small grids)
     float *final_T;      // P
     uint32_t *n_contrib; // P
 };
@@ -115,6 +115,8 @@ int radix_num_passes(int total_bits);
 size_t radix_hist_entries(int64_t n);
 
 // slot_base[i] = exclusive scan over i of tiles_touched[i]; *total_dev = the sum (pair count D)
+bool tile_order_in_use(int num_tiles);   // api.hip: the blend kernels take their tiles from ImageView::long_tiles + T
+
 // Pieces lvdgs_tracking_tail (pose.hip) puts into one launch.
 struct LossTail {            // what photometric_finish_kernel<2> reads and writes (loss.hip)
     const float *partial; int nblk; int P; float w_rgb, w_d; float *loss, *d_a, *d_b;
