@@ -159,12 +159,15 @@ __device__ __forceinline__ void wave_sort_segment(const KeySource &src, uint32_t
 constexpr int CLASS_W = 1024;  // longest segment one wave sorts in registers (16 keys per lane)
 
 // one wave per tile; longer segments are queued for the workgroup kernels
+// tile_order (small grids, or null): the tiles by descending list length -- the four waves of a workgroup then sort
+// segments of similar length, and the long ones start first.
 __global__ void __launch_bounds__(256) tile_depth_sort_wave_kernel(const uint2 *__restrict__ ranges, int num_tiles, KeySource src,
                                                                    uint32_t *__restrict__ point_list, uint32_t *queue_count,
-                                                                   uint32_t *__restrict__ queue) {
+                                                                   uint32_t *__restrict__ queue, const uint32_t *__restrict__ tile_order) {
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= num_tiles) return;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= num_tiles) return;
+    const int tile = tile_order ? (int)tile_order[slot] : slot;
     const uint2 r = ranges[tile];
     const int n = (int)(r.y - r.x);
     if (n < 2) {
@@ -220,7 +223,7 @@ int launch_tile_depth_sort(const ImageView &im, int num_tiles, const float *rec,
     {
         ProfScope ps("tile_sort", s);
         hipLaunchKernelGGL(tile_depth_sort_wave_kernel, dim3(cdiv(num_tiles, 4)), dim3(256), 0, s, (const uint2 *)im.ranges, num_tiles, src,
-                           point_list, im.long_count, im.long_tiles);
+                           point_list, im.long_count, im.long_tiles, (keys_ready && tile_order_in_use(num_tiles)) ? im.long_tiles + num_tiles : nullptr);
         LVDGS_LAUNCH_CHECK("tile_sort", dbg, s);
     }
     {
