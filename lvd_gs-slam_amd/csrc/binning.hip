@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int N, int gx, int gy, 
 }
 
 // ---- grouping by tile without a sort --------------------------------------------------------------------------
-// A workgroup owns GROUP_CHUNK consecutive Gaussians and keeps one counter per tile in LDS.
+// A workgroup owns a chunk of consecutive Gaussians (1024 x PER, see group_per_thread_for) and keeps one counter per tile in LDS.
 //   count:    counter[tile] += 1 for every (Gaussian, tile) pair of the chunk        -> hist[chunk][tile]
 //   colscan:  per tile, exclusive prefix of hist over the chunks, and the tile total
 //   tilescan: exclusive scan of the totals                                           -> ranges[tile]
@@ -47,17 +47,20 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int N, int gx, int gy, 
 // Rectangles larger than a wave's worth of tiles are walked by the whole wave, so one screen-filling Gaussian does
 // not serialise thousands of atomics on one lane.
 constexpr int GROUP_THREADS = 1024;
-constexpr int GROUP_PER_THREAD = 4;
-constexpr int GROUP_CHUNK = GROUP_THREADS * GROUP_PER_THREAD;
+// Gaussians per workgroup = 1024 x PER.  Few, large chunks keep the [chunk][tile] count matrix and its scan small (2 M
+// Gaussians: 489 chunks of 4096); many, small ones spread the counting and scattering over the chip (200 k Gaussians
+// are 49 chunks of 4096 on 256 CUs, 98 of 2048).  Measured (same box): 100k / 640x480 0.2235 -> 0.2088 ms per tracking
+// iteration with 2048, KITTI geometry 0.2881 -> 0.2795, config 3 0.6247 -> 0.6230, 2 M / 1920x1280 1.49 -> 1.52.
+__host__ __device__ constexpr int group_per_thread_for(int N) { return N <= (1 << 20) ? 2 : 4; }
 constexpr int GROUP_MAX_TILES = 16384;  // 64 KiB of LDS counters
 constexpr int GROUP_BIG_RECT = 64;
 
-template <typename F>
+template <int PER, typename F>
 __device__ __forceinline__ void for_each_pair_of_chunk(int N, int gx, const uint2 *__restrict__ rect, F visit) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int k = 0; k < GROUP_PER_THREAD; k++) {
-        const int i = blockIdx.x * GROUP_CHUNK + k * GROUP_THREADS + (int)threadIdx.x;
+    for (int k = 0; k < PER; k++) {
+        const int i = blockIdx.x * (GROUP_THREADS * PER) + k * GROUP_THREADS + (int)threadIdx.x;
         const uint2 r = i < N ? rect[i] : make_uint2(0u, 0u);
         const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
         const int w = x1 - x0, area = w * (y1 - y0);
@@ -104,13 +107,15 @@ __device__ __forceinline__ uint32_t scan_1024(uint32_t v, uint32_t *s_scan, uint
 // (Also clears what the later kernels of the frame accumulate into: n_touched and the tile-sort queue -- two memset
 // launches less -- and, when `tt` is given, makes slot_base[i] = exclusive scan of tiles_touched and the pair total from
 // the sums preprocess_fwd left per 256 Gaussians: the launch of the separate slot scan less.  Every workgroup adds up the
-// block sums in front of its chunk -- at most a few thousand values -- and scans its own 4096 Gaussians.)
+// block sums in front of its chunk -- at most a few thousand values -- and scans its own Gaussians.)
+template <int PER>
 __global__ void __launch_bounds__(GROUP_THREADS) count_pairs_kernel(int N, int gx, int T, const uint2 *__restrict__ rect,
                                                                    uint32_t *__restrict__ hist, int32_t *__restrict__ n_touched,
                                                                    uint32_t *__restrict__ queue_counts,
                                                                    const uint32_t *__restrict__ tt, const uint32_t *__restrict__ blocksums,
                                                                    uint32_t *__restrict__ slot_base, uint32_t *__restrict__ total_out) {
-    static_assert(GROUP_THREADS == 1024 && GROUP_PER_THREAD == 4, "scan_1024 over one uint4 per thread");
+    static_assert(GROUP_THREADS == 1024, "scan_1024");
+    constexpr int GROUP_PER_THREAD = PER, GROUP_CHUNK = GROUP_THREADS * PER;
     extern __shared__ uint32_t s_tile[];
     __shared__ uint32_t s_scan[33];
     for (int t = threadIdx.x; t < T; t += GROUP_THREADS) s_tile[t] = 0u;
@@ -126,21 +131,21 @@ __global__ void __launch_bounds__(GROUP_THREADS) count_pairs_kernel(int N, int g
         uint32_t prefix;
         scan_1024(before, s_scan, &prefix);  // only the total is of interest
         __syncthreads();                     // s_scan is used again
-        const int base = blockIdx.x * GROUP_CHUNK + (int)threadIdx.x * 4;
-        uint32_t v[4];
+        const int base = blockIdx.x * GROUP_CHUNK + (int)threadIdx.x * GROUP_PER_THREAD;
+        uint32_t v[GROUP_PER_THREAD], mine = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = base + k < N ? tt[base + k] : 0u;
+        for (int k = 0; k < GROUP_PER_THREAD; k++) { v[k] = base + k < N ? tt[base + k] : 0u; mine += v[k]; }
         uint32_t total;
-        uint32_t run = scan_1024(v[0] + v[1] + v[2] + v[3], s_scan, &total) + prefix;
+        uint32_t run = scan_1024(mine, s_scan, &total) + prefix;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < GROUP_PER_THREAD; k++) {
             if (base + k < N) slot_base[base + k] = run;
             run += v[k];
         }
         if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total_out = prefix + total;
     }
     __syncthreads();
-    for_each_pair_of_chunk(N, gx, rect, [&](int tile, uint32_t) { atomicAdd(&s_tile[tile], 1u); });
+    for_each_pair_of_chunk<PER>(N, gx, rect, [&](int tile, uint32_t) { atomicAdd(&s_tile[tile], 1u); });
     __syncthreads();
     uint32_t *row = hist + (size_t)blockIdx.x * T;
     for (int t = threadIdx.x; t < T; t += GROUP_THREADS) row[t] = s_tile[t];
@@ -264,6 +269,7 @@ __global__ void __launch_bounds__(1024) group_tilescan_kernel(int T, const uint3
     if (threadIdx.x == 0) *order_valid = 1u;   // (cleared with the tile-sort queue at the start of every frame)
 }
 
+template <int PER>
 __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int gx, int T, const uint2 *__restrict__ rect,
                                                                      const uint32_t *__restrict__ hist,
                                                                      const uint2 *__restrict__ ranges, uint32_t capacity,
@@ -273,7 +279,7 @@ __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int
     const uint32_t *row = hist + (size_t)blockIdx.x * T;
     for (int t = threadIdx.x; t < T; t += GROUP_THREADS) s_tile[t] = ranges[t].x + row[t];  // (empty tiles are never visited)
     __syncthreads();
-    for_each_pair_of_chunk(N, gx, rect, [&](int tile, uint32_t id) {
+    for_each_pair_of_chunk<PER>(N, gx, rect, [&](int tile, uint32_t id) {
         const uint32_t pos = atomicAdd(&s_tile[tile], 1u);
         // the tile sort's key, so that it need not gather depths; beyond the caller's capacity: dropped (the caller
         // is told and re-runs)
@@ -294,20 +300,28 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t *__rest
 }  // namespace
 
 int group_max_tiles() { return GROUP_MAX_TILES; }
-size_t group_hist_entries(int N, int num_tiles) { return (size_t)cdiv(N > 0 ? N : 1, GROUP_CHUNK) * (size_t)num_tiles; }
+size_t group_hist_entries(int N, int num_tiles) {
+    return (size_t)cdiv(N > 0 ? N : 1, GROUP_THREADS * group_per_thread_for(N)) * (size_t)num_tiles;
+}
 
 int launch_group_count(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, bool slot_scan, hipStream_t s) {
     const int N = a.num_gaussians;
     const int gx = (a.image_width + TILE - 1) / TILE, gy = (a.image_height + TILE - 1) / TILE, T = gx * gy;
     if (N == 0 || T == 0) return LVDGS_OK;
-    const int nchunks = cdiv(N, GROUP_CHUNK);
+    const int per = group_per_thread_for(N), nchunks = cdiv(N, GROUP_THREADS * per);
     const size_t lds = (size_t)T * sizeof(uint32_t);
-    static unsigned char count_done[16];
-    if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&count_pairs_kernel), GROUP_MAX_TILES * 4, count_done)) return e;
+    static unsigned char count_done2[16], count_done4[16];
+    const uint32_t *tt = slot_scan ? (const uint32_t *)g.tiles_touched : nullptr;
     ProfScope ps("group_count", s);
-    hipLaunchKernelGGL(count_pairs_kernel, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint2 *)g.rect, w.group_hist,
-                       a.n_touched, im.long_count, slot_scan ? (const uint32_t *)g.tiles_touched : nullptr,
-                       (const uint32_t *)w.blocksums, g.slot_base, g.total);
+    if (per == 2) {
+        if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&count_pairs_kernel<2>), GROUP_MAX_TILES * 4, count_done2)) return e;
+        hipLaunchKernelGGL(count_pairs_kernel<2>, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint2 *)g.rect, w.group_hist,
+                           a.n_touched, im.long_count, tt, (const uint32_t *)w.blocksums, g.slot_base, g.total);
+    } else {
+        if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&count_pairs_kernel<4>), GROUP_MAX_TILES * 4, count_done4)) return e;
+        hipLaunchKernelGGL(count_pairs_kernel<4>, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint2 *)g.rect, w.group_hist,
+                           a.n_touched, im.long_count, tt, (const uint32_t *)w.blocksums, g.slot_base, g.total);
+    }
     LVDGS_LAUNCH_CHECK("group_count", a.debug, s);
     return LVDGS_OK;
 }
@@ -317,10 +331,11 @@ int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView
     const int N = a.num_gaussians;
     const int gx = (a.image_width + TILE - 1) / TILE, gy = (a.image_height + TILE - 1) / TILE, T = gx * gy;
     if (N == 0 || T == 0) return LVDGS_OK;
-    const int nchunks = cdiv(N, GROUP_CHUNK);
+    const int per = group_per_thread_for(N), nchunks = cdiv(N, GROUP_THREADS * per);
     const size_t lds = (size_t)T * sizeof(uint32_t);
-    static unsigned char scatter_done[16];
-    if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&scatter_pairs_kernel), GROUP_MAX_TILES * 4, scatter_done)) return e;
+    static unsigned char scatter_done2[16], scatter_done4[16];
+    if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&scatter_pairs_kernel<2>), GROUP_MAX_TILES * 4, scatter_done2)) return e;
+    if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&scatter_pairs_kernel<4>), GROUP_MAX_TILES * 4, scatter_done4)) return e;
     {
         ProfScope ps("group_scan", s);
         hipLaunchKernelGGL(group_colscan_kernel, dim3(cdiv(T, COLSCAN_TILES)), dim3(COLSCAN_TILES * COLSCAN_GROUPS), 0, s, T, nchunks, w.group_hist,
@@ -331,9 +346,14 @@ int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView
     }
     {
         ProfScope ps("group_scatter", s);
-        hipLaunchKernelGGL(scatter_pairs_kernel, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint2 *)g.rect,
-                           (const uint32_t *)w.group_hist, (const uint2 *)im.ranges, (uint32_t)capacity,
-                           (const uint32_t *)g.depth_bits, keys64);
+        if (per == 2)
+            hipLaunchKernelGGL(scatter_pairs_kernel<2>, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint2 *)g.rect,
+                               (const uint32_t *)w.group_hist, (const uint2 *)im.ranges, (uint32_t)capacity,
+                               (const uint32_t *)g.depth_bits, keys64);
+        else
+            hipLaunchKernelGGL(scatter_pairs_kernel<4>, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint2 *)g.rect,
+                               (const uint32_t *)w.group_hist, (const uint2 *)im.ranges, (uint32_t)capacity,
+                               (const uint32_t *)g.depth_bits, keys64);
         LVDGS_LAUNCH_CHECK("group_scatter", a.debug, s);
     }
     return LVDGS_OK;
