@@ -58,13 +58,13 @@ class MapViewPass:
 
     # ---- eligibility -------------------------------------------------------------------------------------------------
     @staticmethod
-    def usable(backend, viewpoint) -> bool:
+    def usable(backend, viewpoint, allow_static_mask=False) -> bool:
         G = backend.gaussians
         dev = G.get_xyz.device
         pp = backend.pipeline_params
         if dev.type != "cuda" or getattr(pp, "compute_cov3D_python", False) or getattr(pp, "convert_SHs_python", False):
             return False
-        if getattr(viewpoint, "static_mask", None) is not None or _raw_parameters(G) is None:
+        if (not allow_static_mask and getattr(viewpoint, "static_mask", None) is not None) or _raw_parameters(G) is None:
             return False
         if not all(_gpu_f32c(getattr(G, n, None), dev) and getattr(G, n).requires_grad for n in _PARAM_FIELDS):
             return False
@@ -118,11 +118,15 @@ class MapViewPass:
         a.scratch, a.scratch_bytes = _P(self.scratch), self.scratch.numel()
 
     # ---- one view ----------------------------------------------------------------------------------------------------
-    def run(self, backend, viewpoint, initialization=False, first=None):
+    def run(self, backend, viewpoint, initialization=False, first=None, image_loss=None):
         """Render ``viewpoint``, evaluate ``get_loss_mapping`` and add its gradients to the model's and the viewpoint's
         ``.grad`` fields (``first``: buffers, by parameter field, for a view that finds no gradients yet to write into --
         the sharded loop passes slices of its all-reduce bucket -- instead of the pass's own).  Returns the render package (fresh tensors, ``viewspace_points`` carries ``.grad``) and the
-        loss (0-dim tensor)."""
+        loss (0-dim tensor).
+
+        ``image_loss(color) -> (loss, d_color)`` (optional) replaces ``get_loss_mapping``: a loss of the rendered colour
+        alone that brings its own gradient image -- colour refinement's ``(1 - l) L1 + l (1 - SSIM)`` from the fused
+        L1 + SSIM kernel -- after which the plain ``lvdgs_backward`` runs (no depth / exposure terms)."""
         G, cfg, dev, L = backend.gaussians, backend.config, self.dev, self.L
         T = cfg["Training"]
         N, K = int(G._xyz.shape[0]), 1 + int(G._features_rest.shape[1])
@@ -169,23 +173,24 @@ class MapViewPass:
         d_tau, d_a, d_b, d_m2 = e(6), e(1), e(1), e(N, 3)
         a.dL_dtau, a.dL_dmeans2D = None, _P(d_m2)   # the pose gradient's partial sums are reduced together with the loss's
 
-        # ---- get_loss_mapping (reference utils/slam_utils.py:82-121) ----
-        # (monodepth=True at every call site of the mapping loop, so the loss is the rgb-d one whatever Training.monocular says)
-        gt = f32c(_gt_image(viewpoint, color))
-        keep.append(gt)
-        la.image, la.gt_image = _P(color), _P(gt)
-        la.rgb_boundary_threshold = float(T["rgb_boundary_threshold"])
-        if initialization:
-            la.exposure_a = la.exposure_b = la.d_exposure_a = la.d_exposure_b = None
-        else:
-            la.exposure_a, la.exposure_b, la.d_exposure_a, la.d_exposure_b = _P(viewpoint.exposure_a), _P(viewpoint.exposure_b), _P(d_a), _P(d_b)
-        alpha = T.get("alpha", 0.95)
-        md = f32c(_mono_depth(viewpoint, color))
-        keep.append(md)
-        la.depth, la.gt_depth = _P(depth), _P(md)
-        la.weight_rgb, la.weight_depth = float(alpha), float(1 - alpha)
         loss = e(())
-        la.loss = _P(loss)
+        if image_loss is None:
+            # ---- get_loss_mapping (reference utils/slam_utils.py:82-121) ----
+            # (monodepth=True at every call site of the mapping loop, so the loss is the rgb-d one whatever Training.monocular says)
+            gt = f32c(_gt_image(viewpoint, color))
+            keep.append(gt)
+            la.image, la.gt_image = _P(color), _P(gt)
+            la.rgb_boundary_threshold = float(T["rgb_boundary_threshold"])
+            if initialization:
+                la.exposure_a = la.exposure_b = la.d_exposure_a = la.d_exposure_b = None
+            else:
+                la.exposure_a, la.exposure_b, la.d_exposure_a, la.d_exposure_b = _P(viewpoint.exposure_a), _P(viewpoint.exposure_b), _P(d_a), _P(d_b)
+            alpha = T.get("alpha", 0.95)
+            md = f32c(_mono_depth(viewpoint, color))
+            keep.append(md)
+            la.depth, la.gt_depth = _P(depth), _P(md)
+            la.weight_rgb, la.weight_depth = float(alpha), float(1 - alpha)
+            la.loss = _P(loss)
 
         with _lib.on_device(dev):
             stream = _lib.raw_stream(dev)
@@ -199,8 +204,18 @@ class MapViewPass:
             else:
                 _lib.check(status, "lvdgs_forward")
             a.num_rendered = D
-            _lib.check(L.lvdgs_backward_fused_loss(C.byref(a), C.byref(la), 0, stream), "lvdgs_backward_fused_loss")
-            _lib.check(L.lvdgs_tracking_tail(C.byref(la), C.byref(a), None, _P(d_tau), 1, stream), "lvdgs_tracking_tail")
+            if image_loss is None:
+                _lib.check(L.lvdgs_backward_fused_loss(C.byref(a), C.byref(la), 0, stream), "lvdgs_backward_fused_loss")
+                _lib.check(L.lvdgs_tracking_tail(C.byref(la), C.byref(a), None, _P(d_tau), 1, stream), "lvdgs_tracking_tail")
+        if image_loss is not None:
+            loss, d_color = image_loss(color)
+            d_color = f32c(d_color)
+            keep.append(d_color)
+            a.dL_dout_color, a.dL_dout_depth, a.dL_dout_opacity, a.dL_dtau = _P(d_color), None, None, _P(d_tau)
+            with _lib.on_device(dev):
+                _lib.check(L.lvdgs_backward(C.byref(a), _lib.raw_stream(dev)), "lvdgs_backward")
+            a.dL_dout_color = a.dL_dtau = None
+            initialization = True   # no exposure gradients from this loss
 
         # ---- hand the gradients over exactly where autograd would have put them ----
         if K > 1:

@@ -23,13 +23,22 @@ def initialize_map(backend, cur_frame_idx, viewpoint, render_fn=render, on_itera
     Adam step on one view (reference utils/slam_backend.py:95-149).  Returns the last render package."""
     G = backend.gaussians
     render_pkg = None
+    # on the GPU with the default renderer: render + loss + backward as three C-ABI calls without the autograd engine
+    # (fast_mapping.MapViewPass, as in backend_map.map_window), the gradients written where autograd would have put them
+    vpass = None
+    if render_fn is render and G.get_xyz.is_cuda:
+        from .fast_mapping import MapViewPass
+        vpass = MapViewPass(G.get_xyz.device)
     for mapping_iteration in range(backend.init_itr_num):
         backend.iteration_count += 1
-        render_pkg = render_fn(viewpoint, G, backend.pipeline_params, backend.background)
-        image, viewspace_point_tensor, visibility_filter = render_pkg["render"], render_pkg["viewspace_points"], render_pkg["visibility_filter"]
-        radii, depth, n_touched = render_pkg["radii"], render_pkg["depth"], render_pkg["n_touched"]
-        loss_init = get_loss_mapping(backend.config, image, viewpoint, depth=depth, initialization=True)
-        loss_init.backward()
+        if vpass is not None and G.get_xyz.shape[0] > 0 and type(vpass).usable(backend, viewpoint):
+            render_pkg, loss_init = vpass.run(backend, viewpoint, initialization=True)
+        else:
+            render_pkg = render_fn(viewpoint, G, backend.pipeline_params, backend.background)
+            loss_init = get_loss_mapping(backend.config, render_pkg["render"], viewpoint, depth=render_pkg["depth"], initialization=True)
+            loss_init.backward()
+        viewspace_point_tensor, visibility_filter = render_pkg["viewspace_points"], render_pkg["visibility_filter"]
+        radii, n_touched = render_pkg["radii"], render_pkg["n_touched"]
         if on_iteration is not None:
             on_iteration(mapping_iteration, loss_init, render_pkg)
         with torch.no_grad():
@@ -59,16 +68,35 @@ def color_refinement(backend, iteration_total=26000, render_fn=render, loss_fn=N
     if loss_fn is None:
         from .loss_utils import l1_dssim_loss as loss_fn
     G = backend.gaussians
+    # on the GPU with the default renderer and loss: forward, the fused L1 + SSIM kernel (value and gradient image in one
+    # launch) and backward as three library calls without the autograd engine (fast_mapping.MapViewPass)
+    vpass = None
+    if render_fn is render and G.get_xyz.is_cuda:
+        from .fast_mapping import MapViewPass
+        from .loss_utils import _launch, _mask_bytes, l1_dssim_loss
+        if loss_fn is l1_dssim_loss:
+            vpass = MapViewPass(G.get_xyz.device)
     for iteration in range(1, iteration_total + 1):
         viewpoint_idx_stack = list(backend.viewpoints.keys())
         viewpoint_cam_idx = viewpoint_idx_stack.pop(random.randint(0, len(viewpoint_idx_stack) - 1))
         viewpoint_cam = backend.viewpoints[viewpoint_cam_idx]
-        render_pkg = render_fn(viewpoint_cam, G, backend.pipeline_params, backend.background)
-        image, visibility_filter, radii = render_pkg["render"], render_pkg["visibility_filter"], render_pkg["radii"]
-        gt_image = viewpoint_cam.original_image.to(image.device)
         static_mask = getattr(viewpoint_cam, "static_mask", None)
-        loss = loss_fn(image, gt_image, backend.opt_params.lambda_dssim, static_mask, backend.background if static_mask is not None else None)
-        loss.backward()
+        lam = float(backend.opt_params.lambda_dssim)
+        if vpass is not None and G.get_xyz.shape[0] > 0 and type(vpass).usable(backend, viewpoint_cam, allow_static_mask=True):
+            def image_loss(color):
+                gt = viewpoint_cam.original_image.to(color.device)
+                keep_mask = _mask_bytes(static_mask, color.shape[1], color.shape[2])
+                bg = backend.background.detach().float().contiguous() if keep_mask is not None else None
+                out, d = _launch(color, gt, keep_mask, bg, 1.0 - lam, -lam, True)   # as loss_utils.l1_dssim_loss
+                return (1.0 - lam) * out[0] - lam * out[1] + lam, d
+            render_pkg, loss = vpass.run(backend, viewpoint_cam, image_loss=image_loss)
+            visibility_filter, radii = render_pkg["visibility_filter"], render_pkg["radii"]
+        else:
+            render_pkg = render_fn(viewpoint_cam, G, backend.pipeline_params, backend.background)
+            image, visibility_filter, radii = render_pkg["render"], render_pkg["visibility_filter"], render_pkg["radii"]
+            gt_image = viewpoint_cam.original_image.to(image.device)
+            loss = loss_fn(image, gt_image, backend.opt_params.lambda_dssim, static_mask, backend.background if static_mask is not None else None)
+            loss.backward()
         if on_iteration is not None:
             on_iteration(iteration, viewpoint_cam_idx, loss)
         with torch.no_grad():

@@ -65,22 +65,53 @@ def _check_case(c):
     try:
         _check_backward_of_case(c, b_hip, b_ora, solid, clean, names)
     except AssertionError as strict:
-        # About one random scene in a thousand has a gradient that float32 itself cannot hold to the strict bounds (the
-        # opacity gradient of a faint Gaussian is a sum of sign-alternating terms; stacks of opaque Gaussians recover T by
-        # division): there the float32 ORACLE is as far from the float64 oracle as the kernels are from it.  Such a case
-        # passes if the kernels are no farther from the float64 result than the float32 restatement is (x 1.5, + the
-        # strict tolerance), tensor by tensor; anything else is a failure with both messages.
-        f64, b64 = hr.run_oracle(orc, g, cam, c["W"], c["H"], bg, grads=grads, prec="f64")
-        for n in names + ["tau"]:
-            ref64 = np.asarray(b64[n], np.float64).reshape(b_hip[n].shape)
-            ref32 = np.asarray(b_ora[n], np.float64).reshape(b_hip[n].shape)
-            hip = np.asarray(b_hip[n], np.float64)
-            norm = max(np.linalg.norm(ref64), 1e-300)
-            e_hip, e_ora = np.linalg.norm(hip - ref64) / norm, np.linalg.norm(ref32 - ref64) / norm
-            assert e_hip <= 2e-5 + 1.5 * e_ora, f"{n}: kernels {e_hip:.3e} from float64, float32 oracle {e_ora:.3e} | strict check said: {strict}"
-            m_hip, m_ora = np.abs(hip - ref64).max(), np.abs(ref32 - ref64).max()
-            scale = max(np.abs(ref64).max(), 1e-300)
-            assert m_hip <= (1e-5 if solid.all() else 2e-2) * scale + 1.5 * m_ora, f"{n}: max error {m_hip:.3e} vs {m_ora:.3e} (scale {scale:.3e}) | {strict}"
+        _second_look(c, g, cam, bg, grads, b_hip, b_ora, solid, names, strict)
+
+
+def _second_look(c, g, cam, bg, grads, b_hip, b_ora, solid, names, strict):
+    """About one random scene in a thousand fails the strict bounds for a reason that is not a defect; two are known, each
+    with a check of its own that still fails on anything else (15 000-scene sweep: cases 413, 524, 2172, 2845, 3324, 6294,
+    8171 of `tools/fuzz_case.py`):
+
+    * fragile pixels under tiny or faint Gaussians -- a contribution that is in on one side and out on the other can be
+      most of a Gaussian's gradient.  The image gradients are zeroed on the fragile pixels and BOTH sides run again: what
+      the remaining pixels contribute must agree strictly, for every Gaussian and the pose;
+    * a gradient float32 cannot hold to the bounds -- the opacity gradient of a faint, screen-filling Gaussian is a sum of
+      tens of thousands of sign-alternating terms; stacks of opaque Gaussians recover T by division.  The float64 oracle
+      says how far the float32 ORACLE is from the truth and how ill-conditioned the sums are (their change when every
+      pixel's image gradient moves by a relative 1e-6 with a random sign): the kernels pass if they are no farther from the float64 result than the
+      float32 restatement (x 1.5) plus the strict tolerance plus sixteen float32 roundings times the condition number."""
+    orc, hr, syn = tp._mods()
+    if not solid.all():
+        masked = tuple(torch.where(torch.from_numpy(np.broadcast_to(solid, t.shape[1:]).copy())[None], t, torch.zeros_like(t)) for t in grads)
+        _, bh = hr.run_hip(g, cam, c["W"], c["H"], bg, grads=masked)
+        _, bo = hr.run_oracle(orc, g, cam, c["W"], c["H"], bg, grads=masked)
+        try:
+            tp._check_backward(bh, bo, names + ["tau"])
+            return
+        except AssertionError as again:
+            strict = AssertionError(f"{strict} | with the fragile pixels' gradients zeroed: {again}")
+            b_hip, b_ora, grads = bh, bo, masked   # ... and perhaps ill-conditioned on top: the float64 look, on the masked problem
+    _, b64 = hr.run_oracle(orc, g, cam, c["W"], c["H"], bg, grads=grads, prec="f64")
+    # condition number of every gradient as a SUM over pixels: its change when every pixel's image gradient moves by a
+    # relative 1e-6 with a random sign (what independent roundings of the summands do)
+    gen = torch.Generator().manual_seed(12345)
+    jitter = tuple(t.double() * (1.0 + 1e-6 * (torch.randint(0, 2, t.shape, generator=gen).double() * 2 - 1)) for t in grads)
+    _, b64p = hr.run_oracle(orc, g, cam, c["W"], c["H"], bg, grads=jitter, prec="f64")
+    for n in names + ["tau"]:
+        ref64 = np.asarray(b64[n], np.float64).reshape(b_hip[n].shape)
+        ref32 = np.asarray(b_ora[n], np.float64).reshape(b_hip[n].shape)
+        pert = np.asarray(b64p[n], np.float64).reshape(b_hip[n].shape)
+        hip = np.asarray(b_hip[n], np.float64)
+        norm = max(np.linalg.norm(ref64), 1e-300)
+        e_hip, e_ora = np.linalg.norm(hip - ref64) / norm, np.linalg.norm(ref32 - ref64) / norm
+        cond = np.linalg.norm(pert - ref64) / norm / 1e-6
+        assert e_hip <= 2e-5 + 1.5 * e_ora + 16 * 6e-8 * cond, (
+            f"{n}: kernels {e_hip:.3e} from float64, float32 oracle {e_ora:.3e}, condition number {cond:.3g} | strict check said: {strict}")
+        m_hip, m_ora = np.abs(hip - ref64).max(), np.abs(ref32 - ref64).max()
+        scale = max(np.abs(ref64).max(), 1e-300)
+        assert m_hip <= 1e-5 * scale + 1.5 * m_ora + 16 * 6e-8 * np.abs(pert - ref64).max() / 1e-6, (
+            f"{n}: max error {m_hip:.3e} vs {m_ora:.3e} (scale {scale:.3e}) | {strict}")
 
 
 def _gaussians_without_fragile_pixels(c, f_ora, solid):
