@@ -64,6 +64,8 @@ class MapViewPass:
         pp = backend.pipeline_params
         if dev.type != "cuda" or getattr(pp, "compute_cov3D_python", False) or getattr(pp, "convert_SHs_python", False):
             return False
+        if G.get_xyz.shape[0] == 0:   # an empty map renders the background; the autograd path returns None for it
+            return False
         if (not allow_static_mask and getattr(viewpoint, "static_mask", None) is not None) or _raw_parameters(G) is None:
             return False
         if not all(_gpu_f32c(getattr(G, n, None), dev) and getattr(G, n).requires_grad for n in _PARAM_FIELDS):

@@ -439,3 +439,30 @@ def test_tracking_tail_and_fused_loss_backward_equal_the_separate_launches():
         else:
             torch.testing.assert_close(z, x, rtol=2e-6, atol=1e-9, msg=n)
     assert not torch.equal(ra[0], snap[0])   # the step moved the pose
+
+
+def test_fused_loss_backward_refuses_an_empty_map_and_mismatched_sizes():
+    """lvdgs_backward_fused_loss validates like the calls it replaces: no Gaussians / no pairs and a loss block of another
+    image size are errors with a message, not launches."""
+    import ctypes as C
+    from lvdgs import _lib
+    L = _lib.lib()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    a, la = _lib.Args(), _lib.LossArgs()
+    a.image_width, a.image_height, a.num_gaussians, a.num_rendered = 64, 48, 0, 0
+    img = torch.zeros(3, 48, 64, device=dev)
+    scratch = torch.empty(int(L.lvdgs_loss_scratch_bytes(64, 48)), dtype=torch.uint8, device=dev)
+    la.width, la.height = 64, 48
+    la.image, la.gt_image = C.c_void_p(img.data_ptr()), C.c_void_p(img.data_ptr())
+    la.scratch, la.scratch_bytes = C.c_void_p(scratch.data_ptr()), scratch.numel()
+    la.weight_rgb = 1.0
+    with _lib.on_device(dev):
+        stream = _lib.raw_stream(dev)
+        assert L.lvdgs_backward_fused_loss(C.byref(a), C.byref(la), 0, stream) == _lib.E_INVALID
+        assert b"empty map" in L.lvdgs_last_error()
+        la.width = 32
+        assert L.lvdgs_backward_fused_loss(C.byref(a), C.byref(la), 0, stream) == _lib.E_INVALID
+    # the scratch the loss kernels ask for holds four sums per tile as well as per 1024 pixels
+    for W, H in ((64, 48), (1920, 1080), (17, 300)):
+        tiles = ((W + 15) // 16) * ((H + 15) // 16)
+        assert L.lvdgs_loss_scratch_bytes(W, H) >= 16 * tiles
