@@ -7,28 +7,22 @@ namespace lvdgs {
 namespace {
 
 // One lane per Gaussian, in id order.  A Gaussian's pairs occupy [slot_base[i], slot_base[i] + tiles) of the
-// unsorted pair list, tiles in row-major order of its rectangle.
-__global__ void __launch_bounds__(256) emit_pairs_kernel(int N, int gx, int gy, const uint32_t *__restrict__ slot_base,
-                                                         const uint32_t *__restrict__ tiles_touched, const float *__restrict__ rec,
+// unsorted pair list, the kept tiles of its rectangle (common.hpp: rect_keeps) in row-major order.
+__global__ void __launch_bounds__(256) emit_pairs_kernel(int N, int gx, const uint32_t *__restrict__ slot_base,
+                                                         const uint32_t *__restrict__ tiles_touched, const uint4 *__restrict__ rect,
                                                          uint32_t *__restrict__ tile_keys, uint32_t *__restrict__ ids,
                                                          uint32_t capacity) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= (uint32_t)N) return;
-    const uint32_t cnt = tiles_touched[id];
-    if (cnt == 0) return;
-    const uint32_t first = slot_base[id];
-    const float4 *r4 = reinterpret_cast<const float4 *>(rec + (size_t)id * REC_FLOATS);
-    const float4 r0 = r4[0];
-    const int rad = __float_as_int(r4[2].w);
-    const float px = r0.x, py = r0.y;
-    int x0 = (int)((px - (float)rad) / (float)TILE), y0 = (int)((py - (float)rad) / (float)TILE);
-    int x1 = (int)((px + (float)rad + (float)(TILE - 1)) / (float)TILE);
-    int y1 = (int)((py + (float)rad + (float)(TILE - 1)) / (float)TILE);
-    x0 = min(gx, max(0, x0)); x1 = min(gx, max(0, x1));
-    y0 = min(gy, max(0, y0)); y1 = min(gy, max(0, y1));
-    uint32_t o = first;
+    if (tiles_touched[id] == 0) return;
+    const uint4 r = rect[id];
+    const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
+    const int area = (x1 - x0) * (y1 - y0);
+    uint32_t o = slot_base[id];
+    int k = 0;
     for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) {
+        for (int x = x0; x < x1; x++, k++) {
+            if (!rect_keeps(r, k, area)) continue;
             if (o < capacity) {  // pairs beyond the caller's capacity are dropped (the caller is told and re-runs)
                 tile_keys[o] = (uint32_t)(y * gx + x);
                 ids[o] = id;
@@ -56,17 +50,21 @@ constexpr int GROUP_MAX_TILES = 16384;  // 64 KiB of LDS counters
 constexpr int GROUP_BIG_RECT = 64;
 
 template <int PER, typename F>
-__device__ __forceinline__ void for_each_pair_of_chunk(int N, int gx, const uint2 *__restrict__ rect, F visit) {
+__device__ __forceinline__ void for_each_pair_of_chunk(int N, int gx, const uint4 *__restrict__ rect, F visit) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         const int i = blockIdx.x * (GROUP_THREADS * PER) + k * GROUP_THREADS + (int)threadIdx.x;
-        const uint2 r = i < N ? rect[i] : make_uint2(0u, 0u);
+        const uint4 r = i < N ? rect[i] : make_uint4(0u, 0u, 0u, 0u);
         const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
         const int w = x1 - x0, area = w * (y1 - y0);
-        if (area > 0 && area <= GROUP_BIG_RECT)
+        if (area > 0 && area <= GROUP_BIG_RECT) {
+            // only the tiles the Gaussian can reach (common.hpp: rect_keeps); bit t of the mask is tile t of the rectangle
+            uint64_t m = (uint64_t)r.z | ((uint64_t)r.w << 32);
             for (int y = y0; y < y1; y++)
-                for (int x = x0; x < x1; x++) visit(y * gx + x, (uint32_t)i);
+                for (int x = x0; x < x1; x++, m >>= 1)
+                    if (m & 1ull) visit(y * gx + x, (uint32_t)i);
+        }
         uint64_t big = __ballot(area > GROUP_BIG_RECT);
         while (big) {
             const int src = __builtin_ctzll(big);
@@ -77,6 +75,7 @@ __device__ __forceinline__ void for_each_pair_of_chunk(int N, int gx, const uint
         }
     }
 }
+static_assert(GROUP_BIG_RECT == RECT_MASK_TILES, "rectangles walked by the whole wave are the ones without a tile mask");
 
 // Exclusive scan of one value per thread over a workgroup of 1024 threads (wave shifts, then the 16 wave totals by wave
 // 0: two barriers); *total = sum over the workgroup.  s_scan: 33 words.
@@ -109,7 +108,7 @@ __device__ __forceinline__ uint32_t scan_1024(uint32_t v, uint32_t *s_scan, uint
 // the sums preprocess_fwd left per 256 Gaussians: the launch of the separate slot scan less.  Every workgroup adds up the
 // block sums in front of its chunk -- at most a few thousand values -- and scans its own Gaussians.)
 template <int PER>
-__global__ void __launch_bounds__(GROUP_THREADS) count_pairs_kernel(int N, int gx, int T, const uint2 *__restrict__ rect,
+__global__ void __launch_bounds__(GROUP_THREADS) count_pairs_kernel(int N, int gx, int T, const uint4 *__restrict__ rect,
                                                                    uint32_t *__restrict__ hist, int32_t *__restrict__ n_touched,
                                                                    uint32_t *__restrict__ queue_counts,
                                                                    const uint32_t *__restrict__ tt, const uint32_t *__restrict__ blocksums,
@@ -271,7 +270,7 @@ __global__ void __launch_bounds__(1024) group_tilescan_kernel(int T, const uint3
 }
 
 template <int PER>
-__global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int gx, int T, const uint2 *__restrict__ rect,
+__global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int gx, int T, const uint4 *__restrict__ rect,
                                                                      const uint32_t *__restrict__ hist,
                                                                      const uint2 *__restrict__ ranges, uint32_t capacity,
                                                                      const uint32_t *__restrict__ depth_bits,
@@ -316,11 +315,11 @@ int launch_group_count(const lvdgs_args &a, const GeomView &g, const ImageView &
     ProfScope ps("group_count", s);
     if (per == 2) {
         if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&count_pairs_kernel<2>), GROUP_MAX_TILES * 4, count_done2)) return e;
-        hipLaunchKernelGGL(count_pairs_kernel<2>, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint2 *)g.rect, w.group_hist,
+        hipLaunchKernelGGL(count_pairs_kernel<2>, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint4 *)g.rect, w.group_hist,
                            a.n_touched, im.long_count, tt, (const uint32_t *)w.blocksums, g.slot_base, g.total);
     } else {
         if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&count_pairs_kernel<4>), GROUP_MAX_TILES * 4, count_done4)) return e;
-        hipLaunchKernelGGL(count_pairs_kernel<4>, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint2 *)g.rect, w.group_hist,
+        hipLaunchKernelGGL(count_pairs_kernel<4>, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint4 *)g.rect, w.group_hist,
                            a.n_touched, im.long_count, tt, (const uint32_t *)w.blocksums, g.slot_base, g.total);
     }
     LVDGS_LAUNCH_CHECK("group_count", a.debug, s);
@@ -348,11 +347,11 @@ int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView
     {
         ProfScope ps("group_scatter", s);
         if (per == 2)
-            hipLaunchKernelGGL(scatter_pairs_kernel<2>, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint2 *)g.rect,
+            hipLaunchKernelGGL(scatter_pairs_kernel<2>, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint4 *)g.rect,
                                (const uint32_t *)w.group_hist, (const uint2 *)im.ranges, (uint32_t)capacity,
                                (const uint32_t *)g.depth_bits, keys64);
         else
-            hipLaunchKernelGGL(scatter_pairs_kernel<4>, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint2 *)g.rect,
+            hipLaunchKernelGGL(scatter_pairs_kernel<4>, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint4 *)g.rect,
                                (const uint32_t *)w.group_hist, (const uint2 *)im.ranges, (uint32_t)capacity,
                                (const uint32_t *)g.depth_bits, keys64);
         LVDGS_LAUNCH_CHECK("group_scatter", a.debug, s);
@@ -363,10 +362,10 @@ int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView
 int launch_emit_pairs(const lvdgs_args &a, const GeomView &g, uint32_t *tile_keys, uint32_t *ids, int64_t capacity, hipStream_t s) {
     const int N = a.num_gaussians;
     if (N == 0) return LVDGS_OK;
-    const int gx = (a.image_width + TILE - 1) / TILE, gy = (a.image_height + TILE - 1) / TILE;
+    const int gx = (a.image_width + TILE - 1) / TILE;
     ProfScope ps("emit_pairs", s);
-    hipLaunchKernelGGL(emit_pairs_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, N, gx, gy, g.slot_base, g.tiles_touched,
-                       g.rec, tile_keys, ids, (uint32_t)capacity);
+    hipLaunchKernelGGL(emit_pairs_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, N, gx, g.slot_base, g.tiles_touched,
+                       (const uint4 *)g.rect, tile_keys, ids, (uint32_t)capacity);
     LVDGS_LAUNCH_CHECK("emit_pairs", a.debug, s);
     return LVDGS_OK;
 }

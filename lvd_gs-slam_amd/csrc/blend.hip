@@ -15,7 +15,7 @@
 // "pixel pass" leaves the two state-dependent numbers of every (pixel, Gaussian) in an LDS matrix and a "splat pass"
 // (lane -> Gaussian of a batch of eight) accumulates the ten sums in registers, one fold per batch; then per-wave
 // LDS slots, a fixed-order 4-wave sum, and one 48-byte record per (Gaussian, tile) pair
-// stored at slot_base[id] + (ty - y0) * width + (tx - x0): a Gaussian's records form one contiguous
+// stored at slot_base[id] + (rank of the tile among the Gaussian's kept tiles): a Gaussian's records form one contiguous
 // run, and the runs follow each other in id order, so the per-Gaussian kernel (one lane per id) reads
 // whole cache lines.  Gradients are therefore bitwise reproducible.
 //
@@ -46,6 +46,7 @@ struct BlendParams {
     const uint32_t *point_list;
     const float *rec;
     const uint32_t *slot_base;
+    const uint4 *rect;           // tile rectangle + kept-tile mask of every Gaussian (backward: pair_slot)
     const float *bg;
     // forward
     float *out_color, *out_depth, *out_opacity, *final_T;
@@ -58,6 +59,15 @@ struct BlendParams {
     LossParams loss;             // loss.partial: 4 sums per TILE
     int loss_propagate_opacity;  // dL/d(opacity image) feeds the blend (rasterizer.PROPAGATE_OPACITY_GRAD)
 };
+
+// Where the partial gradient of the pair (Gaussian id, tile (tx, ty)) goes: the Gaussian's slots follow its kept tiles in
+// row-major order of its rectangle (common.hpp: rect_rank), the order the pairs were counted in.
+__device__ __forceinline__ uint32_t pair_slot(const BlendParams &p, uint32_t id, int tx, int ty) {
+    const uint4 r = p.rect[id];
+    const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
+    const int w = x1 - x0;
+    return p.slot_base[id] + rect_rank(r, (ty - y0) * w + (tx - x0), w * (y1 - y0));
+}
 
 // Workgroup -> tile.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one) and an XCD takes its
 // workgroups in order.  Runs of TILE_RUN row-major tiles go to the XCDs in turn: neighbouring tiles share most of their
@@ -73,31 +83,6 @@ __device__ __forceinline__ int tile_of_workgroup(int b, int n) {
     if (b >= grouped) return b;
     const int xcd = b & 7, k = b >> 3;
     return ((k / TILE_RUN) * 8 + xcd) * TILE_RUN + k % TILE_RUN;
-}
-
-// Can a Gaussian (mean m, conic a,b,c, opacity op) reach alpha >= 1/255 anywhere in the pixel
-// rectangle [x0,x1] x [y0,y1]?  Exact minimum of q(d) = 1/2 (a dx^2 + c dy^2) + b dx dy over the
-// rectangle (convex: interior point or one of four clamped edge minima), compared against
-// ln(255 op) with a safety margin that covers float rounding of the per-pixel evaluation.
-__device__ __forceinline__ bool reaches_rect(float mx, float my, float a, float b, float c, float op, float x0, float y0,
-                                             float x1, float y1) {
-    if (!(op >= ALPHA_MIN)) return false;
-    if (!(a > 0.f && c > 0.f && a * c - b * b > 0.f)) return true;  // not an ellipse: let the pixel test decide
-    const float dx_lo = mx - x1, dx_hi = mx - x0, dy_lo = my - y1, dy_hi = my - y0;  // d = mean - pixel
-    if (dx_lo <= 0.f && dx_hi >= 0.f && dy_lo <= 0.f && dy_hi >= 0.f) return true;
-    const float inv_a = __builtin_amdgcn_rcpf(a), inv_c = __builtin_amdgcn_rcpf(c);
-    auto along_y = [&](float dx) {
-        const float dy = fminf(fmaxf(-b * dx * inv_c, dy_lo), dy_hi);
-        return 0.5f * (a * dx * dx + c * dy * dy) + b * dx * dy;
-    };
-    auto along_x = [&](float dy) {
-        const float dx = fminf(fmaxf(-b * dy * inv_a, dx_lo), dx_hi);
-        return 0.5f * (a * dx * dx + c * dy * dy) + b * dx * dy;
-    };
-    const float qmin = fminf(fminf(along_y(dx_lo), along_y(dx_hi)), fminf(along_x(dy_lo), along_x(dy_hi)));
-    const float dxm = fmaxf(fabsf(dx_lo), fabsf(dx_hi)), dym = fmaxf(fabsf(dy_lo), fabsf(dy_hi));
-    const float margin = 0.02f + 2e-5f * (a * dxm * dxm + c * dym * dym);
-    return qmin <= __logf(op * 255.f) + margin;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -430,12 +415,7 @@ __global__ void __launch_bounds__(256, 8) blend_bwd_kernel(BlendParams p) {
             s_a[tid] = r0;
             s_b[tid] = make_float4(r1.x, r1.y, r2.y, -0.5f * LOG2E * r0.z);
             s_c[tid] = make_float4(r1.z, r1.w, r2.x, -LOG2E * r0.w);
-            // slot of this (Gaussian, tile) pair in the unsorted pair list
-            const int rad = __float_as_int(r2.w);
-            int x0 = (int)((r0.x - (float)rad) / (float)TILE), y0 = (int)((r0.y - (float)rad) / (float)TILE);
-            int x1 = (int)((r0.x + (float)rad + (float)(TILE - 1)) / (float)TILE);
-            x0 = min(p.gx, max(0, x0)); x1 = min(p.gx, max(0, x1)); y0 = min(p.gy, max(0, y0));
-            s_slot[tid] = p.slot_base[id] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+            s_slot[tid] = pair_slot(p, id, tx, ty);
         }
         if (tid < 4 * (BR / 64)) (&s_mask[0][0])[tid] = 0ull;
         __syncthreads();
@@ -611,11 +591,7 @@ __global__ void __launch_bounds__(256, 4) blend_bwd2_kernel(BlendParams p) {
             sh.a[tid] = r0;
             sh.b[tid] = make_float4(r1.x, r1.y, r2.y, -0.5f * LOG2E * r0.z);
             sh.c[tid] = make_float4(r1.z, r1.w, r2.x, -LOG2E * r0.w);
-            const int rad = __float_as_int(r2.w);
-            int x0 = (int)((r0.x - (float)rad) / (float)TILE), y0 = (int)((r0.y - (float)rad) / (float)TILE);
-            int x1 = (int)((r0.x + (float)rad + (float)(TILE - 1)) / (float)TILE);
-            x0 = min(p.gx, max(0, x0)); x1 = min(p.gx, max(0, x1)); y0 = min(p.gy, max(0, y0));
-            sh.slot[tid] = p.slot_base[id] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+            sh.slot[tid] = pair_slot(p, id, tx, ty);
         }
         __syncthreads();
         uint64_t wrote = 0ull;
@@ -860,11 +836,7 @@ __global__ void __launch_bounds__(256, 5) blend_bwd3_kernel(BlendParams p) {
             sh.b[tid] = make_float4(-0.5f * LOG2E * r1.x, r1.y, r2.y, -0.5f * LOG2E * r0.z);
             sh.c[tid] = make_float4(r1.z, r1.w, r2.x, -LOG2E * r0.w);
             sh.craw[tid] = r1.x;
-            const int rad = __float_as_int(r2.w);
-            int x0 = (int)((r0.x - (float)rad) / (float)TILE), y0 = (int)((r0.y - (float)rad) / (float)TILE);
-            int x1 = (int)((r0.x + (float)rad + (float)(TILE - 1)) / (float)TILE);
-            x0 = min(p.gx, max(0, x0)); x1 = min(p.gx, max(0, x1)); y0 = min(p.gy, max(0, y0));
-            sh.slot[tid] = p.slot_base[id] + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0));
+            sh.slot[tid] = pair_slot(p, id, tx, ty);
         }
         __syncthreads();
         uint64_t wrote = 0ull;
@@ -1007,7 +979,7 @@ BlendParams make_params(const lvdgs_args &a, const GeomView &g, const BinView &b
     BlendParams p{};
     p.W = a.image_width; p.H = a.image_height;
     p.gx = (p.W + TILE - 1) / TILE; p.gy = (p.H + TILE - 1) / TILE; p.num_tiles = p.gx * p.gy;
-    p.ranges = im.ranges; p.tile_order = tile_order_in_use(p.num_tiles) ? im.long_tiles + p.num_tiles : nullptr; p.order_valid = im.long_count + 1; p.point_list = b.point_list; p.rec = g.rec; p.slot_base = g.slot_base; p.bg = a.bg;
+    p.ranges = im.ranges; p.tile_order = tile_order_in_use(p.num_tiles) ? im.long_tiles + p.num_tiles : nullptr; p.order_valid = im.long_count + 1; p.point_list = b.point_list; p.rec = g.rec; p.slot_base = g.slot_base; p.rect = g.rect; p.bg = a.bg;
     p.out_color = a.out_color; p.out_depth = a.out_depth; p.out_opacity = a.out_opacity;
     p.final_T = im.final_T; p.n_contrib = im.n_contrib; p.n_touched = a.n_touched;
     p.dL_dcolor = a.dL_dout_color; p.dL_ddepth = a.dL_dout_depth; p.dL_dopacity = a.dL_dout_opacity;

@@ -56,12 +56,82 @@ struct ProfScope {
         }                                                                       \
     } while (0)
 
+// Can a Gaussian (mean m, conic a,b,c, opacity op) reach alpha >= 1/255 anywhere in the pixel
+// rectangle [x0,x1] x [y0,y1]?  Exact minimum of q(d) = 1/2 (a dx^2 + c dy^2) + b dx dy over the
+// rectangle (convex: interior point or one of four clamped edge minima), compared against
+// ln(255 op) with a safety margin that covers float rounding of the per-pixel evaluation.
+__device__ __forceinline__ bool reaches_rect(float mx, float my, float a, float b, float c, float op, float x0, float y0,
+                                             float x1, float y1) {
+    if (!(op >= ALPHA_MIN)) return false;
+    if (!(a > 0.f && c > 0.f && a * c - b * b > 0.f)) return true;  // not an ellipse: let the pixel test decide
+    const float dx_lo = mx - x1, dx_hi = mx - x0, dy_lo = my - y1, dy_hi = my - y0;  // d = mean - pixel
+    if (dx_lo <= 0.f && dx_hi >= 0.f && dy_lo <= 0.f && dy_hi >= 0.f) return true;
+    const float inv_a = __builtin_amdgcn_rcpf(a), inv_c = __builtin_amdgcn_rcpf(c);
+    auto along_y = [&](float dx) {
+        const float dy = fminf(fmaxf(-b * dx * inv_c, dy_lo), dy_hi);
+        return 0.5f * (a * dx * dx + c * dy * dy) + b * dx * dy;
+    };
+    auto along_x = [&](float dy) {
+        const float dx = fminf(fmaxf(-b * dy * inv_a, dx_lo), dx_hi);
+        return 0.5f * (a * dx * dx + c * dy * dy) + b * dx * dy;
+    };
+    const float qmin = fminf(fminf(along_y(dx_lo), along_y(dx_hi)), fminf(along_x(dy_lo), along_x(dy_hi)));
+    const float dxm = fmaxf(fabsf(dx_lo), fabsf(dx_hi)), dym = fmaxf(fabsf(dy_lo), fabsf(dy_hi));
+    const float margin = 0.02f + 2e-5f * (a * dxm * dxm + c * dym * dym);
+    return qmin <= __logf(op * 255.f) + margin;
+}
+
+// reaches_rect() for the tiles of one Gaussian's rectangle, with the per-Gaussian part hoisted: the same bound (exact
+// minimum of q over the tile against ln(255 op) plus the rounding margin, here the margin of the whole rectangle), the
+// minimum taken over the two edges that face the mean -- a convex q with its minimum at the mean cannot have its
+// rectangle minimum on an edge that faces away.
+struct TileReach {
+    float mx, my, a, b, c, nb_inv_a, nb_inv_c, bound;
+    bool never, always;
+    __device__ __forceinline__ TileReach(float mx_, float my_, float a_, float b_, float c_, float op, float far_x, float far_y)
+        : mx(mx_), my(my_), a(a_), b(b_), c(c_) {
+        never = !(op >= ALPHA_MIN);
+        always = !(a > 0.f && c > 0.f && a * c - b * b > 0.f);   // not an ellipse: let the pixel test decide
+        nb_inv_a = -b * __builtin_amdgcn_rcpf(a); nb_inv_c = -b * __builtin_amdgcn_rcpf(c);
+        // far_x, far_y: the largest |mean - pixel| over the rectangle
+        bound = __logf(op * 255.f) + 0.02f + 2e-5f * (a * far_x * far_x + c * far_y * far_y);
+    }
+    // pixel rectangle [x0, x0 + 15] x [y0, y0 + 15]
+    __device__ __forceinline__ bool tile(float x0, float y0) const {
+        const float dx_hi = mx - x0, dx_lo = dx_hi - (float)(TILE - 1), dy_hi = my - y0, dy_lo = dy_hi - (float)(TILE - 1);
+        const float dxn = __builtin_amdgcn_fmed3f(0.f, dx_lo, dx_hi), dyn = __builtin_amdgcn_fmed3f(0.f, dy_lo, dy_hi);
+        const float dy1 = __builtin_amdgcn_fmed3f(nb_inv_c * dxn, dy_lo, dy_hi);   // along the edge dx = dxn
+        const float dx2 = __builtin_amdgcn_fmed3f(nb_inv_a * dyn, dx_lo, dx_hi);   // along the edge dy = dyn
+        const float q1 = 0.5f * (a * dxn * dxn + c * dy1 * dy1) + b * dxn * dy1;
+        const float q2 = 0.5f * (a * dx2 * dx2 + c * dyn * dyn) + b * dx2 * dyn;
+        return (fminf(q1, q2) <= bound || always) && !never;   // (mean inside the tile: q1 = q2 = 0)
+    }
+};
+
+// ---- the tile rectangle of a Gaussian and which of its tiles it can reach ----
+// rect[i] = (x0 | x1 << 16, y0 | y1 << 16, mask lo, mask hi): the rectangle of 16x16 tiles covered by the 3-sigma
+// radius (what the reference pairs the Gaussian with), and, for rectangles of up to 64 tiles, one bit per tile in
+// row-major order: set when reaches_rect() cannot rule out alpha >= 1/255 on some pixel of the tile.  Only those
+// (Gaussian, tile) pairs are listed; a dropped pair contributes nothing to any pixel, so every output is unchanged.
+// Larger rectangles keep all their tiles (mask = all ones).
+constexpr int RECT_MASK_TILES = 64;
+__device__ __forceinline__ bool rect_keeps(const uint4 r, int k, int area) {
+    if (area > RECT_MASK_TILES) return true;
+    return (k < 32 ? r.z >> k : r.w >> (k - 32)) & 1u;
+}
+// position of tile k of the rectangle among the kept ones (the pair's slot behind slot_base[i])
+__device__ __forceinline__ uint32_t rect_rank(const uint4 r, int k, int area) {
+    if (area > RECT_MASK_TILES) return (uint32_t)k;
+    const uint64_t m = (uint64_t)r.z | ((uint64_t)r.w << 32);
+    return (uint32_t)__popcll(m & ((1ull << k) - 1ull));
+}
+
 // ---- state layouts ----
 struct GeomView {
     float *rec;              // N*12
-    uint32_t *tiles_touched; // N
+    uint32_t *tiles_touched; // N: tiles of the rectangle the Gaussian can reach (= pairs listed for it)
     uint32_t *depth_bits;    // N: view depth as ordered bits (positive floats compare like unsigned integers)
-    uint2 *rect;             // N: tile rectangle, x0 | x1 << 16, y0 | y1 << 16 (empty for culled Gaussians)
+    uint4 *rect;             // N: tile rectangle x0 | x1 << 16, y0 | y1 << 16 (empty for culled Gaussians) and the kept-tile mask
     uint32_t *slot_base;     // N: exclusive scan of tiles_touched in id order: first pair / gradient slot of a Gaussian
     uint32_t *total;         // 1: pair count D of this frame (device copy)
 };

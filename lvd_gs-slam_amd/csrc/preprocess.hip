@@ -165,10 +165,11 @@ __device__ __forceinline__ void load_scale_rot(const float *__restrict__ scales,
 struct FwdParams {
     Cam cam;
     int N, act;
+    int tile_cull;         // 0: list every tile of the rectangle (the reference's pair list)
     const float *means3D, *opacities, *scales, *rotations, *cov3D_precomp, *shs, *colors_precomp;
     float *rec;
     uint32_t *tiles_touched, *depth_bits;
-    uint2 *rect;
+    uint4 *rect;
     int32_t *radii;
     uint32_t *blocksums;   // per workgroup: sum of tiles_touched (first level of the slot scan, sortscan.hip)
 };
@@ -193,7 +194,7 @@ __device__ __forceinline__ void preprocess_one(const FwdParams &p, int i, uint32
     // culled unless proven visible
     int radius = 0;
     uint32_t tiles = 0;
-    uint2 rect = make_uint2(0u, 0u);
+    uint4 rect = make_uint4(0u, 0u, 0u, 0u);
     uint32_t depth_bits = 0u;
     float pos[3] = {p.means3D[3 * i], p.means3D[3 * i + 1], p.means3D[3 * i + 2]};
     float pv[3];
@@ -256,13 +257,28 @@ __device__ __forceinline__ void preprocess_one(const FwdParams &p, int i, uint32
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) { rgb[ch] += 0.5f; rgb[ch] = rgb[ch] < 0.f ? 0.f : rgb[ch]; }
                 }
+                float opac = p.opacities[i];
+                if (p.act & ACT_SIGMOID_OPACITY) opac = 1.f / (1.f + expf(-opac));
+                // the tiles of the rectangle the Gaussian can reach with alpha >= 1/255 (common.hpp: rect_keeps)
+                uint64_t mask = ~0ull;
                 radius = rad; tiles = (uint32_t)area;
-                rect = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16));
+                if (p.tile_cull && area <= RECT_MASK_TILES) {
+                    const float far_x = fmaxf(fabsf(px - (float)(x0 * TILE)), fabsf(px - (float)(x1 * TILE - 1)));
+                    const float far_y = fmaxf(fabsf(py - (float)(y0 * TILE)), fabsf(py - (float)(y1 * TILE - 1)));
+                    const TileReach reach(px, py, k0, k1, k2, opac, far_x, far_y);
+                    mask = 0ull;
+                    uint64_t bit = 1ull;
+                    for (int y = y0; y < y1; y++)
+                        for (int x = x0; x < x1; x++) {
+                            if (reach.tile((float)(x * TILE), (float)(y * TILE))) mask |= bit;
+                            bit <<= 1;
+                        }
+                    tiles = (uint32_t)__popcll(mask);
+                }
+                rect = make_uint4((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
                 depth_bits = __float_as_uint(pv[2]);
                 float4 *r4 = reinterpret_cast<float4 *>(p.rec + (size_t)i * REC_FLOATS);
                 r4[0] = make_float4(px, py, k0, k1);
-                float opac = p.opacities[i];
-                if (p.act & ACT_SIGMOID_OPACITY) opac = 1.f / (1.f + expf(-opac));
                 r4[1] = make_float4(k2, opac, rgb[0], rgb[1]);
                 r4[2] = make_float4(rgb[2], pv[2], 0.f, __int_as_float(rad));
             }
@@ -584,6 +600,8 @@ int launch_preprocess_fwd(const lvdgs_args &a, const GeomView &g, uint32_t *bloc
     FwdParams p;
     p.blocksums = blocksums;
     p.cam = make_cam(a); p.N = a.num_gaussians; p.act = a.activations;
+    // LVDGS_TILE_CULL=0 (read at every call; the tests switch it) keeps the pair list the reference's
+    { const char *e = getenv("LVDGS_TILE_CULL"); p.tile_cull = !(e && e[0] == '0'); }
     p.means3D = a.means3D; p.opacities = a.opacities; p.scales = a.scales; p.rotations = a.rotations;
     p.cov3D_precomp = a.cov3D_precomp; p.shs = a.shs; p.colors_precomp = a.colors_precomp;
     p.rec = g.rec; p.tiles_touched = g.tiles_touched; p.depth_bits = g.depth_bits; p.rect = g.rect; p.radii = a.radii;

@@ -24,9 +24,24 @@ def _view(buf, off, count, dtype):
 
 
 def run_hip(g, cam, W, H, bg, use_sh=False, sh_degree=0, cov_precomp=None, grads=None, pose=True, dev="cuda",
-            propagate_opacity=True):
+            propagate_opacity=True, tile_cull=True):
     """g: dict of float32 CPU tensors (synthetic.make_gaussians).  grads: optional (dL_dcolor, dL_ddepth,
-    dL_dopacity) CPU tensors.  Returns (forward dict, backward dict or None)."""
+    dL_dopacity) CPU tensors.  Returns (forward dict, backward dict or None).
+
+    tile_cull=False (LVDGS_TILE_CULL=0 for the call) lists every tile of a Gaussian's rectangle, which makes the pair
+    list, the ranges and n_contrib the reference's bit for bit; the default drops the tiles the Gaussian cannot reach."""
+    cull_before = os.environ.get("LVDGS_TILE_CULL")
+    os.environ["LVDGS_TILE_CULL"] = "1" if tile_cull else "0"
+    try:
+        return _run_hip(g, cam, W, H, bg, use_sh, sh_degree, cov_precomp, grads, pose, dev, propagate_opacity, tile_cull)
+    finally:
+        if cull_before is None:
+            del os.environ["LVDGS_TILE_CULL"]
+        else:
+            os.environ["LVDGS_TILE_CULL"] = cull_before
+
+
+def _run_hip(g, cam, W, H, bg, use_sh, sh_degree, cov_precomp, grads, pose, dev, propagate_opacity, tile_cull):
     rasterizer.KEEP_DEBUG_STATE = True
     # the parity tests feed a gradient of the opacity image too: switch that (non-default) path on for the run
     propagate_before = rasterizer.PROPAGATE_OPACITY_GRAD
@@ -64,7 +79,7 @@ def run_hip(g, cam, W, H, bg, use_sh=False, sh_degree=0, cov_precomp=None, grads
         point_list=_view(st["binning"], lay.bin_point_list, D, np.uint32) if D else np.zeros(0, np.uint32),
         ranges=_view(st["image"], lay.img_ranges, NT * 2, np.uint32).reshape(NT, 2),
         final_T=_view(st["image"], lay.img_final_T, W * H, np.float32).reshape(H, W),
-        n_contrib=_view(st["image"], lay.img_n_contrib, W * H, np.uint32).reshape(H, W),
+        n_contrib=_view(st["image"], lay.img_n_contrib, W * H, np.uint32).reshape(H, W), tile_cull=bool(tile_cull),
     )
     # tile id of every entry of point_list, from the ranges (the counting path never materialises tile keys)
     r = fwd["ranges"].astype(np.int64)
@@ -113,3 +128,67 @@ def run_oracle(orc, g, cam, W, H, bg, use_sh=False, sh_degree=0, cov_precomp=Non
         bwd = o.backward(gc.numpy(), None if gd is None else gd.numpy(), None if go is None else go.numpy())
     o.free()
     return fwd, bwd
+
+
+def check_pair_lists(f_hip, f_ora, W, H, max_dropped_checked=200_000):
+    """The per-tile lists of the HIP path against the oracle's (= the reference's: every tile of the 3-sigma rectangle).
+
+    Without tile culling they are identical.  With it the HIP list must be the oracle's list with some pairs REMOVED
+    (same order otherwise), and every removed (Gaussian, tile) pair must be one that cannot contribute: alpha < 1/255
+    on all 256 pixels of the tile, evaluated here in float64 from the oracle's projected means / conics / opacities.
+    Returns the fraction of pairs removed."""
+    N = f_ora["radii"].shape[0]
+    D = f_ora["num_rendered"]
+    ora_ids = f_ora["ids_sorted"].astype(np.int64)
+    ora_tiles = (f_ora["keys_sorted"] >> np.uint64(32)).astype(np.int64)
+    if not f_hip["tile_cull"]:
+        np.testing.assert_array_equal(f_hip["tiles_touched"], f_ora["tiles_touched"])
+        assert f_hip["num_rendered"] == D
+        np.testing.assert_array_equal(f_hip["point_list"], f_ora["ids_sorted"])
+        np.testing.assert_array_equal(f_hip["tile_keys"], ora_tiles.astype(np.uint32))
+        np.testing.assert_array_equal(f_hip["ranges"], f_ora["ranges"])
+        f_hip["kept_in_oracle_list"] = np.ones(D, bool)
+        return 0.0
+    assert (f_hip["tiles_touched"] <= f_ora["tiles_touched"]).all()
+    assert f_hip["num_rendered"] == int(f_hip["tiles_touched"].sum()) <= D
+    hip_key = f_hip["tile_keys"].astype(np.int64) * max(N, 1) + f_hip["point_list"].astype(np.int64)
+    ora_key = ora_tiles * max(N, 1) + ora_ids
+    kept = np.isin(ora_key, hip_key)
+    np.testing.assert_array_equal(ora_key[kept], hip_key)     # a sub-list, order (tile, depth, id) preserved
+    f_hip["kept_in_oracle_list"] = kept
+    r = f_hip["ranges"].astype(np.int64)
+    assert (np.diff(r[r[:, 1] > r[:, 0]].reshape(-1)) >= 0).all()
+    np.testing.assert_array_equal(np.bincount(f_hip["point_list"], minlength=N).astype(np.uint32), f_hip["tiles_touched"])
+    dropped = np.nonzero(~kept)[0]
+    if len(dropped) > max_dropped_checked:
+        dropped = dropped[np.random.default_rng(0).choice(len(dropped), max_dropped_checked, replace=False)]
+    if len(dropped):
+        gx = (W + 15) // 16
+        gid, tile = ora_ids[dropped], ora_tiles[dropped]
+        m = f_ora["means2D"].astype(np.float64)[gid]
+        co = f_ora["conic_opacity"].astype(np.float64)[gid]
+        worst = np.zeros(len(dropped))
+        for lo in range(0, len(dropped), 50_000):
+            sl = slice(lo, lo + 50_000)
+            px = (tile[sl] % gx * 16)[:, None] + (np.arange(256) % 16)[None, :]
+            py = (tile[sl] // gx * 16)[:, None] + (np.arange(256) // 16)[None, :]
+            dx, dy = m[sl, 0:1] - px, m[sl, 1:2] - py
+            power = -0.5 * (co[sl, 0:1] * dx * dx + co[sl, 2:3] * dy * dy) - co[sl, 1:2] * dx * dy
+            alpha = np.where(power > 0, 0.0, co[sl, 3:4] * np.exp(np.minimum(power, 0)))
+            worst[sl] = alpha.max(1)
+        assert worst.max() < 1.0 / 255.0, f"a dropped pair reaches alpha {worst.max():.6f} >= 1/255"
+    return 1.0 - len(hip_key) / max(D, 1)
+
+
+def expected_n_contrib(f_hip, f_ora):
+    """The oracle's per-pixel count of list entries up to the last contributor, restated for the HIP path's (possibly
+    shorter) lists: the number of KEPT entries among the tile's first n_contrib ones.  check_pair_lists() first."""
+    kept = f_hip["kept_in_oracle_list"]
+    if kept.all():
+        return f_ora["n_contrib"]
+    H, W = f_ora["n_contrib"].shape
+    gx = (W + 15) // 16
+    prefix = np.concatenate([[0], np.cumsum(kept)]).astype(np.int64)
+    ys, xs = np.mgrid[0:H, 0:W]
+    start = f_ora["ranges"].astype(np.int64)[(ys // 16) * gx + xs // 16, 0]
+    return (prefix[start + f_ora["n_contrib"].astype(np.int64)] - prefix[start]).astype(np.uint32)

@@ -48,11 +48,10 @@ def _close(a, b, rtol=RTOL, atol_scale=1e-5, what="", rel_l2=2e-5, max_rel_sig=1
 
 
 def _check_forward(f_hip, f_ora, W, H):
+    import hip_runner
     N = f_ora["radii"].shape[0]
     # ---- bit-exact integer / index state ----
     np.testing.assert_array_equal(f_hip["radii"], f_ora["radii"])
-    np.testing.assert_array_equal(f_hip["tiles_touched"], f_ora["tiles_touched"])
-    assert f_hip["num_rendered"] == f_ora["num_rendered"]
     vis = f_ora["radii"] > 0
     rec = f_hip["rec"]
     # per-Gaussian projection: same float32 operations in the same order -> identical bits
@@ -61,14 +60,13 @@ def _check_forward(f_hip, f_ora, W, H):
     np.testing.assert_array_equal(rec[vis, 2:5], f_ora["conic_opacity"][vis, 0:3])
     np.testing.assert_array_equal(rec[vis, 11].view(np.int32), f_ora["radii"][vis])
     _close(rec[vis, 6:9], f_ora["rgb"][vis], rtol=1e-6, what="rgb")
-    # sorted (tile, depth, id) list and per-tile ranges
-    D = f_ora["num_rendered"]
-    np.testing.assert_array_equal(f_hip["point_list"], f_ora["ids_sorted"])
-    np.testing.assert_array_equal(f_hip["tile_keys"], (f_ora["keys_sorted"] >> np.uint64(32)).astype(np.uint32))
-    depth_bits = rec[:, 9].view(np.uint32)[f_hip["point_list"]] if D else np.zeros(0, np.uint32)
-    keys64 = (f_hip["tile_keys"].astype(np.uint64) << np.uint64(32)) | depth_bits.astype(np.uint64)
-    np.testing.assert_array_equal(keys64, f_ora["keys_sorted"])
-    np.testing.assert_array_equal(f_hip["ranges"], f_ora["ranges"])
+    # sorted (tile, depth, id) list and per-tile ranges: the reference's, or (tile culling, the default) the reference's
+    # minus pairs that provably contribute to no pixel
+    hip_runner.check_pair_lists(f_hip, f_ora, W, H)
+    if len(f_hip["point_list"]):
+        depth_bits = rec[:, 9].view(np.uint32)[f_hip["point_list"]]
+        keys64 = (f_hip["tile_keys"].astype(np.uint64) << np.uint64(32)) | depth_bits.astype(np.uint64)
+        np.testing.assert_array_equal(keys64, f_ora["keys_sorted"][f_hip["kept_in_oracle_list"]])
     # ---- images ----
     # A pixel is "fragile" when the oracle saw alpha within 1e-5 of 1/255 (or T within 1e-5 of 1e-4 / 0.5):
     # there exp() rounding may include or drop one faint Gaussian, which moves the pixel by at most
@@ -82,7 +80,7 @@ def _check_forward(f_hip, f_ora, W, H):
         assert np.abs(f_hip[k] - f_ora[k]).max() <= 5e-3 * scale, k + " (fragile pixels)"
     _close(np.where(solid, f_hip["final_T"], 0), np.where(solid, f_ora["final_T"], 0), what="final_T")
     # ---- blend-time counters ----
-    np.testing.assert_array_equal(f_hip["n_contrib"][solid], f_ora["n_contrib"][solid])
+    np.testing.assert_array_equal(f_hip["n_contrib"][solid], hip_runner.expected_n_contrib(f_hip, f_ora)[solid])
     n_fragile = int((~solid).sum())
     diff = np.abs(f_hip["n_touched"].astype(np.int64) - f_ora["n_touched"].astype(np.int64))
     assert diff.sum() <= 4 * n_fragile + 0, (diff.sum(), n_fragile)
@@ -368,3 +366,36 @@ def test_fused_activations_match_the_accessor_path():
     for x, y in zip(a["grads"], b["grads"]):
         _close(x, y, rtol=1e-3, atol_scale=1e-4, what="raw-parameter gradient", rel_l2=1e-3, max_rel_sig=5e-2)
     _close(a["tau"], b["tau"], rtol=1e-3, atol_scale=1e-4, what="tau", rel_l2=1e-3, max_rel_sig=5e-2)
+
+
+@pytest.mark.parametrize("opacity_scale,r_max", [(1.0, 12.0), (0.05, 25.0)])
+def test_tile_culling_changes_no_output_bit_and_without_it_the_lists_are_the_references(opacity_scale, r_max):
+    """The default path lists a (Gaussian, tile) pair only when the Gaussian can reach alpha >= 1/255 somewhere on the
+    tile (common.hpp: reaches_rect / rect_keeps).  LVDGS_TILE_CULL=0 lists every tile of the 3-sigma rectangle, as the
+    reference does.  (1) Without culling the pair list, ranges and n_contrib equal the oracle's bit for bit; (2) with it
+    the list is the oracle's minus pairs that provably contribute nothing (hip_runner.check_pair_lists); (3) images,
+    radii and n_touched are bitwise the same in the two modes, and the gradients agree to summation-order rounding."""
+    orc, hr, syn = _mods()
+    W, H, N = 333, 205, 4000
+    g = syn.make_gaussians(N, W, H, seed=91, r_min=0.5, r_max=r_max)
+    with torch.no_grad():
+        g["opacities"].mul_(opacity_scale)
+    cam = syn.make_camera(W, H, pose_seed=4)
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    grads = syn.make_image_grads(W, H, 12)
+    f_on, b_on = hr.run_hip(g, cam, W, H, bg, grads=grads, tile_cull=True)
+    f_off, b_off = hr.run_hip(g, cam, W, H, bg, grads=grads, tile_cull=False)
+    f_ora, b_ora = hr.run_oracle(orc, g, cam, W, H, bg, grads=grads)
+    _check_forward(f_off, f_ora, W, H)
+    assert f_off["num_rendered"] == f_ora["num_rendered"]
+    dropped = hr.check_pair_lists(f_on, f_ora, W, H)
+    assert dropped > 0.1, dropped
+    _check_forward(f_on, f_ora, W, H)
+    for k in ("color", "depth", "opacity", "final_T", "radii", "n_touched"):
+        np.testing.assert_array_equal(f_on[k], f_off[k], err_msg=k)
+    # gradients: the same terms, but a Gaussian's place in its batch of eight decides the order its 256 pixels are
+    # summed in (blend_bwd3's row rotations), and the batches differ once pairs are dropped: rounding-level differences
+    for k in b_on:
+        _close(b_on[k], b_off[k], rtol=1e-4, what=f"cull on/off {k}")
+    _check_backward(b_off, b_ora, ["means3D", "means2D", "opacities", "scales", "rotations", "colors", "tau"], f_ora, W, H)
+    _check_backward(b_on, b_ora, ["means3D", "means2D", "opacities", "scales", "rotations", "colors", "tau"], f_ora, W, H)

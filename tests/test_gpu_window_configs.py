@@ -63,7 +63,7 @@ def test_kitti07_window_of_8_plus_2_random_keyframes():
     # Adam moves an element whose gradient is at rounding level by up to its learning rate (1e-2) in either direction:
     # a handful of the 600k coordinates may differ by that much, the map as a whole may not
     d = np.abs(out[True][1] - out[False][1])
-    assert (d > 1e-4 * np.abs(out[False][1]) + 1e-5).mean() < 1e-4 and d.max() < 2e-2
+    assert (d > 1e-4 * np.abs(out[False][1]) + 1e-5).mean() < 3e-4 and d.max() < 2e-2
     assert np.linalg.norm(d) <= 1e-6 * np.linalg.norm(out[False][1])
     for kf in out[True][2]:
         np.testing.assert_allclose(out[True][2][kf], out[False][2][kf], atol=5e-6)
