@@ -21,6 +21,7 @@ peak with the algorithmic byte count of SURVEY.md section 8(d); `cpu_baseline` t
 (a scalar C port, 1 core) on one iteration of the same scene.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -217,6 +218,11 @@ def main():
     rasterizer.KEEP_DEBUG_STATE = False
     rasterizer._DEBUG_LAST.clear()
 
+    # Everything built so far (torch, the scene, the warm-up's leftovers) leaves the garbage collector's generations: a
+    # full collection over that heap is one stall of about 40 ms, which otherwise lands somewhere in the first hundred
+    # iterations of whichever loop allocates Python objects (tools/autograd_variance.py).  The collector stays on.
+    gc.collect()
+    gc.freeze()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -280,8 +286,10 @@ def main():
     autograd_rate = None
     if rank == 0 and session is not None:
         # the same iteration through the public autograd API (render() / get_loss_tracking / backward), for comparison
-        for _ in range(3):
+        for _ in range(10):
             autograd_step()
+        gc.collect()
+        gc.freeze()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(args.steps):

@@ -130,7 +130,11 @@ size_t lvdgs_backward_scratch_bytes(int32_t num_gaussians, int64_t num_rendered)
 
 /* ---- rasterizer ---- */
 /* Projects the Gaussians and counts (Gaussian, tile) pairs.  Writes radii and
- * geom_state; returns the pair count D in *num_rendered (synchronises the stream once). */
+ * geom_state; returns the pair count D in *num_rendered (synchronises the stream once).
+ * D counts the (Gaussian, tile) pairs that are listed: the tiles of the reference's 3-sigma rectangle
+ * (forward.cu's getRect) on which the Gaussian can reach alpha >= 1/255.  Pairs that cannot are dropped
+ * (they contribute to no pixel; outputs are unchanged), so D <= the reference's num_rendered.  With the
+ * environment variable LVDGS_TILE_CULL=0 every tile of the rectangle is listed and D equals it. */
 int lvdgs_forward_prepare(const lvdgs_args *a, int64_t *num_rendered, void *stream);
 /* Groups the pairs by tile, orders each tile's list by (depth, id) and composites front to back.
  * Writes out_color / out_depth / out_opacity / n_touched, binning_state and image_state. */
@@ -152,8 +156,9 @@ int lvdgs_mark_visible(int32_t num_gaussians, const float *means3D, const float 
 /* ---- views into the state buffers (parity tests read intermediates through these) ---- */
 typedef struct lvdgs_state_layout {
     /* byte offsets into geom_state */
-    size_t geom_rec;           /* N x 12 float: x, y, conic a, b, c, opacity, r, g, b, view depth,
-                                  (unused), i32 radius */
+    size_t geom_rec;           /* N x geom_rec_floats float: x, y, conic a, b, c, opacity, r, g, b, view depth,
+                                  (unused), i32 radius, then (16-float records) the tile rectangle x0 | x1 << 16,
+                                  y0 | y1 << 16 and the 64-bit mask of its tiles that are listed */
     size_t geom_tiles_touched; /* N x u32 */
     size_t geom_slot_base;     /* N x u32: exclusive scan of tiles_touched in id order (first pair of a Gaussian) */
     /* byte offsets into binning_state */
@@ -164,6 +169,7 @@ typedef struct lvdgs_state_layout {
     size_t img_ranges;         /* T x 2 u32: [begin, end) of each tile in point_list */
     size_t img_final_T;        /* P x float */
     size_t img_n_contrib;      /* P x u32 */
+    size_t geom_rec_floats;    /* floats per record of geom_rec (16) */
 } lvdgs_state_layout;
 int lvdgs_state_layout_query(int32_t num_gaussians, int64_t num_rendered, int32_t width, int32_t height,
                              lvdgs_state_layout *out);

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liblvdgs.so")
+# LVDGS_LIB: another build of the library (same-box A/B of compile-time variants: `make OUT=../lib_b EXTRA=-D...`)
+LIB_PATH = os.environ.get("LVDGS_LIB") or os.path.join(_HERE, "lib", "liblvdgs.so")
 
 OK, E_INVALID, E_HIP, E_RANGE, E_CAPACITY = 0, 1, 2, 3, 4
 
@@ -93,7 +94,7 @@ class SsimArgs(C.Structure):
 class StateLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "geom_rec", "geom_tiles_touched", "geom_slot_base", "bin_point_list", "bin_tile_keys",
-        "img_ranges", "img_final_T", "img_n_contrib")]
+        "img_ranges", "img_final_T", "img_n_contrib", "geom_rec_floats")]
 
 
 class KernelTime(C.Structure):

@@ -272,6 +272,7 @@ int lvdgs_state_layout_query(int32_t N, int64_t D, int32_t W, int32_t H, lvdgs_s
     out->bin_point_list = (char *)b.point_list - base; out->bin_tile_keys = (char *)b.tile_keys - base;
     out->img_ranges = (char *)im.ranges - base; out->img_final_T = (char *)im.final_T - base;
     out->img_n_contrib = (char *)im.n_contrib - base;
+    out->geom_rec_floats = REC_FLOATS;
     return LVDGS_OK;
 }
 

@@ -2,7 +2,7 @@
 //
 // Layout of one workgroup: 256 threads = 4 waves = one 16x16 tile; each wave owns an 8x8 pixel
 // quadrant (lane -> pixel).  The tile's depth-ordered Gaussian list is consumed in rounds of 256
-// entries: every thread gathers one entry's 48-byte record from HBM/L2 into LDS, then each wave
+// entries: every thread gathers one entry's 64-byte record (its first 48 bytes in the forward pass) from HBM/L2 into LDS, then each wave
 //   1. tests 64 staged Gaussians at once (lane -> Gaussian) against its own quadrant with an
 //      exact ellipse-vs-rectangle minimum of the exponent, giving a 64-bit survivor mask, and
 //   2. walks only the survivors (scalar loop over mask bits), broadcasting one Gaussian from LDS
@@ -63,7 +63,13 @@ struct BlendParams {
 // Where the partial gradient of the pair (Gaussian id, tile (tx, ty)) goes: the Gaussian's slots follow its kept tiles in
 // row-major order of its rectangle (common.hpp: rect_rank), the order the pairs were counted in.
 __device__ __forceinline__ uint32_t pair_slot(const BlendParams &p, uint32_t id, int tx, int ty) {
-    const uint4 r = p.rect[id];
+    uint4 r;
+    if constexpr (REC_FLOATS >= 16) {   // the copy in the record: the line the staging loads have just brought in
+        const float4 q = reinterpret_cast<const float4 *>(p.rec + (size_t)id * REC_FLOATS)[3];
+        r = make_uint4(__float_as_uint(q.x), __float_as_uint(q.y), __float_as_uint(q.z), __float_as_uint(q.w));
+    } else {
+        r = p.rect[id];
+    }
     const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
     const int w = x1 - x0;
     return p.slot_base[id] + rect_rank(r, (ty - y0) * w + (tx - x0), w * (y1 - y0));

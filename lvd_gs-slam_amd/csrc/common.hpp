@@ -20,7 +20,15 @@ constexpr float T_STOP = 0.0001f;
 constexpr float T_TOUCH = 0.5f;
 
 constexpr int WAVE = 64;
-constexpr int REC_FLOATS = 12;   // per-Gaussian 2D record (48 B)
+// Per-Gaussian 2D record: x, y, conic a, b | conic c, opacity, r, g | b, view depth, (unused), radius | tile rectangle and
+// kept-tile mask (a copy of rect[i], for the backward pass's slot arithmetic).  64 bytes, 64-byte aligned: a gathered
+// record lies in one cache line (the 48-byte record of earlier rounds straddled two lines for a third of the ids, and
+// the rectangle was a second gather).  The forward blend reads the first three quarters only.
+#ifndef LVDGS_REC_FLOATS
+#define LVDGS_REC_FLOATS 16
+#endif
+constexpr int REC_FLOATS = LVDGS_REC_FLOATS;
+static_assert(REC_FLOATS == 12 || REC_FLOATS == 16, "12: the record without the rectangle copy (A/B builds)");
 constexpr int PAIR_FLOATS = 12;  // per-(Gaussian, tile) partial gradient record (48 B, 10 used)
 
 constexpr int SORT_THREADS = 256;

@@ -279,6 +279,7 @@ __device__ __forceinline__ void preprocess_one(const FwdParams &p, int i, uint32
                 depth_bits = __float_as_uint(pv[2]);
                 float4 *r4 = reinterpret_cast<float4 *>(p.rec + (size_t)i * REC_FLOATS);
                 r4[0] = make_float4(px, py, k0, k1);
+                if constexpr (REC_FLOATS >= 16) r4[3] = make_float4(__uint_as_float(rect.x), __uint_as_float(rect.y), __uint_as_float(rect.z), __uint_as_float(rect.w));
                 r4[1] = make_float4(k2, opac, rgb[0], rgb[1]);
                 r4[2] = make_float4(rgb[2], pv[2], 0.f, __int_as_float(rad));
             }

@@ -70,7 +70,8 @@ def _run_hip(g, cam, W, H, bg, use_sh, sh_degree, cov_precomp, grads, pose, dev,
     lay = _lib.StateLayout()
     _lib.check(_lib.lib().lvdgs_state_layout_query(N, st["binning_pairs"], W, H, C.byref(lay)), "layout")
     NT = ((W + 15) // 16) * ((H + 15) // 16)
-    rec = _view(st["geom"], lay.geom_rec, N * 12, np.float32).reshape(N, 12) if N else np.zeros((0, 12), np.float32)
+    RF = int(lay.geom_rec_floats)
+    rec = _view(st["geom"], lay.geom_rec, N * RF, np.float32).reshape(N, RF) if N else np.zeros((0, RF), np.float32)
     fwd = dict(
         color=color.detach().cpu().numpy(), depth=depth.detach().cpu().numpy(), opacity=opacity.detach().cpu().numpy(),
         radii=radii.cpu().numpy(), n_touched=n_touched.cpu().numpy(), num_rendered=D, rec=rec, overflowed=st["overflowed"],

@@ -7,6 +7,7 @@
 usage: python tools/track_bench.py [workload ...]"""
 import os
 import sys
+import gc
 import time
 from types import SimpleNamespace
 
@@ -42,6 +43,7 @@ def camera_for(workload):
 def timed(fn, n, warm=5):
     for _ in range(warm):
         fn()
+    gc.collect(); gc.freeze()   # no full collection over torch's heap (one ~50 ms stall) inside the timed loop: tools/autograd_variance.py
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n):
@@ -71,6 +73,7 @@ for workload in (sys.argv[1:] or ["kitti07_geom", "cfg2_100k_640x480", "cfg3_500
     def frame(fused):   # one whole track_frame call (session set-up, 50 iterations, convergence polling, read-back); a warm one
         cams = [camera_for(workload), camera_for(workload)]   # (building a camera uploads its image: not part of the loop)
         track_frame(cams[0], model, CFG, pipe, bg, tracking_itr_num=50, fused=fused)
+        gc.collect(); gc.freeze()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         _, _, n_it = track_frame(cams[1], model, CFG, pipe, bg, tracking_itr_num=50, fused=fused)
