@@ -399,3 +399,28 @@ def test_tile_culling_changes_no_output_bit_and_without_it_the_lists_are_the_ref
         _close(b_on[k], b_off[k], rtol=1e-4, what=f"cull on/off {k}")
     _check_backward(b_off, b_ora, ["means3D", "means2D", "opacities", "scales", "rotations", "colors", "tau"], f_ora, W, H)
     _check_backward(b_on, b_ora, ["means3D", "means2D", "opacities", "scales", "rotations", "colors", "tau"], f_ora, W, H)
+
+
+def test_rectangles_of_more_than_64_tiles_keep_every_tile_next_to_culled_small_ones():
+    """A Gaussian whose 3-sigma square spans more than 64 tiles has no kept-tile mask (every tile listed, gradient slot =
+    tile index in the rectangle, walked by a whole wave in the grouping kernels); small ones beside it are culled per
+    tile.  Both kinds in one scene, forward and backward against the oracle."""
+    orc, hr, syn = _mods()
+    W, H, N = 272, 176, 600                        # 17 x 11 = 187 tiles
+    g = syn.make_gaussians(N, W, H, seed=33, r_min=0.5, r_max=6.0)
+    with torch.no_grad():                          # three screen-filling ones, faint enough not to hide the rest
+        for i, z in ((0, 2.0), (1, 5.0), (2, 9.0)):
+            g["means3D"][i] = torch.tensor([0.02 * i, -0.01 * i, z])
+            g["scales"][i] = torch.tensor([0.5, 0.35, 0.2]) * z
+            g["opacities"][i] = 0.15
+    cam = syn.make_camera(W, H, pose_seed=6)
+    bg = torch.tensor([0.2, 0.2, 0.2])
+    grads = syn.make_image_grads(W, H, 5)
+    f_hip, b_hip = hr.run_hip(g, cam, W, H, bg, grads=grads)
+    f_ora, b_ora = hr.run_oracle(orc, g, cam, W, H, bg, grads=grads)
+    big = f_ora["tiles_touched"] > 64
+    assert big.sum() >= 3
+    np.testing.assert_array_equal(f_hip["tiles_touched"][big], f_ora["tiles_touched"][big])     # no tile dropped
+    assert (f_hip["tiles_touched"][~big] < f_ora["tiles_touched"][~big]).any()                  # culled beside them
+    _check_forward(f_hip, f_ora, W, H)
+    _check_backward(b_hip, b_ora, ["means3D", "means2D", "opacities", "scales", "rotations", "colors", "tau"], f_ora, W, H)

@@ -31,6 +31,8 @@ def short(name):
 
 def main(tag, workload="cfg3_500k_1920x1080"):
     src = os.path.join(ROOT, "gpurun_out", tag)
+    if tag.startswith("-") or not os.path.isdir(src):
+        raise SystemExit(f"usage: summarize_profiles.py <tag>   ({src} does not exist)")
     dst = os.path.join(ROOT, "profiles")
     stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
