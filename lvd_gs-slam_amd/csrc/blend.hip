@@ -204,12 +204,69 @@ __global__ void __launch_bounds__(256) blend_fwd_kernel(BlendParams p) {
 // under EXEC instead of through selects (the compiler's form of the same statements is 31 vector + 17 scalar
 // instructions per survivor; this one 25 + 8, and both pipes are what blend_fwd is bound by).  Arithmetic, operand for
 // operand, as in blend_fwd_kernel.  Returns the number of pixels with transmittance still above 1/2 after this Gaussian.
+#ifndef LVDGS_FWD_CMPX
+#define LVDGS_FWD_CMPX 1
+#endif
+#ifndef LVDGS_FWD_SKIP_COUNT
+#define LVDGS_FWD_SKIP_COUNT 2   // A/B builds: 0 counts touched pixels for every survivor, 1 decides once per chunk of 64 staged entries
+#endif
+// The survivor step up to and including the update of T and the last contributor.  The two hit tests narrow EXEC
+// themselves (v_cmpx, gfx9: writes EXEC and VCC) and the hit block runs without a branch around it: a survivor of the
+// exact quadrant test nearly always has a hit pixel, and with EXEC = 0 the block is ten empty issue slots whose last
+// compare leaves VCC = 0, i.e. a count of 0 by itself.  Three scalar instructions per survivor in this block instead
+// of seven, on a scalar unit four SIMDs share (blend_fwd 141.1 -> 139.0 us at config 3, same box).
+#define LVDGS_COMPOSITE_HEAD                                                                                            \
+    "v_sub_f32 %[dx], %[ax], %[pxe]\n\t"                                                                                \
+    "v_sub_f32 %[dy], %[ay], %[pyf]\n\t"                                                                                \
+    "v_mul_f32 %[t], %[ab], %[dy]\n\t"   /* kb * dy */                                                                  \
+    "v_mul_f32 %[u], %[bc], %[dy]\n\t"   /* kc * dy */                                                                  \
+    "v_fmac_f32 %[t], %[aa], %[dx]\n\t"  /* ka * dx + kb * dy */                                                        \
+    "v_mul_f32 %[u], %[u], %[dy]\n\t"    /* (kc * dy) * dy */                                                           \
+    "v_fmac_f32 %[u], %[dx], %[t]\n\t"   /* log2 of the falloff */                                                      \
+    "v_exp_f32 %[t], %[u]\n\t"                                                                                          \
+    "v_cmpx_ge_f32 vcc, 0, %[u]\n\t"     /* EXEC: exponent not positive ... */                                          \
+    "v_mul_f32 %[a], %[op], %[t]\n\t"                                                                                   \
+    "v_min_f32 %[a], %[amax], %[a]\n\t"                                                                                 \
+    "v_cmpx_le_f32 vcc, %[amin], %[a]\n\t" /* ... and alpha >= 1/255: the lanes that hit */                             \
+    "v_sub_f32 %[t], 1.0, %[a]\n\t"                                                                                     \
+    "v_mul_f32 %[tt], %[T], %[t]\n\t"    /* transmittance behind this Gaussian */                                       \
+    "v_cmp_gt_f32 vcc, %[tstop], %[tt]\n\t" /* ... below 1e-4: the pixel is finished, this Gaussian not composited */   \
+    "v_cndmask_b32 %[pxe], %[pxe], %[far], vcc\n\t"                                                                     \
+    "s_andn2_b64 exec, exec, vcc\n\t"                                                                                   \
+    "v_mul_f32 %[t], %[a], %[T]\n\t"     /* weight */                                                                   \
+    "v_fmac_f32 %[C0], %[cr], %[t]\n\t"                                                                                 \
+    "v_fmac_f32 %[C1], %[cg], %[t]\n\t"                                                                                 \
+    "v_fmac_f32 %[C2], %[cb], %[t]\n\t"                                                                                 \
+    "v_fmac_f32 %[Dp], %[cd], %[t]\n\t"                                                                                 \
+    "v_mov_b32 %[T], %[tt]\n\t"                                                                                         \
+    "v_mov_b32 %[last], %[index]\n\t"
+#define LVDGS_COMPOSITE_OUT                                                                                             \
+    [dx] "=&v"(dx), [dy] "=&v"(dy), [t] "=&v"(t), [u] "=&v"(u), [a] "=&v"(a), [tt] "=&v"(tt), [pxe] "+v"(pxe), [T] "+v"(T),      \
+        [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2), [Dp] "+v"(Dp), [last] "+v"(last)
+#define LVDGS_COMPOSITE_IN                                                                                              \
+    [ax] "v"(A.x), [ay] "v"(A.y), [aa] "v"(A.z), [ab] "v"(A.w), [bc] "v"(B.x), [op] "v"(B.y), [cr] "v"(Cc.x), [cg] "v"(Cc.y),    \
+        [cb] "v"(Cc.z), [cd] "v"(Cc.w), [pyf] "v"(pyf), [far] "v"(far_away), [index] "s"(index), [amax] "s"(ALPHA_MAX),          \
+        [amin] "s"(ALPHA_MIN), [tstop] "s"(T_STOP), [full] "s"(full)
+// `full`: the EXEC mask outside (all of the wave's lanes; read once per chunk, restored after every survivor).
+// COUNT = false: no pixel of the quadrant has transmittance above 1/2 any more (it only falls), the count is 0 and the
+// compare, the population count and the caller's v_writelane are left out.
+template <bool COUNT = true>
 __device__ __forceinline__ int composite_one(const float4 A, const float2 B, const float4 Cc, float &pxe, const float pyf, float &T,
                                              float &C0, float &C1, float &C2, float &Dp, uint32_t &last, const uint32_t index,
-                                             const float far_away) {
+                                             const float far_away, const unsigned long long full) {
     float dx, dy, t, u, a, tt;
+    int n = 0;
+#if LVDGS_FWD_CMPX
+    if constexpr (COUNT)
+        asm(LVDGS_COMPOSITE_HEAD
+            "v_cmp_lt_f32 vcc, 0.5, %[tt]\n\t"
+            "s_bcnt1_i32_b64 %[n], vcc\n\t"
+            "s_mov_b64 exec, %[full]"
+            : LVDGS_COMPOSITE_OUT, [n] "=&s"(n) : LVDGS_COMPOSITE_IN : "vcc", "scc");
+    else
+        asm(LVDGS_COMPOSITE_HEAD "s_mov_b64 exec, %[full]" : LVDGS_COMPOSITE_OUT : LVDGS_COMPOSITE_IN : "vcc", "scc");
+#else
     unsigned long long saved, m;
-    int n;
     asm("v_sub_f32 %[dx], %[ax], %[pxe]\n\t"
         "v_sub_f32 %[dy], %[ay], %[pyf]\n\t"
         "v_mul_f32 %[t], %[ab], %[dy]\n\t"                  // kb * dy
@@ -248,6 +305,7 @@ __device__ __forceinline__ int composite_one(const float4 A, const float2 B, con
           [cb] "v"(Cc.z), [cd] "v"(Cc.w), [pyf] "v"(pyf), [far] "v"(far_away), [index] "s"(index), [amax] "s"(ALPHA_MAX),
           [amin] "s"(ALPHA_MIN), [tstop] "s"(T_STOP)
         : "vcc", "scc");
+#endif
     return n;
 }
 
@@ -314,23 +372,35 @@ __global__ void __launch_bounds__(256) blend_fwd2_kernel(BlendParams p) {
                 uint64_t live = __ballot(keep);
                 // ---- lane -> pixel: composite the survivors in list order ----
                 int vcnt = 0;  // lane -> staged Gaussian c0 + lane: pixels of this quadrant it "touched"
-                auto one = [&]() {
+                const unsigned long long full = __ballot(true);
+                // Transmittance only falls: once no pixel of the quadrant is above 1/2, nothing is "touched" any more
+                // and the survivors take the step without the count (two vector and two scalar instructions less each).
+                auto any_above_half = [&]() { return !LVDGS_FWD_SKIP_COUNT || __ballot(T > T_TOUCH && pxe != FAR_AWAY) != 0ull; };
+                bool counting = any_above_half();
+                auto one = [&](auto count) {
                     const int jb = __builtin_ctzll(live);
                     const int jj = c0 + jb;
                     live = mask_clear_bit(live, jb);
                     const float4 A = s_a[jj];
                     const float2 B = *reinterpret_cast<const float2 *>(&s_b[jj]);
                     const float4 Cc = s_c[jj];
-                    const int n = composite_one(A, B, Cc, pxe, pyf, T, C0, C1, C2, Dp, last, (uint32_t)(base + jj + 1), far_away);
-                    vcnt = write_lane(vcnt, n, jb);  // 0 by itself once no pixel of the quadrant has transmittance above 1/2
+                    const int n = composite_one<decltype(count)::value>(A, B, Cc, pxe, pyf, T, C0, C1, C2, Dp, last, (uint32_t)(base + jj + 1), far_away, full);
+                    if constexpr (decltype(count)::value) vcnt = write_lane(vcnt, n, jb);  // 0 by itself once no pixel of the quadrant has transmittance above 1/2
                 };
                 // eight survivors per trip while there are that many (batches of 1 / 4 / 8: 149.7 / 147.7 / 146.5 us at config 3): the compiler is free to issue the next survivors' reads
                 // above the current one's (register-only) compositing block, and the loop test is paid once in eight
+                while (counting && __popcll(live) >= LVDGS_FWD_BATCH) {   // (looked at again after every batch)
+#pragma unroll
+                    for (int u = 0; u < LVDGS_FWD_BATCH; u++) one(std::true_type{});
+                    if (LVDGS_FWD_SKIP_COUNT > 1) counting = any_above_half();
+                }
+                if (counting)
+                    while (live) one(std::true_type{});
                 while (__popcll(live) >= LVDGS_FWD_BATCH) {
 #pragma unroll
-                    for (int u = 0; u < LVDGS_FWD_BATCH; u++) one();
+                    for (int u = 0; u < LVDGS_FWD_BATCH; u++) one(std::false_type{});
                 }
-                while (live) one();
+                while (live) one(std::false_type{});
                 if (vcnt) atomicAdd(&s_touch[c0 + lane], vcnt);
             }
         }
