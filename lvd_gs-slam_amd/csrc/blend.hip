@@ -832,7 +832,9 @@ struct Bwd3Shared {
     uint32_t bj[4][NB];                  // per wave: entry (position in the round) of every batch slot
 };
 
-template <bool FUSED_LOSS>
+// DEPTH_GRAD = false: the loss has no depth term / the caller passed no gradient of the depth image (monocular tracking):
+// the depth image's gradient is identically zero and its terms (one multiply-add per survivor in each pass) are left out.
+template <bool FUSED_LOSS, bool DEPTH_GRAD = true>
 __global__ void __launch_bounds__(256, 5) blend_bwd3_kernel(BlendParams p) {
     constexpr int NB = Bwd3Shared::NB;
     __shared__ Bwd3Shared sh;
@@ -879,6 +881,7 @@ __global__ void __launch_bounds__(256, 5) blend_bwd3_kernel(BlendParams p) {
         if (p.dL_ddepth) gD = p.dL_ddepth[pix];
         if (p.dL_dopacity) gO = p.dL_dopacity[pix];
     }
+    if constexpr (!DEPTH_GRAD) gD = 0.f;
     const float tail = T_final * (p.bg[0] * gC0 + p.bg[1] * gC1 + p.bg[2] * gC2 - gO);
 
     uint32_t m = my_last;
@@ -947,7 +950,8 @@ __global__ void __launch_bounds__(256, 5) blend_bwd3_kernel(BlendParams p) {
                     // lanes that miss run the same arithmetic with alpha = G = 0: 1 / (1 - 0) is exactly 1, so T and R
                     // keep their values and (u, w) = (0, 0)
                     const float alpha_h = hit ? alpha : 0.f, G_h = hit ? G : 0.f;
-                    const float k = fmaf(B.z, gD, fmaf(Cc.z, gC2, fmaf(Cc.y, gC1, Cc.x * gC0)));
+                    const float k_rgb = fmaf(Cc.z, gC2, fmaf(Cc.y, gC1, Cc.x * gC0));
+                    const float k = DEPTH_GRAD ? fmaf(B.z, gD, k_rgb) : k_rgb;
                     const float inv = __builtin_amdgcn_rcpf(1.f - alpha_h);
                     T *= inv;
                     const float w = alpha_h * T;
@@ -1000,7 +1004,8 @@ __global__ void __launch_bounds__(256, 5) blend_bwd3_kernel(BlendParams p) {
                     Sxx = fmaf(t1, dx, Sxx); Sxy = fmaf(t1, dy, Sxy); Syy = fmaf(t2, dy, Syy);       \
                     Su += uw.x;                                                                      \
                     C0 = fma_rotated<S>(gC0, uw.y, C0); C1 = fma_rotated<S>(gC1, uw.y, C1);          \
-                    C2 = fma_rotated<S>(gC2, uw.y, C2); CD = fma_rotated<S>(gD, uw.y, CD);           \
+                    C2 = fma_rotated<S>(gC2, uw.y, C2);                                              \
+                    if constexpr (DEPTH_GRAD) CD = fma_rotated<S>(gD, uw.y, CD);                     \
                 }
                 LVDGS_SPLAT_STEP(0) LVDGS_SPLAT_STEP(1) LVDGS_SPLAT_STEP(2) LVDGS_SPLAT_STEP(3)
                 LVDGS_SPLAT_STEP(4) LVDGS_SPLAT_STEP(5) LVDGS_SPLAT_STEP(6) LVDGS_SPLAT_STEP(7)
@@ -1083,6 +1088,9 @@ int launch_blend_fwd(const lvdgs_args &a, const GeomView &g, const BinView &b, c
     return LVDGS_OK;
 }
 
+#ifndef LVDGS_BWD_DEPTH_ALWAYS
+#define LVDGS_BWD_DEPTH_ALWAYS 0   // A/B builds: 1 keeps the depth-gradient terms whatever the loss
+#endif
 // LVDGS_BLEND_BWD: "3" two passes with straight-line batches of 8 survivors (default), "2" two passes with per-entry
 // control flow, "1" the single-pass kernel (batches of 16 were measured too: 50 KB LDS, 3 waves/SIMD, 437 us).
 int launch_blend_bwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, const BwdScratch &w,
@@ -1099,7 +1107,8 @@ int launch_blend_bwd(const lvdgs_args &a, const GeomView &g, const BinView &b, c
             // LVDGS_BWD3_LDS_PAD (experiments): unused dynamic LDS lowers the workgroups a CU holds (30.4 KB static: 5;
             // + 2560: 4).  Measured: config 3 302 us with five, 328 with four; KITTI geometry 136 / 132; 1200 tiles 83 / 96.
             static const int pad = [] { const char *e = getenv("LVDGS_BWD3_LDS_PAD"); return e ? atoi(e) : 0; }();
-            hipLaunchKernelGGL(blend_bwd3_kernel<false>, dim3(p.num_tiles), dim3(256), pad, s, p);
+            if (LVDGS_BWD_DEPTH_ALWAYS || p.dL_ddepth) hipLaunchKernelGGL((blend_bwd3_kernel<false, true>), dim3(p.num_tiles), dim3(256), pad, s, p);
+            else hipLaunchKernelGGL((blend_bwd3_kernel<false, false>), dim3(p.num_tiles), dim3(256), pad, s, p);
             break;
         }
     }
@@ -1116,7 +1125,8 @@ int launch_blend_bwd_fused_loss(const lvdgs_args &a, const GeomView &g, const Bi
     p.loss_propagate_opacity = propagate_opacity;
     if (p.num_tiles == 0) return LVDGS_OK;
     ProfScope ps("blend_bwd", s);
-    hipLaunchKernelGGL(blend_bwd3_kernel<true>, dim3(p.num_tiles), dim3(256), 0, s, p);
+    if (LVDGS_BWD_DEPTH_ALWAYS || (loss.depth && loss.gt_depth && loss.w_d != 0.f)) hipLaunchKernelGGL((blend_bwd3_kernel<true, true>), dim3(p.num_tiles), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((blend_bwd3_kernel<true, false>), dim3(p.num_tiles), dim3(256), 0, s, p);
     LVDGS_LAUNCH_CHECK("blend_bwd", a.debug, s);
     return LVDGS_OK;
 }
