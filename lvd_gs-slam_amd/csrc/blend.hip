@@ -887,6 +887,9 @@ __global__ void __launch_bounds__(256, 5) blend_bwd3_kernel(BlendParams p) {
     uint32_t m = my_last;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+    // A quadrant whose 64 pixels all receive a zero gradient (masked out of the loss: the tracking loss's edge and
+    // brightness masks, a static mask) adds exactly zero to every sum: its wave sits the lists out.
+    if (__ballot(gC0 != 0.f || gC1 != 0.f || gC2 != 0.f || gD != 0.f || gO != 0.f) == 0ull) m = 0u;
     if (lane == 0) sh.wmax[wave] = m;
     const int wave_last = (int)m;
     __syncthreads();

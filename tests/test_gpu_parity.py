@@ -424,3 +424,23 @@ def test_rectangles_of_more_than_64_tiles_keep_every_tile_next_to_culled_small_o
     assert (f_hip["tiles_touched"][~big] < f_ora["tiles_touched"][~big]).any()                  # culled beside them
     _check_forward(f_hip, f_ora, W, H)
     _check_backward(b_hip, b_ora, ["means3D", "means2D", "opacities", "scales", "rotations", "colors", "tau"], f_ora, W, H)
+
+
+def test_image_regions_without_gradient_add_nothing():
+    """blend_bwd lets a wave sit out the lists when all 64 pixels of its quadrant receive a zero gradient (loss masks).
+    Gradient images that vanish on a band and on scattered 8x8 / 16x16 blocks, against the oracle fed the same images."""
+    orc, hr, syn = _mods()
+    W, H, N = 200, 136, 2500
+    g, cam = _scene(syn, N, W, H, 57, pose_seed=3)
+    bg = torch.tensor([0.3, 0.2, 0.1])
+    gc, gd, go = syn.make_image_grads(W, H, 8)
+    keep = torch.ones(H, W)
+    keep[:, 40:123] = 0                      # a band that covers whole tiles and cuts through others
+    blocks = torch.rand(H // 8, W // 8, generator=torch.Generator().manual_seed(5)) > 0.5
+    keep *= blocks.repeat_interleave(8, 0).repeat_interleave(8, 1).float()[:H, :W]
+    grads = (gc * keep, gd * keep, go * keep)
+    f_hip, b_hip = hr.run_hip(g, cam, W, H, bg, grads=grads)
+    f_ora, b_ora = hr.run_oracle(orc, g, cam, W, H, bg, grads=grads)
+    assert 0.2 < float(keep.mean()) < 0.5
+    _check_forward(f_hip, f_ora, W, H)
+    _check_backward(b_hip, b_ora, ["means3D", "means2D", "opacities", "scales", "rotations", "colors", "tau"], f_ora, W, H)
