@@ -26,7 +26,9 @@ window = list(range(n_window + n_older, n_older, -1))      # the newest n_window
 be.current_window = window
 groups = [gp for gp in be.keyframe_optimizers.param_groups if any(gp["name"].endswith(f"_{kf}") for kf in window)]
 be.keyframe_optimizers = torch.optim.Adam(groups)
-for fused in (True, False):
+# MAP_BENCH_FUSED_ONLY=1 (under rocprofv3 --kernel-trace --stats): 28 fused iterations and nothing else, so that the trace's
+# kernel time / 28 is the GPU-busy time of one iteration without this script's own event timing
+for fused in ((True,) if os.environ.get("MAP_BENCH_FUSED_ONLY") else (True, False)):
     for _ in range(3):
         backend_map.map_window(be, window, iters=1, fused=fused)
     torch.cuda.synchronize()
