@@ -71,6 +71,13 @@ def main():
             ms = max(makespan(d, slots) for d in order)
             sh = max(sum(d) for d in order) / (dur.sum() / 8)
             print(f"      runs of {chunk:3d} tiles round-robin: {ms / ideal:.3f} x balanced, heaviest XCD {sh:.3f} x its share")
+            # the same runs, heaviest run first (neighbouring tiles stay together; the grid's last workgroups are the lightest)
+            runs = sorted((dur[c:c + chunk] for c in range(0, NT, chunk)), key=lambda r: -r.sum())
+            order = [[] for _ in range(8)]
+            for k, r in enumerate(runs):
+                order[k % 8].extend(r)
+            ms = max(makespan(d, slots) for d in order)
+            print(f"      runs of {chunk:3d} tiles, heaviest run first:  {ms / ideal:.3f} x balanced")
 
 
 if __name__ == "__main__":
