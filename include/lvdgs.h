@@ -118,7 +118,26 @@ typedef struct lvdgs_args {
      * norm), bit 2: `opacities` holds logits (sigmoid applied).  The matching gradient outputs are then
      * w.r.t. the raw values.  0 = inputs are already activated, as upstream's render() passes them. */
     int32_t activations;
+
+    /* ---- optional switches (P R B; the same value in all calls of one frame) ---- */
+    int32_t flags;          /* LVDGS_FLAG_* below; 0 = default behaviour */
+    /* ---- optional: render a horizontal band of the image only (P R B) ----
+     * Tile rows [tile_row_begin, tile_row_end) of the 16-pixel tile grid; both 0 = the whole image.  Pixels outside the
+     * band are not written (out_color / out_depth / out_opacity / image_state keep what they held), only the band's
+     * (Gaussian, tile) pairs are listed, n_touched counts the band's pixels, and the backward returns the band's share
+     * of every gradient: bands that partition the image add up to the whole frame's gradients (the loss's partial sums
+     * of lvdgs_backward_fused_loss are left for the band's tiles, zeros elsewhere).  This is what lets one view of the
+     * mapping window (reference utils/slam_backend.py:180-306: losses summed over views before one backward) be split
+     * between GPUs. */
+    int32_t tile_row_begin, tile_row_end;
 } lvdgs_args;
+
+/* lvdgs_args.flags */
+enum {
+    LVDGS_FLAG_LIST_ALL_TILES = 1  /* list every tile of a Gaussian's 3-sigma rectangle -- the reference's pair list, bit
+                                      for bit (num_rendered, point_list, ranges, n_contrib) -- instead of only the tiles
+                                      on which it can reach alpha >= 1/255 (outputs are the same either way) */
+};
 
 /* ---- sizes ---- */
 size_t lvdgs_geom_bytes(int32_t num_gaussians);
@@ -133,8 +152,8 @@ size_t lvdgs_backward_scratch_bytes(int32_t num_gaussians, int64_t num_rendered)
  * geom_state; returns the pair count D in *num_rendered (synchronises the stream once).
  * D counts the (Gaussian, tile) pairs that are listed: the tiles of the reference's 3-sigma rectangle
  * (forward.cu's getRect) on which the Gaussian can reach alpha >= 1/255.  Pairs that cannot are dropped
- * (they contribute to no pixel; outputs are unchanged), so D <= the reference's num_rendered.  With the
- * environment variable LVDGS_TILE_CULL=0 every tile of the rectangle is listed and D equals it. */
+ * (they contribute to no pixel; outputs are unchanged), so D <= the reference's num_rendered.  With
+ * LVDGS_FLAG_LIST_ALL_TILES in a->flags every tile of the rectangle is listed and D equals it. */
 int lvdgs_forward_prepare(const lvdgs_args *a, int64_t *num_rendered, void *stream);
 /* Groups the pairs by tile, orders each tile's list by (depth, id) and composites front to back.
  * Writes out_color / out_depth / out_opacity / n_touched, binning_state and image_state. */
@@ -275,7 +294,8 @@ int lvdgs_pose_step_batch(const lvdgs_pose_step_args *steps, int32_t count, void
  * loss->d_image / d_depth / d_opacity are ignored; the opacity image's gradient feeds the blend iff
  * propagate_opacity_grad.  The loss's four partial sums are left per TILE in loss->scratch
  * (lvdgs_loss_scratch_bytes covers that layout too) for lvdgs_tracking_tail(..., partials_per_tile = 1), which writes
- * loss->loss and loss->d_exposure_a / _b.  Needs a non-empty map (num_gaussians, num_rendered > 0). */
+ * loss->loss and loss->d_exposure_a / _b.  An empty map or a view that lists no pair (num_gaussians or num_rendered == 0) is
+ * fine: the loss of the background image is evaluated, every Gaussian / pose gradient is zero. */
 int lvdgs_backward_fused_loss(const lvdgs_args *a, const lvdgs_loss_args *loss, int32_t propagate_opacity_grad, void *stream);
 
 /* The end of a tracking iteration in ONE launch (instead of three at ~6 us each on the iteration's critical path):

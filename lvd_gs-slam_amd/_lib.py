@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LVDGS_LIB") or os.path.join(_HERE, "lib", "liblvdgs.so")
 
 OK, E_INVALID, E_HIP, E_RANGE, E_CAPACITY = 0, 1, 2, 3, 4
+FLAG_LIST_ALL_TILES = 1   # lvdgs_args.flags
 
 _fp = C.c_void_p
 
@@ -35,6 +36,7 @@ class Args(C.Structure):
         ("dL_dmeans3D", _fp), ("dL_dmeans2D", _fp), ("dL_dopacities", _fp), ("dL_dscales", _fp),
         ("dL_drotations", _fp), ("dL_dcov3D", _fp), ("dL_dshs", _fp), ("dL_dcolors", _fp), ("dL_dtau", _fp),
         ("pair_capacity", C.c_int64), ("activations", C.c_int32),
+        ("flags", C.c_int32), ("tile_row_begin", C.c_int32), ("tile_row_end", C.c_int32),
     ]
 
 

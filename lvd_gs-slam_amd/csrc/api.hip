@@ -193,10 +193,11 @@ size_t render_scratch_layout(int N, int64_t D, int W, int H, RenderScratch *v, v
     carve(v->blocksums, scan_blocks(N), b, off);  // as in prep_scratch_layout: left by preprocess_fwd, read by count_pairs
     carve(v->keys, d, b, off);
     carve(v->vals, d, b, off);
-    v->hist = v->totals = v->group_hist = v->group_totals = nullptr;
+    v->hist = v->totals = v->group_hist = v->group_totals = v->chunk_sums = nullptr;
     if (use_counting_path(T)) {
         carve(v->group_hist, group_hist_entries(N, T), b, off);
-        carve(v->group_totals, (size_t)(T > 0 ? T : 1), b, off);
+        carve(v->group_totals, (size_t)(T > 0 ? T : 1) + 4, b, off);   // (+4: the tile-range scan reads them 16 bytes at a time)
+        carve(v->chunk_sums, group_chunks(N), b, off);
     } else {
         carve(v->hist, radix_hist_entries(D), b, off);
         carve(v->totals, (size_t)1 << SORT_MAX_BITS, b, off);
@@ -209,7 +210,7 @@ size_t bwd_scratch_layout(int N, int64_t D, BwdScratch *v, void *base) {
     if (!v) v = &tmp;
     size_t off = 0;
     char *b = (char *)base;
-    carve(v->pair_grads, (size_t)(D > 0 ? D : 1) * PAIR_FLOATS, b, off);
+    carve(v->pair_grads, (size_t)(D > 0 ? D : 1) * PAIR_FLOATS + 8, b, off);   // (+8: the staging loads of preprocess_bwd are 16 bytes wide)
     carve(v->tau_part, (size_t)(cdiv(N > 0 ? N : 1, 256)) * 6, b, off);
     return off;
 }
@@ -281,8 +282,10 @@ int lvdgs_state_layout_query(int32_t N, int64_t D, int32_t W, int32_t H, lvdgs_s
 namespace {
 struct PairProbe {
     int device = -1;
-    uint32_t *pinned = nullptr;
+    uint32_t *pinned = nullptr;   // [0] pair count, [1] longest queued tile segment of the frame
     hipEvent_t ready = nullptr;
+    int big_segments = 0;         // > 0: a recent frame on this device had tile segments beyond the in-launch sort's reach; the
+                                  // next frames launch the 128 KiB-LDS sort behind the tile sort (a hint, never a result)
 };
 thread_local PairProbe g_probe[16];
 
@@ -300,31 +303,31 @@ int get_probe(PairProbe **out) {
 }
 
 // preprocess -> prefix sum of tiles touched; the pair count ends up in g.total (device)
-// (slot_scan = false: the counting path's first kernel does the prefix sum, enqueue_render is told so)
-int enqueue_prepare(const lvdgs_args *a, const GeomView &g, bool slot_scan, hipStream_t s) {
+int enqueue_prepare(const lvdgs_args *a, const GeomView &g, hipStream_t s) {
     const int N = a->num_gaussians;
     PrepScratch w;
     prep_scratch_layout(N, &w, a->scratch);
     if (int e = launch_preprocess_fwd(*a, g, w.blocksums, s)) return e;
-    if (!slot_scan) return LVDGS_OK;
     return launch_slot_scan(g.tiles_touched, g.slot_base, w.blocksums, g.total, N, a->debug, s);
 }
 
 int enqueue_count_probe(PairProbe *probe, const uint32_t *total, hipStream_t s) {
-    if (int e = check_hip(hipMemcpyAsync(probe->pinned, total, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read pair count")) return e;
+    if (int e = check_hip(hipMemcpyAsync(probe->pinned, total, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read pair count")) return e;
     return check_hip(hipEventRecord(probe->ready, s), "record pair count event");
 }
 
-// pair emission -> grouping by tile -> ranges -> depth order inside each tile -> blend.  `cap` sizes grids and buffers; when `count_on_device`
+// (pair emission ->) grouping by tile -> ranges -> depth order inside each tile -> blend.  `cap` sizes grids and buffers; when `count_on_device`
 // the kernels take the actual pair count from g.total (clamped to cap), otherwise cap IS the count.
-// probe (optional): the pair count is copied to the host as soon as it exists -- after the first grouping kernel when
-// that one makes it (fused_slot_scan), else the caller has done so already.
-int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipStream_t s, bool fused_slot_scan = false,
-                   PairProbe *probe = nullptr) {
+// counted (lvdgs_forward on the counting path): the projection kernel has left the per-chunk tile counts already; the
+// tile-range scan then makes the pair count, which is copied to the host (probe) as soon as it exists, and the scatter
+// makes slot_base.
+int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipStream_t s, bool counted = false, PairProbe *probe = nullptr) {
     const int N = a->num_gaussians, W = a->image_width, H = a->image_height;
     GeomView g{}; BinView b{}; ImageView im; RenderScratch w{};
     image_layout(W, H, &im, a->image_state);
-    const int num_tiles = cdiv(W, TILE) * cdiv(H, TILE);
+    const int gx = cdiv(W, TILE), num_tiles = gx * cdiv(H, TILE);
+    int row0, row1;
+    tile_row_band(*a, &row0, &row1);
     const uint32_t *count = nullptr;
     if (N > 0) {
         geom_layout(N, &g, a->geom_state);
@@ -339,10 +342,12 @@ int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipSt
         render_scratch_layout(N, cap, W, H, &w, a->scratch);
         if (use_counting_path(num_tiles)) {
             // counting path: no pair list is materialised, the tile ranges fall out of the counts
-            if (int e = launch_group_count(*a, g, im, w, fused_slot_scan, s)) return e;
-            if (fused_slot_scan && probe)
+            if (!counted)
+                if (int e = launch_group_count(*a, g, im, w, s)) return e;
+            if (int e = launch_group_scan(*a, im, w, cap, counted ? g.total : nullptr, s)) return e;
+            if (counted && probe)
                 if (int e = enqueue_count_probe(probe, g.total, s)) return e;
-            if (int e = launch_group_scatter(*a, g, im, w, (unsigned long long *)w.keys, cap, s)) return e;
+            if (int e = launch_group_scatter(*a, g, im, w, (unsigned long long *)w.keys, cap, counted, s)) return e;
             grouped = true;
         } else {
             if (!w.hist) { set_error("internal: scratch was not laid out for the radix grouping"); return LVDGS_E_INVALID; }
@@ -360,8 +365,11 @@ int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipSt
     if (!grouped)
         if (int e = launch_tile_ranges(b.tile_keys, cap, count, im, num_tiles, a->debug, s)) return e;
     // w.keys + w.vals: the (depth, id) keys the counting path scattered, or scratch for over-long segments after the radix path
-    if (cap > 0)
-        if (int e = launch_tile_depth_sort(im, num_tiles, g.rec, b.point_list, w.keys, grouped, a->debug, s)) return e;
+    if (cap > 0) {
+        // segments beyond the in-launch sort's reach: expected when a recent frame had them (single-call forward), assumed otherwise
+        const bool big = probe ? probe->big_segments > 0 : true;
+        if (int e = launch_tile_depth_sort(im, num_tiles, row0 * gx, row1 * gx, g.rec, b.point_list, w.keys, grouped, big, a->debug, s)) return e;
+    }
     return launch_blend_fwd(*a, g, b, im, s);
 }
 
@@ -394,7 +402,7 @@ int lvdgs_forward_prepare(const lvdgs_args *a, int64_t *num_rendered, void *stre
     }
     GeomView g;
     geom_layout(N, &g, a->geom_state);
-    if (int e = enqueue_prepare(a, g, true, s)) return e;
+    if (int e = enqueue_prepare(a, g, s)) return e;
     uint32_t total = 0;
     if (int e = check_hip(hipMemcpyAsync(&total, g.total, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read pair count")) return e;
     if (int e = check_hip(hipStreamSynchronize(s), "synchronize after prepare")) return e;
@@ -434,19 +442,27 @@ int lvdgs_forward(const lvdgs_args *a, int64_t *num_rendered, void *stream) {
     if (int e = get_probe(&probe)) return e;
     GeomView g;
     geom_layout(N, &g, a->geom_state);
-    // The counting path's first kernel makes the slot prefix sum and the pair count itself: one launch less (-5 us per frame
-    // at config 3, -2 us at KITTI geometry and at 100k / 640x480, same-box A/B; LVDGS_FUSE_SLOT_SCAN_MIN_N sets a lower
-    // bound on the map size for experiments).
-    static const int fuse_min_n = [] { const char *e = getenv("LVDGS_FUSE_SLOT_SCAN_MIN_N"); return e ? atoi(e) : 0; }();
-    const bool fused = N >= fuse_min_n && use_counting_path(cdiv(a->image_width, TILE) * cdiv(a->image_height, TILE));
-    if (int e = enqueue_prepare(a, g, !fused, s)) return e;
-    if (!fused)
+    // On the counting path the projection kernel counts the pairs per (chunk, tile) as it goes, the tile-range scan makes
+    // the pair count and the scatter the slot prefix sum: three launches fewer than project / scan / count in turn.
+    const bool counted = use_counting_path(cdiv(a->image_width, TILE) * cdiv(a->image_height, TILE));
+    if (counted) {
+        ImageView im; RenderScratch w{};
+        image_layout(a->image_width, a->image_height, &im, a->image_state);
+        render_scratch_layout(N, cap, a->image_width, a->image_height, &w, a->scratch);
+        if (int e = launch_preprocess_count(*a, g, im, w, s)) return e;
+    } else {
+        if (int e = enqueue_prepare(a, g, s)) return e;
         if (int e = enqueue_count_probe(probe, g.total, s)) return e;
+    }
     // Everything after the count is enqueued BEFORE the host waits for it: the GPU keeps working on
     // the tile sort and the blend while the host learns whether the capacity was enough.
-    if (int e = enqueue_render(a, cap, true, s, fused, probe)) return e;
+    if (int e = enqueue_render(a, cap, true, s, counted, probe)) return e;
     if (int e = check_hip(hipEventSynchronize(probe->ready), "wait for pair count")) return e;
-    const uint32_t total = *probe->pinned;
+    const uint32_t total = probe->pinned[0];
+    if (counted) {   // keep launching the big-segment sort for a while after a frame that needed it
+        if ((int)probe->pinned[1] > tile_sort_in_launch_limit()) probe->big_segments = 64;
+        else if (probe->big_segments > 0) probe->big_segments--;
+    }
     if (total > 0x7FFFFFFFu) { set_error("%u (Gaussian, tile) pairs exceed the 2^31 limit", total); return LVDGS_E_RANGE; }
     *num_rendered = (int64_t)total;
     if ((int64_t)total > cap) {
@@ -460,29 +476,34 @@ static int backward_impl(const lvdgs_args *a, const LossParams *fused, int propa
     if (int e = check_common(a)) return e;
     if (int e = check_gaussians(a)) return e;
     const int N = a->num_gaussians, W = a->image_width, H = a->image_height;
-    if (N == 0) return a->dL_dtau ? check_hip(hipMemsetAsync(a->dL_dtau, 0, 6 * sizeof(float), s), "memset tau") : LVDGS_OK;
-    const int64_t D = a->num_rendered;
+    const int64_t D = N == 0 ? 0 : a->num_rendered;
     if (D < 0) { set_error("negative num_rendered"); return LVDGS_E_INVALID; }
-    if ((!fused && !a->dL_dout_color) || !a->dL_dmeans3D || !a->dL_dmeans2D || !a->dL_dopacities || !a->projmatrix_raw || !a->radii) {
-        set_error("a required backward pointer is NULL"); return LVDGS_E_INVALID;
-    }
-    if (a->cov3D_precomp ? !a->dL_dcov3D : (!a->dL_dscales || !a->dL_drotations)) { set_error("covariance gradient output is NULL"); return LVDGS_E_INVALID; }
-    if (a->shs ? !a->dL_dshs : !a->dL_dcolors) { set_error("colour gradient output is NULL"); return LVDGS_E_INVALID; }
-    if (!a->geom_state || !a->image_state || !a->scratch || (D > 0 && !a->binning_state)) { set_error("a state / scratch buffer is NULL"); return LVDGS_E_INVALID; }
-    if (a->geom_bytes < lvdgs_geom_bytes(N) || a->image_bytes < lvdgs_image_bytes(W, H) ||
-        (D > 0 && a->binning_bytes < lvdgs_binning_bytes(D)) || a->scratch_bytes < lvdgs_backward_scratch_bytes(N, D)) {
-        set_error("a state / scratch buffer is too small"); return LVDGS_E_INVALID;
-    }
-    GeomView g; BinView b{}; ImageView im; BwdScratch w;
-    geom_layout(N, &g, a->geom_state);
+    if (!a->image_state || a->image_bytes < lvdgs_image_bytes(W, H)) { set_error("image_state is NULL or too small"); return LVDGS_E_INVALID; }
+    GeomView g{}; BinView b{}; ImageView im; BwdScratch w{};
     image_layout(W, H, &im, a->image_state);
-    bwd_scratch_layout(N, D, &w, a->scratch);
-    if (D > 0) {
-        bin_layout(D, &b, a->binning_state);
-        if (fused) {
-            if (int e = launch_blend_bwd_fused_loss(*a, g, b, im, w, *fused, propagate_opacity, s)) return e;
-        } else if (int e = launch_blend_bwd(*a, g, b, im, w, s)) return e;
+    if (N > 0) {
+        if ((!fused && !a->dL_dout_color) || !a->dL_dmeans3D || !a->dL_dmeans2D || !a->dL_dopacities || !a->projmatrix_raw || !a->radii) {
+            set_error("a required backward pointer is NULL"); return LVDGS_E_INVALID;
+        }
+        if (a->cov3D_precomp ? !a->dL_dcov3D : (!a->dL_dscales || !a->dL_drotations)) { set_error("covariance gradient output is NULL"); return LVDGS_E_INVALID; }
+        if (a->shs ? !a->dL_dshs : !a->dL_dcolors) { set_error("colour gradient output is NULL"); return LVDGS_E_INVALID; }
+        if (!a->geom_state || !a->scratch || (D > 0 && !a->binning_state)) { set_error("a state / scratch buffer is NULL"); return LVDGS_E_INVALID; }
+        if (a->geom_bytes < lvdgs_geom_bytes(N) || (D > 0 && a->binning_bytes < lvdgs_binning_bytes(D)) ||
+            a->scratch_bytes < lvdgs_backward_scratch_bytes(N, D)) {
+            set_error("a state / scratch buffer is too small"); return LVDGS_E_INVALID;
+        }
+        geom_layout(N, &g, a->geom_state);
+        bwd_scratch_layout(N, D, &w, a->scratch);
+        if (D > 0) bin_layout(D, &b, a->binning_state);
     }
+    // With the loss inside, the blend pass runs even over empty lists (a view that sees nothing, an empty map): it is what
+    // evaluates the loss of the background image -- value and exposure gradients -- and no pair record is written.
+    if (fused) {
+        if (int e = launch_blend_bwd_fused_loss(*a, g, b, im, w, *fused, propagate_opacity, s)) return e;
+    } else if (D > 0) {
+        if (int e = launch_blend_bwd(*a, g, b, im, w, s)) return e;
+    }
+    if (N == 0) return a->dL_dtau ? check_hip(hipMemsetAsync(a->dL_dtau, 0, 6 * sizeof(float), s), "memset tau") : LVDGS_OK;
     return launch_preprocess_bwd(*a, g, w, s);
 }
 
@@ -493,11 +514,6 @@ int lvdgs_backward_fused_loss(const lvdgs_args *a, const lvdgs_loss_args *loss, 
     LossParams lp;
     if (int e = loss_fused_params(loss, &lp)) return e;
     if (loss->width != a->image_width || loss->height != a->image_height) { set_error("fused loss: image size differs from the rasterizer's"); return LVDGS_E_INVALID; }
-    if (a->num_gaussians == 0 || a->num_rendered == 0) {
-        // nothing was composited: the loss of the (background) image has no gradient to push anywhere, but its value is
-        // still wanted: zero partial sums are not it -- callers with an empty map use the separate loss kernels
-        set_error("fused loss: empty map (use lvdgs_photometric_loss_value_and_grad + lvdgs_backward)"); return LVDGS_E_INVALID;
-    }
     return backward_impl(a, &lp, propagate_opacity_grad != 0, (hipStream_t)stream);
 }
 

@@ -1,0 +1,71 @@
+// Pieces the grouping-by-counting kernels share (binning.hip, and the projection kernel that counts as it goes,
+// preprocess.hip).
+#pragma once
+#include "common.hpp"
+
+namespace lvdgs {
+
+// A workgroup owns a chunk of consecutive Gaussians (1024 x PER) and keeps one counter per tile in LDS.
+constexpr int GROUP_THREADS = 1024;
+// Gaussians per workgroup = 1024 x PER.  Few, large chunks keep the [chunk][tile] count matrix and its scan small (2 M
+// Gaussians: 489 chunks of 4096); many, small ones spread the counting and scattering over the chip (200 k Gaussians
+// are 49 chunks of 4096 on 256 CUs, 98 of 2048).  Measured (same box): 100k / 640x480 0.2235 -> 0.2088 ms per tracking
+// iteration with 2048, KITTI geometry 0.2881 -> 0.2795, config 3 0.6247 -> 0.6230, 2 M / 1920x1280 1.49 -> 1.52.
+__host__ __device__ constexpr int group_per_thread_for(int N) { return N <= (1 << 20) ? 2 : 4; }
+constexpr int GROUP_MAX_TILES = 16384;  // 64 KiB of LDS counters
+constexpr int GROUP_BIG_RECT = 64;
+static_assert(GROUP_BIG_RECT == RECT_MASK_TILES, "rectangles walked by the whole wave are the ones without a tile mask");
+
+// visit(tile, id) for every listed (Gaussian, tile) pair of the rectangles the wave's lanes hold (r: the lane's rect[],
+// all zero for a lane without a Gaussian).  Must be reached by all lanes of the wave: rectangles of more than 64 tiles
+// (no mask, every tile listed) are walked by the whole wave, so that one screen-filling Gaussian does not serialise
+// thousands of LDS atomics on one lane.
+template <typename F>
+__device__ __forceinline__ void for_each_pair_of_rect(const uint4 r, int i, int gx, F visit) {
+    const int lane = threadIdx.x & 63;
+    const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
+    const int w = x1 - x0, area = w * (y1 - y0);
+    if (area > 0 && area <= GROUP_BIG_RECT) {
+        // only the tiles the Gaussian can reach (common.hpp: rect_keeps); bit t of the mask is tile t of the rectangle
+        uint64_t m = (uint64_t)r.z | ((uint64_t)r.w << 32);
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++, m >>= 1)
+                if (m & 1ull) visit(y * gx + x, (uint32_t)i);
+    }
+    uint64_t big = __ballot(area > GROUP_BIG_RECT);
+    while (big) {
+        const int src = __builtin_ctzll(big);
+        big &= big - 1;
+        const int bx0 = __shfl(x0, src, 64), by0 = __shfl(y0, src, 64), bw = __shfl(w, src, 64), barea = __shfl(area, src, 64);
+        const uint32_t bi = (uint32_t)__shfl(i, src, 64);
+        for (int t = lane; t < barea; t += 64) visit((by0 + t / bw) * gx + bx0 + t % bw, bi);
+    }
+}
+
+// Exclusive scan of one value per thread over a workgroup of 1024 threads (wave shifts, then the 16 wave totals by wave
+// 0: two barriers); *total = sum over the workgroup.  s_scan: 33 words.
+__device__ __forceinline__ uint32_t scan_1024(uint32_t v, uint32_t *s_scan, uint32_t *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t x = (uint32_t)__shfl_up((int)inc, off, 64);
+        if (lane >= off) inc += x;
+    }
+    if (lane == 63) s_scan[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t w = lane < 16 ? s_scan[lane] : 0u;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            const uint32_t x = (uint32_t)__shfl_up((int)w, off, 64);
+            if (lane >= off) w += x;
+        }
+        if (lane < 16) s_scan[16 + lane] = w;   // inclusive over the waves
+    }
+    __syncthreads();
+    *total = s_scan[31];
+    return inc - v + (wave ? s_scan[16 + wave - 1] : 0u);
+}
+
+}  // namespace lvdgs

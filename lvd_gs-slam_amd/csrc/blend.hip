@@ -14,18 +14,16 @@
 // 1-alpha).  The per-Gaussian sums over pixels are done without atomics: in the current kernel (blend_bwd3) a
 // "pixel pass" leaves the two state-dependent numbers of every (pixel, Gaussian) in an LDS matrix and a "splat pass"
 // (lane -> Gaussian of a batch of eight) accumulates the ten sums in registers, one fold per batch; then per-wave
-// LDS slots, a fixed-order 4-wave sum, and one 48-byte record per (Gaussian, tile) pair
+// LDS slots, a fixed-order 4-wave sum, and one 40-byte record per (Gaussian, tile) pair
 // stored at slot_base[id] + (rank of the tile among the Gaussian's kept tiles): a Gaussian's records form one contiguous
 // run, and the runs follow each other in id order, so the per-Gaussian kernel (one lane per id) reads
 // whole cache lines.  Gradients are therefore bitwise reproducible.
 //
-// Kernels in this file: blend_fwd2_kernel (default; its survivor step is the hand-scheduled composite_one) and
-// blend_fwd_kernel (the compiler's form, LVDGS_BLEND_FWD=1); blend_bwd3_kernel<FUSED_LOSS> (default; with the
-// photometric loss evaluated in its prologue for lvdgs_backward_fused_loss), blend_bwd2_kernel and blend_bwd_kernel
-// (earlier forms, LVDGS_BLEND_BWD=2 / 1, kept for A/B measurements).  What bounds them and what was tried:
-// DESIGN.md section 2, profiles/experiments/README.md.
-#include <stdlib.h>
-
+// Kernels in this file: blend_fwd2_kernel (its survivor step is the hand-scheduled composite_one) and
+// blend_bwd3_kernel<FUSED_LOSS, DEPTH_GRAD> (with the photometric loss evaluated in its prologue for
+// lvdgs_backward_fused_loss).  Their predecessors (the compiler's form of the forward step, the single-pass and the
+// first two-pass backward) left the library in round 3: profiles/experiments/r02_superseded_blend_kernels.hip.txt.
+// What bounds the kernels and what was tried: DESIGN.md section 2, profiles/experiments/README.md.
 #include <type_traits>
 
 #include "common.hpp"
@@ -39,7 +37,8 @@ namespace {
 constexpr float LOG2E = 1.4426950408889634f;
 
 struct BlendParams {
-    int W, H, gx, gy, num_tiles;
+    int W, H, gx, gy;
+    int num_tiles, tile_base;    // tiles rendered by this launch (a band of whole tile rows, lvdgs_args.tile_row_*) and the first of them
     const uint2 *ranges;
     const uint32_t *tile_order;  // tiles by descending list length, or null (tile_of_workgroup)
     const uint32_t *order_valid; // 1 once this frame's grouping has written tile_order
@@ -92,121 +91,10 @@ __device__ __forceinline__ int tile_of_workgroup(int b, int n) {
 }
 
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) blend_fwd_kernel(BlendParams p) {
-    // one shared object, so that the three reads of a survivor share one address register; laid out so that they are
-    // a 16-, an 8- and a 16-byte read (4 + 2 + 4 LDS cycles per wave; a 12-byte read alone costs 8)
-    __shared__ struct { float4 a[256], b[256], c[256]; float d[256]; } s_recs;
-    float4 *const s_a = s_recs.a;  // x, y, -a/2*log2e, -b*log2e
-    float4 *const s_b = s_recs.b;  // -c/2*log2e, opacity | raw conic a, b (for the quadrant test; survivors read the first half only)
-    float4 *const s_c = s_recs.c;  // r, g, b, depth
-    float *const s_d = s_recs.d;   // raw conic c
-    __shared__ int s_touch[256]; // pixels of this tile each staged Gaussian "touched" (T after it > 0.5)
-
-    const int tile = (p.tile_order && *p.order_valid) ? (int)p.tile_order[blockIdx.x] : tile_of_workgroup(blockIdx.x, p.num_tiles);
-    const int tx = tile % p.gx, ty = tile / p.gx;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;
-    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
-    const bool inside = px < p.W && py < p.H;
-    const float pxf = (float)px, pyf = (float)py;
-    const float rx0 = (float)qx0, ry0 = (float)qy0, rx1 = (float)(qx0 + 7), ry1 = (float)(qy0 + 7);
-
-    const uint2 range = p.ranges[tile];
-    const int todo = (int)(range.y - range.x);
-    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
-    uint32_t last = 0;
-    // A finished pixel (transmittance below 1e-4, or outside the image) is moved to x = 1e30: every later Gaussian
-    // then evaluates to alpha = 0 there and fails the 1/255 test by itself, so the per-Gaussian code carries no
-    // "done" mask (that mask cost five scalar instructions per Gaussian, on a scalar unit shared by four SIMDs).
-    constexpr float FAR_AWAY = 1e30f;
-    float pxe = inside ? pxf : FAR_AWAY;
-
-    for (int base = 0; base < todo; base += 256) {
-        const bool done = pxe == FAR_AWAY;
-        if (__syncthreads_and(done)) break;
-        const int cnt = min(256, todo - base);
-        uint32_t my_id = 0;
-        if (tid < cnt) {
-            my_id = p.point_list[range.x + base + tid];
-            const float4 *r4 = reinterpret_cast<const float4 *>(p.rec + (size_t)my_id * REC_FLOATS);
-            const float4 r0 = r4[0], r1 = r4[1], r2 = r4[2];
-            s_a[tid] = make_float4(r0.x, r0.y, -0.5f * LOG2E * r0.z, -LOG2E * r0.w);
-            s_b[tid] = make_float4(-0.5f * LOG2E * r1.x, r1.y, r0.z, r0.w);
-            s_c[tid] = make_float4(r1.z, r1.w, r2.x, r2.y);
-            s_d[tid] = r1.x;
-        }
-        s_touch[tid] = 0;
-        __syncthreads();
-        if (__ballot(!done) != 0ull) {
-            for (int c0 = 0; c0 < cnt; c0 += 64) {
-                // ---- lane -> Gaussian: which of these 64 can touch this wave's quadrant? ----
-                const int jl = c0 + lane;
-                bool keep = false;
-                if (jl < cnt) {
-                    const float4 A = s_a[jl];
-                    const float4 B = s_b[jl];
-                    keep = reaches_rect(A.x, A.y, B.z, B.w, s_d[jl], B.y, rx0, ry0, rx1, ry1);
-                }
-                uint64_t live = __ballot(keep);
-                // n_touched only counts pixels whose transmittance is still above 1/2: once no pixel of the quadrant
-                // is (transmittance never grows), the rest of the list skips that bookkeeping
-                const bool wave_touching = __ballot(T > T_TOUCH && pxe != FAR_AWAY) != 0ull;
-                // ---- lane -> pixel: composite the survivors in list order ----
-                while (live) {
-                    const int jb = __builtin_ctzll(live);
-                    const int jj = c0 + jb;
-                    live = mask_clear_bit(live, jb);
-                    const float4 A = s_a[jj];
-                    const float2 B = *reinterpret_cast<const float2 *>(&s_b[jj]);
-                    const float dx = A.x - pxe, dy = A.y - pyf;
-                    const float pw2 = fmaf(dx, fmaf(A.z, dx, A.w * dy), B.x * dy * dy);  // log2 of the falloff (backward repeats this exactly)
-                    const float alpha = fminf(ALPHA_MAX, B.y * __builtin_amdgcn_exp2f(pw2));
-                    const float test_T = T * (1.f - alpha);
-                    bool hit = (pw2 <= 0.f) && (alpha >= ALPHA_MIN);
-                    if (__ballot(hit) == 0ull) continue;
-                    const bool stop = hit && (test_T < T_STOP);
-                    pxe = stop ? FAR_AWAY : pxe;
-                    hit = hit && !stop;
-                    const float4 Cc = s_c[jj];
-                    const float w = hit ? alpha * T : 0.f;
-                    C0 = fmaf(Cc.x, w, C0); C1 = fmaf(Cc.y, w, C1); C2 = fmaf(Cc.z, w, C2);
-                    Dp = fmaf(Cc.w, w, Dp);
-                    T = hit ? test_T : T;
-                    last = hit ? (uint32_t)(base + jj + 1) : last;
-                    if (wave_touching) {
-                        const uint64_t touched = __ballot(hit && test_T > T_TOUCH);
-                        if (touched != 0ull && lane == 0) atomicAdd(&s_touch[jj], (int)__popcll(touched));
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        // one integer atomic per (tile, Gaussian) that touched anything
-        if (tid < cnt) {
-            const int n = s_touch[tid];
-            if (n) atomicAdd(&p.n_touched[my_id], n);
-        }
-    }
-    if (inside) {
-        const size_t pix = (size_t)py * p.W + px, P = (size_t)p.W * p.H;
-        p.final_T[pix] = T;
-        p.n_contrib[pix] = last;
-        p.out_color[pix] = fmaf(T, p.bg[0], C0);
-        p.out_color[P + pix] = fmaf(T, p.bg[1], C1);
-        p.out_color[2 * P + pix] = fmaf(T, p.bg[2], C2);
-        p.out_depth[pix] = Dp;
-        p.out_opacity[pix] = 1.f - T;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // One survivor of the quadrant test against the wave's 64 pixels, hand-scheduled: the hit lanes run the compositing
 // under EXEC instead of through selects (the compiler's form of the same statements is 31 vector + 17 scalar
 // instructions per survivor; this one 25 + 8, and both pipes are what blend_fwd is bound by).  Arithmetic, operand for
-// operand, as in blend_fwd_kernel.  Returns the number of pixels with transmittance still above 1/2 after this Gaussian.
-#ifndef LVDGS_FWD_CMPX
-#define LVDGS_FWD_CMPX 1
-#endif
+// operand, as the plain C++ statements.  Returns the number of pixels with transmittance still above 1/2 after this Gaussian.
 #ifndef LVDGS_FWD_SKIP_COUNT
 #define LVDGS_FWD_SKIP_COUNT 2   // A/B builds: 0 counts touched pixels for every survivor, 1 decides once per chunk of 64 staged entries
 #endif
@@ -256,7 +144,6 @@ __device__ __forceinline__ int composite_one(const float4 A, const float2 B, con
                                              const float far_away, const unsigned long long full) {
     float dx, dy, t, u, a, tt;
     int n = 0;
-#if LVDGS_FWD_CMPX
     if constexpr (COUNT)
         asm(LVDGS_COMPOSITE_HEAD
             "v_cmp_lt_f32 vcc, 0.5, %[tt]\n\t"
@@ -265,47 +152,6 @@ __device__ __forceinline__ int composite_one(const float4 A, const float2 B, con
             : LVDGS_COMPOSITE_OUT, [n] "=&s"(n) : LVDGS_COMPOSITE_IN : "vcc", "scc");
     else
         asm(LVDGS_COMPOSITE_HEAD "s_mov_b64 exec, %[full]" : LVDGS_COMPOSITE_OUT : LVDGS_COMPOSITE_IN : "vcc", "scc");
-#else
-    unsigned long long saved, m;
-    asm("v_sub_f32 %[dx], %[ax], %[pxe]\n\t"
-        "v_sub_f32 %[dy], %[ay], %[pyf]\n\t"
-        "v_mul_f32 %[t], %[ab], %[dy]\n\t"                  // kb * dy
-        "v_mul_f32 %[u], %[bc], %[dy]\n\t"                  // kc * dy
-        "v_fmac_f32 %[t], %[aa], %[dx]\n\t"                 // ka * dx + kb * dy
-        "v_mul_f32 %[u], %[u], %[dy]\n\t"                   // (kc * dy) * dy
-        "v_fmac_f32 %[u], %[dx], %[t]\n\t"                  // log2 of the falloff
-        "v_exp_f32 %[t], %[u]\n\t"
-        "s_mov_b32 %[n], 0\n\t"
-        "v_cmp_ge_f32 vcc, 0, %[u]\n\t"
-        "v_mul_f32 %[a], %[op], %[t]\n\t"
-        "v_min_f32 %[a], %[amax], %[a]\n\t"
-        "v_cmp_le_f32 %[m], %[amin], %[a]\n\t"
-        "s_and_b64 vcc, vcc, %[m]\n\t"
-        "s_and_saveexec_b64 %[saved], vcc\n\t"               // EXEC = lanes that hit
-        "s_cbranch_execz 1f\n\t"
-        "v_sub_f32 %[t], 1.0, %[a]\n\t"
-        "v_mul_f32 %[tt], %[T], %[t]\n\t"                   // transmittance behind this Gaussian
-        "v_cmp_gt_f32 vcc, %[tstop], %[tt]\n\t"             // ... below 1e-4: the pixel is finished, this Gaussian not composited
-        "v_cndmask_b32 %[pxe], %[pxe], %[far], vcc\n\t"
-        "s_andn2_b64 exec, exec, vcc\n\t"
-        "v_mul_f32 %[t], %[a], %[T]\n\t"                    // weight
-        "v_fmac_f32 %[C0], %[cr], %[t]\n\t"
-        "v_fmac_f32 %[C1], %[cg], %[t]\n\t"
-        "v_fmac_f32 %[C2], %[cb], %[t]\n\t"
-        "v_fmac_f32 %[Dp], %[cd], %[t]\n\t"
-        "v_mov_b32 %[T], %[tt]\n\t"
-        "v_mov_b32 %[last], %[index]\n\t"
-        "v_cmp_lt_f32 vcc, 0.5, %[tt]\n\t"
-        "s_bcnt1_i32_b64 %[n], vcc\n"
-        "1:\n\t"
-        "s_mov_b64 exec, %[saved]"
-        : [dx] "=&v"(dx), [dy] "=&v"(dy), [t] "=&v"(t), [u] "=&v"(u), [a] "=&v"(a), [tt] "=&v"(tt), [saved] "=&s"(saved), [m] "=&s"(m),
-          [n] "=&s"(n), [pxe] "+v"(pxe), [T] "+v"(T), [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2), [Dp] "+v"(Dp), [last] "+v"(last)
-        : [ax] "v"(A.x), [ay] "v"(A.y), [aa] "v"(A.z), [ab] "v"(A.w), [bc] "v"(B.x), [op] "v"(B.y), [cr] "v"(Cc.x), [cg] "v"(Cc.y),
-          [cb] "v"(Cc.z), [cd] "v"(Cc.w), [pyf] "v"(pyf), [far] "v"(far_away), [index] "s"(index), [amax] "s"(ALPHA_MAX),
-          [amin] "s"(ALPHA_MIN), [tstop] "s"(T_STOP)
-        : "vcc", "scc");
-#endif
     return n;
 }
 
@@ -323,7 +169,7 @@ __global__ void __launch_bounds__(256) blend_fwd2_kernel(BlendParams p) {
     float *const s_d = s_recs.d;   // raw conic c
     __shared__ int s_touch[256]; // pixels of this tile each staged Gaussian "touched" (T after it > 0.5)
 
-    const int tile = (p.tile_order && *p.order_valid) ? (int)p.tile_order[blockIdx.x] : tile_of_workgroup(blockIdx.x, p.num_tiles);
+    const int tile = (p.tile_order && *p.order_valid) ? (int)p.tile_order[blockIdx.x] : p.tile_base + tile_of_workgroup(blockIdx.x, p.num_tiles);
     const int tx = tile % p.gx, ty = tile / p.gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;
@@ -427,368 +273,6 @@ __global__ void __launch_bounds__(256) blend_fwd2_kernel(BlendParams p) {
 constexpr int ACC_STRIDE = 10;  // floats per (wave, entry) accumulator slot
 constexpr int BR = 64;          // list entries staged per round in the backward pass
 
-__global__ void __launch_bounds__(256, 8) blend_bwd_kernel(BlendParams p) {
-    __shared__ float4 s_a[BR];               // x, y, a, b
-    __shared__ float4 s_b[BR];               // c, opacity, depth, -a/2*log2e
-    __shared__ float4 s_c[BR];               // r, g, b, -b*log2e
-    __shared__ uint32_t s_slot[BR];          // where this entry's partial gradient goes
-    __shared__ float s_acc[4][BR * ACC_STRIDE];
-    __shared__ unsigned long long s_mask[4][BR / 64];  // [wave][chunk]: entries this wave accumulated
-    __shared__ uint32_t s_max[4];
-
-    const int tile = (p.tile_order && *p.order_valid) ? (int)p.tile_order[blockIdx.x] : tile_of_workgroup(blockIdx.x, p.num_tiles);
-    const int tx = tile % p.gx, ty = tile / p.gx;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;
-    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
-    const bool inside = px < p.W && py < p.H;
-    const float pxf = (float)px, pyf = (float)py;
-    const float rx0 = (float)qx0, ry0 = (float)qy0, rx1 = (float)(qx0 + 7), ry1 = (float)(qy0 + 7);
-    const size_t pix = (size_t)py * p.W + px, P = (size_t)p.W * p.H;
-
-    const uint2 range = p.ranges[tile];
-    const float T_final = inside ? p.final_T[pix] : 0.f;
-    const uint32_t my_last = inside ? p.n_contrib[pix] : 0u;
-    float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gD = 0.f, gO = 0.f;
-    if (inside) {
-        gC0 = p.dL_dcolor[pix]; gC1 = p.dL_dcolor[P + pix]; gC2 = p.dL_dcolor[2 * P + pix];
-        if (p.dL_ddepth) gD = p.dL_ddepth[pix];
-        if (p.dL_dopacity) gO = p.dL_dopacity[pix];
-    }
-    // background and the opacity image depend on alpha only through the final transmittance
-    const float tail = T_final * (p.bg[0] * gC0 + p.bg[1] * gC1 + p.bg[2] * gC2 - gO);
-
-    // deepest list position any pixel of the tile reached
-    uint32_t m = my_last;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
-    if (lane == 0) s_max[wave] = m;
-    const int wave_last = (int)m;  // no pixel of this wave's quadrant composited an entry at or beyond this position
-    __syncthreads();
-    const int depth_max = (int)max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
-    // every pair of this tile must receive a record (zeros included): walk the whole list
-    const int todo = (int)(range.y - range.x);
-
-    float T = T_final;
-    // Everything composited BEHIND the current entry enters its alpha gradient through one scalar per pixel:
-    //   L = sum_i k_i alpha_i T_i + T_final (bg . gC - gO),  k_i = c_i . gC + depth_i gD
-    //   dL/dalpha_i = k_i T_i - R_i / (1 - alpha_i),         R_i = sum_{j behind i} k_j alpha_j T_j + T_final (bg . gC - gO)
-    // (the published kernel carries the same quantity as a normalised 4-vector "accumulated colour behind" and
-    // contracts it with the pixel gradient at every hit: 20 instructions per hit instead of 12).
-    float R = tail;
-    // which accumulator floats the lane that ends a 16-lane row writes (see the fold below)
-    const int row_off = (lane >> 4) == 0 ? 0 : ((lane >> 4) == 1 ? 3 : ((lane >> 4) == 2 ? 5 : 8));
-    const bool row_end = (lane & 15) == 15, row3 = ((lane >> 4) & 1) == 0;
-
-    const int rounds = (todo + BR - 1) / BR;
-    for (int r = rounds - 1; r >= 0; r--) {
-        const int base = r * BR;
-        const int cnt = min(BR, todo - base);
-        if (tid < cnt) {
-            const uint32_t id = p.point_list[range.x + base + tid];
-            const float4 *r4 = reinterpret_cast<const float4 *>(p.rec + (size_t)id * REC_FLOATS);
-            const float4 r0 = r4[0], r1 = r4[1], r2 = r4[2];
-            s_a[tid] = r0;
-            s_b[tid] = make_float4(r1.x, r1.y, r2.y, -0.5f * LOG2E * r0.z);
-            s_c[tid] = make_float4(r1.z, r1.w, r2.x, -LOG2E * r0.w);
-            s_slot[tid] = pair_slot(p, id, tx, ty);
-        }
-        if (tid < 4 * (BR / 64)) (&s_mask[0][0])[tid] = 0ull;
-        __syncthreads();
-        if (base < depth_max) {
-            for (int c0 = ((cnt - 1) / 64) * 64; c0 >= 0; c0 -= 64) {
-                const int jl = c0 + lane;
-                bool keep = false;
-                if (jl < cnt && base + jl < wave_last) {
-                    const float4 A = s_a[jl];
-                    const float4 B = s_b[jl];
-                    keep = reaches_rect(A.x, A.y, A.z, A.w, B.x, B.y, rx0, ry0, rx1, ry1);
-                }
-                uint64_t live = __ballot(keep);
-                uint64_t wrote = 0ull;
-                while (live) {
-                    const int j = 63 - __builtin_clzll(live);
-                    live = mask_clear_bit(live, j);
-                    const int jj = c0 + j;
-                    const float4 A = s_a[jj];
-                    const float4 B = s_b[jj];
-                    const float4 Cc = s_c[jj];
-                    const float dx = A.x - pxf, dy = A.y - pyf;
-                    // the same expression, operand for operand, as the forward pass: identical hit set
-                    const float pw2 = fmaf(dx, fmaf(B.w, dx, Cc.w * dy), (-0.5f * LOG2E * B.x) * dy * dy);
-                    const float G = __builtin_amdgcn_exp2f(pw2);
-                    const float alpha = fminf(ALPHA_MAX, B.y * G);
-                    const bool hit = ((uint32_t)(base + jj) < my_last) && (pw2 <= 0.f) && (alpha >= ALPHA_MIN);
-                    if (__ballot(hit) == 0ull) continue;
-                    // Only the per-pixel state lives under the hit mask; lanes that miss keep w = v5 = 0, so
-                    // the ten products below come out zero for them without ten separate zero-initialisations.
-                    float w = 0.f, v5 = 0.f;
-                    if (hit) {
-                        const float k = fmaf(B.z, gD, fmaf(Cc.z, gC2, fmaf(Cc.y, gC1, Cc.x * gC0)));
-                        const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
-                        T *= inv;           // transmittance in front of this entry
-                        w = alpha * T;
-                        const float dL_dalpha = fmaf(k, T, -(R * inv));
-                        R = fmaf(k, w, R);
-                        v5 = G * dL_dalpha;
-                    }
-                    // The sums are accumulated without their constant factors (-1, -1/2, ...), and the two mean
-                    // gradients as sum(h dx), sum(h dy): the flush applies the factors and the conic (a b; b c) once
-                    // per (Gaussian, tile) pair instead of once per pixel.
-                    const float v6 = w * gC0, v7 = w * gC1, v8 = w * gC2, v9 = w * gD;
-                    const float h = B.y * v5;  // dL/dG * G
-                    const float v0 = h * dx, v1 = h * dy;
-                    const float v2 = v0 * dx, v3 = v0 * dy, v4 = v1 * dy;
-                    // ---- sum the ten values over the 64 pixels: two pairwise folds (64 -> 32 -> 16 lanes,
-                    //      ten registers -> five -> three), then one 16-lane DPP sum of the three ----
-                    float q0 = fold16(fold32(v0, v1), fold32(v2, v3));  // rows: v0 v2 v1 v3
-                    float q1 = fold16(fold32(v4, v5), fold32(v6, v7));  // rows: v4 v6 v5 v7
-                    float q2 = fold16(fold32(v8, v9), v7);              // rows: v8 x  v9 x (x: unused)
-                    row_sums3(q0, q1, q2);
-                    if (row_end) {
-                        float *o = &s_acc[wave][jj * ACC_STRIDE + row_off];
-                        o[0] = q0; o[1] = q1;
-                        if (row3) o[2] = q2;
-                    }
-                    wrote = mask_set_bit(wrote, j);
-                }
-                if (lane == 0) s_mask[wave][c0 >> 6] = wrote;
-            }
-        }
-        __syncthreads();
-        if (tid < cnt) {
-            float acc[ACC_STRIDE];
-#pragma unroll
-            for (int k = 0; k < ACC_STRIDE; k++) acc[k] = 0.f;
-            const int ch = tid >> 6;
-            const unsigned long long bit = 1ull << (tid & 63);
-#pragma unroll
-            for (int w = 0; w < 4; w++)
-                if (s_mask[w][ch] & bit) {
-                    const float2 *o = reinterpret_cast<const float2 *>(&s_acc[w][tid * ACC_STRIDE]);
-#pragma unroll
-                    for (int k = 0; k < 5; k++) { const float2 t = o[k]; acc[2 * k] += t.x; acc[2 * k + 1] += t.y; }
-                }
-            // slot order written above: v0 v4 v8 | v2 v6 | v1 v5 v9 | v3 v7
-            const float4 A = s_a[tid];
-            const float cc = s_b[tid].x;
-            const float sx = acc[0], sy = acc[5];  // sum(h dx), sum(h dy)
-            float4 *dst = reinterpret_cast<float4 *>(p.pair_grads + (size_t)s_slot[tid] * PAIR_FLOATS);
-            dst[0] = make_float4(-fmaf(A.z, sx, A.w * sy), -fmaf(cc, sy, A.w * sx), -0.5f * acc[3], -acc[8]);
-            dst[1] = make_float4(-0.5f * acc[1], acc[6], acc[4], acc[9]);
-            dst[2] = make_float4(acc[2], acc[7], 0.f, 0.f);
-        }
-        __syncthreads();
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Backward pass in two phases per batch of NB surviving entries ("pixel pass" + "splat pass").
-//
-// The single-pass kernel above spends more than half of its vector instructions summing ten values over the 64 pixels
-// of a quadrant for every surviving (quadrant, Gaussian): cross-lane folds (v_permlane*_swap cost 2.7, DPP adds 1.5
-// plain instructions each).  But per (pixel, Gaussian) hit only TWO numbers depend on the sequential compositing
-// state: u = G dL/dalpha and w = alpha T.  Everything else in the ten sums is a product of u or w with quantities
-// of the pixel alone (position, image gradients) or of the Gaussian alone.  So:
-//   pixel pass (lane -> pixel, as before): walk the survivors back to front, update T and R, and store (u, w) of
-//     the lane's pixel into an LDS matrix M[slot][pixel] -- no sums at all;
-//   splat pass (lane -> (slot, group of 64/NB lanes)): every lane owns one Gaussian of the batch and loops over NB
-//     pixels of its 16-pixel row, accumulating the ten sums in its OWN registers (the pixel's coordinates come by a
-//     DPP rotation inside the row, its image gradients from LDS); one fold over the 64/NB lanes of a slot per
-//     BATCH instead of one per Gaussian finishes the sums.
-// Same arithmetic per product as the single-pass kernel (dx, dy are formed from the Gaussian's centre and the
-// pixel's coordinates, no shifted moments), same hit set, same per-pair records, still no atomics.
-template <int NB>
-struct Bwd2Shared {
-    float4 a[BR];                        // x, y, a, b
-    float4 b[BR];                        // c, opacity, depth, -a/2*log2e
-    float4 c[BR];                        // r, g, b, -b*log2e
-    uint32_t slot[BR];
-    float acc[4][BR * ACC_STRIDE];       // per wave: Sx Sy Sxx Sxy Syy Su C0 C1 C2 CD of every entry it accumulated
-    unsigned long long mask[4];
-    uint32_t wmax[4];
-    float2 M[4][NB][64];                 // per wave: (u, w) of [batch slot][pixel]
-    float4 pixg[4][64];                  // per wave: dL/d(colour, depth) of its 64 pixels
-    uint32_t bj[4][NB];                  // per wave: entry (position in the round) of every batch slot
-};
-
-template <int NB>
-__global__ void __launch_bounds__(256, 4) blend_bwd2_kernel(BlendParams p) {
-    static_assert(NB == 8 || NB == 16, "batch of 8 or 16 entries");
-    constexpr int STEPS = NB;            // pixels a lane visits per batch (16-pixel row / lanes per slot in the row)
-    __shared__ Bwd2Shared<NB> sh;
-
-    const int tile = (p.tile_order && *p.order_valid) ? (int)p.tile_order[blockIdx.x] : tile_of_workgroup(blockIdx.x, p.num_tiles);
-    const int tx = tile % p.gx, ty = tile / p.gx;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;
-    const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
-    const bool inside = px < p.W && py < p.H;
-    const float pxf = (float)px, pyf = (float)py;
-    const float rx0 = (float)qx0, ry0 = (float)qy0, rx1 = (float)(qx0 + 7), ry1 = (float)(qy0 + 7);
-    const size_t pix = (size_t)py * p.W + px, P = (size_t)p.W * p.H;
-
-    const uint2 range = p.ranges[tile];
-    const float T_final = inside ? p.final_T[pix] : 0.f;
-    const uint32_t my_last = inside ? p.n_contrib[pix] : 0u;
-    float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gD = 0.f, gO = 0.f;
-    if (inside) {
-        gC0 = p.dL_dcolor[pix]; gC1 = p.dL_dcolor[P + pix]; gC2 = p.dL_dcolor[2 * P + pix];
-        if (p.dL_ddepth) gD = p.dL_ddepth[pix];
-        if (p.dL_dopacity) gO = p.dL_dopacity[pix];
-    }
-    sh.pixg[wave][lane] = make_float4(gC0, gC1, gC2, gD);
-    const float tail = T_final * (p.bg[0] * gC0 + p.bg[1] * gC1 + p.bg[2] * gC2 - gO);
-
-    uint32_t m = my_last;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
-    if (lane == 0) sh.wmax[wave] = m;
-    const int wave_last = (int)m;
-    __syncthreads();
-    const int depth_max = (int)max(max(sh.wmax[0], sh.wmax[1]), max(sh.wmax[2], sh.wmax[3]));
-    const int todo = (int)(range.y - range.x);
-
-    float T = T_final, R = tail;  // see the single-pass kernel for the scalar recurrence
-    // splat pass: this lane's slot in the batch, its 16-lane row, and where the folded sums of the row go
-    const int row = lane >> 4, col = lane & 15;
-    const int my_slot = col & (NB - 1);
-    const float2 *Mrow = &sh.M[wave][my_slot][row * 16];
-    const float4 *Grow = &sh.pixg[wave][row * 16];
-
-    const int rounds = (todo + BR - 1) / BR;
-    for (int r = rounds - 1; r >= 0; r--) {
-        const int base = r * BR;
-        const int cnt = min(BR, todo - base);
-        if (tid < cnt) {
-            const uint32_t id = p.point_list[range.x + base + tid];
-            const float4 *r4 = reinterpret_cast<const float4 *>(p.rec + (size_t)id * REC_FLOATS);
-            const float4 r0 = r4[0], r1 = r4[1], r2 = r4[2];
-            sh.a[tid] = r0;
-            sh.b[tid] = make_float4(r1.x, r1.y, r2.y, -0.5f * LOG2E * r0.z);
-            sh.c[tid] = make_float4(r1.z, r1.w, r2.x, -LOG2E * r0.w);
-            sh.slot[tid] = pair_slot(p, id, tx, ty);
-        }
-        __syncthreads();
-        uint64_t wrote = 0ull;
-        if (base < depth_max) {
-            bool keep = false;
-            if (lane < cnt && base + lane < wave_last) {
-                const float4 A = sh.a[lane];
-                const float4 B = sh.b[lane];
-                keep = reaches_rect(A.x, A.y, A.z, A.w, B.x, B.y, rx0, ry0, rx1, ry1);
-            }
-            uint64_t live = __ballot(keep);
-            while (live) {
-                // ---------------- pixel pass: up to NB entries with at least one hit ----------------
-                uint64_t batch = 0ull;
-                int nb = 0;
-                const uint32_t rel_last = my_last > (uint32_t)base ? my_last - (uint32_t)base : 0u;  // entries below this position composited
-                do {   // scalar loop control kept minimal: one test of `live` per entry, one of the batch size per hit
-                    const int j = 63 - __builtin_clzll(live);
-                    live = mask_clear_bit(live, j);
-                    const float4 A = sh.a[j];
-                    const float4 B = sh.b[j];
-                    const float4 Cc = sh.c[j];
-                    const float dx = A.x - pxf, dy = A.y - pyf;
-                    // the same expression, operand for operand, as the forward pass: identical hit set
-                    const float pw2 = fmaf(dx, fmaf(B.w, dx, Cc.w * dy), (-0.5f * LOG2E * B.x) * dy * dy);
-                    const float G = __builtin_amdgcn_exp2f(pw2);
-                    const float alpha = fminf(ALPHA_MAX, B.y * G);
-                    const bool hit = ((uint32_t)j < rel_last) && (pw2 <= 0.f) && (alpha >= ALPHA_MIN);
-                    if (__ballot(hit) == 0ull) continue;
-                    float u = 0.f, w = 0.f;
-                    if (hit) {
-                        const float k = fmaf(B.z, gD, fmaf(Cc.z, gC2, fmaf(Cc.y, gC1, Cc.x * gC0)));
-                        const float inv = __builtin_amdgcn_rcpf(1.f - alpha);
-                        T *= inv;
-                        w = alpha * T;
-                        const float dL_dalpha = fmaf(k, T, -(R * inv));
-                        R = fmaf(k, w, R);
-                        u = G * dL_dalpha;
-                    }
-                    sh.M[wave][nb][lane] = make_float2(u, w);
-                    batch = mask_set_bit(batch, j);
-                    if (++nb == NB) break;
-                } while (live);
-                if (nb == 0) break;
-                wrote |= batch;
-                // slot table: the entry at bit position `lane` of the batch was given slot = number of batch bits above it
-                if ((batch >> lane) & 1ull) sh.bj[wave][__popcll(batch >> lane) - 1] = (uint32_t)lane;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                // ---------------- splat pass: lane -> (slot, 8 or 16 pixels of its row) ----------------
-                const bool valid = my_slot < nb;
-                const int jj = valid ? (int)sh.bj[wave][my_slot] : 0;
-                const float4 Aj = sh.a[jj];
-                float rx = pxf, ry = pyf;  // coordinates of the pixel this lane looks at; rotate through the row
-                float Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Su = 0.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, CD = 0.f;
-#pragma unroll
-                for (int s = 0; s < STEPS; s++) {
-                    const int q = (col - s) & 15;  // row_ror:1 hands lane i the value of lane i-1: after s steps, of lane i-s
-                    const float2 uw = Mrow[q];
-                    const float4 g = Grow[q];
-                    const float dx = Aj.x - rx, dy = Aj.y - ry;
-                    const float t1 = uw.x * dx, t2 = uw.x * dy;
-                    Sx += t1; Sy += t2;
-                    Sxx = fmaf(t1, dx, Sxx); Sxy = fmaf(t1, dy, Sxy); Syy = fmaf(t2, dy, Syy);
-                    Su += uw.x;
-                    C0 = fmaf(uw.y, g.x, C0); C1 = fmaf(uw.y, g.y, C1); C2 = fmaf(uw.y, g.z, C2); CD = fmaf(uw.y, g.w, CD);
-                    if (s + 1 < STEPS) {
-                        rx = row_rotate<1>(rx);
-                        ry = row_rotate<1>(ry);
-                    }
-                }
-                // fold the 64/NB partial sums of every slot: rows first (two pairwise folds, ten registers -> three) ...
-                float q0 = fold16(fold32(Sx, Sy), fold32(Sxx, Sxy));   // rows: Sx Sxx Sy Sxy
-                float q1 = fold16(fold32(Syy, Su), fold32(C0, C1));    // rows: Syy C0 Su C1
-                float q2 = fold16(fold32(C2, CD), C1);                  // rows: C2 x CD x
-                if constexpr (NB == 8) {  // ... then the two half-rows that share a slot
-                    q0 += row_rotate<8>(q0);
-                    q1 += row_rotate<8>(q1);
-                    q2 += row_rotate<8>(q2);
-                }
-                if (valid && col < NB) {
-                    // value index held by this row: q0 -> {Sx, Sxx, Sy, Sxy}, q1 -> {Syy, C0, Su, C1}, q2 -> {C2, -, CD, -}
-                    const int i0 = row == 0 ? 0 : (row == 1 ? 2 : (row == 2 ? 1 : 3));
-                    const int i1 = row == 0 ? 4 : (row == 1 ? 6 : (row == 2 ? 5 : 7));
-                    float *o = &sh.acc[wave][jj * ACC_STRIDE];
-                    o[i0] = q0; o[i1] = q1;
-                    if ((row & 1) == 0) o[row == 0 ? 8 : 9] = q2;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        if (lane == 0) sh.mask[wave] = wrote;
-        __syncthreads();
-        if (tid < cnt) {
-            float acc[ACC_STRIDE];
-#pragma unroll
-            for (int k = 0; k < ACC_STRIDE; k++) acc[k] = 0.f;
-            const unsigned long long bit = 1ull << tid;
-#pragma unroll
-            for (int w = 0; w < 4; w++)
-                if (sh.mask[w] & bit) {
-                    const float2 *o = reinterpret_cast<const float2 *>(&sh.acc[w][tid * ACC_STRIDE]);
-#pragma unroll
-                    for (int k = 0; k < 5; k++) { const float2 t = o[k]; acc[2 * k] += t.x; acc[2 * k + 1] += t.y; }
-                }
-            // acc: Sx Sy Sxx Sxy Syy Su C0 C1 C2 CD (sums of u, not yet of h = opacity * u)
-            const float4 A = sh.a[tid];
-            const float4 B = sh.b[tid];
-            const float op = B.y;
-            const float sx = op * acc[0], sy = op * acc[1];
-            float4 *dst = reinterpret_cast<float4 *>(p.pair_grads + (size_t)sh.slot[tid] * PAIR_FLOATS);
-            dst[0] = make_float4(-fmaf(A.z, sx, A.w * sy), -fmaf(B.x, sy, A.w * sx), -0.5f * (op * acc[2]), -(op * acc[3]));
-            dst[1] = make_float4(-0.5f * (op * acc[4]), acc[5], acc[6], acc[7]);
-            dst[2] = make_float4(acc[8], acc[9], 0.f, 0.f);
-        }
-        __syncthreads();
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // Third form of the backward pass: the two passes above with the per-entry control flow taken out.
 //
@@ -839,7 +323,7 @@ __global__ void __launch_bounds__(256, 5) blend_bwd3_kernel(BlendParams p) {
     constexpr int NB = Bwd3Shared::NB;
     __shared__ Bwd3Shared sh;
 
-    const int tile = (p.tile_order && *p.order_valid) ? (int)p.tile_order[blockIdx.x] : tile_of_workgroup(blockIdx.x, p.num_tiles);
+    const int tile = (p.tile_order && *p.order_valid) ? (int)p.tile_order[blockIdx.x] : p.tile_base + tile_of_workgroup(blockIdx.x, p.num_tiles);
     const int tx = tile % p.gx, ty = tile / p.gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;
@@ -1050,10 +534,13 @@ __global__ void __launch_bounds__(256, 5) blend_bwd3_kernel(BlendParams p) {
             const float4 A = sh.a[tid];
             const float op = sh.b[tid].y;
             const float sx = op * acc[0], sy = op * acc[1];
-            float4 *dst = reinterpret_cast<float4 *>(p.pair_grads + (size_t)sh.slot[tid] * PAIR_FLOATS);
-            dst[0] = make_float4(-fmaf(A.z, sx, A.w * sy), -fmaf(sh.craw[tid], sy, A.w * sx), -0.5f * (op * acc[2]), -(op * acc[3]));
-            dst[1] = make_float4(-0.5f * (op * acc[4]), acc[5], acc[6], acc[7]);
-            dst[2] = make_float4(acc[8], acc[9], 0.f, 0.f);
+            // the pair's record: ten floats, 40 bytes (8-byte aligned: five 8-byte stores)
+            float2 *dst = reinterpret_cast<float2 *>(p.pair_grads + (size_t)sh.slot[tid] * PAIR_FLOATS);
+            dst[0] = make_float2(-fmaf(A.z, sx, A.w * sy), -fmaf(sh.craw[tid], sy, A.w * sx));
+            dst[1] = make_float2(-0.5f * (op * acc[2]), -(op * acc[3]));
+            dst[2] = make_float2(-0.5f * (op * acc[4]), acc[5]);
+            dst[3] = make_float2(acc[6], acc[7]);
+            dst[4] = make_float2(acc[8], acc[9]);
         }
         __syncthreads();
     }
@@ -1062,8 +549,12 @@ __global__ void __launch_bounds__(256, 5) blend_bwd3_kernel(BlendParams p) {
 BlendParams make_params(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im) {
     BlendParams p{};
     p.W = a.image_width; p.H = a.image_height;
-    p.gx = (p.W + TILE - 1) / TILE; p.gy = (p.H + TILE - 1) / TILE; p.num_tiles = p.gx * p.gy;
-    p.ranges = im.ranges; p.tile_order = tile_order_in_use(p.num_tiles) ? im.long_tiles + p.num_tiles : nullptr; p.order_valid = im.long_count + 1; p.point_list = b.point_list; p.rec = g.rec; p.slot_base = g.slot_base; p.rect = g.rect; p.bg = a.bg;
+    p.gx = (p.W + TILE - 1) / TILE; p.gy = (p.H + TILE - 1) / TILE;
+    int row0, row1;
+    tile_row_band(a, &row0, &row1);
+    p.num_tiles = p.gx * (row1 - row0); p.tile_base = p.gx * row0;
+    const int all_tiles = p.gx * p.gy;
+    p.ranges = im.ranges; p.tile_order = tile_order_in_use(all_tiles) ? im.long_tiles + all_tiles : nullptr; p.order_valid = im.long_count + 1; p.point_list = b.point_list; p.rec = g.rec; p.slot_base = g.slot_base; p.rect = g.rect; p.bg = a.bg;
     p.out_color = a.out_color; p.out_depth = a.out_depth; p.out_opacity = a.out_opacity;
     p.final_T = im.final_T; p.n_contrib = im.n_contrib; p.n_touched = a.n_touched;
     p.dL_dcolor = a.dL_dout_color; p.dL_ddepth = a.dL_dout_depth; p.dL_dopacity = a.dL_dout_opacity;
@@ -1072,21 +563,11 @@ BlendParams make_params(const lvdgs_args &a, const GeomView &g, const BinView &b
 
 }  // namespace
 
-// LVDGS_BLEND_FWD / LVDGS_BLEND_BWD select other forms of the kernels for A/B measurements in one process tree.
-static int blend_variant(const char *name, int count, int dflt) {
-    const char *e = getenv(name);
-    const int x = e ? atoi(e) : dflt;
-    return (x >= 1 && x <= count) ? x : dflt;
-}
-
 int launch_blend_fwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, hipStream_t s) {
     BlendParams p = make_params(a, g, b, im);
     if (p.num_tiles == 0) return LVDGS_OK;
     ProfScope ps("blend_fwd", s);
-    // LVDGS_BLEND_FWD: "2" the survivor step hand-scheduled under EXEC (default), "1" the compiler's form of the same statements
-    static const int variant = blend_variant("LVDGS_BLEND_FWD", 2, 2);
-    if (variant == 1) hipLaunchKernelGGL(blend_fwd_kernel, dim3(p.num_tiles), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(blend_fwd2_kernel, dim3(p.num_tiles), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(blend_fwd2_kernel, dim3(p.num_tiles), dim3(256), 0, s, p);
     LVDGS_LAUNCH_CHECK("blend_fwd", a.debug, s);
     return LVDGS_OK;
 }
@@ -1094,31 +575,17 @@ int launch_blend_fwd(const lvdgs_args &a, const GeomView &g, const BinView &b, c
 #ifndef LVDGS_BWD_DEPTH_ALWAYS
 #define LVDGS_BWD_DEPTH_ALWAYS 0   // A/B builds: 1 keeps the depth-gradient terms whatever the loss
 #endif
-// LVDGS_BLEND_BWD: "3" two passes with straight-line batches of 8 survivors (default), "2" two passes with per-entry
-// control flow, "1" the single-pass kernel (batches of 16 were measured too: 50 KB LDS, 3 waves/SIMD, 437 us).
 int launch_blend_bwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, const BwdScratch &w,
                      hipStream_t s) {
     BlendParams p = make_params(a, g, b, im);
     p.pair_grads = w.pair_grads;
     if (p.num_tiles == 0) return LVDGS_OK;
     ProfScope ps("blend_bwd", s);
-    static const int variant = blend_variant("LVDGS_BLEND_BWD", 3, 3);  // read once per process
-    switch (variant) {
-        case 1: hipLaunchKernelGGL(blend_bwd_kernel, dim3(p.num_tiles), dim3(256), 0, s, p); break;
-        case 2: hipLaunchKernelGGL(blend_bwd2_kernel<8>, dim3(p.num_tiles), dim3(256), 0, s, p); break;
-        default: {
-            // LVDGS_BWD3_LDS_PAD (experiments): unused dynamic LDS lowers the workgroups a CU holds (30.4 KB static: 5;
-            // + 2560: 4).  Measured: config 3 302 us with five, 328 with four; KITTI geometry 136 / 132; 1200 tiles 83 / 96.
-            static const int pad = [] { const char *e = getenv("LVDGS_BWD3_LDS_PAD"); return e ? atoi(e) : 0; }();
-            if (LVDGS_BWD_DEPTH_ALWAYS || p.dL_ddepth) hipLaunchKernelGGL((blend_bwd3_kernel<false, true>), dim3(p.num_tiles), dim3(256), pad, s, p);
-            else hipLaunchKernelGGL((blend_bwd3_kernel<false, false>), dim3(p.num_tiles), dim3(256), pad, s, p);
-            break;
-        }
-    }
+    if (LVDGS_BWD_DEPTH_ALWAYS || p.dL_ddepth) hipLaunchKernelGGL((blend_bwd3_kernel<false, true>), dim3(p.num_tiles), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((blend_bwd3_kernel<false, false>), dim3(p.num_tiles), dim3(256), 0, s, p);
     LVDGS_LAUNCH_CHECK("blend_bwd", a.debug, s);
     return LVDGS_OK;
 }
-
 
 int launch_blend_bwd_fused_loss(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, const BwdScratch &w,
                                 const LossParams &loss, int propagate_opacity, hipStream_t s) {

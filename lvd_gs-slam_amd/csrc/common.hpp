@@ -29,7 +29,7 @@ constexpr int WAVE = 64;
 #endif
 constexpr int REC_FLOATS = LVDGS_REC_FLOATS;
 static_assert(REC_FLOATS == 12 || REC_FLOATS == 16, "12: the record without the rectangle copy (A/B builds)");
-constexpr int PAIR_FLOATS = 12;  // per-(Gaussian, tile) partial gradient record (48 B, 10 used)
+constexpr int PAIR_FLOATS = 10;  // per-(Gaussian, tile) partial gradient record: 40 bytes (48 with two pad floats until round 3)
 
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_IPT = 16;                       // elements per thread per radix pass
@@ -38,6 +38,13 @@ constexpr int SORT_MAX_BITS = 8;                   // digit width limit: <= 256 
                                                    // for the scatter's stores to coalesce
 
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+// the tile rows a call renders (lvdgs_args.tile_row_begin / _end; both 0 = all of them)
+inline void tile_row_band(const lvdgs_args &a, int *row0, int *row1) {
+    const int gy = (a.image_height + TILE - 1) / TILE;
+    if (a.tile_row_begin == 0 && a.tile_row_end == 0) { *row0 = 0; *row1 = gy; return; }
+    *row0 = a.tile_row_begin < 0 ? 0 : (a.tile_row_begin > gy ? gy : a.tile_row_begin);
+    *row1 = a.tile_row_end < *row0 ? *row0 : (a.tile_row_end > gy ? gy : a.tile_row_end);
+}
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ---- error plumbing ----
@@ -154,6 +161,7 @@ struct RenderScratch {
     uint32_t *totals;       // radix path only
     uint32_t *group_hist;   // counting path: [Gaussian chunk][tile] pair counts, then exclusive prefixes over the chunks
     uint32_t *group_totals; // counting path: pairs per tile
+    uint32_t *chunk_sums;   // counting path: pairs per Gaussian chunk (left by the projection kernel that counts, read by the slot scan in the scatter)
 };
 struct BinView {
     uint32_t *point_list; // D
@@ -167,7 +175,7 @@ struct ImageView {
     uint32_t *n_contrib; // P
 };
 struct BwdScratch {
-    float *pair_grads; // D*12
+    float *pair_grads; // D*10
     float *tau_part;   // nblk*6
 };
 
@@ -213,18 +221,26 @@ int launch_slot_scan(const uint32_t *tiles_touched, uint32_t *slot_base, uint32_
 // the tile sort makes it canonical.  Only for images of at most group_max_tiles() tiles (LDS counters).
 int group_max_tiles();
 size_t group_hist_entries(int N, int num_tiles);
-// Grouping by counting in two calls, so that the caller can enqueue the read-back of the pair count between them.
-// slot_scan: the first kernel also makes slot_base / the pair total from tiles_touched and w.blocksums (the separate
-// launch_slot_scan is then not needed).
-int launch_group_count(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, bool slot_scan, hipStream_t s);
+size_t group_chunks(int N);
+// lvdgs_forward: projection + per-chunk tile counts in one kernel (preprocess.hip); the two-call API projects in
+// lvdgs_forward_prepare and counts with launch_group_count.
+int launch_preprocess_count(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, hipStream_t s);
+int launch_group_count(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, hipStream_t s);
+// prefixes over the chunks, tile ranges, the pair count (*total_out, may be null), the queue of over-long segments
+int launch_group_scan(const lvdgs_args &a, const ImageView &im, const RenderScratch &w, int64_t capacity, uint32_t *total_out, hipStream_t s);
+// slot_scan: also makes slot_base from tiles_touched and w.chunk_sums (launch_preprocess_count's leftovers)
 int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, unsigned long long *keys64,
-                         int64_t capacity, hipStream_t s);
+                         int64_t capacity, bool slot_scan, hipStream_t s);
 int launch_emit_pairs(const lvdgs_args &a, const GeomView &g, uint32_t *tile_keys, uint32_t *ids, int64_t capacity, hipStream_t s);
-// Sorts every tile's segment by (view-depth bits, id) and leaves the ids in point_list.  keys64 holds D 64-bit
-// keys: already filled per segment (counting path, keys_ready), or scratch for over-long segments whose keys are
-// gathered from the ids in point_list (radix path).
-int launch_tile_depth_sort(const ImageView &im, int num_tiles, const float *rec, uint32_t *point_list, void *keys64, bool keys_ready,
-                           int dbg, hipStream_t s);
+// Sorts the segment of every tile in [t_lo, t_hi) by (view-depth bits, id) and leaves the ids in point_list.  keys64 holds
+// D 64-bit keys: already filled per segment (counting path, keys_ready; the queue of segments longer than
+// tile_sort_wave_limit() is then filled too), or scratch for over-long segments whose keys are gathered from the ids in
+// point_list (radix path).  big_segments_expected: launch the 128 KiB-LDS kernel for segments beyond
+// tile_sort_in_launch_limit() (a hint; without it such segments are sorted in place on global memory).
+int tile_sort_wave_limit();
+int tile_sort_in_launch_limit();
+int launch_tile_depth_sort(const ImageView &im, int num_tiles, int t_lo, int t_hi, const float *rec, uint32_t *point_list, void *keys64,
+                           bool keys_ready, bool big_segments_expected, int dbg, hipStream_t s);
 int launch_tile_ranges(const uint32_t *tile_keys, int64_t D, const uint32_t *D_dev, const ImageView &im, int num_tiles, int dbg,
                        hipStream_t s);
 

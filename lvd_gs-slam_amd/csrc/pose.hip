@@ -230,10 +230,18 @@ extern "C" int lvdgs_tracking_tail(const lvdgs_loss_args *loss, const lvdgs_args
         if (int e = check_pose_args(pose)) return e;
     TailParams t{};
     if (int e = loss_tail_params(loss, partials_per_tile != 0, &t.loss)) return e;
+    if (partials_per_tile) {   // a band of tile rows (lvdgs_args.tile_row_*): the backward left partial sums for its tiles only
+        int row0, row1;
+        tile_row_band(*bwd, &row0, &row1);
+        const int gx = cdiv(bwd->image_width, TILE);
+        if (loss->width != bwd->image_width || loss->height != bwd->image_height) { set_error("tracking tail: image size differs between loss and backward arguments"); return LVDGS_E_INVALID; }
+        t.loss.partial += 4 * (size_t)row0 * gx;
+        t.loss.nblk = (row1 - row0) * gx;
+    }
     const int N = bwd->num_gaussians;
     if (N < 0 || bwd->num_rendered < 0 || (N > 0 && !bwd->scratch)) { set_error("tracking tail: bad backward arguments"); return LVDGS_E_INVALID; }
     if (N > 0) {
-        if (bwd->scratch_bytes < lvdgs_backward_scratch_bytes(N, bwd->num_rendered)) { set_error("tracking tail: scratch too small"); return LVDGS_E_INVALID; }
+        if (bwd->scratch_bytes < lvdgs_backward_scratch_bytes(N, N == 0 ? 0 : bwd->num_rendered)) { set_error("tracking tail: scratch too small"); return LVDGS_E_INVALID; }
         BwdScratch w;
         bwd_scratch_layout(N, bwd->num_rendered, &w, bwd->scratch);
         t.tau_part = w.tau_part;

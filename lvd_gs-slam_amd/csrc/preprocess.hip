@@ -4,6 +4,7 @@
 // writes the 14-float parameter gradient.  Compiled with -ffp-contract=off: the float expressions
 // that decide integers (radius, tile rectangle, depth sort key) are evaluated as written.
 #include "common.hpp"
+#include "binning.hpp"
 #include "device_utils.hpp"
 
 namespace lvdgs {
@@ -166,6 +167,7 @@ struct FwdParams {
     Cam cam;
     int N, act;
     int tile_cull;         // 0: list every tile of the rectangle (the reference's pair list)
+    int row_begin, row_end; // tile rows that are rendered (lvdgs_args.tile_row_begin / _end): pairs outside are not listed
     const float *means3D, *opacities, *scales, *rotations, *cov3D_precomp, *shs, *colors_precomp;
     float *rec;
     uint32_t *tiles_touched, *depth_bits;
@@ -174,13 +176,14 @@ struct FwdParams {
     uint32_t *blocksums;   // per workgroup: sum of tiles_touched (first level of the slot scan, sortscan.hip)
 };
 
-__device__ __forceinline__ void preprocess_one(const FwdParams &p, int i, uint32_t &tiles_out);
+__device__ __forceinline__ void preprocess_one(const FwdParams &p, int i, uint32_t &tiles_out, uint4 &rect_out);
 
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(FwdParams p) {
     __shared__ uint32_t s_sum[4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t tiles = 0;
-    if (i < p.N) preprocess_one(p, i, tiles);
+    uint4 rect;
+    if (i < p.N) preprocess_one(p, i, tiles, rect);
     // the workgroup's pair count: the slot scan starts from these sums instead of re-reading tiles_touched in a launch of its own
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tiles += (uint32_t)__shfl_xor((int)tiles, off, 64);
@@ -189,7 +192,48 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(FwdParams p) {
     if (threadIdx.x == 0) p.blocksums[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
 }
 
-__device__ __forceinline__ void preprocess_one(const FwdParams &p, int i, uint32_t &tiles_out) {
+// The projection that also counts: a workgroup owns the chunk of 1024 x PER consecutive Gaussians the grouping kernels
+// (binning.hip) work in, keeps the per-tile pair counters of that chunk in LDS while it projects, and leaves the chunk's
+// row of the [chunk][tile] count matrix and the chunk's pair total -- the grouping's first kernel and its re-read of
+// every rectangle are gone from the single-call forward (lvdgs_forward).  Also clears what the later kernels of the
+// frame accumulate into (n_touched, the tile-sort queue counters).
+template <int PER>
+__global__ void __launch_bounds__(GROUP_THREADS) preprocess_count_kernel(FwdParams p, int T, uint32_t *__restrict__ hist,
+                                                                        uint32_t *__restrict__ chunk_sums, int32_t *__restrict__ n_touched,
+                                                                        uint32_t *__restrict__ queue_counts) {
+    extern __shared__ uint32_t s_tile[];
+    __shared__ uint32_t s_sum[GROUP_THREADS / 64];
+    for (int t = threadIdx.x; t < T; t += GROUP_THREADS) s_tile[t] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < 64) queue_counts[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t mine = 0;
+#pragma unroll 1
+    for (int k = 0; k < PER; k++) {
+        const int i = blockIdx.x * (GROUP_THREADS * PER) + k * GROUP_THREADS + (int)threadIdx.x;
+        uint32_t tiles = 0;
+        uint4 rect = make_uint4(0u, 0u, 0u, 0u);
+        if (i < p.N) {
+            preprocess_one(p, i, tiles, rect);
+            n_touched[i] = 0;
+        }
+        mine += tiles;
+        for_each_pair_of_rect(rect, i, p.cam.gx, [&](int tile, uint32_t) { atomicAdd(&s_tile[tile], 1u); });
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += (uint32_t)__shfl_xor((int)mine, off, 64);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+#pragma unroll
+        for (int w = 0; w < GROUP_THREADS / 64; w++) total += s_sum[w];
+        chunk_sums[blockIdx.x] = total;
+    }
+    uint32_t *row = hist + (size_t)blockIdx.x * T;
+    for (int t = threadIdx.x; t < T; t += GROUP_THREADS) row[t] = s_tile[t];
+}
+
+__device__ __forceinline__ void preprocess_one(const FwdParams &p, int i, uint32_t &tiles_out, uint4 &rect_out) {
     const Cam &c = p.cam;
     // culled unless proven visible
     int radius = 0;
@@ -235,8 +279,12 @@ __device__ __forceinline__ void preprocess_one(const FwdParams &p, int i, uint32
             int y1 = (int)((py + (float)rad + (float)(TILE - 1)) / (float)TILE);
             x0 = min(c.gx, max(0, x0)); x1 = min(c.gx, max(0, x1));
             y0 = min(c.gy, max(0, y0)); y1 = min(c.gy, max(0, y1));
+            // (a Gaussian is visible -- radius > 0, record written -- when its rectangle meets the IMAGE; which of its tiles
+            // are listed is then a matter of the band being rendered and of the tile culling)
+            const bool on_image = (x1 - x0) * (y1 - y0) > 0;
+            y0 = min(p.row_end, max(p.row_begin, y0)); y1 = min(p.row_end, max(p.row_begin, y1));
             const int area = (x1 - x0) * (y1 - y0);
-            if (area > 0) {
+            if (on_image) {
                 float rgb[3];
                 if (p.colors_precomp) {
                     rgb[0] = p.colors_precomp[3 * i]; rgb[1] = p.colors_precomp[3 * i + 1]; rgb[2] = p.colors_precomp[3 * i + 2];
@@ -262,7 +310,8 @@ __device__ __forceinline__ void preprocess_one(const FwdParams &p, int i, uint32
                 // the tiles of the rectangle the Gaussian can reach with alpha >= 1/255 (common.hpp: rect_keeps)
                 uint64_t mask = ~0ull;
                 radius = rad; tiles = (uint32_t)area;
-                if (p.tile_cull && area <= RECT_MASK_TILES) {
+                if (area == 0) { x0 = x1 = y0 = y1 = 0; mask = 0ull; }   // not in this band
+                else if (p.tile_cull && area <= RECT_MASK_TILES) {
                     const float far_x = fmaxf(fabsf(px - (float)(x0 * TILE)), fabsf(px - (float)(x1 * TILE - 1)));
                     const float far_y = fmaxf(fabsf(py - (float)(y0 * TILE)), fabsf(py - (float)(y1 * TILE - 1)));
                     const TileReach reach(px, py, k0, k1, k2, opac, far_x, far_y);
@@ -290,13 +339,14 @@ __device__ __forceinline__ void preprocess_one(const FwdParams &p, int i, uint32
     p.rect[i] = rect;
     p.depth_bits[i] = depth_bits;
     tiles_out = tiles;
+    rect_out = rect;
 }
 
 // ------------------------------------------------------------------------------------------
 struct BwdParams {
     Cam cam;
     int N, act;
-    const float *means3D, *scales, *rotations, *cov3D_precomp, *shs, *colors_precomp;
+    const float *means3D, *opacities, *scales, *rotations, *cov3D_precomp, *shs, *colors_precomp;
     const int32_t *radii;
     const float *rec;
     const uint32_t *tiles_touched, *slot_base;
@@ -305,7 +355,7 @@ struct BwdParams {
     float *tau_part;
 };
 
-constexpr int PAIR_CHUNK = 256;  // pair records staged per round: 12 KB of LDS
+constexpr int PAIR_CHUNK = 256;  // pair records staged per round: 10 KB of LDS
 
 __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
     __shared__ float s_tau[4][6];
@@ -324,39 +374,42 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
         if (p.dcolors) { for (int k = 0; k < 3; k++) p.dcolors[3 * (size_t)i + k] = 0.f; }
         if (p.dshs) { for (int k = 0; k < 3 * c.M; k++) p.dshs[(size_t)i * 3 * c.M + k] = 0.f; }
     }
-    // ---- sum every Gaussian's per-tile partial gradients (a contiguous run of 48-byte records, fixed order) ----
+    // ---- sum every Gaussian's per-tile partial gradients (a contiguous run of 40-byte records, fixed order) ----
     // The runs of a workgroup's 256 Gaussians follow each other in memory (slots are in id order), so the workgroup
     // streams that region through LDS in chunks with coalesced 16-byte loads and every lane picks its own records out
-    // of the chunk -- instead of 64 lanes walking 64 different runs with one 48-byte gather each per step, which moved
+    // of the chunk -- instead of 64 lanes walking 64 different runs with one gather each per step, which moved
     // 2.2x the bytes (r01 / r02_a counters).  Same additions in the same order as before.
-    __shared__ float4 s_pg[3 * PAIR_CHUNK];
+    // (A chunk starts at an even record, i.e. on a 16-byte boundary: 2 records = 80 bytes = 5 loads.)
+    __shared__ float4 s_pg4[(PAIR_CHUNK + 2) * PAIR_FLOATS / 4 + 1];
     __shared__ uint32_t s_region[2];
+    const float2 *s_pg = reinterpret_cast<const float2 *>(s_pg4);
     float A[10];
 #pragma unroll
     for (int k = 0; k < 10; k++) A[k] = 0.f;
     {
         const int blk_first = blockIdx.x * blockDim.x, blk_last = min(p.N, blk_first + (int)blockDim.x) - 1;
-        if (threadIdx.x == 0) { s_region[0] = p.slot_base[blk_first]; s_region[1] = p.slot_base[blk_last] + p.tiles_touched[blk_last]; }
+        if (threadIdx.x == 0) { s_region[0] = p.slot_base[blk_first] & ~1u; s_region[1] = p.slot_base[blk_last] + p.tiles_touched[blk_last]; }
         const uint32_t first = live ? p.slot_base[i] : 0u, last = live ? first + p.tiles_touched[i] : 0u;
         __syncthreads();
         const uint32_t r_lo = s_region[0], r_hi = s_region[1];
         const float4 *pg_all = reinterpret_cast<const float4 *>(p.pair_grads);
         for (uint32_t c0 = r_lo; c0 < r_hi; c0 += PAIR_CHUNK) {
             const uint32_t n = min((uint32_t)PAIR_CHUNK, r_hi - c0);
-            for (uint32_t k = threadIdx.x; k < 3 * n; k += blockDim.x) s_pg[k] = pg_all[(size_t)3 * c0 + k];
+            const uint32_t quads = (n * PAIR_FLOATS + 3) / 4, q0 = c0 / 2 * 5;   // c0 is even: record c0 starts at float4 c0 * 10 / 4
+            for (uint32_t k = threadIdx.x; k < quads; k += blockDim.x) s_pg4[k] = pg_all[(size_t)q0 + k];
             __syncthreads();
             const uint32_t lo = max(first, c0), hi = min(last, c0 + n);
             for (uint32_t t = lo; t < hi; t++) {
-                const float4 a0 = s_pg[3 * (t - c0)], a1 = s_pg[3 * (t - c0) + 1], a2 = s_pg[3 * (t - c0) + 2];
-                A[0] += a0.x; A[1] += a0.y; A[2] += a0.z; A[3] += a0.w;
-                A[4] += a1.x; A[5] += a1.y; A[6] += a1.z; A[7] += a1.w;
-                A[8] += a2.x; A[9] += a2.y;
+                const float2 *r = s_pg + 5 * (t - c0);
+                const float2 a0 = r[0], a1 = r[1], a2 = r[2], a3 = r[3], a4 = r[4];
+                A[0] += a0.x; A[1] += a0.y; A[2] += a1.x; A[3] += a1.y;
+                A[4] += a2.x; A[5] += a2.y; A[6] += a3.x; A[7] += a3.y;
+                A[8] += a4.x; A[9] += a4.y;
             }
             __syncthreads();
         }
     }
     if (live) {
-        const float4 *r4 = reinterpret_cast<const float4 *>(p.rec + (size_t)i * REC_FLOATS);
         // A: [0,1] d/d pixel mean, [2..4] d/d conic a,b,c, [5] d/d opacity, [6..8] d/d rgb, [9] d/d view depth
         const float pos[3] = {p.means3D[3 * i], p.means3D[3 * i + 1], p.means3D[3 * i + 2]};
         float pv[3], ph[3];
@@ -364,9 +417,11 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
         xform3(pos, PM, ph);
         const float phw = xform_w(pos, PM);
         {
-            // d/d(logit) = d/d(opacity) * o (1 - o) when the sigmoid is fused (o is in the record)
-            const float o = r4[1].y;
-            p.dopac[i] = (p.act & ACT_SIGMOID_OPACITY) ? A[5] * o * (1.f - o) : A[5];
+            // d/d(logit) = d/d(opacity) * o (1 - o) when the sigmoid is fused (o re-evaluated with the forward's expression: the
+            // record holds it too, but reading 4 bytes of a 64-byte record per Gaussian moved 20 MB for 2)
+            float o = p.opacities[i];
+            if (p.act & ACT_SIGMOID_OPACITY) { o = 1.f / (1.f + expf(-o)); p.dopac[i] = A[5] * o * (1.f - o); }
+            else p.dopac[i] = A[5];
         }
         const float g_ndc[2] = {A[0] * 0.5f * (float)c.W, A[1] * 0.5f * (float)c.H};
         p.dmeans2D[3 * (size_t)i] = g_ndc[0]; p.dmeans2D[3 * (size_t)i + 1] = g_ndc[1]; p.dmeans2D[3 * (size_t)i + 2] = 0.f;
@@ -596,19 +651,47 @@ Cam make_cam(const lvdgs_args &a) {
 
 }  // namespace
 
-int launch_preprocess_fwd(const lvdgs_args &a, const GeomView &g, uint32_t *blocksums, hipStream_t s) {
-    if (a.num_gaussians == 0) return LVDGS_OK;
+static FwdParams make_fwd_params(const lvdgs_args &a, const GeomView &g) {
     FwdParams p;
-    p.blocksums = blocksums;
+    p.blocksums = nullptr;
     p.cam = make_cam(a); p.N = a.num_gaussians; p.act = a.activations;
-    // LVDGS_TILE_CULL=0 (read at every call; the tests switch it) keeps the pair list the reference's
-    { const char *e = getenv("LVDGS_TILE_CULL"); p.tile_cull = !(e && e[0] == '0'); }
+    p.tile_cull = !(a.flags & LVDGS_FLAG_LIST_ALL_TILES);
+    tile_row_band(a, &p.row_begin, &p.row_end);
     p.means3D = a.means3D; p.opacities = a.opacities; p.scales = a.scales; p.rotations = a.rotations;
     p.cov3D_precomp = a.cov3D_precomp; p.shs = a.shs; p.colors_precomp = a.colors_precomp;
     p.rec = g.rec; p.tiles_touched = g.tiles_touched; p.depth_bits = g.depth_bits; p.rect = g.rect; p.radii = a.radii;
+    return p;
+}
+
+int launch_preprocess_fwd(const lvdgs_args &a, const GeomView &g, uint32_t *blocksums, hipStream_t s) {
+    if (a.num_gaussians == 0) return LVDGS_OK;
+    FwdParams p = make_fwd_params(a, g);
+    p.blocksums = blocksums;
     ProfScope ps("preprocess_fwd", s);
     hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(cdiv(p.N, 256)), dim3(256), 0, s, p);
     LVDGS_LAUNCH_CHECK("preprocess_fwd", a.debug, s);
+    return LVDGS_OK;
+}
+
+int launch_preprocess_count(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, hipStream_t s) {
+    const int N = a.num_gaussians;
+    if (N == 0) return LVDGS_OK;
+    FwdParams p = make_fwd_params(a, g);
+    const int T = p.cam.gx * p.cam.gy;
+    const int per = group_per_thread_for(N), nchunks = cdiv(N, GROUP_THREADS * per);
+    const size_t lds = (size_t)T * sizeof(uint32_t);
+    static unsigned char done2[16], done4[16];
+    ProfScope ps("preprocess_fwd", s);
+    if (per == 2) {
+        if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&preprocess_count_kernel<2>), GROUP_MAX_TILES * 4, done2)) return e;
+        hipLaunchKernelGGL(preprocess_count_kernel<2>, dim3(nchunks), dim3(GROUP_THREADS), lds, s, p, T, w.group_hist, w.chunk_sums, a.n_touched,
+                           im.long_count);
+    } else {
+        if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&preprocess_count_kernel<4>), GROUP_MAX_TILES * 4, done4)) return e;
+        hipLaunchKernelGGL(preprocess_count_kernel<4>, dim3(nchunks), dim3(GROUP_THREADS), lds, s, p, T, w.group_hist, w.chunk_sums, a.n_touched,
+                           im.long_count);
+    }
+    LVDGS_LAUNCH_CHECK("preprocess_count", a.debug, s);
     return LVDGS_OK;
 }
 
@@ -618,7 +701,7 @@ int launch_preprocess_bwd(const lvdgs_args &a, const GeomView &g, const BwdScrat
     if (N > 0) {
         BwdParams p;
         p.cam = make_cam(a); p.N = N; p.act = a.activations;
-        p.means3D = a.means3D; p.scales = a.scales; p.rotations = a.rotations; p.cov3D_precomp = a.cov3D_precomp;
+        p.means3D = a.means3D; p.opacities = a.opacities; p.scales = a.scales; p.rotations = a.rotations; p.cov3D_precomp = a.cov3D_precomp;
         p.shs = a.shs; p.colors_precomp = a.colors_precomp; p.radii = a.radii;
         p.rec = g.rec; p.tiles_touched = g.tiles_touched; p.slot_base = g.slot_base; p.pair_grads = b.pair_grads;
         p.dmeans3D = a.dL_dmeans3D; p.dmeans2D = a.dL_dmeans2D; p.dopac = a.dL_dopacities; p.dscales = a.dL_dscales;

@@ -157,17 +157,67 @@ __device__ __forceinline__ void wave_sort_segment(const KeySource &src, uint32_t
 }
 
 constexpr int CLASS_W = 1024;  // longest segment one wave sorts in registers (16 keys per lane)
+constexpr int CLASS_L = 4096;  // longest segment a workgroup of the same launch sorts in (static) LDS
+constexpr int CLASS_B = 16384; // longest segment the separate 1024-thread kernel sorts in (dynamic) LDS
+constexpr int SORT_WAVES = 16; // tiles per workgroup
+constexpr int LONG_WGS = 64;   // workgroups at the end of the grid that take the queue of over-long segments
 
-// one wave per tile; longer segments are queued for the workgroup kernels
-// tile_order (small grids, or null): the tiles by descending list length -- the four waves of a workgroup then sort
-// segments of similar length, and the long ones start first.
-__global__ void __launch_bounds__(256) tile_depth_sort_wave_kernel(const uint2 *__restrict__ ranges, int num_tiles, KeySource src,
-                                                                   uint32_t *__restrict__ point_list, uint32_t *queue_count,
-                                                                   uint32_t *__restrict__ queue, const uint32_t *__restrict__ tile_order) {
+// `count` queued segments, one workgroup (1024 threads) per segment in turn: in LDS up to `lds_cap` entries, in place on
+// global memory beyond (64-bit key scratch).  Segments of more than `skip_above` entries are left alone (another launch
+// takes them).
+__device__ __forceinline__ void sort_queued_segments(u64 *s_keys, int lds_cap, int skip_above, const uint2 *__restrict__ ranges, const KeySource &src,
+                                                     uint32_t *__restrict__ point_list, int count, const uint32_t *__restrict__ queue, u64 *keys,
+                                                     int first, int stride) {
+    const int tid = threadIdx.x;
+    for (int q = first; q < count; q += stride) {
+        const uint2 r = ranges[queue[q]];
+        const int n = (int)(r.y - r.x);
+        if (n > skip_above) continue;
+        if (n <= lds_cap) {
+            for (int i = tid; i < n; i += 1024) s_keys[i] = src.load(r.x + i);
+            __syncthreads();
+            bitonic_sort_ascending<false>(s_keys, n, tid, 1024);
+            __syncthreads();
+            for (int i = tid; i < n; i += 1024) point_list[r.x + i] = (uint32_t)s_keys[i];
+        } else {
+            volatile u64 *g = keys + r.x;
+            if (!src.keys) {  // otherwise the keys are already in place
+                for (int i = tid; i < n; i += 1024) g[i] = src.load(r.x + i);
+                __threadfence_block();
+                __syncthreads();
+            }
+            bitonic_sort_ascending<true>(g, n, tid, 1024);
+            for (int i = tid; i < n; i += 1024) point_list[r.x + i] = (uint32_t)g[i];
+        }
+        __syncthreads();
+    }
+}
+
+// One wave per tile (16 tiles per workgroup); segments of more than CLASS_W entries are left to whole workgroups:
+//  * counting path (QUEUED): the tile-range scan has queued them already (binning.hip) and the LAST LONG_WGS workgroups
+//    of this very launch take them -- no launch of their own on every frame's critical path for a queue that is nearly
+//    always empty.  In LDS up to CLASS_L entries; beyond that in place on global memory, unless the host announces
+//    (big_follows) the 128 KiB-LDS kernel behind this one: it does so when an earlier frame on this device had such
+//    segments (a hint: results never depend on it);
+//  * radix path: queued here with one atomic each, sorted by the launch that follows.
+// tile_order (small grids, or null): the tiles by descending list length -- the waves of a workgroup then sort
+// segments of similar length, and the long ones start first.  Only tiles [t_lo, t_hi) are looked at (the band being
+// rendered).
+template <bool QUEUED>
+__global__ void __launch_bounds__(1024) tile_depth_sort_wave_kernel(const uint2 *__restrict__ ranges, int t_lo, int t_hi, KeySource src,
+                                                                    uint32_t *__restrict__ point_list, uint32_t *queue_count,
+                                                                    uint32_t *__restrict__ queue, const uint32_t *__restrict__ tile_order,
+                                                                    u64 *keys, int sort_wgs, int big_follows) {
+    __shared__ u64 s_long[QUEUED ? CLASS_L : 1];
+    if (QUEUED && (int)blockIdx.x >= sort_wgs) {
+        sort_queued_segments(s_long, CLASS_L, big_follows ? CLASS_L : 0x7fffffff, ranges, src, point_list, (int)*queue_count, queue, keys,
+                             (int)blockIdx.x - sort_wgs, LONG_WGS);
+        return;
+    }
     const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (slot >= num_tiles) return;
-    const int tile = tile_order ? (int)tile_order[slot] : slot;
+    const int slot = blockIdx.x * SORT_WAVES + (threadIdx.x >> 6);
+    if (slot >= t_hi - t_lo) return;
+    const int tile = tile_order ? (int)tile_order[slot] : t_lo + slot;
     const uint2 r = ranges[tile];
     const int n = (int)(r.y - r.x);
     if (n < 2) {
@@ -177,21 +227,21 @@ __global__ void __launch_bounds__(256) tile_depth_sort_wave_kernel(const uint2 *
     if (n <= 256) wave_sort_segment<4>(src, r.x, point_list + r.x, n, lane);
     else if (n <= 512) wave_sort_segment<8>(src, r.x, point_list + r.x, n, lane);
     else if (n <= CLASS_W) wave_sort_segment<16>(src, r.x, point_list + r.x, n, lane);
-    else if (lane == 0) queue[atomicAdd(queue_count, 1u)] = (uint32_t)tile;
+    else if (!QUEUED && lane == 0) queue[atomicAdd(queue_count, 1u)] = (uint32_t)tile;
 }
 
-constexpr int CLASS_B = 16384;
-
-// queued segments: in 128 KiB of LDS up to CLASS_B entries, in place on global memory beyond
+// queued segments: in 128 KiB of LDS up to CLASS_B entries, in place on global memory beyond; segments of up to
+// `done_below` entries were sorted by the launch before
 __global__ void __launch_bounds__(1024) tile_depth_sort_long_kernel(const uint2 *__restrict__ ranges, KeySource src,
                                                                     uint32_t *__restrict__ point_list, const uint32_t *long_count,
-                                                                    const uint32_t *__restrict__ long_tiles, u64 *keys) {
+                                                                    const uint32_t *__restrict__ long_tiles, u64 *keys, int done_below) {
     extern __shared__ u64 s_dyn[];
     const int tid = threadIdx.x;
     const int count = (int)*long_count;
     for (int q = blockIdx.x; q < count; q += gridDim.x) {
         const uint2 r = ranges[long_tiles[q]];
         const int n = (int)(r.y - r.x);
+        if (n <= done_below) continue;
         if (n <= CLASS_B) {
             for (int i = tid; i < n; i += 1024) s_dyn[i] = src.load(r.x + i);
             __syncthreads();
@@ -214,22 +264,31 @@ __global__ void __launch_bounds__(1024) tile_depth_sort_long_kernel(const uint2 
 
 }  // namespace
 
-int launch_tile_depth_sort(const ImageView &im, int num_tiles, const float *rec, uint32_t *point_list, void *keys64, bool keys_ready,
-                           int dbg, hipStream_t s) {
-    if (num_tiles == 0) return LVDGS_OK;
+int tile_sort_wave_limit() { return CLASS_W; }
+int tile_sort_in_launch_limit() { return CLASS_L; }
+
+int launch_tile_depth_sort(const ImageView &im, int num_tiles, int t_lo, int t_hi, const float *rec, uint32_t *point_list, void *keys64,
+                           bool keys_ready, bool big_segments_expected, int dbg, hipStream_t s) {
+    if (num_tiles == 0 || t_hi <= t_lo) return LVDGS_OK;
     static unsigned char lds_done[16];
     if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&tile_depth_sort_long_kernel), CLASS_B * 8, lds_done)) return e;
     const KeySource src{rec, point_list, keys_ready ? (const u64 *)keys64 : nullptr};
+    const int sort_wgs = cdiv(t_hi - t_lo, SORT_WAVES);
     {
         ProfScope ps("tile_sort", s);
-        hipLaunchKernelGGL(tile_depth_sort_wave_kernel, dim3(cdiv(num_tiles, 4)), dim3(256), 0, s, (const uint2 *)im.ranges, num_tiles, src,
-                           point_list, im.long_count, im.long_tiles, (keys_ready && tile_order_in_use(num_tiles)) ? im.long_tiles + num_tiles : nullptr);
+        if (keys_ready)   // counting path: the queue is there already, the last workgroups of the launch take it
+            hipLaunchKernelGGL(tile_depth_sort_wave_kernel<true>, dim3(sort_wgs + LONG_WGS), dim3(1024), 0, s, (const uint2 *)im.ranges, t_lo, t_hi, src,
+                               point_list, im.long_count, im.long_tiles, tile_order_in_use(num_tiles) ? im.long_tiles + num_tiles : nullptr,
+                               (u64 *)keys64, sort_wgs, big_segments_expected ? 1 : 0);
+        else
+            hipLaunchKernelGGL(tile_depth_sort_wave_kernel<false>, dim3(sort_wgs), dim3(1024), 0, s, (const uint2 *)im.ranges, t_lo, t_hi, src,
+                               point_list, im.long_count, im.long_tiles, (const uint32_t *)nullptr, (u64 *)keys64, sort_wgs, 0);
         LVDGS_LAUNCH_CHECK("tile_sort", dbg, s);
     }
-    {
+    if (!keys_ready || big_segments_expected) {
         ProfScope ps("tile_sort_long", s);
         hipLaunchKernelGGL(tile_depth_sort_long_kernel, dim3(256), dim3(1024), CLASS_B * 8, s, (const uint2 *)im.ranges, src, point_list,
-                           (const uint32_t *)im.long_count, (const uint32_t *)im.long_tiles, (unsigned long long *)keys64);
+                           (const uint32_t *)im.long_count, (const uint32_t *)im.long_tiles, (unsigned long long *)keys64, keys_ready ? CLASS_L : 0);
         LVDGS_LAUNCH_CHECK("tile_sort_long", dbg, s);
     }
     return LVDGS_OK;

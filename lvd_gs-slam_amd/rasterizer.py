@@ -33,6 +33,11 @@ from . import _lib
 # (opacity = 1 - final transmittance; checked against the oracle); set this to True to use it.
 PROPAGATE_OPACITY_GRAD = False
 
+# True: list every tile of a Gaussian's 3-sigma rectangle (lvdgs_args.flags |= LVDGS_FLAG_LIST_ALL_TILES) -- the reference's
+# (Gaussian, tile) pair list, num_rendered and n_contrib bit for bit -- instead of only the tiles the Gaussian can reach with
+# alpha >= 1/255.  Images, radii, n_touched are the same either way (a dropped pair contributes to no pixel).
+LIST_ALL_TILES = False
+
 # Parity tests set this to read intermediates (state buffers) of the most recent forward.
 KEEP_DEBUG_STATE = False
 _DEBUG_LAST = {}
@@ -122,6 +127,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raise ValueError("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
         a.num_gaussians = N
         a.activations = int(activations)
+        a.flags = _lib.FLAG_LIST_ALL_TILES if LIST_ALL_TILES else 0
         a.sh_coeffs = int(shs.shape[1]) if shs is not None else 0
         a.means3D, a.opacities, a.scales, a.rotations = _ptr(m3), _ptr(op), _ptr(sc), _ptr(rot)
         a.cov3D_precomp, a.shs, a.colors_precomp = _ptr(cov), _ptr(shs), _ptr(col)
@@ -175,6 +181,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.num_rendered = D
         ctx.activations = int(activations)
+        ctx.flags = int(a.flags)
         ctx.pose = (torch.is_tensor(theta) and theta.numel() == 3, torch.is_tensor(rho) and rho.numel() == 3)
         ctx.save_for_backward(m3, op, sc, rot, cov, shs, col, radii, geom, binning, image)
         ctx.mark_non_differentiable(radii, n_touched)
@@ -198,6 +205,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         a.cov3D_precomp, a.shs, a.colors_precomp = _ptr(cov), _ptr(shs), _ptr(col)
         a.radii = _ptr(radii)
         a.activations = ctx.activations
+        a.flags = ctx.flags
         a.num_rendered = D
         a.geom_state, a.geom_bytes = _ptr(geom), geom.numel()
         a.binning_state, a.binning_bytes = _ptr(binning), binning.numel()

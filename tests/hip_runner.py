@@ -28,17 +28,15 @@ def run_hip(g, cam, W, H, bg, use_sh=False, sh_degree=0, cov_precomp=None, grads
     """g: dict of float32 CPU tensors (synthetic.make_gaussians).  grads: optional (dL_dcolor, dL_ddepth,
     dL_dopacity) CPU tensors.  Returns (forward dict, backward dict or None).
 
-    tile_cull=False (LVDGS_TILE_CULL=0 for the call) lists every tile of a Gaussian's rectangle, which makes the pair
-    list, the ranges and n_contrib the reference's bit for bit; the default drops the tiles the Gaussian cannot reach."""
-    cull_before = os.environ.get("LVDGS_TILE_CULL")
-    os.environ["LVDGS_TILE_CULL"] = "1" if tile_cull else "0"
+    tile_cull=False (rasterizer.LIST_ALL_TILES for the call: LVDGS_FLAG_LIST_ALL_TILES in lvdgs_args.flags) lists every tile of
+    a Gaussian's rectangle, which makes the pair list, the ranges and n_contrib the reference's bit for bit; the default
+    drops the tiles the Gaussian cannot reach."""
+    before = rasterizer.LIST_ALL_TILES
+    rasterizer.LIST_ALL_TILES = not tile_cull
     try:
         return _run_hip(g, cam, W, H, bg, use_sh, sh_degree, cov_precomp, grads, pose, dev, propagate_opacity, tile_cull)
     finally:
-        if cull_before is None:
-            del os.environ["LVDGS_TILE_CULL"]
-        else:
-            os.environ["LVDGS_TILE_CULL"] = cull_before
+        rasterizer.LIST_ALL_TILES = before
 
 
 def _run_hip(g, cam, W, H, bg, use_sh, sh_degree, cov_precomp, grads, pose, dev, propagate_opacity, tile_cull):

@@ -441,9 +441,9 @@ def test_tracking_tail_and_fused_loss_backward_equal_the_separate_launches():
     assert not torch.equal(ra[0], snap[0])   # the step moved the pose
 
 
-def test_fused_loss_backward_refuses_an_empty_map_and_mismatched_sizes():
-    """lvdgs_backward_fused_loss validates like the calls it replaces: no Gaussians / no pairs and a loss block of another
-    image size are errors with a message, not launches."""
+def test_fused_loss_backward_refuses_mismatched_sizes():
+    """lvdgs_backward_fused_loss validates like the calls it replaces: a loss block of another image size is an error with a
+    message, not a launch."""
     import ctypes as C
     from lvdgs import _lib
     L = _lib.lib()
@@ -452,17 +452,75 @@ def test_fused_loss_backward_refuses_an_empty_map_and_mismatched_sizes():
     a.image_width, a.image_height, a.num_gaussians, a.num_rendered = 64, 48, 0, 0
     img = torch.zeros(3, 48, 64, device=dev)
     scratch = torch.empty(int(L.lvdgs_loss_scratch_bytes(64, 48)), dtype=torch.uint8, device=dev)
-    la.width, la.height = 64, 48
+    la.width, la.height = 32, 48
     la.image, la.gt_image = C.c_void_p(img.data_ptr()), C.c_void_p(img.data_ptr())
     la.scratch, la.scratch_bytes = C.c_void_p(scratch.data_ptr()), scratch.numel()
     la.weight_rgb = 1.0
     with _lib.on_device(dev):
         stream = _lib.raw_stream(dev)
         assert L.lvdgs_backward_fused_loss(C.byref(a), C.byref(la), 0, stream) == _lib.E_INVALID
-        assert b"empty map" in L.lvdgs_last_error()
-        la.width = 32
-        assert L.lvdgs_backward_fused_loss(C.byref(a), C.byref(la), 0, stream) == _lib.E_INVALID
+        assert b"image size" in L.lvdgs_last_error()
     # the scratch the loss kernels ask for holds four sums per tile as well as per 1024 pixels
     for W, H in ((64, 48), (1920, 1080), (17, 300)):
         tiles = ((W + 15) // 16) * ((H + 15) // 16)
         assert L.lvdgs_loss_scratch_bytes(W, H) >= 16 * tiles
+
+
+def test_a_view_that_sees_nothing_tracks_and_maps_like_the_autograd_path():
+    """A camera turned away from every Gaussian lists no (Gaussian, tile) pair.  The reference's loops just get the
+    background image: the loss is that image's loss, every Gaussian and pose gradient is zero.  The fused paths (the
+    defaults) do the same instead of raising: the backward with the loss inside still evaluates the loss over empty
+    lists."""
+    sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
+    from loop_scene import build_scene, loop_config
+    from lvdgs.fast_mapping import MapViewPass
+    from lvdgs.gaussian_renderer import render
+    from lvdgs.pose_utils import SE3_exp
+    from lvdgs.slam_loops import track_frame
+    from lvdgs.slam_utils import get_loss_mapping, get_loss_tracking
+    from types import SimpleNamespace
+    cfg = loop_config()
+    away = SE3_exp(torch.tensor([0.0, 0.0, 0.0, 0.0, math.pi, 0.0])).cuda()   # half a turn about y: the scene is behind the camera
+    res = {}
+    for fused in (False, True):
+        torch.manual_seed(2)
+        sc = build_scene("cuda")
+        cam, prev = sc["track_camera"], sc["cameras"][0]
+        cam.mono_depth = sc["track_mono_depth"]
+        cam.update_RT(away[:3, :3] @ prev.R, away[:3, :3] @ prev.T)
+        with torch.no_grad():
+            assert int((render(cam, sc["gaussians"], sc["pipe"], sc["background"])["radii"] > 0).sum()) == 0
+        losses = []
+        pkg, med, n_it = track_frame(cam, sc["gaussians"], cfg, sc["pipe"], sc["background"], tracking_itr_num=4, fused=fused,
+                                     on_iteration=lambda i, loss, p: losses.append(float(loss.detach())))
+        res[fused] = (np.array(losses), cam.R.cpu().numpy(), cam.T.cpu().numpy(), float(cam.exposure_a.detach()), float(cam.exposure_b.detach()),
+                      pkg["render"].detach().cpu().numpy())
+    for x, y in zip(res[True], res[False]):
+        np.testing.assert_allclose(x, y, rtol=2e-5, atol=1e-7)
+    bgc = sc["background"].cpu().numpy()
+    np.testing.assert_allclose(res[True][5], np.broadcast_to(bgc[:, None, None], res[True][5].shape), atol=0)
+
+    # one mapping view of the same kind through MapViewPass against render() -> get_loss_mapping() -> backward()
+    torch.manual_seed(2)
+    sc = build_scene("cuda")
+    G, cam = sc["gaussians"], sc["cameras"][1]
+    cam.update_RT(away[:3, :3] @ cam.R, away[:3, :3] @ cam.T)
+    backend = SimpleNamespace(gaussians=G, config=cfg, pipeline_params=sc["pipe"], background=sc["background"])
+    assert MapViewPass.usable(backend, cam)
+    pkg, loss = MapViewPass(G.get_xyz.device).run(backend, cam)
+    got = [getattr(G, n).grad.clone() for n in ("_xyz", "_features_dc", "_scaling", "_rotation", "_opacity")]
+    got_pose = [cam.cam_rot_delta.grad.clone(), cam.cam_trans_delta.grad.clone(), cam.exposure_a.grad.clone(), cam.exposure_b.grad.clone()]
+    for n in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"):
+        getattr(G, n).grad = None
+    for n in ("cam_rot_delta", "cam_trans_delta", "exposure_a", "exposure_b"):
+        getattr(cam, n).grad = None
+    ref_pkg = render(cam, G, sc["pipe"], sc["background"])
+    ref_loss = get_loss_mapping(cfg, ref_pkg["render"], cam, depth=ref_pkg["depth"], monodepth=True)
+    ref_loss.backward()
+    torch.testing.assert_close(loss, ref_loss.detach(), rtol=2e-6, atol=1e-9)
+    for g in got:
+        assert not g.any()
+    assert not got_pose[0].any() and not got_pose[1].any()
+    torch.testing.assert_close(got_pose[2], cam.exposure_a.grad, rtol=2e-5, atol=1e-9)
+    torch.testing.assert_close(got_pose[3], cam.exposure_b.grad, rtol=2e-5, atol=1e-9)
+    assert int(pkg["n_touched"].sum()) == 0 and not pkg["visibility_filter"].any()

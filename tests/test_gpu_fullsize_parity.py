@@ -49,6 +49,22 @@ def test_full_size_forward_and_backward_match_oracle(name, pose_seed):
     assert f_ora["num_rendered"] > 2 * N
     tp._check_forward(f_hip, f_ora, W, H)
     tp._check_backward(b_hip, b_ora, GRADS, f_ora, W, H)
+    if name == "cfg5_2m_1920x1280":
+        return
+    # The index state at BASELINE's sizes, bit for bit: with LVDGS_FLAG_LIST_ALL_TILES (every tile of the 3-sigma rectangle
+    # listed, as the reference does) tiles_touched, the pair count, the sorted (tile, depth, id) list, the tile ranges
+    # and n_contrib ARE the oracle's (check_pair_lists / _check_forward compare them with assert_array_equal in this
+    # mode), and the images and counters of the two modes are the same bits.
+    f_all, _ = hr.run_hip(g, cam, W, H, bg, tile_cull=False)
+    assert f_all["num_rendered"] == f_ora["num_rendered"] > f_hip["num_rendered"]
+    tp._check_forward(f_all, f_ora, W, H)
+    np.testing.assert_array_equal(f_all["tiles_touched"], f_ora["tiles_touched"])
+    np.testing.assert_array_equal(f_all["point_list"], f_ora["ids_sorted"])
+    np.testing.assert_array_equal(f_all["ranges"], f_ora["ranges"])
+    solid = f_ora["fragile"] == 0
+    np.testing.assert_array_equal(f_all["n_contrib"][solid], f_ora["n_contrib"][solid])
+    for k in ("color", "depth", "opacity", "final_T", "radii", "n_touched"):
+        np.testing.assert_array_equal(f_all[k], f_hip[k], err_msg=k)
 
 
 # ---------------------------------------------------------------------------------------------------------------

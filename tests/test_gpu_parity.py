@@ -371,7 +371,7 @@ def test_fused_activations_match_the_accessor_path():
 @pytest.mark.parametrize("opacity_scale,r_max", [(1.0, 12.0), (0.05, 25.0)])
 def test_tile_culling_changes_no_output_bit_and_without_it_the_lists_are_the_references(opacity_scale, r_max):
     """The default path lists a (Gaussian, tile) pair only when the Gaussian can reach alpha >= 1/255 somewhere on the
-    tile (common.hpp: reaches_rect / rect_keeps).  LVDGS_TILE_CULL=0 lists every tile of the 3-sigma rectangle, as the
+    tile (common.hpp: reaches_rect / rect_keeps).  LVDGS_FLAG_LIST_ALL_TILES (lvdgs_args.flags) lists every tile of the 3-sigma rectangle, as the
     reference does.  (1) Without culling the pair list, ranges and n_contrib equal the oracle's bit for bit; (2) with it
     the list is the oracle's minus pairs that provably contribute nothing (hip_runner.check_pair_lists); (3) images,
     radii and n_touched are bitwise the same in the two modes, and the gradients agree to summation-order rounding."""
