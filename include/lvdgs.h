@@ -329,9 +329,17 @@ int lvdgs_isotropic_reg(int32_t num_gaussians, const float *raw_scales /* N*3 */
                         float weight, void *scratch, size_t scratch_bytes, float *loss, void *stream);
 /* What the back end derives from one view's render package (utils/slam_backend.py:311-315, :350-357), accumulated over
  * the views rendered so far: radii_max = max(radii_max, radii); for visible Gaussians (radii > 0) norm_sum += |viewspace
- * gradient xy|, vis_count += 1, seen = 1; touched_row[i] = n_touched[i] > 0 (NULL for views outside the window). */
+ * gradient xy| and vis_count += 1 (NULL: not counted); touched_row[i] = n_touched[i] > 0 (NULL for views outside the window).
+ * A view rendered in bands by several GPUs (lvdgs_args.tile_row_*) holds only a share of the gradient on each: pass
+ * split_xy (N x 2) and the band's xy is written THERE instead of its norm being added to norm_sum -- the caller sums the
+ * bands (all-reduce) and lvdgs_map_stats_apply takes the norm of the sum; vis_count then goes with ONE of the bands. */
 int lvdgs_view_stats(int32_t num_gaussians, const int32_t *radii, const int32_t *n_touched, const float *viewspace_grad /* N*3 or NULL */,
-                     int32_t *radii_max, float *norm_sum, float *vis_count, uint8_t *seen, uint8_t *touched_row, void *stream);
+                     int32_t *radii_max, float *norm_sum, float *vis_count, uint8_t *touched_row, float *split_xy, void *stream);
+/* ... and their way into the model, one launch (:350-357 on the reduced values):
+ *   max_radii2D = max(max_radii2D, radii_max); xyz_gradient_accum += norm_sum + sum_k |split_xy[k]|; denom += vis_count
+ * split_xy: n_split planes of N x 2 floats (the summed band gradients of the views that were split), or NULL with 0. */
+int lvdgs_map_stats_apply(int32_t num_gaussians, const int32_t *radii_max, const float *norm_sum, const float *vis_count,
+                          const float *split_xy, int32_t n_split, float *max_radii2D, float *xyz_gradient_accum, float *denom, void *stream);
 
 /* ---- depth term of the static-mask mapping loss (reference utils/slam_backend.py:216-261) ----
  *   M    = static_mask & (mono_depth > 0) & (rendered depth > 0)          (static_mask NULL = every pixel)

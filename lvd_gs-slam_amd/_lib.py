@@ -111,7 +111,7 @@ EXPORTS = (
     "lvdgs_backward", "lvdgs_mark_visible", "lvdgs_state_layout_query", "lvdgs_knn_scratch_bytes",
     "lvdgs_dist2_knn3", "lvdgs_rope2d", "lvdgs_rope2d_strided", "lvdgs_loss_scratch_bytes", "lvdgs_photometric_loss_forward",
     "lvdgs_photometric_loss_backward", "lvdgs_photometric_loss_value_and_grad", "lvdgs_photometric_loss_partials", "lvdgs_tracking_tail", "lvdgs_backward_fused_loss", "lvdgs_masked_depth_scratch_bytes", "lvdgs_masked_depth_l1_forward",
-    "lvdgs_masked_depth_l1_backward", "lvdgs_pose_step", "lvdgs_pose_step_batch", "lvdgs_adam_step", "lvdgs_isotropic_scratch_bytes", "lvdgs_isotropic_reg", "lvdgs_view_stats", "lvdgs_ssim_scratch_bytes", "lvdgs_ssim_l1", "lvdgs_last_error", "lvdgs_version", "lvdgs_profile_enable",
+    "lvdgs_masked_depth_l1_backward", "lvdgs_pose_step", "lvdgs_pose_step_batch", "lvdgs_adam_step", "lvdgs_isotropic_scratch_bytes", "lvdgs_isotropic_reg", "lvdgs_view_stats", "lvdgs_map_stats_apply", "lvdgs_ssim_scratch_bytes", "lvdgs_ssim_l1", "lvdgs_last_error", "lvdgs_version", "lvdgs_profile_enable",
     "lvdgs_profile_reset", "lvdgs_profile_read",
 )
 
@@ -175,6 +175,7 @@ def lib():
         L.lvdgs_isotropic_scratch_bytes.argtypes = [C.c_int32]
         L.lvdgs_isotropic_reg.argtypes = [C.c_int32, _fp, _fp, C.c_float, _fp, C.c_size_t, _fp, C.c_void_p]
         L.lvdgs_view_stats.argtypes = [C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_void_p]
+        L.lvdgs_map_stats_apply.argtypes = [C.c_int32, _fp, _fp, _fp, _fp, C.c_int32, _fp, _fp, _fp, C.c_void_p]
         L.lvdgs_ssim_scratch_bytes.restype = C.c_size_t
         L.lvdgs_ssim_scratch_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
         L.lvdgs_ssim_l1.argtypes = [C.POINTER(SsimArgs), C.c_void_p]

@@ -6,14 +6,21 @@ the window's keyframes (<= 8, ``Training.window_size``) plus two random older on
 ``torch.distributed`` group.  With one rank (or no process group) it is the reference's loop, step for step; that
 path is what ``tests/golden/map_loop.npz`` (produced by running the reference's own ``BackEnd.map``) pins.
 
+Views are dealt whole as far as they divide evenly; the rest are cut into BANDS of tile rows (``plan_pieces``): a view's
+tiles are independent and its loss is a sum over pixels, so a band's forward + backward (``lvdgs_args.tile_row_begin /
+_end``) yields that band's share of every gradient and the shares add up in the all-reduce.  Ten views on eight ranks
+are 1.25 views of blend work per rank instead of two renders on the busiest one.
+
 Per iteration and rank:
   1. render + loss + backward of the rank's own views -- three C-ABI calls per view on the GPU (fast_mapping.MapViewPass:
      no autograd engine, gradients written where autograd would have put them), the autograd path for views with a
      static mask and off the GPU -- and the isotropic regulariser on rank 0 (:303-305);
   2. ONE float32 SUM all-reduce (RCCL) of a flat bucket
         [ Gaussian parameter gradients (N x 14 at SH degree 0) | pose / exposure gradients of the window keyframes
-          | sum over views of the screen-space gradient norms (N) | visibility counts (N) | loss ]
-     and ONE int32 MAX all-reduce of [ max radii (N) | per-view (n_touched > 0) and visibility bytes ];
+          | sum over views of the screen-space gradient norms (N) | visibility counts (N)
+          | screen-space gradients (N x 2) of the views that were split into bands | loss ],
+     one int32 MAX all-reduce of the max radii (N) and one uint8 MAX all-reduce of the per-view (n_touched > 0) bytes
+     (a byte-wise OR: several ranks hold flags of a view that was split);
   3. the bookkeeping of :309-389 on the reduced values, identically on every rank: occlusion-aware visibility,
      pruning, max_radii2D, densification statistics, densify / prune, opacity reset, the Gaussian Adam step, the
      keyframe Adam step and ``update_pose``.
@@ -47,20 +54,104 @@ def _world(group=None):
     return 0, 1
 
 
+# "leftover": views are dealt whole as far as they divide evenly, the remaining ones are cut into bands; "all": every
+# splittable view is cut into one band per rank (tests; also the finest balance); "none": whole views only (round 2).
+SPLIT_POLICY = "leftover"
+
+
+def plan_pieces(rows: Sequence[int], world: int, iteration: int = 0, splittable: Optional[Sequence[bool]] = None,
+                policy: Optional[str] = None):
+    """The iteration's work as pieces ``(view, row0, row1, rank)``: tile rows [row0, row1) of view ``view`` (``rows[v]``
+    = tile rows of view v) go to ``rank``.  Whole views first -- view i of the first ``(V // world) * world`` to rank
+    i mod world, so a window keyframe stays with its rank for as long as the window stands -- then the remaining
+    V mod world views as bands: their rows, laid end to end, are cut into ``world`` equal shares (to whole tile rows),
+    starting at a rank that rotates with the iteration count.  A view that cannot be rendered in bands (``splittable[v]``
+    false: it goes through autograd with a loss that is no sum over pixels) is dealt whole to the least loaded rank.
+    Every rank ends with the same number of rows (+- one tile row per cut) as long as the views are of one size."""
+    policy = SPLIT_POLICY if policy is None else policy
+    V = len(rows)
+    splittable = [True] * V if splittable is None else list(splittable)
+    if world <= 1:
+        return [(v, 0, int(rows[v]), 0) for v in range(V)]
+    pieces, load = [], [0] * world          # load: tile rows per rank
+    n_whole = V if policy == "none" else ((V // world) * world if policy == "leftover" else 0)
+    split = []
+    for v in range(V):
+        if v < n_whole and policy != "none":
+            pieces.append((v, 0, int(rows[v]), v % world)); load[v % world] += int(rows[v])
+        elif policy != "none" and splittable[v] and rows[v] > 0:
+            split.append(v)
+        else:   # whole, to the least loaded rank (rotating among equals)
+            k = len(pieces)
+            r = min(range(world), key=lambda q: (load[q], (q - iteration - k) % world))
+            pieces.append((v, 0, int(rows[v]), r)); load[r] += int(rows[v])
+    if split and policy == "all":
+        for v in split:
+            n = int(rows[v])
+            cuts = [round(n * k / world) for k in range(world + 1)]
+            for k in range(world):
+                if cuts[k + 1] > cuts[k]:
+                    pieces.append((v, cuts[k], cuts[k + 1], (k + v + iteration) % world))
+    elif split:
+        # the split views' rows laid end to end, cut so that every rank ends with the same number of rows: a rank that
+        # already carries more (an unsplittable view dealt whole) gets a shorter share
+        total = sum(int(rows[v]) for v in split)
+        order = sorted(range(world), key=lambda q: (load[q], (q - iteration) % world))
+        level = (total + sum(load)) / world
+        want = [max(0.0, level - load[q]) for q in order]
+        scale = total / max(sum(want), 1e-9)
+        cuts, acc = [0], 0.0
+        for w in want:
+            acc += w * scale
+            cuts.append(min(total, round(acc)))
+        cuts[-1] = total
+        start = 0
+        for v in split:
+            n = int(rows[v])
+            for k in range(world):
+                lo, hi = max(cuts[k], start), min(cuts[k + 1], start + n)
+                if hi > lo:
+                    pieces.append((v, lo - start, hi - start, order[k]))
+            start += n
+    return pieces
+
+
 def assign_views(n_window: int, n_random: int, world: int, iteration: int = 0) -> List[int]:
-    """Owner rank of every view of one iteration.  Window keyframe i belongs to rank i mod world for as long as the
-    window stands.  The random views go to the least-loaded ranks, starting from a rank that rotates with the iteration
-    count so that no rank carries the extra view every time.  (10 views on 8 ranks still take two renders on the
-    busiest rank: the iteration cannot be more than 5 x faster than on one GPU; 5 or 10 ranks divide it evenly.)"""
-    owners = [i % world for i in range(n_window)]
-    load = [0] * world
-    for o in owners:
-        load[o] += 1
-    for k in range(n_random):
-        order = sorted(range(world), key=lambda r: (load[r], (r - iteration - k) % world))
-        owners.append(order[0])
-        load[order[0]] += 1
-    return owners
+    """Owner rank of every view when views are dealt whole (``plan_pieces(..., policy="none")``)."""
+    return [p[3] for p in plan_pieces([1] * (n_window + n_random), world, iteration, policy="none")]
+
+
+class _BandView:
+    """A viewpoint whose target image and mono depth are zero outside pixel rows [y0, y1): every pixel outside fails the
+    loss's own validity masks (reference utils/slam_utils.py:97-98, :112: ``gt.sum(0) > rgb_boundary_threshold``,
+    ``gt_depth > 0.01``), so ``get_loss_mapping`` of the WHOLE rendered image is the band's share of the view's loss --
+    the means keep the whole image's pixel count.  For pieces that go through autograd (CPU tests, views MapViewPass
+    does not take); everything else is the viewpoint's own attribute (pose and exposure tensors included)."""
+
+    def __init__(self, viewpoint, y0, y1):
+        object.__setattr__(self, "_vp", viewpoint)
+        img = viewpoint.original_image
+        band = torch.zeros_like(img)
+        band[..., y0:y1, :] = img[..., y0:y1, :]
+        md = viewpoint.mono_depth
+        mdt = md if torch.is_tensor(md) else torch.from_numpy(md)
+        mband = torch.zeros_like(mdt)
+        mband[..., y0:y1, :] = mdt[..., y0:y1, :]
+        object.__setattr__(self, "original_image", band)
+        object.__setattr__(self, "mono_depth", mband if torch.is_tensor(md) else mband.numpy())
+
+    def __getattr__(self, name):
+        return getattr(object.__getattribute__(self, "_vp"), name)
+
+    def __setattr__(self, name, value):
+        if name in ("_lvdgs_mono_depth",):
+            object.__setattr__(self, name, value)
+        else:
+            setattr(object.__getattribute__(self, "_vp"), name, value)
+
+
+def _tile_rows(viewpoint):
+    return (int(viewpoint.image_height) + 15) // 16
 
 
 def random_view_indices(n_candidates: int, k: int, iteration: int, world: int, seed: int = 0) -> List[int]:
@@ -160,10 +251,13 @@ class FlatReducer:
         return list(flat.split(sizes))
 
 
-def _flag_words(rows: int, n: int, device):
-    """rows x n byte flags, stored so that the same memory reads as int32 words (row length padded to 4)."""
-    n4 = (n + 3) // 4 * 4
-    return torch.zeros(rows, n4, dtype=torch.uint8, device=device)
+def _max_bytes(flags: torch.Tensor, group=None):
+    """uint8 all-reduce MAX in place: the byte-wise OR of 0 / 1 flags.  (Packed into int32 words and reduced with MAX --
+    round 2 -- a word's high byte decided for all four: flags of other ranks were dropped.)"""
+    _, world = _world(group)
+    if world > 1 and flags.numel():
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
+    return flags
 
 
 _P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
@@ -276,49 +370,69 @@ class KeyframeStepper:
 
 
 class _ViewStats:
-    """radii_max / norm_sum / vis_count / flags of the views a rank rendered, filled by one ``lvdgs_view_stats`` launch per
-    view on the GPU (the PyTorch statements otherwise)."""
+    """radii_max / norm_sum / vis_count / flags of the pieces a rank rendered, filled by one ``lvdgs_view_stats`` launch per
+    piece on the GPU (the PyTorch statements otherwise).  ``split``: the views of the iteration that were cut into bands,
+    in order: a band's screen-space gradient goes to that view's plane of ``split_xy`` (the norm is of the sum over the
+    bands, which only exists after the all-reduce), and the view is counted as seen by the rank holding its first band."""
 
-    def __init__(self, N, n_window, dev, reducer=None, float_pieces=None):
-        """``reducer`` / ``float_pieces`` (sharded runs): the integer pieces are laid out in the reducer's int bucket and the
-        two float pieces are the given slices of its float bucket, so neither collective has anything to pack."""
+    def __init__(self, N, n_window, dev, split: Sequence[int] = (), float_pieces=None):
+        """``float_pieces`` (sharded runs): norm_sum, vis_count and the split planes are the given slices of the reducer's
+        float bucket, so the collective has nothing to pack."""
         self.N, self.n_window, self.dev = N, n_window, dev
-        n4 = (N + 3) // 4 * 4
-        words = N + (n_window + 1) * (n4 // 4)
-        if reducer is not None:
-            ints = reducer.plan_ints(words, dev)
-            ints.zero_()
-        else:
-            ints = torch.zeros(words, dtype=torch.int32, device=dev)
-        self.radii_max = ints[:N]
-        self.flags = ints[N:].view(torch.uint8).view(n_window + 1, n4)   # rows 0..n_window-1: n_touched > 0 ; last row: seen by any view
+        self.split = list(split)
+        self.radii_max = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.flags = torch.zeros(n_window, N, dtype=torch.uint8, device=dev)   # row i: n_touched > 0 in window view i
         if float_pieces is not None:
-            self.norm_sum, self.vis_count = float_pieces
-            self.norm_sum.zero_(); self.vis_count.zero_()
+            self.norm_sum, self.vis_count, self.split_xy = float_pieces
+            self.norm_sum.zero_(); self.vis_count.zero_(); self.split_xy.zero_()
         else:
-            both = torch.zeros(2 * N, dtype=torch.float32, device=dev)
-            self.norm_sum, self.vis_count = both[:N], both[N:]
+            both = torch.zeros((2 + 2 * len(self.split)) * N, dtype=torch.float32, device=dev)
+            self.norm_sum, self.vis_count, self.split_xy = both[:N], both[N:2 * N], both[2 * N:]
 
-    def add(self, i, pkg):
+    def add(self, view, row0, pkg):
+        """One piece of view ``view`` (``row0``: its first tile row; the piece starting at row 0 counts the view as seen)."""
         N, n_window = self.N, self.n_window
         radii, nt, vg = pkg["radii"], pkg["n_touched"], pkg["viewspace_points"].grad
+        k = self.split.index(view) if view in self.split else -1
+        plane = self.split_xy[2 * N * k:2 * N * (k + 1)] if k >= 0 else None
+        counts = row0 == 0
         fast = (self.dev.type == "cuda" and radii.dtype is torch.int32 and nt.dtype is torch.int32 and radii.is_contiguous()
                 and nt.is_contiguous() and (vg is None or _on_gpu_f32(vg)))
         if fast:
-            row = self.flags[i] if i < n_window else None
+            row = self.flags[view] if view < n_window else None
             with _lib.on_device(self.dev):
                 _lib.check(_lib.lib().lvdgs_view_stats(N, _P(radii), _P(nt), _P(vg), _P(self.radii_max), _P(self.norm_sum),
-                                                       _P(self.vis_count), _P(self.flags[n_window]), _P(row),
+                                                       _P(self.vis_count) if counts else None, _P(row), _P(plane),
                                                        _lib.raw_stream(self.dev)), "lvdgs_view_stats")
             return
         vis = pkg["visibility_filter"]
-        self.radii_max = torch.maximum(self.radii_max, radii.to(torch.int32))
+        self.radii_max.copy_(torch.maximum(self.radii_max, radii.to(torch.int32)))
         if vg is not None:
-            self.norm_sum += torch.where(vis, torch.norm(vg[:, :2], dim=-1), torch.zeros_like(self.norm_sum))
-        self.vis_count += vis.to(torch.float32)
-        self.flags[n_window, :N] |= vis.to(torch.uint8)
-        if i < n_window:
-            self.flags[i, :N] = (nt > 0).to(torch.uint8)
+            if plane is not None:
+                plane.view(N, 2).copy_(torch.where(vis[:, None], vg[:, :2], torch.zeros_like(vg[:, :2])))
+            else:
+                self.norm_sum += torch.where(vis, torch.norm(vg[:, :2], dim=-1), torch.zeros_like(self.norm_sum))
+        if counts:
+            self.vis_count += vis.to(torch.float32)
+        if view < n_window:
+            self.flags[view] = (nt > 0).to(torch.uint8)
+
+    def apply(self, G, radii_max, norm_sum, vis_count, split_xy):
+        """``max_radii2D`` / ``xyz_gradient_accum`` / ``denom`` from the (reduced) statistics (reference :350-357)."""
+        N, n_split = self.N, len(self.split)
+        fast = (self.dev.type == "cuda" and _on_gpu_f32(G.max_radii2D, G.xyz_gradient_accum, G.denom, norm_sum, vis_count)
+                and radii_max.dtype is torch.int32 and radii_max.is_contiguous() and (n_split == 0 or _on_gpu_f32(split_xy))
+                and G.max_radii2D.numel() == N and G.xyz_gradient_accum.numel() == N and G.denom.numel() == N)
+        if fast:
+            with _lib.on_device(self.dev):
+                _lib.check(_lib.lib().lvdgs_map_stats_apply(N, _P(radii_max), _P(norm_sum), _P(vis_count), _P(split_xy) if n_split else None,
+                                                            n_split, _P(G.max_radii2D), _P(G.xyz_gradient_accum), _P(G.denom),
+                                                            _lib.raw_stream(self.dev)), "lvdgs_map_stats_apply")
+            return
+        G.max_radii2D = torch.maximum(G.max_radii2D, radii_max)   # (int32 promotes to the float32 of max_radii2D)
+        if n_split:
+            norm_sum = norm_sum + torch.norm(split_xy.view(n_split, N, 2), dim=-1).sum(0)
+        torch._foreach_add_([G.xyz_gradient_accum, G.denom], [norm_sum[:, None], vis_count[:, None]])
 
 
 def _isotropic_term(G, weight=10.0):
@@ -396,32 +510,41 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
         picks = random_view_indices(len(random_viewpoint_stack), 2, backend.iteration_count, world,
                                     seed=getattr(backend, "shard_seed", 0))
         views = viewpoint_stack + [random_viewpoint_stack[i] for i in picks]
-        owners = assign_views(n_window, len(picks), world, backend.iteration_count)
-        mine = [i for i, o in enumerate(owners) if o == rank]
-
-        loss_mapping = 0      # views that go through autograd (a graph)
-        loss_direct = None    # views rendered, scored and differentiated by MapViewPass (values only)
-        pkgs = {}
         vpass = _view_pass(backend) if (fused and render_fn is render and view_loss_fn is view_loss) else None
-        # sharded: the first view's backward writes the parameter gradients straight into their slices of the float
+        # a view renders in bands when its loss is a sum over pixels: get_loss_mapping, i.e. no static mask (L1 + SSIM and a
+        # count-normalised depth term are not); window views without MapViewPass take the _BandView route through autograd
+        splittable = [getattr(v, "static_mask", None) is None or i >= n_window for i, v in enumerate(views)]
+        pieces = plan_pieces([_tile_rows(v) for v in views], world, backend.iteration_count, splittable)
+        split = sorted({v for v, r0, r1, _ in pieces if (r0, r1) != (0, _tile_rows(views[v]))})
+        mine = [(v, r0, r1) for v, r0, r1, o in pieces if o == rank]
+
+        loss_mapping = 0      # pieces that go through autograd (a graph)
+        loss_direct = None    # pieces rendered, scored and differentiated by MapViewPass (values only)
+        pkgs = []
+        # sharded: the first piece's backward writes the parameter gradients straight into their slices of the float
         # bucket the all-reduce works on (no packing copy); the statistics' float pieces live there too
         plan = first = None
-        if vpass is not None and world > 1:
+        N0 = G.get_xyz.shape[0]
+        if world > 1:
             live = G.parameters()
-            plan = reducer.plan_floats([p.numel() for p in live] + [p.numel() for p in kf_params] + [live[0].shape[0]] * 2 + [1],
+            plan = reducer.plan_floats([p.numel() for p in live] + [p.numel() for p in kf_params] + [N0, N0, 2 * N0 * len(split), 1],
                                        live[0].device)
-            first = {n: plan[k].view_as(p) for k, (n, p) in enumerate(zip(_PARAM_FIELDS, live))}
-        for i in mine:
-            if vpass is not None and MapViewPass.usable(backend, views[i]):
-                pkgs[i], l = vpass.run(backend, views[i], first=first)
+            if vpass is not None:
+                first = {n: plan[k].view_as(p) for k, (n, p) in enumerate(zip(_PARAM_FIELDS, live))}
+        for v, r0, r1 in mine:
+            whole = (r0, r1) == (0, _tile_rows(views[v]))
+            if vpass is not None and MapViewPass.usable(backend, views[v]):
+                pkg, l = vpass.run(backend, views[v], first=first, band=None if whole else (r0, r1))
+                pkgs.append((v, r0, pkg))
                 loss_direct = l if loss_direct is None else loss_direct + l
                 continue
-            pkg = render_fn(views[i], G, backend.pipeline_params, backend.background)
-            pkgs[i] = pkg
-            if i < n_window:
-                loss_mapping = loss_mapping + view_loss_fn(backend, views[i], pkg)
+            pkg = render_fn(views[v], G, backend.pipeline_params, backend.background)
+            pkgs.append((v, r0, pkg))
+            target = views[v] if whole else _BandView(views[v], 16 * r0, min(16 * r1, int(views[v].image_height)))
+            if v < n_window:
+                loss_mapping = loss_mapping + view_loss_fn(backend, target, pkg)
             else:
-                loss_mapping = loss_mapping + get_loss_mapping(cfg, pkg["render"], views[i], depth=pkg["depth"], monodepth=True)
+                loss_mapping = loss_mapping + get_loss_mapping(cfg, pkg["render"], target, depth=pkg["depth"], monodepth=True)
         # isotropic regulariser (:303-305), rank 0 only: fused kernel after the backward where it applies, else in the graph
         fuse_iso = rank == 0 and fused and G.get_xyz.is_cuda and getattr(G, "standard_activations", False)
         if rank == 0 and not fuse_iso:
@@ -441,35 +564,32 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
         with torch.no_grad():
             N = G.get_xyz.shape[0]
             dev = G.get_xyz.device
-            # ---- what this rank's views say, in view order ----
-            vs = _ViewStats(N, n_window, dev, reducer if (plan is not None and dev.type == "cuda") else None,
-                            (plan[-3], plan[-2]) if plan is not None else None)
-            for i in mine:
-                vs.add(i, pkgs[i])
-            radii_max, norm_sum, vis_count, flags = vs.radii_max, vs.norm_sum, vs.vis_count, vs.flags
-            # ---- two collectives (a pruning pass reduces the flags only, see below) ----
+            # ---- what this rank's pieces say, in order ----
+            vs = _ViewStats(N, n_window, dev, split, (plan[-4], plan[-3], plan[-2]) if plan is not None else None)
+            for v, r0, pkg in pkgs:
+                vs.add(v, r0, pkg)
+            radii_max, norm_sum, vis_count, split_xy, flags = vs.radii_max, vs.norm_sum, vs.vis_count, vs.split_xy, vs.flags
+            # ---- the collectives (a pruning pass reduces the flags only, see below) ----
             params = G.parameters()
-            t0 = _now(dev) if stats is not None else None
+            timer = _CommTimer(dev) if stats is not None else None
             if not prune and world > 1:
-                tensors = [p.grad for p in params] + [p.grad for p in kf_params] + [norm_sum, vis_count,
+                tensors = [p.grad for p in params] + [p.grad for p in kf_params] + [norm_sum, vis_count, split_xy,
                            loss_mapping.detach().reshape(1).float() if torch.is_tensor(loss_mapping) else None]
-                sizes = [p.numel() for p in params] + [p.numel() for p in kf_params] + [N, N, 1]
+                sizes = [p.numel() for p in params] + [p.numel() for p in kf_params] + [N, N, 2 * N * len(split), 1]
                 red = reducer.sum_floats(tensors, sizes, dev, group)
                 for p, g in zip(params + kf_params, red):
                     p.grad = g.view_as(p)
-                norm_sum, vis_count = red[-3], red[-2]
+                norm_sum, vis_count, split_xy = red[-4], red[-3], red[-2]
                 if stats is not None:
                     stats.setdefault("losses", []).append(red[-1].clone())
             elif stats is not None and torch.is_tensor(loss_mapping):
                 stats.setdefault("losses", []).append(loss_mapping.detach().reshape(1).float())
             if world > 1:
-                ired = reducer.max_ints([radii_max, flags.view(torch.int32)], dev, group)
-                radii_max = ired[0]
-                flags = ired[1].view(torch.uint8).view(n_window + 1, -1)
-            flags = flags[:, :N]
+                radii_max = reducer.max_ints([radii_max], dev, group)[0]
+                flags = _max_bytes(flags, group)
             if stats is not None:
-                stats.setdefault("iterations", []).append(dict(views=list(mine), comm_s=_now(dev) - t0))
-            seen_by_any = flags[n_window].bool()
+                stats.setdefault("iterations", []).append(dict(views=[v for v, _, _ in mine], pieces=list(mine), comm_s=timer.stop()))
+            seen_by_any = vis_count > 0   # (every view is counted by exactly one rank: a sum that reduces correctly)
 
             # ---- bookkeeping of reference :309-389 on the reduced values ----
             backend.occ_aware_visibility = {}
@@ -507,8 +627,7 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
                         backend.initialized = True
                 return False
 
-            G.max_radii2D = torch.maximum(G.max_radii2D, radii_max)   # (int32 promotes to the float32 of max_radii2D)
-            torch._foreach_add_([G.xyz_gradient_accum, G.denom], [norm_sum[:, None], vis_count[:, None]])
+            vs.apply(G, radii_max, norm_sum, vis_count, split_xy)
 
             update_gaussian = backend.iteration_count % backend.gaussian_update_every == backend.gaussian_update_offset
             gaussian_split = False
@@ -580,8 +699,39 @@ def _keyframe_stepper(backend, viewpoint_stack, pose_window):
     return st
 
 
-def _now(dev):
-    import time
-    if dev.type == "cuda":
-        torch.cuda.synchronize(dev)
-    return time.perf_counter()
+class _CommTimer:
+    """Time between two points of the device's stream, by events on the GPU (no device-wide synchronisation around the
+    collectives: the wait happens once, when the value is asked for); wall time off the GPU."""
+
+    def __init__(self, dev):
+        import time
+        self.dev = dev
+        if dev.type == "cuda":
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record(torch.cuda.current_stream(dev))
+        else:
+            self.t0 = time.perf_counter()
+
+    def stop(self):
+        import time
+        if self.dev.type == "cuda":
+            self.e1.record(torch.cuda.current_stream(self.dev))
+            return _LazySeconds(self.e0, self.e1)
+        return time.perf_counter() - self.t0
+
+
+class _LazySeconds:
+    """float(x) waits for the second event and returns the seconds between the two."""
+
+    def __init__(self, e0, e1):
+        self.e0, self.e1 = e0, e1
+
+    def __float__(self):
+        self.e1.synchronize()
+        return self.e0.elapsed_time(self.e1) * 1e-3
+
+    def __radd__(self, other):
+        return other + float(self)
+
+    def __add__(self, other):
+        return float(self) + other

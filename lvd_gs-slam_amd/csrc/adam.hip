@@ -137,25 +137,43 @@ __global__ void __launch_bounds__(256) isotropic_finish_kernel(int nblk, const f
 
 // What the back end derives from one view's render package (slam_backend.py:311-315, :350-357), accumulated over the
 // views a rank rendered: element-wise max of the radii, sum of the screen-space gradient norms and count of the views that
-// saw each Gaussian, "seen by any view", and the view's own (n_touched > 0) row.  One launch per view instead of ~10.
+// saw each Gaussian, and the view's own (n_touched > 0) row.  One launch per view instead of ~10.
+// A view rendered in bands by several ranks (lvdgs_args.tile_row_*) has only a share of its screen-space gradient here:
+// the norm is of the SUM over the bands, so the band's xy goes to split_xy (N x 2, summed over the ranks by the caller's
+// all-reduce; lvdgs_map_stats_apply then takes the norm) instead of into norm_sum; vis_count is passed for one band only.
 __global__ void __launch_bounds__(256) view_stats_kernel(int N, const int32_t *__restrict__ radii, const int32_t *__restrict__ n_touched,
                                                          const float *__restrict__ viewspace_grad, int32_t *__restrict__ radii_max,
                                                          float *__restrict__ norm_sum, float *__restrict__ vis_count,
-                                                         uint8_t *__restrict__ seen, uint8_t *__restrict__ touched_row) {
+                                                         uint8_t *__restrict__ touched_row, float *__restrict__ split_xy) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const int r = radii[i];
     const bool vis = r > 0;
     if (r > radii_max[i]) radii_max[i] = r;
-    if (vis) {
-        if (viewspace_grad) {
-            const float gx = viewspace_grad[3 * (size_t)i], gy = viewspace_grad[3 * (size_t)i + 1];
-            norm_sum[i] += sqrtf(gx * gx + gy * gy);
-        }
-        vis_count[i] += 1.f;
-        seen[i] = 1;
-    }
+    float gx = 0.f, gy = 0.f;
+    if (vis && viewspace_grad) { gx = viewspace_grad[3 * (size_t)i]; gy = viewspace_grad[3 * (size_t)i + 1]; }
+    if (split_xy) *reinterpret_cast<float2 *>(split_xy + 2 * (size_t)i) = make_float2(gx, gy);
+    else if (vis && viewspace_grad) norm_sum[i] += sqrtf(gx * gx + gy * gy);
+    if (vis && vis_count) vis_count[i] += 1.f;
     if (touched_row) touched_row[i] = n_touched[i] > 0 ? 1 : 0;
+}
+
+// The statistics' way into the model, one launch (slam_backend.py:350-357 on the reduced values):
+//   max_radii2D = max(max_radii2D, radii_max);  xyz_gradient_accum += norm_sum + sum over split views |split_xy|;  denom += vis_count
+__global__ void __launch_bounds__(256) map_stats_apply_kernel(int N, const int32_t *__restrict__ radii_max, const float *__restrict__ norm_sum,
+                                                              const float *__restrict__ vis_count, const float *__restrict__ split_xy, int n_split,
+                                                              float *__restrict__ max_radii2D, float *__restrict__ grad_accum, float *__restrict__ denom) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float r = (float)radii_max[i];
+    if (r > max_radii2D[i]) max_radii2D[i] = r;
+    float g = norm_sum[i];
+    for (int k = 0; k < n_split; k++) {
+        const float2 v = *reinterpret_cast<const float2 *>(split_xy + 2 * ((size_t)k * N + i));
+        g += sqrtf(v.x * v.x + v.y * v.y);
+    }
+    grad_accum[i] += g;
+    denom[i] += vis_count[i];
 }
 
 }  // namespace
@@ -177,14 +195,28 @@ extern "C" int lvdgs_isotropic_reg(int32_t N, const float *raw_scales, float *gr
 }
 
 extern "C" int lvdgs_view_stats(int32_t N, const int32_t *radii, const int32_t *n_touched, const float *viewspace_grad, int32_t *radii_max,
-                                float *norm_sum, float *vis_count, uint8_t *seen, uint8_t *touched_row, void *stream) {
+                                float *norm_sum, float *vis_count, uint8_t *touched_row, float *split_xy, void *stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (N < 0 || (N > 0 && (!radii || !radii_max || !norm_sum || !vis_count || !seen || (touched_row && !n_touched)))) {
+    if (N < 0 || (N > 0 && (!radii || !radii_max || (!norm_sum && !split_xy) || (touched_row && !n_touched)))) {
         set_error("view stats: a required pointer is NULL"); return LVDGS_E_INVALID;
     }
     if (N == 0) return LVDGS_OK;
     ProfScope ps("view_stats", s);
-    hipLaunchKernelGGL(view_stats_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, N, radii, n_touched, viewspace_grad, radii_max, norm_sum, vis_count, seen, touched_row);
+    hipLaunchKernelGGL(view_stats_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, N, radii, n_touched, viewspace_grad, radii_max, norm_sum, vis_count, touched_row, split_xy);
     LVDGS_LAUNCH_CHECK("view_stats", 0, s);
+    return LVDGS_OK;
+}
+
+extern "C" int lvdgs_map_stats_apply(int32_t N, const int32_t *radii_max, const float *norm_sum, const float *vis_count, const float *split_xy,
+                                     int32_t n_split, float *max_radii2D, float *xyz_gradient_accum, float *denom, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (N < 0 || n_split < 0 || (N > 0 && (!radii_max || !norm_sum || !vis_count || !max_radii2D || !xyz_gradient_accum || !denom || (n_split > 0 && !split_xy)))) {
+        set_error("map stats apply: a required pointer is NULL"); return LVDGS_E_INVALID;
+    }
+    if (N == 0) return LVDGS_OK;
+    ProfScope ps("map_stats_apply", s);
+    hipLaunchKernelGGL(map_stats_apply_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, N, radii_max, norm_sum, vis_count, split_xy, n_split, max_radii2D,
+                       xyz_gradient_accum, denom);
+    LVDGS_LAUNCH_CHECK("map_stats_apply", 0, s);
     return LVDGS_OK;
 }

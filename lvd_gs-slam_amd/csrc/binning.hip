@@ -1,4 +1,6 @@
 // Grouping of the (Gaussian, tile) pairs by tile: by counting (default), or pair emission + tile ranges for the radix path.
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "binning.hpp"
 #include "device_utils.hpp"
@@ -304,6 +306,10 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t *__rest
 
 }  // namespace
 
+int group_per_thread_for(int N) {
+    static const int forced = [] { const char *e = getenv("LVDGS_GROUP_PER"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 0; }();
+    return forced ? forced : group_per_thread_default(N);
+}
 int group_max_tiles() { return GROUP_MAX_TILES; }
 size_t group_chunks(int N) { return (size_t)cdiv(N > 0 ? N : 1, GROUP_THREADS * group_per_thread_for(N)); }
 size_t group_hist_entries(int N, int num_tiles) {
@@ -316,17 +322,16 @@ int launch_group_count(const lvdgs_args &a, const GeomView &g, const ImageView &
     if (N == 0 || T == 0) return LVDGS_OK;
     const int per = group_per_thread_for(N), nchunks = cdiv(N, GROUP_THREADS * per);
     const size_t lds = (size_t)T * sizeof(uint32_t);
-    static unsigned char count_done2[16], count_done4[16];
+    static unsigned char done[3][16];
     ProfScope ps("group_count", s);
-    if (per == 2) {
-        if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&count_pairs_kernel<2>), GROUP_MAX_TILES * 4, count_done2)) return e;
-        hipLaunchKernelGGL(count_pairs_kernel<2>, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint4 *)g.rect, w.group_hist,
-                           a.n_touched, im.long_count);
-    } else {
-        if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&count_pairs_kernel<4>), GROUP_MAX_TILES * 4, count_done4)) return e;
-        hipLaunchKernelGGL(count_pairs_kernel<4>, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint4 *)g.rect, w.group_hist,
-                           a.n_touched, im.long_count);
+#define LVDGS_COUNT(PER_, D_)                                                                                                      \
+    {                                                                                                                              \
+        if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&count_pairs_kernel<PER_>), GROUP_MAX_TILES * 4, done[D_])) return e; \
+        hipLaunchKernelGGL(count_pairs_kernel<PER_>, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint4 *)g.rect, w.group_hist, \
+                           a.n_touched, im.long_count);                                                                            \
     }
+    if (per == 1) LVDGS_COUNT(1, 0) else if (per == 2) LVDGS_COUNT(2, 1) else LVDGS_COUNT(4, 2)
+#undef LVDGS_COUNT
     LVDGS_LAUNCH_CHECK("group_count", a.debug, s);
     return LVDGS_OK;
 }
@@ -360,7 +365,7 @@ int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView
     if (N == 0 || T == 0) return LVDGS_OK;
     const int per = group_per_thread_for(N), nchunks = cdiv(N, GROUP_THREADS * per);
     const size_t lds = (size_t)T * sizeof(uint32_t);
-    static unsigned char done[4][16];
+    static unsigned char done[6][16];
     ProfScope ps("group_scatter", s);
 #define LVDGS_SCATTER(PER_, SS_, D_)                                                                                               \
     {                                                                                                                              \
@@ -369,7 +374,9 @@ int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView
                            (const uint32_t *)w.group_hist, (const uint2 *)im.ranges, (uint32_t)capacity, (const uint32_t *)g.depth_bits, keys64, \
                            (const uint32_t *)g.tiles_touched, (const uint32_t *)w.chunk_sums, g.slot_base);                        \
     }
-    if (per == 2 && slot_scan) LVDGS_SCATTER(2, true, 0)
+    if (per == 1 && slot_scan) LVDGS_SCATTER(1, true, 4)
+    else if (per == 1) LVDGS_SCATTER(1, false, 5)
+    else if (per == 2 && slot_scan) LVDGS_SCATTER(2, true, 0)
     else if (per == 2) LVDGS_SCATTER(2, false, 1)
     else if (slot_scan) LVDGS_SCATTER(4, true, 2)
     else LVDGS_SCATTER(4, false, 3)

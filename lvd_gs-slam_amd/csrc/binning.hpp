@@ -11,7 +11,8 @@ constexpr int GROUP_THREADS = 1024;
 // Gaussians: 489 chunks of 4096); many, small ones spread the counting and scattering over the chip (200 k Gaussians
 // are 49 chunks of 4096 on 256 CUs, 98 of 2048).  Measured (same box): 100k / 640x480 0.2235 -> 0.2088 ms per tracking
 // iteration with 2048, KITTI geometry 0.2881 -> 0.2795, config 3 0.6247 -> 0.6230, 2 M / 1920x1280 1.49 -> 1.52.
-__host__ __device__ constexpr int group_per_thread_for(int N) { return N <= (1 << 20) ? 2 : 4; }
+__host__ __device__ constexpr int group_per_thread_default(int N) { return N <= (1 << 20) ? 2 : 4; }
+int group_per_thread_for(int N);   // binning.hip: the default, or LVDGS_GROUP_PER (1, 2 or 4; read once per process, for A/B measurements)
 constexpr int GROUP_MAX_TILES = 16384;  // 64 KiB of LDS counters
 constexpr int GROUP_BIG_RECT = 64;
 static_assert(GROUP_BIG_RECT == RECT_MASK_TILES, "rectangles walked by the whole wave are the ones without a tile mask");

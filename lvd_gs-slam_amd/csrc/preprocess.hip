@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(FwdParams p) {
 // every rectangle are gone from the single-call forward (lvdgs_forward).  Also clears what the later kernels of the
 // frame accumulate into (n_touched, the tile-sort queue counters).
 template <int PER>
-__global__ void __launch_bounds__(GROUP_THREADS) preprocess_count_kernel(FwdParams p, int T, uint32_t *__restrict__ hist,
+__global__ void __launch_bounds__(GROUP_THREADS, 8) preprocess_count_kernel(FwdParams p, int T, uint32_t *__restrict__ hist,
                                                                         uint32_t *__restrict__ chunk_sums, int32_t *__restrict__ n_touched,
                                                                         uint32_t *__restrict__ queue_counts) {
     extern __shared__ uint32_t s_tile[];
@@ -680,17 +680,16 @@ int launch_preprocess_count(const lvdgs_args &a, const GeomView &g, const ImageV
     const int T = p.cam.gx * p.cam.gy;
     const int per = group_per_thread_for(N), nchunks = cdiv(N, GROUP_THREADS * per);
     const size_t lds = (size_t)T * sizeof(uint32_t);
-    static unsigned char done2[16], done4[16];
+    static unsigned char done[3][16];
     ProfScope ps("preprocess_fwd", s);
-    if (per == 2) {
-        if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&preprocess_count_kernel<2>), GROUP_MAX_TILES * 4, done2)) return e;
-        hipLaunchKernelGGL(preprocess_count_kernel<2>, dim3(nchunks), dim3(GROUP_THREADS), lds, s, p, T, w.group_hist, w.chunk_sums, a.n_touched,
-                           im.long_count);
-    } else {
-        if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&preprocess_count_kernel<4>), GROUP_MAX_TILES * 4, done4)) return e;
-        hipLaunchKernelGGL(preprocess_count_kernel<4>, dim3(nchunks), dim3(GROUP_THREADS), lds, s, p, T, w.group_hist, w.chunk_sums, a.n_touched,
-                           im.long_count);
+#define LVDGS_PCOUNT(PER_, D_)                                                                                                     \
+    {                                                                                                                              \
+        if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&preprocess_count_kernel<PER_>), GROUP_MAX_TILES * 4, done[D_])) return e; \
+        hipLaunchKernelGGL(preprocess_count_kernel<PER_>, dim3(nchunks), dim3(GROUP_THREADS), lds, s, p, T, w.group_hist, w.chunk_sums, a.n_touched, \
+                           im.long_count);                                                                                         \
     }
+    if (per == 1) LVDGS_PCOUNT(1, 0) else if (per == 2) LVDGS_PCOUNT(2, 1) else LVDGS_PCOUNT(4, 2)
+#undef LVDGS_PCOUNT
     LVDGS_LAUNCH_CHECK("preprocess_count", a.debug, s);
     return LVDGS_OK;
 }

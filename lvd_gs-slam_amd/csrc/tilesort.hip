@@ -157,43 +157,43 @@ __device__ __forceinline__ void wave_sort_segment(const KeySource &src, uint32_t
 }
 
 constexpr int CLASS_W = 1024;  // longest segment one wave sorts in registers (16 keys per lane)
-constexpr int CLASS_L = 4096;  // longest segment a workgroup of the same launch sorts in (static) LDS
+constexpr int CLASS_L = 2048;  // longest segment a workgroup of the same launch sorts in (static) LDS: 16 KB
 constexpr int CLASS_B = 16384; // longest segment the separate 1024-thread kernel sorts in (dynamic) LDS
-constexpr int SORT_WAVES = 16; // tiles per workgroup
+constexpr int SORT_WAVES = 4;  // tiles per workgroup (16 were measured: the same at 8160 tiles, twice the time at 1848 -- too few workgroups)
 constexpr int LONG_WGS = 64;   // workgroups at the end of the grid that take the queue of over-long segments
 
-// `count` queued segments, one workgroup (1024 threads) per segment in turn: in LDS up to `lds_cap` entries, in place on
+// `count` queued segments, one workgroup per segment in turn: in LDS up to `lds_cap` entries, in place on
 // global memory beyond (64-bit key scratch).  Segments of more than `skip_above` entries are left alone (another launch
 // takes them).
 __device__ __forceinline__ void sort_queued_segments(u64 *s_keys, int lds_cap, int skip_above, const uint2 *__restrict__ ranges, const KeySource &src,
                                                      uint32_t *__restrict__ point_list, int count, const uint32_t *__restrict__ queue, u64 *keys,
                                                      int first, int stride) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, nt = blockDim.x;
     for (int q = first; q < count; q += stride) {
         const uint2 r = ranges[queue[q]];
         const int n = (int)(r.y - r.x);
         if (n > skip_above) continue;
         if (n <= lds_cap) {
-            for (int i = tid; i < n; i += 1024) s_keys[i] = src.load(r.x + i);
+            for (int i = tid; i < n; i += nt) s_keys[i] = src.load(r.x + i);
             __syncthreads();
-            bitonic_sort_ascending<false>(s_keys, n, tid, 1024);
+            bitonic_sort_ascending<false>(s_keys, n, tid, nt);
             __syncthreads();
-            for (int i = tid; i < n; i += 1024) point_list[r.x + i] = (uint32_t)s_keys[i];
+            for (int i = tid; i < n; i += nt) point_list[r.x + i] = (uint32_t)s_keys[i];
         } else {
             volatile u64 *g = keys + r.x;
             if (!src.keys) {  // otherwise the keys are already in place
-                for (int i = tid; i < n; i += 1024) g[i] = src.load(r.x + i);
+                for (int i = tid; i < n; i += nt) g[i] = src.load(r.x + i);
                 __threadfence_block();
                 __syncthreads();
             }
-            bitonic_sort_ascending<true>(g, n, tid, 1024);
-            for (int i = tid; i < n; i += 1024) point_list[r.x + i] = (uint32_t)g[i];
+            bitonic_sort_ascending<true>(g, n, tid, nt);
+            for (int i = tid; i < n; i += nt) point_list[r.x + i] = (uint32_t)g[i];
         }
         __syncthreads();
     }
 }
 
-// One wave per tile (16 tiles per workgroup); segments of more than CLASS_W entries are left to whole workgroups:
+// One wave per tile (four tiles per workgroup); segments of more than CLASS_W entries are left to whole workgroups:
 //  * counting path (QUEUED): the tile-range scan has queued them already (binning.hip) and the LAST LONG_WGS workgroups
 //    of this very launch take them -- no launch of their own on every frame's critical path for a queue that is nearly
 //    always empty.  In LDS up to CLASS_L entries; beyond that in place on global memory, unless the host announces
@@ -204,7 +204,7 @@ __device__ __forceinline__ void sort_queued_segments(u64 *s_keys, int lds_cap, i
 // segments of similar length, and the long ones start first.  Only tiles [t_lo, t_hi) are looked at (the band being
 // rendered).
 template <bool QUEUED>
-__global__ void __launch_bounds__(1024) tile_depth_sort_wave_kernel(const uint2 *__restrict__ ranges, int t_lo, int t_hi, KeySource src,
+__global__ void __launch_bounds__(64 * SORT_WAVES) tile_depth_sort_wave_kernel(const uint2 *__restrict__ ranges, int t_lo, int t_hi, KeySource src,
                                                                     uint32_t *__restrict__ point_list, uint32_t *queue_count,
                                                                     uint32_t *__restrict__ queue, const uint32_t *__restrict__ tile_order,
                                                                     u64 *keys, int sort_wgs, int big_follows) {
@@ -277,11 +277,11 @@ int launch_tile_depth_sort(const ImageView &im, int num_tiles, int t_lo, int t_h
     {
         ProfScope ps("tile_sort", s);
         if (keys_ready)   // counting path: the queue is there already, the last workgroups of the launch take it
-            hipLaunchKernelGGL(tile_depth_sort_wave_kernel<true>, dim3(sort_wgs + LONG_WGS), dim3(1024), 0, s, (const uint2 *)im.ranges, t_lo, t_hi, src,
+            hipLaunchKernelGGL(tile_depth_sort_wave_kernel<true>, dim3(sort_wgs + LONG_WGS), dim3(64 * SORT_WAVES), 0, s, (const uint2 *)im.ranges, t_lo, t_hi, src,
                                point_list, im.long_count, im.long_tiles, tile_order_in_use(num_tiles) ? im.long_tiles + num_tiles : nullptr,
                                (u64 *)keys64, sort_wgs, big_segments_expected ? 1 : 0);
         else
-            hipLaunchKernelGGL(tile_depth_sort_wave_kernel<false>, dim3(sort_wgs), dim3(1024), 0, s, (const uint2 *)im.ranges, t_lo, t_hi, src,
+            hipLaunchKernelGGL(tile_depth_sort_wave_kernel<false>, dim3(sort_wgs), dim3(64 * SORT_WAVES), 0, s, (const uint2 *)im.ranges, t_lo, t_hi, src,
                                point_list, im.long_count, im.long_tiles, (const uint32_t *)nullptr, (u64 *)keys64, sort_wgs, 0);
         LVDGS_LAUNCH_CHECK("tile_sort", dbg, s);
     }

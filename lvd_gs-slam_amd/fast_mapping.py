@@ -120,7 +120,7 @@ class MapViewPass:
         a.scratch, a.scratch_bytes = _P(self.scratch), self.scratch.numel()
 
     # ---- one view ----------------------------------------------------------------------------------------------------
-    def run(self, backend, viewpoint, initialization=False, first=None, image_loss=None):
+    def run(self, backend, viewpoint, initialization=False, first=None, image_loss=None, band=None):
         """Render ``viewpoint``, evaluate ``get_loss_mapping`` and add its gradients to the model's and the viewpoint's
         ``.grad`` fields (``first``: buffers, by parameter field, for a view that finds no gradients yet to write into --
         the sharded loop passes slices of its all-reduce bucket -- instead of the pass's own).  Returns the render package (fresh tensors, ``viewspace_points`` carries ``.grad``) and the
@@ -128,7 +128,11 @@ class MapViewPass:
 
         ``image_loss(color) -> (loss, d_color)`` (optional) replaces ``get_loss_mapping``: a loss of the rendered colour
         alone that brings its own gradient image -- colour refinement's ``(1 - l) L1 + l (1 - SSIM)`` from the fused
-        L1 + SSIM kernel -- after which the plain ``lvdgs_backward`` runs (no depth / exposure terms)."""
+        L1 + SSIM kernel -- after which the plain ``lvdgs_backward`` runs (no depth / exposure terms).
+
+        ``band = (row0, row1)``: only tile rows [row0, row1) of the view (``lvdgs_args.tile_row_begin / _end``): the band's
+        pixels of the images, the band's share of the loss and of every gradient; ``radii`` are the whole view's,
+        ``n_touched`` counts the band's pixels.  The other pixels of the returned images are not written."""
         G, cfg, dev, L = backend.gaussians, backend.config, self.dev, self.L
         T = cfg["Training"]
         N, K = int(G._xyz.shape[0]), 1 + int(G._features_rest.shape[1])
@@ -150,6 +154,10 @@ class MapViewPass:
         keep += cam
         a.bg, a.viewmatrix, a.projmatrix, a.projmatrix_raw, a.campos = (_P(t) for t in cam)
         a.activations = _rz.ACT_EXP_SCALES | _rz.ACT_NORMALIZE_ROTATIONS | _rz.ACT_SIGMOID_OPACITIES
+        a.flags = _lib.FLAG_LIST_ALL_TILES if _rz.LIST_ALL_TILES else 0
+        a.tile_row_begin, a.tile_row_end = (0, 0) if band is None else (int(band[0]), int(band[1]))
+        if band is not None and (image_loss is not None or not 0 <= band[0] < band[1]):
+            raise _lib.LvdgsError("MapViewPass: a band needs 0 <= row0 < row1 and the built-in mapping loss")
         if K > 1:
             torch.cat((G._features_dc.detach(), G._features_rest.detach()), dim=1, out=self.shs)
             shs = self.shs

@@ -95,6 +95,7 @@ class TrackingSession:
         else:
             scales, rotations, opacity = gaussians.get_scaling, gaussians.get_rotation, gaussians.get_opacity
             a.activations = 0
+        a.flags = _lib.FLAG_LIST_ALL_TILES if _rz.LIST_ALL_TILES else 0
         m3, sc, rot, op, shs = (_f32c(t, dev) for t in (gaussians.get_xyz, scales, rotations, opacity, gaussians.get_features))
         keep += [m3, sc, rot, op, shs]
         a.num_gaussians, a.sh_coeffs = N, int(shs.shape[1])

@@ -1,6 +1,7 @@
-"""world_size-2 gloo test (CPU) of the sharded mapping loop ``lvdgs.backend_map.map_window``: four iterations on the
-toy scene (a densification in the third, an opacity reset of the non-visible in the fourth... see loop_scene.py), then the
-pruning pass -- on two ranks and in one process.
+"""gloo tests (CPU, world sizes 2, 3 and 4) of the sharded mapping loop ``lvdgs.backend_map.map_window``: four iterations on
+the toy scene (a densification in the second), then the pruning pass and one more iteration -- on several ranks and in
+one process -- with the views dealt whole (six views on two or three ranks), cut into bands where they do not divide
+evenly (four ranks), and all of them cut into one band per rank (``SPLIT_POLICY = "all"``).
 
 Checked: (1) the two replicas end bit-identical (parameters, Adam moments, keyframe poses and exposures, bookkeeping),
 which is what lets the ranks go on without ever broadcasting parameters; (2) they agree with the single-process run
@@ -30,14 +31,35 @@ def _paths():
     import lvdgs  # noqa: F401
 
 
-def _run(group_world):
+def _half_blind(render_fn):
+    """A renderer whose views each see only half of the Gaussians (by parity of index + keyframe id) as far as the
+    bookkeeping can tell: radii, visibility and n_touched of the other half are zeroed.  With it the views of different
+    ranks see different subsets -- what the opacity reset of the non-visible (reference utils/slam_backend.py:367-370)
+    and the per-view visibility rows need to get right across ranks."""
+    def render(viewpoint, G, pipe, bg, **kw):
+        pkg = render_fn(viewpoint, G, pipe, bg, **kw)
+        keep = (torch.arange(pkg["radii"].shape[0]) + int(viewpoint.uid)) % 2 == 0
+        pkg = dict(pkg)
+        pkg["radii"] = torch.where(keep, pkg["radii"], torch.zeros_like(pkg["radii"]))
+        pkg["n_touched"] = torch.where(keep, pkg["n_touched"], torch.zeros_like(pkg["n_touched"]))
+        pkg["visibility_filter"] = pkg["radii"] > 0
+        return pkg
+    return render
+
+
+def _run(group_world, policy="leftover", half_blind=False):
     """One run of ITERS iterations + the pruning pass; returns a dict of numpy results."""
     _paths()
     import test_loop_golden as tl
     from dense_render import dense_render
     from loop_scene import build_scene, loop_config
     from lvdgs import backend_map as bm
+    bm.SPLIT_POLICY = policy
+    if half_blind:
+        dense_render = _half_blind(dense_render)
     cfg = loop_config()
+    if half_blind:   # reach the opacity reset of the non-visible inside the run (iteration 3; densification at 2 and 6)
+        cfg["Training"]["gaussian_reset"] = 3
     sc = build_scene("cpu")
     be = tl._backend(sc, cfg)
     be.initialized = True
@@ -78,57 +100,74 @@ def _run(group_world):
     for kf in window:
         out[f"occ{kf}"] = be.occ_aware_visibility[kf].numpy().copy()
     out["views_per_iteration"] = np.array([len(r["views"]) for r in stats["iterations"]])
+    out["rows_per_iteration"] = np.array([sum(r1 - r0 for _, r0, r1 in r["pieces"]) for r in stats["iterations"]])
     return out
 
 
 def _digest(res):
     h = hashlib.sha256()
     for k in sorted(res):
-        if k != "views_per_iteration":
+        if k not in ("views_per_iteration", "rows_per_iteration"):
             h.update(k.encode())
             h.update(np.ascontiguousarray(res[k]).tobytes())
     return h.hexdigest()
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, policy, half_blind):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.manual_seed(100 + rank)   # the ranks' global generators differ on purpose: nothing may depend on them
-        res = _run(world)
+        res = _run(world, policy, half_blind)
         q.put((rank, _digest(res), res))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_stay_bit_identical_and_match_the_single_process_run():
-    world = 2
+_SINGLE = {}
+
+
+def _single_process(half_blind):
+    if half_blind not in _SINGLE:
+        torch.manual_seed(7)
+        _SINGLE[half_blind] = _run(1, "leftover", half_blind)
+    return _SINGLE[half_blind]
+
+
+@pytest.mark.parametrize("world,policy,half_blind", [(2, "leftover", False), (4, "leftover", False), (2, "all", False), (3, "all", True)])
+def test_ranks_stay_bit_identical_and_match_the_single_process_run(world, policy, half_blind):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    port = 29500 + (os.getpid() % 2000) + 7 * world + (3 if policy == "all" else 0) + (1 if half_blind else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, policy, half_blind)) for r in range(world)]
     for p in procs:
         p.start()
-    results = sorted([q.get(timeout=600) for _ in range(world)], key=lambda r: r[0])
+    results = sorted([q.get(timeout=900) for _ in range(world)], key=lambda r: r[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, d0, r0), (_, d1, r1) = results
+    _, d0, r0 = results[0]
     # (1) replicas: bit-identical, everything
-    for k in r0:
-        if k != "views_per_iteration":
-            np.testing.assert_array_equal(r0[k], r1[k], err_msg=k)
-    assert d0 == d1
-    # the six views of an iteration (4 window + 2 random) split 3 + 3
-    assert r0["views_per_iteration"].tolist() == [3] * ITERS and r1["views_per_iteration"].tolist() == [3] * ITERS
+    for _, dk, rk in results[1:]:
+        for k in r0:
+            if k not in ("views_per_iteration", "rows_per_iteration"):
+                np.testing.assert_array_equal(r0[k], rk[k], err_msg=k)
+        assert d0 == dk
+    # the six views of an iteration (4 window + 2 random), three tile rows each: the same number of rows on every rank
+    # where 18 divides evenly, whole views where six do
+    rows = np.stack([r["rows_per_iteration"] for _, _, r in results])
+    assert (rows.sum(0) == 18).all() and rows.max() - rows.min() <= (3 if policy == "all" else (1 if world == 4 else 0)), rows
+    if policy == "leftover" and world in (2, 3):
+        assert all((r["views_per_iteration"] == 6 // world).all() for _, _, r in results)
+    else:
+        assert max(r["views_per_iteration"].max() for _, _, r in results) > rows.max() // 3   # bands: more pieces than whole views' worth
     # (2) single process, same random keyframes
-    torch.manual_seed(7)
-    ref = _run(1)
+    ref = _single_process(half_blind)
     np.testing.assert_array_equal(ref["counts"], r0["counts"])
     assert int(ref["n_mid"]) == int(r0["n_mid"]) and len(set(ref["counts"].tolist())) > 1   # a densification happened
     for k in ref:
-        if k in ("views_per_iteration", "counts", "n_mid"):
+        if k in ("views_per_iteration", "rows_per_iteration", "counts", "n_mid"):
             continue
         a, b = np.asarray(r0[k], np.float64), np.asarray(ref[k], np.float64)
         assert a.shape == b.shape, k
@@ -137,18 +176,62 @@ def test_two_ranks_stay_bit_identical_and_match_the_single_process_run():
             assert (np.abs(a - b) <= tol).all(), (k, np.abs(a - b).max(), np.abs(b).max())
 
 
-def test_view_assignment_and_random_choice():
+def _or_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _paths()
+        from lvdgs.backend_map import _max_bytes
+        mine = torch.tensor([[1, 0, 0, 1, 0], [0, 0, 0, 0, 1]] if rank == 0 else [[0, 1, 1, 0, 0], [0, 0, 1, 0, 0]], dtype=torch.uint8)
+        q.put((rank, _max_bytes(mine).tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flags_reduce_as_a_bytewise_or():
+    """ADVICE (round 2): flags packed four to an int32 word and reduced with MAX lost the flags of the rank whose word was
+    smaller ([1,0,0,1] against [0,1,1,0] gave [1,0,0,1]).  The rows are reduced as bytes."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31600 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_or_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0] == got[1] == [[1, 1, 1, 1, 0], [0, 0, 1, 0, 1]]
+
+
+def test_piece_plan_and_random_choice():
     _paths()
     from lvdgs import backend_map as bm
-    # window keyframe i -> rank i mod world; the two random views go to the least loaded ranks, rotating
-    assert bm.assign_views(8, 2, 8, 0)[:8] == list(range(8))
+    rows = [24] * 10
+    # ten views on eight ranks: the eight window keyframes whole (keyframe i -> rank i), the two others in quarter bands,
+    # one band per rank: 1.25 views of rows everywhere, every row of every view exactly once
     for it in range(8):
-        owners = bm.assign_views(8, 2, 8, it)
-        load = [owners.count(r) for r in range(8)]
-        assert max(load) == 2 and sum(load) == 10 and owners[8] != owners[9]
-    assert {bm.assign_views(8, 2, 8, it)[8] for it in range(8)} == set(range(8))   # no rank carries the extra view every time
-    assert sorted(bm.assign_views(8, 2, 10, 3)) == list(range(10))                 # ten ranks: one view each
+        ps = bm.plan_pieces(rows, 8, it)
+        assert [p for p in ps if p[0] < 8] == [(v, 0, 24, v) for v in range(8)]
+        load = [sum(r1 - r0 for _, r0, r1, o in ps if o == r) for r in range(8)]
+        assert load == [30] * 8
+        for v in range(10):
+            cover = sorted((r0, r1) for w, r0, r1, _ in ps if w == v)
+            assert cover[0][0] == 0 and cover[-1][1] == 24 and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+        assert len({o for v, _, _, o in ps if v >= 8}) == 8
+    assert len({bm.plan_pieces(rows, 8, it)[8][3] for it in range(8)}) == 8    # the bands rotate over the ranks
+    # other world sizes: rows per rank as equal as whole tile rows allow
+    for world in (2, 3, 4, 5, 6, 7, 10, 16):
+        ps = bm.plan_pieces(rows, world, 1)
+        load = [sum(r1 - r0 for _, r0, r1, o in ps if o == r) for r in range(world)]
+        assert sum(load) == 240 and max(load) - min(load) <= 2, (world, load)
+    # a view that cannot be rendered in bands is dealt whole; whole-view dealing is the round-2 behaviour
+    ps = bm.plan_pieces(rows, 8, 0, splittable=[True] * 9 + [False])
+    assert (9, 0, 24) in [p[:3] for p in ps]
+    assert bm.assign_views(8, 2, 8, 0)[:8] == list(range(8)) and sorted(bm.assign_views(8, 2, 10, 3)) == list(range(10))
     assert bm.assign_views(8, 2, 1, 5) == [0] * 10
+    assert [p[:3] for p in bm.plan_pieces(rows, 1)] == [(v, 0, 24) for v in range(10)]
     # all ranks draw the same random keyframes, different ones from iteration to iteration
     assert bm.random_view_indices(7, 2, 11, 4) == bm.random_view_indices(7, 2, 11, 4)
     assert len({tuple(bm.random_view_indices(7, 2, it, 4)) for it in range(20)}) > 5
