@@ -8,12 +8,15 @@ step: render(viewpoint, gaussians, pipe, bg) -> get_loss_tracking -> backward, w
 every Gaussian parameter and to the 6-DoF camera pose (cam_rot_delta / cam_trans_delta) and the
 exposure parameters (reference utils/slam_frontend.py:1492-1521).
 N > 1 (launched by torch.distributed.run, one process per GPU): one WHOLE mapping iteration of the back end
-(lvdgs.backend_map.map_window = reference utils/slam_backend.py:167-390) on a window of N keyframes, one per GPU
-(weak scaling): render + mapping loss + backward of the rank's keyframe, the two RCCL collectives (float SUM
-bucket: Gaussian gradients, keyframe pose / exposure gradients, densification statistics; int MAX bucket: radii
-and visibility flags), the bookkeeping, the Adam step over all Gaussians, the keyframe Adam step and the pose
-retraction.  `value` counts keyframe renders+backwards per second over the job; the time the collectives take is
-measured in a separate pass and reported as config.comm_us_per_step.
+(lvdgs.backend_map.map_window = reference utils/slam_backend.py:167-390) on the reference's window -- 8 keyframes + 2
+random older ones per iteration (configs/mono/KITTI/base_config.yaml:37, utils/slam_backend.py:275) -- whose ten views
+are dealt to the GPUs whole and in bands of tile rows (backend_map.plan_pieces: 1.25 views of work per GPU at N = 8),
+STRONG scaling: render + mapping loss + backward of the rank's pieces, the RCCL collectives (float SUM bucket: Gaussian
+gradients, keyframe pose / exposure gradients, densification statistics; int32 MAX: radii; uint8 MAX: visibility
+flags), the bookkeeping, the Adam step over all Gaussians, the keyframe Adam step and the pose retraction.  `value`
+counts view renders+backwards per second over the job (10 per iteration); config.same_step_on_one_gpu_iters_per_s is
+the SAME window on one GPU measured inside the job, config.phases_us_per_step the iteration by phase.
+`--window weak` is the round-2 line instead: a window of N keyframes, one whole keyframe per GPU, no random views.
 
 Rank 0 prints ONE JSON line.  `value` is whole-job iterations/s with all inputs resident in HBM.
 `roofline` prices the dominant kernel (by HIP-event time measured here) against the 8 TB/s HBM
@@ -72,7 +75,7 @@ def build_scene(workload, rank, dev):
     from lvdgs.pose_utils import SE3_exp
     cfg = synthetic.CONFIGS[workload]
     N, W, H = cfg["N"], cfg["W"], cfg["H"]
-    g = synthetic.make_gaussians(N, W, H, seed=0)
+    g = synthetic.make_workload_gaussians(workload, seed=0)
     fx, fy = cfg.get("fx", float(W)), cfg.get("fy", float(W))
     cx, cy = cfg.get("cx", W / 2.0), cfg.get("cy", H / 2.0)
     proj = getProjectionMatrix2(znear=0.01, zfar=100.0, fx=fx, fy=fy, cx=cx, cy=cy, W=W, H=H).transpose(0, 1).contiguous().to(dev)
@@ -89,10 +92,11 @@ def build_scene(workload, rank, dev):
     return model, cam, g, (N, W, H)
 
 
-def build_window(workload, world, dev, model):
+def build_window(workload, world, dev, model, n_window=None):
     """A BackEnd-shaped object (the attributes reference utils/slam_backend.py:21-72 sets) holding `world` keyframes
     of the workload's scene, every one from its own seeded pose with its own seeded target image, built identically
-    on every rank."""
+    on every rank.  The window is the newest `n_window` of them (default: all); the others are the older keyframes the
+    iteration draws its two random views from."""
     from lvdgs.camera_utils import Camera
     from lvdgs.graphics_utils import focal2fov, getProjectionMatrix2
     from lvdgs.pose_utils import SE3_exp
@@ -102,15 +106,23 @@ def build_window(workload, world, dev, model):
     cx, cy = cfg.get("cx", W / 2.0), cfg.get("cy", H / 2.0)
     proj = getProjectionMatrix2(znear=0.01, zfar=100.0, fx=fx, fy=fy, cx=cx, cy=cy, W=W, H=H).transpose(0, 1).to(dev)
     viewpoints = {}
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False)
     for k in range(world):
         gen = torch.Generator().manual_seed(4242 + k)
-        image = torch.rand(3, H, W, generator=gen).to(dev)
-        mono = (torch.rand(H, W, generator=gen) * 40 + 1).numpy()
-        cam = Camera(k + 1, image, None, mono, torch.eye(4), proj, fx, fy, cx, cy, focal2fov(fx, W), focal2fov(fy, H), H, W, device=dev)
+        cam = Camera(k + 1, torch.zeros(3, H, W, device=dev), None, None, torch.eye(4), proj, fx, fy, cx, cy, focal2fov(fx, W), focal2fov(fy, H), H, W, device=dev)
         pose = SE3_exp(torch.randn(6, generator=torch.Generator().manual_seed(1000 + k)) * 0.05)
         cam.update_RT(pose[:3, :3], pose[:3, 3])
+        # The keyframe's target image and mono depth are what the map itself shows from the keyframe's pose, plus fixed pixel
+        # noise (sigma 0.05 / 2 %): the state of a converged SLAM map, whose iterations leave the map where it is.  (Targets
+        # unrelated to the map -- random images -- make Adam tear the map apart within a hundred iterations: lists of thousands
+        # of entries per tile, a different workload at every step.)
+        with torch.no_grad():
+            pkg = render(cam, model, pipe, torch.zeros(3, device=dev))
+            cam.original_image = (pkg["render"] + 0.05 * torch.randn(3, H, W, generator=gen).to(dev)).clamp_(0.02, 1.0).contiguous()
+            cam.mono_depth = (pkg["depth"][0] * (1.0 + 0.02 * torch.randn(H, W, generator=gen).to(dev))).clamp_min_(0.05).cpu().numpy()
         viewpoints[k + 1] = cam
-    window = list(range(world, 0, -1))  # newest first
+    n_window = world if n_window is None else n_window
+    window = list(range(world, world - n_window, -1))  # newest first
     model.init_lr(6.0)
     model.training_setup(OPT)
     kf_groups = []
@@ -138,6 +150,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default=os.environ.get("LVDGS_BENCH_WORKLOAD", "cfg3_500k_1920x1080"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--window", choices=["real", "weak"], default="real",
+                    help="mapping step: 'real' = the reference's window, 8 keyframes + 2 random older ones per iteration, its ten "
+                         "views sharded over the GPUs (strong scaling); 'weak' = one keyframe per GPU, no random views")
     ap.add_argument("--step", choices=["auto", "tracking", "tracking-autograd", "mapping"], default="auto",
                     help="auto: tracking iteration on 1 GPU, mapping-window iteration on N > 1.  tracking: one iteration of "
                          "the product's tracking loop (fast_tracking.TrackingSession: render, tracking loss, backward, pose "
@@ -168,6 +183,7 @@ def main():
         else:
             dist.init_process_group(backend_name, rank=rank, world_size=world)
 
+    torch.manual_seed(0)   # (the single-GPU mapping window draws its two random views from the global generator)
     model, cam, g_cpu, (N, W, H) = build_scene(args.workload, rank, dev)
     pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False)
     bg = torch.zeros(3, device=dev)
@@ -177,8 +193,10 @@ def main():
     use_session = tracking and args.step != "tracking-autograd"
     stats = {}
     backend = window = session = None
+    real_window = not tracking and args.window == "real"
+    make_window = (lambda m: build_window(args.workload, 12, dev, m, n_window=8)) if real_window else (lambda m: build_window(args.workload, world, dev, m))
     if not tracking:
-        backend, window = build_window(args.workload, world, dev, model)
+        backend, window = make_window(model)
     elif use_session:
         from lvdgs.fast_tracking import TrackingSession
         session = TrackingSession(cam, model, CONFIG, pipe, bg)
@@ -303,8 +321,9 @@ def main():
         # so that the N-GPU number can be read against the right single-GPU number: bench.py's N = 1 default is the
         # tracking iteration of BASELINE configs[2], a different (lighter) step than the mapping iteration timed here.
         solo_groups = [dist.new_group(ranks=[r]) for r in range(world)]
-        solo_backend, solo_window = build_window(args.workload, 1, dev, GaussianModel.from_activated(
-            g_cpu["means3D"], g_cpu["scales"], g_cpu["rotations"], g_cpu["opacities"], shs=g_cpu["shs"], sh_degree=0, device=dev))
+        solo_model = GaussianModel.from_activated(g_cpu["means3D"], g_cpu["scales"], g_cpu["rotations"], g_cpu["opacities"], shs=g_cpu["shs"],
+                                                  sh_degree=0, device=dev)
+        solo_backend, solo_window = make_window(solo_model) if real_window else build_window(args.workload, 1, dev, solo_model)
         for _ in range(3):
             backend_map.map_window(solo_backend, solo_window, iters=1, group=solo_groups[rank])
         torch.cuda.synchronize()
@@ -317,26 +336,31 @@ def main():
         same_step_single = round(args.steps / float(solo.item()), 3)
         del solo_backend
 
-    comm_us = None
-    if world > 1 and not tracking:
-        # the collectives' share, measured apart (the timers synchronise the device around them)
+    comm_us = phases = None
+    if not tracking:
+        # the iteration by phase (events on the stream at the phase boundaries, one wait at the end of each iteration)
         st = {}
         for _ in range(5):
             backend_map.map_window(backend, window, iters=1, stats=st)
-        comm = torch.tensor([sum(r["comm_s"] for r in st["iterations"]) / len(st["iterations"])], device=dev, dtype=torch.float64)
-        dist.all_reduce(comm, op=dist.ReduceOp.MAX)
-        comm_us = round(float(comm.item()) * 1e6, 1)
+        per = [r["phases"].seconds() for r in st["iterations"]]
+        names = list(per[0])
+        t = torch.tensor([sum(p[n] for p in per) / len(per) for n in names], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        phases = {n: round(float(v) * 1e6, 1) for n, v in zip(names, t.tolist())}
+        comm_us = phases.get("collectives")
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(g_cpu, args.workload, N, W, H)
 
     if rank == 0:
-        value = world * args.steps / elapsed
+        views_per_step = 1 if tracking else (10 if real_window else world)
+        value = views_per_step * args.steps / elapsed
         out = {
             "metric": "render+backward iters/sec @500k Gaussians 1080p; 1/2/4/8-GPU scaling",
             "value": round(value, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "strong" if real_window else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.workload, "gaussians": N, "width": W, "height": H, "visible": stats["V"],
                        "pairs": stats["D"], "sh_degree": 0,
@@ -345,12 +369,17 @@ def main():
                                  if session is not None else
                                  "tracking iteration through the autograd API: render() + get_loss_tracking + backward (pose + all Gaussian grads)")
                                 if tracking else
-                                "mapping iteration (backend_map.map_window): one keyframe per GPU -- render + get_loss_mapping + backward, "
-                                "2 RCCL collectives (gradients + statistics, radii + flags), bookkeeping, Adam over all Gaussians, "
-                                "keyframe Adam, pose retraction"),
-                       "parallelism": f"keyframe-per-gpu x{world}" if world > 1 else "single",
-                       "comm_us_per_step": comm_us, "autograd_api_iters_per_s": autograd_rate,
-                       "same_step_on_one_gpu_iters_per_s": same_step_single},
+                                ("mapping iteration (backend_map.map_window) on the reference's window: 8 keyframes + 2 random older ones = 10 views "
+                                 "per iteration, dealt to the GPUs whole and in bands of tile rows -- render + get_loss_mapping + backward of every "
+                                 "piece, RCCL collectives (gradients + statistics SUM, radii MAX, flags MAX), bookkeeping, Adam over all Gaussians, "
+                                 "keyframe Adam, pose retraction; value = views (render + backward) per second = 10 x iterations/s"
+                                 if real_window else
+                                 "mapping iteration (backend_map.map_window), WEAK scaling: a window of N keyframes, one whole keyframe per GPU, no "
+                                 "random views -- render + get_loss_mapping + backward, the collectives, bookkeeping, Adam over all Gaussians, "
+                                 "keyframe Adam, pose retraction; value = keyframes per second")),
+                       "parallelism": ((f"10 views in pieces over {world} GPUs" if real_window else f"keyframe-per-gpu x{world}") if world > 1 else "single"),
+                       "views_per_step": views_per_step, "comm_us_per_step": comm_us, "phases_us_per_step": phases,
+                       "autograd_api_iters_per_s": autograd_rate, "same_step_on_one_gpu_iters_per_s": same_step_single},
             **({"collective_backend": backend_name + " (functional check only, not a benchmark result)"} if world > 1 and backend_name != "nccl" else {}),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels_us_per_step": {k: round(v["us_per_step"], 2) for k, v in kernels.items()},
         }

@@ -510,6 +510,7 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
         picks = random_view_indices(len(random_viewpoint_stack), 2, backend.iteration_count, world,
                                     seed=getattr(backend, "shard_seed", 0))
         views = viewpoint_stack + [random_viewpoint_stack[i] for i in picks]
+        marks = _PhaseMarks(G.get_xyz.device) if stats is not None else None
         vpass = _view_pass(backend) if (fused and render_fn is render and view_loss_fn is view_loss) else None
         # a view renders in bands when its loss is a sum over pixels: get_loss_mapping, i.e. no static mask (L1 + SSIM and a
         # count-normalised depth term are not); window views without MapViewPass take the _BandView route through autograd
@@ -564,6 +565,7 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
         with torch.no_grad():
             N = G.get_xyz.shape[0]
             dev = G.get_xyz.device
+            if marks: marks.mark("views")
             # ---- what this rank's pieces say, in order ----
             vs = _ViewStats(N, n_window, dev, split, (plan[-4], plan[-3], plan[-2]) if plan is not None else None)
             for v, r0, pkg in pkgs:
@@ -571,7 +573,7 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
             radii_max, norm_sum, vis_count, split_xy, flags = vs.radii_max, vs.norm_sum, vs.vis_count, vs.split_xy, vs.flags
             # ---- the collectives (a pruning pass reduces the flags only, see below) ----
             params = G.parameters()
-            timer = _CommTimer(dev) if stats is not None else None
+            if marks: marks.mark("statistics")
             if not prune and world > 1:
                 tensors = [p.grad for p in params] + [p.grad for p in kf_params] + [norm_sum, vis_count, split_xy,
                            loss_mapping.detach().reshape(1).float() if torch.is_tensor(loss_mapping) else None]
@@ -587,8 +589,9 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
             if world > 1:
                 radii_max = reducer.max_ints([radii_max], dev, group)[0]
                 flags = _max_bytes(flags, group)
+            if marks: marks.mark("collectives")
             if stats is not None:
-                stats.setdefault("iterations", []).append(dict(views=[v for v, _, _ in mine], pieces=list(mine), comm_s=timer.stop()))
+                stats.setdefault("iterations", []).append(dict(views=[v for v, _, _ in mine], pieces=list(mine), phases=marks))
             seen_by_any = vis_count > 0   # (every view is counted by exactly one rank: a sum that reduces correctly)
 
             # ---- bookkeeping of reference :309-389 on the reduced values ----
@@ -641,6 +644,7 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
 
             if stats is not None and callable(stats.get("before_steps")):
                 stats["before_steps"](backend)   # tests look at the (reduced) gradients here
+            if marks: marks.mark("bookkeeping")
             G.optimizer.step()
             G.optimizer.zero_grad(set_to_none=True)
             G.update_learning_rate(backend.iteration_count)
@@ -664,6 +668,7 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
                     if viewpoint.uid == 0:
                         continue
                     update_pose(viewpoint)
+            if marks: marks.mark("optimizer_steps")
     return gaussian_split
 
 
@@ -699,39 +704,29 @@ def _keyframe_stepper(backend, viewpoint_stack, pose_window):
     return st
 
 
-class _CommTimer:
-    """Time between two points of the device's stream, by events on the GPU (no device-wide synchronisation around the
-    collectives: the wait happens once, when the value is asked for); wall time off the GPU."""
+class _PhaseMarks:
+    """Named points on the device's stream (events on the GPU, wall clock off it); ``seconds()`` waits once, at the end, and
+    returns {phase: seconds since the previous mark}.  No device-wide synchronisation around the collectives."""
 
     def __init__(self, dev):
-        import time
-        self.dev = dev
-        if dev.type == "cuda":
-            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            self.e0.record(torch.cuda.current_stream(dev))
-        else:
-            self.t0 = time.perf_counter()
+        self.dev, self.names, self.points = dev, [], []
+        self._point()
 
-    def stop(self):
-        import time
+    def _point(self):
         if self.dev.type == "cuda":
-            self.e1.record(torch.cuda.current_stream(self.dev))
-            return _LazySeconds(self.e0, self.e1)
-        return time.perf_counter() - self.t0
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream(self.dev))
+            self.points.append(e)
+        else:
+            import time
+            self.points.append(time.perf_counter())
 
+    def mark(self, name):
+        self.names.append(name)
+        self._point()
 
-class _LazySeconds:
-    """float(x) waits for the second event and returns the seconds between the two."""
-
-    def __init__(self, e0, e1):
-        self.e0, self.e1 = e0, e1
-
-    def __float__(self):
-        self.e1.synchronize()
-        return self.e0.elapsed_time(self.e1) * 1e-3
-
-    def __radd__(self, other):
-        return other + float(self)
-
-    def __add__(self, other):
-        return float(self) + other
+    def seconds(self):
+        if self.dev.type == "cuda":
+            self.points[-1].synchronize()
+            return {n: a.elapsed_time(b) * 1e-3 for n, a, b in zip(self.names, self.points, self.points[1:])}
+        return {n: b - a for n, a, b in zip(self.names, self.points, self.points[1:])}

@@ -21,16 +21,16 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int N, int gx, const ui
     const uint4 r = rect[id];
     const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
     const int area = (x1 - x0) * (y1 - y0);
-    uint32_t o = slot_base[id];
+    const uint32_t o0 = slot_base[id];
     int k = 0;
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++, k++) {
             if (!rect_keeps(r, k, area)) continue;
+            const uint32_t o = o0 + rect_rank(r, k, area);
             if (o < capacity) {  // pairs beyond the caller's capacity are dropped (the caller is told and re-runs)
                 tile_keys[o] = (uint32_t)(y * gx + x);
                 ids[o] = id;
             }
-            o++;
         }
 }
 

@@ -9,9 +9,10 @@ namespace lvdgs {
 constexpr int GROUP_THREADS = 1024;
 // Gaussians per workgroup = 1024 x PER.  Few, large chunks keep the [chunk][tile] count matrix and its scan small (2 M
 // Gaussians: 489 chunks of 4096); many, small ones spread the counting and scattering over the chip (200 k Gaussians
-// are 49 chunks of 4096 on 256 CUs, 98 of 2048).  Measured (same box): 100k / 640x480 0.2235 -> 0.2088 ms per tracking
-// iteration with 2048, KITTI geometry 0.2881 -> 0.2795, config 3 0.6247 -> 0.6230, 2 M / 1920x1280 1.49 -> 1.52.
-__host__ __device__ constexpr int group_per_thread_default(int N) { return N <= (1 << 20) ? 2 : 4; }
+// are 49 chunks of 4096 on 256 CUs, 98 of 2048, 196 of 1024).  Measured (same box, round 3, ms per tracking iteration with
+// chunks of 1024 / 2048 / 4096): KITTI geometry (200 k) 0.2557 / 0.2683 / -, config 3 (500 k) 0.5667 / 0.5678 / -,
+// 2 M / 1920x1280 - / 1.472 / 1.477.
+__host__ __device__ constexpr int group_per_thread_default(int N) { return N <= (1 << 18) ? 1 : (N <= (1 << 20) ? 2 : 4); }
 int group_per_thread_for(int N);   // binning.hip: the default, or LVDGS_GROUP_PER (1, 2 or 4; read once per process, for A/B measurements)
 constexpr int GROUP_MAX_TILES = 16384;  // 64 KiB of LDS counters
 constexpr int GROUP_BIG_RECT = 64;
@@ -19,8 +20,8 @@ static_assert(GROUP_BIG_RECT == RECT_MASK_TILES, "rectangles walked by the whole
 
 // visit(tile, id) for every listed (Gaussian, tile) pair of the rectangles the wave's lanes hold (r: the lane's rect[],
 // all zero for a lane without a Gaussian).  Must be reached by all lanes of the wave: rectangles of more than 64 tiles
-// (no mask, every tile listed) are walked by the whole wave, so that one screen-filling Gaussian does not serialise
-// thousands of LDS atomics on one lane.
+// (one mask bit per block of tiles, common.hpp: RectBlocks) are walked by the whole wave, so that one screen-filling
+// Gaussian does not serialise thousands of LDS atomics on one lane.
 template <typename F>
 __device__ __forceinline__ void for_each_pair_of_rect(const uint4 r, int i, int gx, F visit) {
     const int lane = threadIdx.x & 63;
@@ -39,7 +40,12 @@ __device__ __forceinline__ void for_each_pair_of_rect(const uint4 r, int i, int 
         big &= big - 1;
         const int bx0 = __shfl(x0, src, 64), by0 = __shfl(y0, src, 64), bw = __shfl(w, src, 64), barea = __shfl(area, src, 64);
         const uint32_t bi = (uint32_t)__shfl(i, src, 64);
-        for (int t = lane; t < barea; t += 64) visit((by0 + t / bw) * gx + bx0 + t % bw, bi);
+        const uint64_t bm = (uint64_t)(uint32_t)__shfl((int)r.z, src, 64) | ((uint64_t)(uint32_t)__shfl((int)r.w, src, 64) << 32);
+        const RectBlocks g(bw, barea / bw);
+        for (int t = lane; t < barea; t += 64) {
+            const int tx = t % bw, ty = t / bw;
+            if ((bm >> g.block_of(tx, ty)) & 1ull) visit((by0 + ty) * gx + bx0 + tx, bi);
+        }
     }
 }
 

@@ -112,33 +112,60 @@ struct TileReach {
         bound = __logf(op * 255.f) + 0.02f + 2e-5f * (a * far_x * far_x + c * far_y * far_y);
     }
     // pixel rectangle [x0, x0 + 15] x [y0, y0 + 15]
-    __device__ __forceinline__ bool tile(float x0, float y0) const {
-        const float dx_hi = mx - x0, dx_lo = dx_hi - (float)(TILE - 1), dy_hi = my - y0, dy_lo = dy_hi - (float)(TILE - 1);
+    __device__ __forceinline__ bool tile(float x0, float y0) const { return rect(x0, y0, (float)(TILE - 1), (float)(TILE - 1)); }
+    // pixel rectangle [x0, x0 + w] x [y0, y0 + h] (a block of tiles: the same bound, the rectangle lies inside the one
+    // the margin was taken over)
+    __device__ __forceinline__ bool rect(float x0, float y0, float w, float h) const {
+        const float dx_hi = mx - x0, dx_lo = dx_hi - w, dy_hi = my - y0, dy_lo = dy_hi - h;
         const float dxn = __builtin_amdgcn_fmed3f(0.f, dx_lo, dx_hi), dyn = __builtin_amdgcn_fmed3f(0.f, dy_lo, dy_hi);
         const float dy1 = __builtin_amdgcn_fmed3f(nb_inv_c * dxn, dy_lo, dy_hi);   // along the edge dx = dxn
         const float dx2 = __builtin_amdgcn_fmed3f(nb_inv_a * dyn, dx_lo, dx_hi);   // along the edge dy = dyn
         const float q1 = 0.5f * (a * dxn * dxn + c * dy1 * dy1) + b * dxn * dy1;
         const float q2 = 0.5f * (a * dx2 * dx2 + c * dyn * dyn) + b * dx2 * dyn;
-        return (fminf(q1, q2) <= bound || always) && !never;   // (mean inside the tile: q1 = q2 = 0)
+        return (fminf(q1, q2) <= bound || always) && !never;   // (mean inside the rectangle: q1 = q2 = 0)
     }
 };
 
 // ---- the tile rectangle of a Gaussian and which of its tiles it can reach ----
 // rect[i] = (x0 | x1 << 16, y0 | y1 << 16, mask lo, mask hi): the rectangle of 16x16 tiles covered by the 3-sigma
-// radius (what the reference pairs the Gaussian with), and, for rectangles of up to 64 tiles, one bit per tile in
-// row-major order: set when reaches_rect() cannot rule out alpha >= 1/255 on some pixel of the tile.  Only those
-// (Gaussian, tile) pairs are listed; a dropped pair contributes nothing to any pixel, so every output is unchanged.
-// Larger rectangles keep all their tiles (mask = all ones).
+// radius (what the reference pairs the Gaussian with) and 64 bits that say which of its tiles are LISTED:
+//  * rectangles of up to 64 tiles: one bit per tile in row-major order, set when TileReach cannot rule out alpha >= 1/255
+//    on some pixel of the tile;
+//  * larger rectangles: one bit per BLOCK of tiles -- the rectangle is cut into an 8 x 8 grid of blocks of
+//    ceil(w / 8) x ceil(h / 8) tiles (bit 8 * block row + block column; fewer blocks where the sizes do not divide) --
+//    set when the Gaussian can reach some pixel of the block; every tile of a kept block is listed.  (Until round 3 such
+//    rectangles listed every tile: the large-footprint Gaussians real maps are made of got no culling at all.)
+// Only listed (Gaussian, tile) pairs exist downstream; a dropped pair contributes nothing to any pixel, so every output is
+// unchanged.  A Gaussian's pairs are numbered 0 .. tiles_touched - 1 (its gradient slots behind slot_base[i]): row-major
+// over the kept tiles, resp. kept blocks in bit order and row-major inside a block (rect_rank).
 constexpr int RECT_MASK_TILES = 64;
-__device__ __forceinline__ bool rect_keeps(const uint4 r, int k, int area) {
-    if (area > RECT_MASK_TILES) return true;
-    return (k < 32 ? r.z >> k : r.w >> (k - 32)) & 1u;
-}
-// position of tile k of the rectangle among the kept ones (the pair's slot behind slot_base[i])
-__device__ __forceinline__ uint32_t rect_rank(const uint4 r, int k, int area) {
-    if (area > RECT_MASK_TILES) return (uint32_t)k;
+struct RectBlocks {   // the block grid of a rectangle of more than RECT_MASK_TILES tiles
+    int w, h, bw, bh;
+    __device__ __forceinline__ RectBlocks(int w_, int h_) : w(w_), h(h_), bw((w_ + 7) >> 3), bh((h_ + 7) >> 3) {}
+    __device__ __forceinline__ int block_of(int tx, int ty) const { return (ty / bh) * 8 + tx / bw; }   // tx, ty relative to the rectangle
+    __device__ __forceinline__ int width(int b) const { return min(bw, w - (b & 7) * bw); }              // <= 0: no such block
+    __device__ __forceinline__ int height(int b) const { return min(bh, h - (b >> 3) * bh); }
+};
+__device__ __forceinline__ bool rect_keeps(const uint4 r, int k, int area) {   // k: row-major tile index inside the rectangle
     const uint64_t m = (uint64_t)r.z | ((uint64_t)r.w << 32);
-    return (uint32_t)__popcll(m & ((1ull << k) - 1ull));
+    if (area <= RECT_MASK_TILES) return (m >> k) & 1ull;
+    const int w = (int)(r.x >> 16) - (int)(r.x & 0xffffu);
+    const RectBlocks g(w, area / w);
+    return (m >> g.block_of(k % w, k / w)) & 1ull;
+}
+// position of tile k of the rectangle among the listed ones (the pair's slot behind slot_base[i])
+__device__ __forceinline__ uint32_t rect_rank(const uint4 r, int k, int area) {
+    const uint64_t m = (uint64_t)r.z | ((uint64_t)r.w << 32);
+    if (area <= RECT_MASK_TILES) return (uint32_t)__popcll(m & ((1ull << k) - 1ull));
+    const int w = (int)(r.x >> 16) - (int)(r.x & 0xffffu);
+    const RectBlocks g(w, area / w);
+    const int tx = k % w, ty = k / w, b = g.block_of(tx, ty);
+    uint32_t rank = (uint32_t)((ty % g.bh) * g.width(b) + tx % g.bw);
+    for (uint64_t below = m & ((1ull << b) - 1ull); below; below &= below - 1) {
+        const int q = __builtin_ctzll(below);
+        rank += (uint32_t)(g.width(q) * g.height(q));
+    }
+    return rank;
 }
 
 // ---- state layouts ----

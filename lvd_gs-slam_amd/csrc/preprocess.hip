@@ -311,18 +311,39 @@ __device__ __forceinline__ void preprocess_one(const FwdParams &p, int i, uint32
                 uint64_t mask = ~0ull;
                 radius = rad; tiles = (uint32_t)area;
                 if (area == 0) { x0 = x1 = y0 = y1 = 0; mask = 0ull; }   // not in this band
-                else if (p.tile_cull && area <= RECT_MASK_TILES) {
+                else if (p.tile_cull) {
                     const float far_x = fmaxf(fabsf(px - (float)(x0 * TILE)), fabsf(px - (float)(x1 * TILE - 1)));
                     const float far_y = fmaxf(fabsf(py - (float)(y0 * TILE)), fabsf(py - (float)(y1 * TILE - 1)));
                     const TileReach reach(px, py, k0, k1, k2, opac, far_x, far_y);
                     mask = 0ull;
-                    uint64_t bit = 1ull;
-                    for (int y = y0; y < y1; y++)
-                        for (int x = x0; x < x1; x++) {
-                            if (reach.tile((float)(x * TILE), (float)(y * TILE))) mask |= bit;
-                            bit <<= 1;
+                    if (area <= RECT_MASK_TILES) {
+                        uint64_t bit = 1ull;
+                        for (int y = y0; y < y1; y++)
+                            for (int x = x0; x < x1; x++) {
+                                if (reach.tile((float)(x * TILE), (float)(y * TILE))) mask |= bit;
+                                bit <<= 1;
+                            }
+                        tiles = (uint32_t)__popcll(mask);
+                    } else {
+                        // one bit per block of tiles (common.hpp: RectBlocks): the same test on the block's pixel rectangle
+                        const RectBlocks g(x1 - x0, y1 - y0);
+                        tiles = 0;
+                        for (int b = 0; b < 64; b++) {
+                            const int bwid = g.width(b), bhei = g.height(b);
+                            if (bwid <= 0 || bhei <= 0) continue;
+                            const int tx = x0 + (b & 7) * g.bw, ty = y0 + (b >> 3) * g.bh;
+                            if (reach.rect((float)(tx * TILE), (float)(ty * TILE), (float)(bwid * TILE - 1), (float)(bhei * TILE - 1))) {
+                                mask |= 1ull << b;
+                                tiles += (uint32_t)(bwid * bhei);
+                            }
                         }
-                    tiles = (uint32_t)__popcll(mask);
+                    }
+                } else if (area > RECT_MASK_TILES) {
+                    // every tile listed: all blocks that exist are kept
+                    const RectBlocks g(x1 - x0, y1 - y0);
+                    mask = 0ull;
+                    for (int b = 0; b < 64; b++)
+                        if (g.width(b) > 0 && g.height(b) > 0) mask |= 1ull << b;
                 }
                 rect = make_uint4((uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16), (uint32_t)mask, (uint32_t)(mask >> 32));
                 depth_bits = __float_as_uint(pv[2]);
@@ -463,9 +484,17 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
                     }
                 }
             for (int k = nb; k < c.M; k++) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
+            // The view direction d = mean - camera centre moves with the mean and with the camera: C = -R^T T, and under
+            // T_w2c <- Exp(tau) T_w2c dC/drho = -R^T, dC/dtheta = 0 at tau = 0, so dL/drho += R g_d (oracle: same statement,
+            // pinned against the dense autograd formulation in float64).  Zero at SH degree 0.
             const float dot = u[0] * g_u[0] + u[1] * g_u[1] + u[2] * g_u[2];
 #pragma unroll
-            for (int a = 0; a < 3; a++) g_world[a] += (g_u[a] - u[a] * dot) / len;
+            for (int a = 0; a < 3; a++) {
+                const float g_d = (g_u[a] - u[a] * dot) / len;
+                g_world[a] += g_d;
+#pragma unroll
+                for (int j = 0; j < 3; j++) tau[j] += V[4 * a + j] * g_d;
+            }
         }
 
         // ---- conic -> cov2D -> (cov3D, T) ----
@@ -551,7 +580,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
 
         // ---- camera pose: T' = Exp(tau) T ----
         const float gv[3] = {g_pview[0] + g_pview_proj[0], g_pview[1] + g_pview_proj[1], g_pview[2] + g_pview_proj[2]};
-        tau[0] = gv[0]; tau[1] = gv[1]; tau[2] = gv[2];
+        tau[0] += gv[0]; tau[1] += gv[1]; tau[2] += gv[2];
         tau[3] = pv[1] * gv[2] - pv[2] * gv[1];
         tau[4] = pv[2] * gv[0] - pv[0] * gv[2];
         tau[5] = pv[0] * gv[1] - pv[1] * gv[0];

@@ -78,6 +78,43 @@ def make_gaussians(N, W, H, seed=0, sh_degree=0, r_min=0.5, r_max=8.0, z_min=1.0
                 opacities=opac.contiguous(), shs=shs.contiguous(), colors=rgb.contiguous())
 
 
+def make_surface_gaussians(N, W, H, seed=0, r_min=4.0, r_max=64.0):
+    """The regime real SLAM maps live in, which ``make_gaussians``' small random blobs never reach: opaque surfaces made
+    of large, flat Gaussians.  Three slanted planes (depths around 3, 6 and 12, half of the Gaussians on the front one),
+    footprints of r_min..r_max pixels (log-uniform, the in-plane sigma; a tenth of it along the normal), opacity
+    sigmoid(N(2, 1)) ~ 0.88: tile lists of 500-2000 entries at ~100 Gaussians per 16x16 tile's worth of area, nearly
+    every pixel saturating (transmittance below 1e-4) long before its list ends, rectangles of up to several hundred
+    tiles.  Same dict as ``make_gaussians``."""
+    g = torch.Generator().manual_seed(seed)
+    u = lambda *s: torch.rand(*s, generator=g)
+    fx = float(W)
+    plane = torch.multinomial(torch.tensor([0.5, 0.3, 0.2]), N, replacement=True, generator=g)
+    z0 = torch.tensor([3.0, 6.0, 12.0])[plane]
+    slant = torch.tensor([[0.25, -0.1], [-0.2, 0.15], [0.1, 0.2]])[plane]
+    px = (u(N) * 1.2 - 0.1) * W
+    py = (u(N) * 1.2 - 0.1) * H
+    z = z0 * (1.0 + slant[:, 0] * (px / W - 0.5) + slant[:, 1] * (py / H - 0.5)) * (1.0 + 0.01 * torch.randn(N, generator=g))
+    x = (px - W / 2.0) * z / fx
+    y = (py - H / 2.0) * z / fx
+    r = torch.exp(u(N) * (math.log(r_max) - math.log(r_min)) + math.log(r_min))
+    s_in = (z * r / fx)[:, None] * (0.7 + 0.6 * u(N, 2))
+    scales = torch.cat([s_in, 0.1 * s_in.mean(1, keepdim=True)], 1)      # thin along the (local) z axis
+    q = torch.cat([torch.ones(N, 1), 0.15 * torch.randn(N, 3, generator=g)], 1)   # near the identity: the thin axis faces the camera
+    q = q / q.norm(dim=1, keepdim=True)
+    opac = torch.sigmoid(2.0 + torch.randn(N, 1, generator=g))
+    rgb = u(N, 3)
+    shs = ((rgb - 0.5) / SH_C0)[:, None, :].contiguous()
+    return dict(means3D=torch.stack([x, y, z], 1).contiguous(), scales=scales.contiguous(), rotations=q.contiguous(),
+                opacities=opac.contiguous(), shs=shs, colors=rgb.contiguous())
+
+
+def make_workload_gaussians(name, seed=0):
+    """The Gaussians of ``CONFIGS[name]`` (``kind``: "blobs", the default, or "surface")."""
+    cfg = CONFIGS[name]
+    make = make_surface_gaussians if cfg.get("kind") == "surface" else make_gaussians
+    return make(cfg["N"], cfg["W"], cfg["H"], seed=seed)
+
+
 def make_image_grads(W, H, seed=0):
     """Fixed seeded N(0,1) upstream gradients for (render, depth, opacity)."""
     g = torch.Generator().manual_seed(7000 + seed)
@@ -96,4 +133,7 @@ CONFIGS = {
     "kitti07_x4": dict(N=800_000, W=2452, H=740, fx=1414.1824, fy=1414.1824, cx=1203.7746, cy=366.2208),
     # BASELINE.json configs[4] shape: 2 M Gaussians, waymo-sized frames (configs/mono/waymo/405841.yaml:15-16)
     "cfg5_2m_1920x1280": dict(N=2_000_000, W=1920, H=1280),
+    # opaque surfaces of large flat Gaussians (make_surface_gaussians): lists of ~1000 entries per tile, saturating pixels
+    "surface_100k_1920x1080": dict(N=100_000, W=1920, H=1080, kind="surface"),
+    "surface_12k_640x480": dict(N=12_000, W=640, H=480, kind="surface"),
 }

@@ -501,6 +501,7 @@ int oracle_backward(oracle_ctx *c) {
         c->dL_dmeans2D[3 * i + 1] = g_pix[1] * (real)0.5 * (real)H;
 
         real g_pview[3] = {0, 0, g_z}; /* gradient w.r.t. the view-space mean (pose path) */
+        real g_tau_sh[3] = {0, 0, 0};  /* d/d rho through the SH view direction */
         real g_world[3] = {0, 0, 0};   /* gradient w.r.t. the world mean */
 
         /* -- colour -- */
@@ -519,10 +520,16 @@ int oracle_backward(oracle_ctx *c) {
                     c->dL_dshs[((size_t)i * M + k) * 3 + ch] = B[k] * g_rgb[ch];
                     for (int a = 0; a < 3; a++) g_u[a] += Gb[k][a] * s * g_rgb[ch];
                 }
-            /* u = d/|d| : du/dd = (I - u u^T)/|d| ; the view direction moves with the mean only
-             * (the camera centre is treated as constant: no pose gradient through colour) */
+            /* u = d/|d| : du/dd = (I - u u^T)/|d|, d = mean - camera centre.  The view direction moves with the mean AND
+             * with the camera: centre C = -R^T T, and under T_w2c <- Exp(tau) T_w2c (utils/pose_utils.py:70-87)
+             * dC/drho = -R^T, dC/dtheta = 0 at tau = 0, so dL/drho += R g_d with g_d = dL/dd (checked against the dense
+             * autograd formulation and finite differences in float64, tests/test_oracle_pinning.py).  Zero at SH degree 0. */
             real dot = u[0] * g_u[0] + u[1] * g_u[1] + u[2] * g_u[2];
-            for (int a = 0; a < 3; a++) g_world[a] += (g_u[a] - u[a] * dot) / len;
+            for (int a = 0; a < 3; a++) {
+                real g_d = (g_u[a] - u[a] * dot) / len;
+                g_world[a] += g_d;
+                for (int j = 0; j < 3; j++) g_tau_sh[j] += V[4 * a + j] * g_d;
+            }
         }
 
         /* -- depth image: z_view = row 2 of the view transform -- */
@@ -598,7 +605,7 @@ int oracle_backward(oracle_ctx *c) {
         /* -- pose: T' = Exp(tau) T.  p_view' = p_view + rho + theta x p_view ;
          *          Wrot' = (I + [theta]x) Wrot  => each column w_c moves by theta x w_c      */
         real gv[3] = {g_pview[0] + g_pview_proj[0], g_pview[1] + g_pview_proj[1], g_pview[2] + g_pview_proj[2]};
-        tau[0] += gv[0]; tau[1] += gv[1]; tau[2] += gv[2];
+        tau[0] += gv[0] + g_tau_sh[0]; tau[1] += gv[1] + g_tau_sh[1]; tau[2] += gv[2] + g_tau_sh[2];
         tau[3] += pv[1] * gv[2] - pv[2] * gv[1];
         tau[4] += pv[2] * gv[0] - pv[0] * gv[2];
         tau[5] += pv[0] * gv[1] - pv[1] * gv[0];

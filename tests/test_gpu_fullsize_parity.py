@@ -33,7 +33,7 @@ def _workload(name, pose_seed):
     from lvdgs import synthetic
     cfg = synthetic.CONFIGS[name]
     N, W, H = cfg["N"], cfg["W"], cfg["H"]
-    g = synthetic.make_gaussians(N, W, H, seed=0)
+    g = synthetic.make_workload_gaussians(name, seed=0)
     cam = synthetic.make_camera(W, H, pose_seed=pose_seed, **{k: cfg[k] for k in ("fx", "fy", "cx", "cy") if k in cfg})
     return g, cam, N, W, H
 
@@ -63,6 +63,33 @@ def test_full_size_forward_and_backward_match_oracle(name, pose_seed):
     np.testing.assert_array_equal(f_all["ranges"], f_ora["ranges"])
     solid = f_ora["fragile"] == 0
     np.testing.assert_array_equal(f_all["n_contrib"][solid], f_ora["n_contrib"][solid])
+    for k in ("color", "depth", "opacity", "final_T", "radii", "n_touched"):
+        np.testing.assert_array_equal(f_all[k], f_hip[k], err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["surface_12k_640x480", "surface_100k_1920x1080"])
+def test_opaque_surfaces_of_large_gaussians_match_oracle(name):
+    """The regime real maps live in (synthetic.make_surface_gaussians): large flat Gaussians on opaque surfaces -- tile
+    lists of ~900-1300 entries (beyond one wave's register sort at the long end: the tile sort's queue and its in-launch
+    workgroup sort), a third of the rectangles above 64 tiles (culled per block of tiles), pixels that saturate after a
+    tenth of their list (early termination, last-contributor culling in the backward pass), a pair count far beyond the
+    first capacity guess (the overflow re-run).  Forward and backward against the oracle, and the exact list mode."""
+    orc, hr, syn = tp._mods()
+    g, cam, N, W, H = _workload(name, 2)
+    bg = torch.tensor([0.1, 0.3, 0.2])
+    grads = syn.make_image_grads(W, H, 0)
+    f_hip, b_hip = hr.run_hip(g, cam, W, H, bg, grads=grads)
+    f_ora, b_ora = hr.run_oracle(orc, g, cam, W, H, bg, grads=grads)
+    lists = f_ora["ranges"][:, 1].astype(np.int64) - f_ora["ranges"][:, 0]
+    assert lists.mean() > 500 and lists.max() > 1024 and (f_ora["tiles_touched"] > 64).mean() > 0.2
+    assert f_ora["n_contrib"].mean() < 0.25 * lists.mean()          # pixels saturate early
+    assert f_hip["num_rendered"] < 0.8 * f_ora["num_rendered"]      # block + tile culling together
+    tp._check_forward(f_hip, f_ora, W, H)
+    tp._check_backward(b_hip, b_ora, GRADS, f_ora, W, H)
+    f_all, _ = hr.run_hip(g, cam, W, H, bg, tile_cull=False)
+    assert f_all["num_rendered"] == f_ora["num_rendered"]
+    np.testing.assert_array_equal(f_all["point_list"], f_ora["ids_sorted"])
+    np.testing.assert_array_equal(f_all["ranges"], f_ora["ranges"])
     for k in ("color", "depth", "opacity", "final_T", "radii", "n_touched"):
         np.testing.assert_array_equal(f_all[k], f_hip[k], err_msg=k)
 

@@ -4,6 +4,7 @@ sorted tile/depth/id lists, tile ranges) must be bit-exact; rendered images and 
 agree within 1e-4 relative (BASELINE.json north_star).  Blend-time counters (n_contrib,
 n_touched) depend on exp() rounding at the 1/255, 1e-4 and 0.5 thresholds, so they are required
 to be exact wherever the oracle did not flag a comparison as within 1e-5 of its threshold."""
+import math
 import os
 import sys
 
@@ -401,27 +402,39 @@ def test_tile_culling_changes_no_output_bit_and_without_it_the_lists_are_the_ref
     _check_backward(b_on, b_ora, ["means3D", "means2D", "opacities", "scales", "rotations", "colors", "tau"], f_ora, W, H)
 
 
-def test_rectangles_of_more_than_64_tiles_keep_every_tile_next_to_culled_small_ones():
-    """A Gaussian whose 3-sigma square spans more than 64 tiles has no kept-tile mask (every tile listed, gradient slot =
-    tile index in the rectangle, walked by a whole wave in the grouping kernels); small ones beside it are culled per
-    tile.  Both kinds in one scene, forward and backward against the oracle."""
+@pytest.mark.parametrize("tile_cull", [True, False])
+def test_rectangles_of_more_than_64_tiles_are_culled_by_blocks_of_tiles(tile_cull):
+    """A Gaussian whose 3-sigma square spans more than 64 tiles has one mask bit per BLOCK of tiles (an 8 x 8 grid of
+    blocks over its rectangle, common.hpp: RectBlocks); its gradient slots follow the kept blocks, and the grouping
+    kernels walk it with a whole wave.  Round blobs keep nearly everything, long thin ones -- the footprint of a wall seen
+    at a grazing angle -- lose most of their square; small Gaussians beside them are culled per tile.  All kinds in one
+    scene, forward and backward against the oracle; with LVDGS_FLAG_LIST_ALL_TILES every tile is listed again."""
     orc, hr, syn = _mods()
-    W, H, N = 272, 176, 600                        # 17 x 11 = 187 tiles
+    W, H, N = 400, 304, 600                        # 25 x 19 = 475 tiles
     g = syn.make_gaussians(N, W, H, seed=33, r_min=0.5, r_max=6.0)
-    with torch.no_grad():                          # three screen-filling ones, faint enough not to hide the rest
-        for i, z in ((0, 2.0), (1, 5.0), (2, 9.0)):
+    with torch.no_grad():
+        for i, z in ((0, 2.0), (1, 5.0), (2, 9.0)):   # three large round ones, faint enough not to hide the rest
             g["means3D"][i] = torch.tensor([0.02 * i, -0.01 * i, z])
-            g["scales"][i] = torch.tensor([0.5, 0.35, 0.2]) * z
+            g["scales"][i] = torch.tensor([0.4, 0.3, 0.2]) * z
             g["opacities"][i] = 0.15
+        for i, (z, ang) in enumerate(((3.0, 0.5), (4.0, -0.9), (6.0, 1.3), (2.5, 0.1)), start=3):   # long thin ones, at an angle
+            g["means3D"][i] = torch.tensor([0.1 * (i - 4), 0.05 * (5 - i), z])
+            g["scales"][i] = torch.tensor([0.45, 0.012, 0.012]) * z
+            g["rotations"][i] = torch.tensor([math.cos(ang / 2), 0.0, 0.0, math.sin(ang / 2)])
+            g["opacities"][i] = 0.6
     cam = syn.make_camera(W, H, pose_seed=6)
     bg = torch.tensor([0.2, 0.2, 0.2])
     grads = syn.make_image_grads(W, H, 5)
-    f_hip, b_hip = hr.run_hip(g, cam, W, H, bg, grads=grads)
+    f_hip, b_hip = hr.run_hip(g, cam, W, H, bg, grads=grads, tile_cull=tile_cull)
     f_ora, b_ora = hr.run_oracle(orc, g, cam, W, H, bg, grads=grads)
     big = f_ora["tiles_touched"] > 64
-    assert big.sum() >= 3
-    np.testing.assert_array_equal(f_hip["tiles_touched"][big], f_ora["tiles_touched"][big])     # no tile dropped
-    assert (f_hip["tiles_touched"][~big] < f_ora["tiles_touched"][~big]).any()                  # culled beside them
+    assert big.sum() >= 7
+    if tile_cull:
+        kept = f_hip["tiles_touched"][big].astype(np.float64) / f_ora["tiles_touched"][big]
+        assert kept.min() < 0.45 and kept.max() > 0.8, kept          # the thin ones lose most of their square, the round ones little
+        assert (f_hip["tiles_touched"][~big] < f_ora["tiles_touched"][~big]).any()                  # culled beside them
+    else:
+        np.testing.assert_array_equal(f_hip["tiles_touched"], f_ora["tiles_touched"])
     _check_forward(f_hip, f_ora, W, H)
     _check_backward(b_hip, b_ora, ["means3D", "means2D", "opacities", "scales", "rotations", "colors", "tau"], f_ora, W, H)
 

@@ -34,7 +34,7 @@ def _dense(g, cam, W, H, bg, tau, use_sh, sh_degree=0, cov_precomp=None, req=())
         kw = dict(cov3D_precomp=cov_precomp)
     out = ref_torch.render_dense(
         leaves["means3D"], leaves["opacities"], H, W, cam.tanfovx, cam.tanfovy, bg, view, proj,
-        campos.detach(), shs=leaves["shs"] if use_sh else None,
+        campos, shs=leaves["shs"] if use_sh else None,
         colors_precomp=None if use_sh else leaves["colors"], sh_degree=sh_degree, **kw)
     return out, leaves
 
@@ -115,7 +115,9 @@ def test_backward_sh_degrees(deg):
     g, cam = _scene(N, W, H, seed=10 + deg, sh_degree=deg)
     g["shs"][:, 0] -= 1.2  # push some channels below zero so the clamp mask is exercised
     bg = torch.zeros(3, dtype=torch.float64)
-    tau = torch.zeros(6, dtype=torch.float64)
+    # tau takes part in the graph: the camera centre in the SH view direction depends on the pose (C = -R^T T), so the
+    # colours -- and with them dL/dtau -- do too once the degree is above 0
+    tau = torch.zeros(6, dtype=torch.float64, requires_grad=True)
     ref, lv = _dense(g, cam, W, H, bg, tau, use_sh=True, sh_degree=deg, req=("means3D", "shs", "opacities"))
     gc, gd, go = _loss_weights(W, H, deg)
     ((ref["color"] * gc).sum() + (ref["depth"] * gd).sum()).backward()
@@ -126,6 +128,8 @@ def test_backward_sh_degrees(deg):
     for name in ("means3D", "shs", "opacities"):
         b = lv[name].grad.numpy().reshape(gr[name].shape)
         np.testing.assert_allclose(gr[name], b, rtol=1e-7, atol=1e-9 * np.abs(b).max(), err_msg=name)
+    t = tau.grad.numpy()
+    np.testing.assert_allclose(gr["tau"], t, rtol=1e-7, atol=1e-9 * np.abs(t).max(), err_msg="tau (incl. the view-direction path)")
     o.free()
 
 

@@ -21,11 +21,7 @@ n_window = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 n_older = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 dev = torch.device("cuda", 0)
 model, _, _, (N, W, H) = bench.build_scene(workload, 0, dev)
-be, _ = bench.build_window(workload, n_window + n_older, dev, model)
-window = list(range(n_window + n_older, n_older, -1))      # the newest n_window keyframes; 1..n_older are the older ones
-be.current_window = window
-groups = [gp for gp in be.keyframe_optimizers.param_groups if any(gp["name"].endswith(f"_{kf}") for kf in window)]
-be.keyframe_optimizers = torch.optim.Adam(groups)
+be, window = bench.build_window(workload, n_window + n_older, dev, model, n_window=n_window)   # the newest n_window keyframes; 1..n_older are the older ones
 # MAP_BENCH_FUSED_ONLY=1 (under rocprofv3 --kernel-trace --stats): 28 fused iterations and nothing else, so that the trace's
 # kernel time / 28 is the GPU-busy time of one iteration without this script's own event timing
 for fused in ((True,) if os.environ.get("MAP_BENCH_FUSED_ONLY") else (True, False)):
