@@ -166,6 +166,7 @@ size_t bin_layout(int64_t D, BinView *v, void *base) {
     const size_t d = (size_t)(D > 0 ? D : 1);
     carve(v->point_list, d, b, off);
     carve(v->tile_keys, d, b, off);
+    carve(v->pair_valid, d + 16, b, off);
     return off;
 }
 
@@ -282,10 +283,10 @@ int lvdgs_state_layout_query(int32_t N, int64_t D, int32_t W, int32_t H, lvdgs_s
 namespace {
 struct PairProbe {
     int device = -1;
-    uint32_t *pinned = nullptr;   // [0] pair count, [1] longest queued tile segment of the frame
+    uint32_t *pinned = nullptr;   // [0] pair count, [1] longest queued tile segment of the frame, [2] length of that queue
     hipEvent_t ready = nullptr;
-    int big_segments = 0;         // > 0: a recent frame on this device had tile segments beyond the in-launch sort's reach; the
-                                  // next frames launch the 128 KiB-LDS sort behind the tile sort (a hint, never a result)
+    int longest = 0, queued = 0;  // of the previous frame on this device: which kernels for long segments the next frame
+    int keep = 0;                 // launches behind its tile sort (a hint, never a result); kept for a few frames
 };
 thread_local PairProbe g_probe[16];
 
@@ -312,7 +313,7 @@ int enqueue_prepare(const lvdgs_args *a, const GeomView &g, hipStream_t s) {
 }
 
 int enqueue_count_probe(PairProbe *probe, const uint32_t *total, hipStream_t s) {
-    if (int e = check_hip(hipMemcpyAsync(probe->pinned, total, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read pair count")) return e;
+    if (int e = check_hip(hipMemcpyAsync(probe->pinned, total, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read pair count")) return e;
     return check_hip(hipEventRecord(probe->ready, s), "record pair count event");
 }
 
@@ -347,7 +348,7 @@ int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipSt
             if (int e = launch_group_scan(*a, im, w, cap, counted ? g.total : nullptr, s)) return e;
             if (counted && probe)
                 if (int e = enqueue_count_probe(probe, g.total, s)) return e;
-            if (int e = launch_group_scatter(*a, g, im, w, (unsigned long long *)w.keys, cap, counted, s)) return e;
+            if (int e = launch_group_scatter(*a, g, im, w, (unsigned long long *)w.keys, cap, counted, b.pair_valid, s)) return e;
             grouped = true;
         } else {
             if (!w.hist) { set_error("internal: scratch was not laid out for the radix grouping"); return LVDGS_E_INVALID; }
@@ -356,6 +357,7 @@ int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipSt
             const bool start_in_state = (radix_num_passes(bits) % 2) == 0;
             uint32_t *k0 = start_in_state ? b.tile_keys : w.keys, *v0 = start_in_state ? b.point_list : w.vals;
             uint32_t *k1 = start_in_state ? w.keys : b.tile_keys, *v1 = start_in_state ? w.vals : b.point_list;
+            if (int e = check_hip(hipMemsetAsync(b.pair_valid, 0, (size_t)cap, s), "memset pair_valid")) return e;
             if (int e = launch_emit_pairs(*a, g, k0, v0, cap, s)) return e;
             bool in_first = true;
             if (int e = radix_sort_pairs(k0, v0, k1, v1, cap, bits, w.hist, w.totals, &in_first, a->debug, s, count)) return e;
@@ -366,9 +368,9 @@ int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipSt
         if (int e = launch_tile_ranges(b.tile_keys, cap, count, im, num_tiles, a->debug, s)) return e;
     // w.keys + w.vals: the (depth, id) keys the counting path scattered, or scratch for over-long segments after the radix path
     if (cap > 0) {
-        // segments beyond the in-launch sort's reach: expected when a recent frame had them (single-call forward), assumed otherwise
-        const bool big = probe ? probe->big_segments > 0 : true;
-        if (int e = launch_tile_depth_sort(im, num_tiles, row0 * gx, row1 * gx, g.rec, b.point_list, w.keys, grouped, big, a->debug, s)) return e;
+        // long segments: expected as the recent frames on this device had them (single-call forward), unknown otherwise
+        if (int e = launch_tile_depth_sort(im, num_tiles, row0 * gx, row1 * gx, g.rec, b.point_list, w.keys, grouped, probe ? probe->longest : -1,
+                                           probe ? probe->queued : 0, a->debug, s)) return e;
     }
     return launch_blend_fwd(*a, g, b, im, s);
 }
@@ -459,9 +461,10 @@ int lvdgs_forward(const lvdgs_args *a, int64_t *num_rendered, void *stream) {
     if (int e = enqueue_render(a, cap, true, s, counted, probe)) return e;
     if (int e = check_hip(hipEventSynchronize(probe->ready), "wait for pair count")) return e;
     const uint32_t total = probe->pinned[0];
-    if (counted) {   // keep launching the big-segment sort for a while after a frame that needed it
-        if ((int)probe->pinned[1] > tile_sort_in_launch_limit()) probe->big_segments = 64;
-        else if (probe->big_segments > 0) probe->big_segments--;
+    if (counted) {   // what the next frames expect: this frame's long segments, or a recent frame's for a while (views alternate)
+        const int longest = (int)probe->pinned[1], queued = (int)probe->pinned[2];
+        if (longest >= probe->longest || probe->keep == 0) { probe->longest = longest; probe->queued = queued; probe->keep = longest ? 32 : 0; }
+        else probe->keep--;
     }
     if (total > 0x7FFFFFFFu) { set_error("%u (Gaussian, tile) pairs exceed the 2^31 limit", total); return LVDGS_E_RANGE; }
     *num_rendered = (int64_t)total;
@@ -504,7 +507,7 @@ static int backward_impl(const lvdgs_args *a, const LossParams *fused, int propa
         if (int e = launch_blend_bwd(*a, g, b, im, w, s)) return e;
     }
     if (N == 0) return a->dL_dtau ? check_hip(hipMemsetAsync(a->dL_dtau, 0, 6 * sizeof(float), s), "memset tau") : LVDGS_OK;
-    return launch_preprocess_bwd(*a, g, w, s);
+    return launch_preprocess_bwd(*a, g, w, b.pair_valid, s);
 }
 
 int lvdgs_backward(const lvdgs_args *a, void *stream) { return backward_impl(a, nullptr, 0, (hipStream_t)stream); }

@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(1024) group_tilescan_kernel(int T, const uint3
     __syncthreads();
     if (threadIdx.x == 0) {
         *queue_count = s_q;
-        if (total_out) total_out[1] = s_longest;   // longest queued segment (0: none), read back with the pair count
+        if (total_out) { total_out[1] = s_longest; total_out[2] = s_q; }   // longest queued segment (0: none) and the queue's length, read back with the pair count
     }
     if (!tile_order) return;
     // counting sort of the tiles by bucket 1023 - min(length / 8, 1023): bucket 0 holds the longest lists
@@ -255,13 +255,15 @@ __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int
                                                                      const uint32_t *__restrict__ depth_bits,
                                                                      unsigned long long *__restrict__ keys64,
                                                                      const uint32_t *__restrict__ tt, const uint32_t *__restrict__ chunk_sums,
-                                                                     uint32_t *__restrict__ slot_base) {
+                                                                     uint32_t *__restrict__ slot_base, uint8_t *__restrict__ pair_valid) {
     static_assert(GROUP_THREADS == 1024, "scan_1024");
     constexpr int GROUP_CHUNK = GROUP_THREADS * PER;
     extern __shared__ uint32_t s_tile[];
     __shared__ uint32_t s_scan[33];
+    __shared__ uint32_t s_slots[2];
     const uint32_t *row = hist + (size_t)blockIdx.x * T;
     for (int t = threadIdx.x; t < T; t += GROUP_THREADS) s_tile[t] = ranges[t].x + row[t];  // (empty tiles are never visited)
+    uint32_t slots_lo = 0, slots_hi = 0;   // the chunk's Gaussians' gradient slots: [lo, hi)
     if constexpr (SLOT_SCAN) {
         uint32_t before = 0;
         for (int b = threadIdx.x; b < (int)blockIdx.x; b += GROUP_THREADS) before += chunk_sums[b];
@@ -279,6 +281,23 @@ __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int
             if (base + k < N) slot_base[base + k] = run;
             run += v[k];
         }
+        slots_lo = prefix; slots_hi = prefix + total;
+    } else {
+        if (threadIdx.x == 0) {
+            const int first = blockIdx.x * GROUP_CHUNK, last = min(N, first + GROUP_CHUNK) - 1;
+            s_slots[0] = slot_base[first]; s_slots[1] = slot_base[last] + tt[last];
+        }
+        __syncthreads();
+        slots_lo = s_slots[0]; slots_hi = s_slots[1];
+    }
+    // nothing of this frame's backward has been written yet: clear the chunk's stretch of pair_valid (16 bytes per store
+    // from the first 16-byte boundary; the edges byte by byte -- a neighbouring chunk owns the rest of those words)
+    if (pair_valid) {
+        slots_hi = min(slots_hi, capacity);
+        const uint32_t a0 = min((slots_lo + 15u) & ~15u, slots_hi), a1 = max(a0, slots_hi & ~15u);
+        for (uint32_t q = slots_lo + threadIdx.x; q < a0; q += GROUP_THREADS) pair_valid[q] = 0;
+        for (uint32_t q = a0 + 16u * threadIdx.x; q < a1; q += 16u * GROUP_THREADS) *reinterpret_cast<uint4 *>(pair_valid + q) = make_uint4(0u, 0u, 0u, 0u);
+        for (uint32_t q = a1 + threadIdx.x; q < slots_hi; q += GROUP_THREADS) pair_valid[q] = 0;
     }
     __syncthreads();
 #pragma unroll
@@ -359,7 +378,7 @@ int launch_group_scan(const lvdgs_args &a, const ImageView &im, const RenderScra
 }
 
 int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, unsigned long long *keys64,
-                         int64_t capacity, bool slot_scan, hipStream_t s) {
+                         int64_t capacity, bool slot_scan, uint8_t *pair_valid, hipStream_t s) {
     const int N = a.num_gaussians;
     const int gx = (a.image_width + TILE - 1) / TILE, gy = (a.image_height + TILE - 1) / TILE, T = gx * gy;
     if (N == 0 || T == 0) return LVDGS_OK;
@@ -372,7 +391,7 @@ int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView
         if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&scatter_pairs_kernel<PER_, SS_>), GROUP_MAX_TILES * 4, done[D_])) return e; \
         hipLaunchKernelGGL((scatter_pairs_kernel<PER_, SS_>), dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint4 *)g.rect,         \
                            (const uint32_t *)w.group_hist, (const uint2 *)im.ranges, (uint32_t)capacity, (const uint32_t *)g.depth_bits, keys64, \
-                           (const uint32_t *)g.tiles_touched, (const uint32_t *)w.chunk_sums, g.slot_base);                        \
+                           (const uint32_t *)g.tiles_touched, (const uint32_t *)w.chunk_sums, g.slot_base, pair_valid);            \
     }
     if (per == 1 && slot_scan) LVDGS_SCATTER(1, true, 4)
     else if (per == 1) LVDGS_SCATTER(1, false, 5)

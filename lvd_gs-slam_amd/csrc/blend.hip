@@ -54,6 +54,7 @@ struct BlendParams {
     // backward
     const float *dL_dcolor, *dL_ddepth, *dL_dopacity;
     float *pair_grads;
+    uint8_t *pair_valid;         // 1 where a record of pair_grads has been written by this backward pass (BinView::pair_valid)
     // backward with the photometric loss evaluated in place of reading dL_d* (lvdgs_backward_fused_loss)
     LossParams loss;             // loss.partial: 4 sums per TILE
     int loss_propagate_opacity;  // dL/d(opacity image) feeds the blend (rasterizer.PROPAGATE_OPACITY_GRAD)
@@ -310,7 +311,7 @@ struct Bwd3Shared {
     uint32_t slot[BR];
     float acc[4][BR * ACC_STRIDE];       // per wave: Sx Sy Sxx Sxy Syy Su C0 C1 C2 CD of every entry it accumulated
     unsigned long long mask[4];
-    uint32_t wmax[4];
+    uint32_t wmax[4], wall[4];           // per wave: deepest list position its pixels reached, among pixels with a gradient / among all
     float loss_sum[4][4];                // fused loss: [sum][wave]
     float2 M[4][NB][64];                 // per wave: (u, w) of [batch slot][pixel]
     uint32_t bj[4][NB];                  // per wave: entry (position in the round) of every batch slot
@@ -373,15 +374,20 @@ __global__ void __launch_bounds__(256, 5) blend_bwd3_kernel(BlendParams p) {
     for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
     // A quadrant whose 64 pixels all receive a zero gradient (masked out of the loss: the tracking loss's edge and
     // brightness masks, a static mask) adds exactly zero to every sum: its wave sits the lists out.
+    const uint32_t m_all = m;
     if (__ballot(gC0 != 0.f || gC1 != 0.f || gC2 != 0.f || gD != 0.f || gO != 0.f) == 0ull) m = 0u;
-    if (lane == 0) sh.wmax[wave] = m;
+    if (lane == 0) { sh.wmax[wave] = m; sh.wall[wave] = m_all; }
     const int wave_last = (int)m;
     __syncthreads();
     if constexpr (FUSED_LOSS) {
         if (tid < 4) p.loss.partial[4 * (size_t)tile + tid] = ((sh.loss_sum[tid][0] + sh.loss_sum[tid][1]) + sh.loss_sum[tid][2]) + sh.loss_sum[tid][3];
     }
     const int depth_max = (int)max(max(sh.wmax[0], sh.wmax[1]), max(sh.wmax[2], sh.wmax[3]));
-    const int todo = (int)(range.y - range.x);
+    // Only the entries some pixel of the tile composited can receive anything: the list is walked from the deepest of them.
+    // The pairs behind it -- on opaque surfaces nine tenths of a list -- are neither staged nor written; their slots keep
+    // pair_valid = 0 and preprocess_bwd passes over them.  (The depth is the forward pass's alone, not this call's
+    // gradients': every backward pass after one forward writes the same set of records.)
+    const int todo = min((int)(range.y - range.x), (int)max(max(sh.wall[0], sh.wall[1]), max(sh.wall[2], sh.wall[3])));
 
     float T = T_final, R = tail;  // see the single-pass kernel for the scalar recurrence
     // splat pass: this lane's slot in the batch and its 16-lane row; at step s it looks at the pixel of lane (col - s) mod 16
@@ -534,7 +540,8 @@ __global__ void __launch_bounds__(256, 5) blend_bwd3_kernel(BlendParams p) {
             const float4 A = sh.a[tid];
             const float op = sh.b[tid].y;
             const float sx = op * acc[0], sy = op * acc[1];
-            // the pair's record: ten floats, 40 bytes (8-byte aligned: five 8-byte stores)
+            // the pair's record: ten floats, 40 bytes (8-byte aligned: five 8-byte stores), and its "written" flag
+            p.pair_valid[sh.slot[tid]] = 1;
             float2 *dst = reinterpret_cast<float2 *>(p.pair_grads + (size_t)sh.slot[tid] * PAIR_FLOATS);
             dst[0] = make_float2(-fmaf(A.z, sx, A.w * sy), -fmaf(sh.craw[tid], sy, A.w * sx));
             dst[1] = make_float2(-0.5f * (op * acc[2]), -(op * acc[3]));
@@ -578,7 +585,7 @@ int launch_blend_fwd(const lvdgs_args &a, const GeomView &g, const BinView &b, c
 int launch_blend_bwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, const BwdScratch &w,
                      hipStream_t s) {
     BlendParams p = make_params(a, g, b, im);
-    p.pair_grads = w.pair_grads;
+    p.pair_grads = w.pair_grads; p.pair_valid = b.pair_valid;
     if (p.num_tiles == 0) return LVDGS_OK;
     ProfScope ps("blend_bwd", s);
     if (LVDGS_BWD_DEPTH_ALWAYS || p.dL_ddepth) hipLaunchKernelGGL((blend_bwd3_kernel<false, true>), dim3(p.num_tiles), dim3(256), 0, s, p);
@@ -590,7 +597,7 @@ int launch_blend_bwd(const lvdgs_args &a, const GeomView &g, const BinView &b, c
 int launch_blend_bwd_fused_loss(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, const BwdScratch &w,
                                 const LossParams &loss, int propagate_opacity, hipStream_t s) {
     BlendParams p = make_params(a, g, b, im);
-    p.pair_grads = w.pair_grads;
+    p.pair_grads = w.pair_grads; p.pair_valid = b.pair_valid;
     p.loss = loss;
     p.loss_propagate_opacity = propagate_opacity;
     if (p.num_tiles == 0) return LVDGS_OK;

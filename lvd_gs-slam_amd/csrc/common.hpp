@@ -193,6 +193,9 @@ struct RenderScratch {
 struct BinView {
     uint32_t *point_list; // D
     uint32_t *tile_keys;  // D
+    uint8_t *pair_valid;  // D: 1 once the backward blend pass has written the pair's gradient record (cleared by the forward pass).
+                          // Pairs behind a tile's last contributor -- nine tenths of the lists on opaque surfaces -- are
+                          // neither staged nor written by blend_bwd, and preprocess_bwd passes over their slots.
 };
 struct ImageView {
     uint2 *ranges;       // T
@@ -216,7 +219,7 @@ int tile_sort_bits(int W, int H);  // number of key bits to sort for the tile id
 
 // ---- launchers (one per kernel family; all enqueue on `stream` and return a status) ----
 int launch_preprocess_fwd(const lvdgs_args &a, const GeomView &g, uint32_t *blocksums /* one per 256 Gaussians */, hipStream_t s);
-int launch_preprocess_bwd(const lvdgs_args &a, const GeomView &g, const BwdScratch &b, hipStream_t s);
+int launch_preprocess_bwd(const lvdgs_args &a, const GeomView &g, const BwdScratch &b, const uint8_t *pair_valid, hipStream_t s);
 int launch_mark_visible(int N, const float *means3D, const float *view, uint8_t *present, hipStream_t s);
 
 // stable LSD radix sort of (key, val) pairs on key bits [0, total_bits); result lands in
@@ -257,17 +260,17 @@ int launch_group_count(const lvdgs_args &a, const GeomView &g, const ImageView &
 int launch_group_scan(const lvdgs_args &a, const ImageView &im, const RenderScratch &w, int64_t capacity, uint32_t *total_out, hipStream_t s);
 // slot_scan: also makes slot_base from tiles_touched and w.chunk_sums (launch_preprocess_count's leftovers)
 int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, unsigned long long *keys64,
-                         int64_t capacity, bool slot_scan, hipStream_t s);
+                         int64_t capacity, bool slot_scan, uint8_t *pair_valid, hipStream_t s);
 int launch_emit_pairs(const lvdgs_args &a, const GeomView &g, uint32_t *tile_keys, uint32_t *ids, int64_t capacity, hipStream_t s);
 // Sorts the segment of every tile in [t_lo, t_hi) by (view-depth bits, id) and leaves the ids in point_list.  keys64 holds
 // D 64-bit keys: already filled per segment (counting path, keys_ready; the queue of segments longer than
 // tile_sort_wave_limit() is then filled too), or scratch for over-long segments whose keys are gathered from the ids in
-// point_list (radix path).  big_segments_expected: launch the 128 KiB-LDS kernel for segments beyond
-// tile_sort_in_launch_limit() (a hint; without it such segments are sorted in place on global memory).
+// point_list (radix path).  longest_expected / queue_expected: the longest queued segment and the queue's length of the
+// previous frame on this device (0: none; longest < 0: unknown) -- which of the kernels for long segments get launched
+// behind the tile sort (a hint; without it such segments are sorted by the tile sort's own last workgroups).
 int tile_sort_wave_limit();
-int tile_sort_in_launch_limit();
 int launch_tile_depth_sort(const ImageView &im, int num_tiles, int t_lo, int t_hi, const float *rec, uint32_t *point_list, void *keys64,
-                           bool keys_ready, bool big_segments_expected, int dbg, hipStream_t s);
+                           bool keys_ready, int longest_expected, int queue_expected, int dbg, hipStream_t s);
 int launch_tile_ranges(const uint32_t *tile_keys, int64_t D, const uint32_t *D_dev, const ImageView &im, int num_tiles, int dbg,
                        hipStream_t s);
 

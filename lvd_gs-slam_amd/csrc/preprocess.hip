@@ -372,11 +372,13 @@ struct BwdParams {
     const float *rec;
     const uint32_t *tiles_touched, *slot_base;
     const float *pair_grads;
+    const uint8_t *pair_valid;   // 1 where blend_bwd wrote the pair's record (pairs behind their tile's last contributor have none)
     float *dmeans3D, *dmeans2D, *dopac, *dscales, *drot, *dcov3D, *dshs, *dcolors;
     float *tau_part;
 };
 
 constexpr int PAIR_CHUNK = 256;  // pair records staged per round: 10 KB of LDS
+constexpr int BIG_RUN = 64;      // a Gaussian with more pairs than this is summed by its whole wave
 
 __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
     __shared__ float s_tau[4][6];
@@ -396,21 +398,24 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
         if (p.dshs) { for (int k = 0; k < 3 * c.M; k++) p.dshs[(size_t)i * 3 * c.M + k] = 0.f; }
     }
     // ---- sum every Gaussian's per-tile partial gradients (a contiguous run of 40-byte records, fixed order) ----
-    // The runs of a workgroup's 256 Gaussians follow each other in memory (slots are in id order), so the workgroup
-    // streams that region through LDS in chunks with coalesced 16-byte loads and every lane picks its own records out
-    // of the chunk -- instead of 64 lanes walking 64 different runs with one gather each per step, which moved
-    // 2.2x the bytes (r01 / r02_a counters).  Same additions in the same order as before.
-    // (A chunk starts at an even record, i.e. on a 16-byte boundary: 2 records = 80 bytes = 5 loads.)
+    // Records exist where blend_bwd wrote them (pair_valid): pairs behind their tile's last contributor have none.
     __shared__ float4 s_pg4[(PAIR_CHUNK + 2) * PAIR_FLOATS / 4 + 1];
+    __shared__ uint8_t s_valid[PAIR_CHUNK + 16];
     __shared__ uint32_t s_region[2];
     const float2 *s_pg = reinterpret_cast<const float2 *>(s_pg4);
     float A[10];
 #pragma unroll
     for (int k = 0; k < 10; k++) A[k] = 0.f;
-    {
+    const uint32_t first = live ? p.slot_base[i] : 0u, npairs = live ? p.tiles_touched[i] : 0u, last = first + npairs;
+    const bool big = npairs > BIG_RUN;
+    if (!__syncthreads_or(big)) {
+        // The runs of a workgroup's 256 Gaussians follow each other in memory (slots are in id order), so the workgroup
+        // streams that region through LDS in chunks with coalesced 16-byte loads and every lane picks its own records out
+        // of the chunk -- instead of 64 lanes walking 64 different runs with one gather each per step, which moved
+        // 2.2x the bytes (r01 / r02_a counters).  Same additions in the same order as before.
+        // (A chunk starts at an even record, i.e. on a 16-byte boundary: 2 records = 80 bytes = 5 loads.)
         const int blk_first = blockIdx.x * blockDim.x, blk_last = min(p.N, blk_first + (int)blockDim.x) - 1;
         if (threadIdx.x == 0) { s_region[0] = p.slot_base[blk_first] & ~1u; s_region[1] = p.slot_base[blk_last] + p.tiles_touched[blk_last]; }
-        const uint32_t first = live ? p.slot_base[i] : 0u, last = live ? first + p.tiles_touched[i] : 0u;
         __syncthreads();
         const uint32_t r_lo = s_region[0], r_hi = s_region[1];
         const float4 *pg_all = reinterpret_cast<const float4 *>(p.pair_grads);
@@ -418,9 +423,11 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
             const uint32_t n = min((uint32_t)PAIR_CHUNK, r_hi - c0);
             const uint32_t quads = (n * PAIR_FLOATS + 3) / 4, q0 = c0 / 2 * 5;   // c0 is even: record c0 starts at float4 c0 * 10 / 4
             for (uint32_t k = threadIdx.x; k < quads; k += blockDim.x) s_pg4[k] = pg_all[(size_t)q0 + k];
+            for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) s_valid[k] = p.pair_valid[c0 + k];
             __syncthreads();
             const uint32_t lo = max(first, c0), hi = min(last, c0 + n);
             for (uint32_t t = lo; t < hi; t++) {
+                if (!s_valid[t - c0]) continue;
                 const float2 *r = s_pg + 5 * (t - c0);
                 const float2 a0 = r[0], a1 = r[1], a2 = r[2], a3 = r[3], a4 = r[4];
                 A[0] += a0.x; A[1] += a0.y; A[2] += a1.x; A[3] += a1.y;
@@ -428,6 +435,38 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
                 A[8] += a4.x; A[9] += a4.y;
             }
             __syncthreads();
+        }
+    } else {
+        // A workgroup that holds large-footprint Gaussians (hundreds of pairs each: the stuff opaque surfaces are made of):
+        // one lane summing 800 records while 63 wait was 1.5 ms of this kernel at 100 k such Gaussians.  The small ones
+        // walk their own few records straight from memory; every large one is summed by its whole wave -- lane l takes
+        // records l, l + 64, ... -- and the 64 partial sums are folded in a fixed order.
+        const float2 *pg = reinterpret_cast<const float2 *>(p.pair_grads);
+        auto add = [&](float (&S)[10], uint32_t t) {
+            const float2 *r = pg + (size_t)5 * t;
+            const float2 a0 = r[0], a1 = r[1], a2 = r[2], a3 = r[3], a4 = r[4];
+            S[0] += a0.x; S[1] += a0.y; S[2] += a1.x; S[3] += a1.y;
+            S[4] += a2.x; S[5] += a2.y; S[6] += a3.x; S[7] += a3.y;
+            S[8] += a4.x; S[9] += a4.y;
+        };
+        if (!big)
+            for (uint32_t t = first; t < last; t++)
+                if (p.pair_valid[t]) add(A, t);
+        const int lane = threadIdx.x & 63;
+        for (uint64_t todo = __ballot(big); todo; todo &= todo - 1) {
+            const int src = __builtin_ctzll(todo);
+            const uint32_t f = (uint32_t)__shfl((int)first, src, 64), l = (uint32_t)__shfl((int)last, src, 64);
+            float S[10];
+#pragma unroll
+            for (int k = 0; k < 10; k++) S[k] = 0.f;
+            for (uint32_t t = f + (uint32_t)lane; t < l; t += 64)
+                if (p.pair_valid[t]) add(S, t);
+#pragma unroll
+            for (int k = 0; k < 10; k++) {
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) S[k] += __shfl_xor(S[k], off, 64);
+                if (lane == src) A[k] = S[k];
+            }
         }
     }
     if (live) {
@@ -723,7 +762,7 @@ int launch_preprocess_count(const lvdgs_args &a, const GeomView &g, const ImageV
     return LVDGS_OK;
 }
 
-int launch_preprocess_bwd(const lvdgs_args &a, const GeomView &g, const BwdScratch &b, hipStream_t s) {
+int launch_preprocess_bwd(const lvdgs_args &a, const GeomView &g, const BwdScratch &b, const uint8_t *pair_valid, hipStream_t s) {
     const int N = a.num_gaussians;
     const int nblk = cdiv(N, 256);
     if (N > 0) {
@@ -731,7 +770,7 @@ int launch_preprocess_bwd(const lvdgs_args &a, const GeomView &g, const BwdScrat
         p.cam = make_cam(a); p.N = N; p.act = a.activations;
         p.means3D = a.means3D; p.opacities = a.opacities; p.scales = a.scales; p.rotations = a.rotations; p.cov3D_precomp = a.cov3D_precomp;
         p.shs = a.shs; p.colors_precomp = a.colors_precomp; p.radii = a.radii;
-        p.rec = g.rec; p.tiles_touched = g.tiles_touched; p.slot_base = g.slot_base; p.pair_grads = b.pair_grads;
+        p.rec = g.rec; p.tiles_touched = g.tiles_touched; p.slot_base = g.slot_base; p.pair_grads = b.pair_grads; p.pair_valid = pair_valid;
         p.dmeans3D = a.dL_dmeans3D; p.dmeans2D = a.dL_dmeans2D; p.dopac = a.dL_dopacities; p.dscales = a.dL_dscales;
         p.drot = a.dL_drotations; p.dcov3D = a.cov3D_precomp ? a.dL_dcov3D : nullptr; p.dshs = a.dL_dshs;
         p.dcolors = a.dL_dcolors; p.tau_part = b.tau_part;

@@ -160,19 +160,20 @@ constexpr int CLASS_W = 1024;  // longest segment one wave sorts in registers (1
 constexpr int CLASS_L = 2048;  // longest segment a workgroup of the same launch sorts in (static) LDS: 16 KB
 constexpr int CLASS_B = 16384; // longest segment the separate 1024-thread kernel sorts in (dynamic) LDS
 constexpr int SORT_WAVES = 4;  // tiles per workgroup (16 were measured: the same at 8160 tiles, twice the time at 1848 -- too few workgroups)
-constexpr int LONG_WGS = 64;   // workgroups at the end of the grid that take the queue of over-long segments
+constexpr int LONG_WGS = 256;  // workgroups at the end of the grid that take the queue of over-long segments
+constexpr int CLASS_M = 2048;  // longest segment one wave of the mid kernel sorts in registers (32 keys per lane)
 
 // `count` queued segments, one workgroup per segment in turn: in LDS up to `lds_cap` entries, in place on
-// global memory beyond (64-bit key scratch).  Segments of more than `skip_above` entries are left alone (another launch
-// takes them).
-__device__ __forceinline__ void sort_queued_segments(u64 *s_keys, int lds_cap, int skip_above, const uint2 *__restrict__ ranges, const KeySource &src,
+// global memory beyond (64-bit key scratch).  Only segments of more than `take_from` and at most `take_upto` entries
+// (other launches take the rest).
+__device__ __forceinline__ void sort_queued_segments(u64 *s_keys, int lds_cap, int take_from, int take_upto, const uint2 *__restrict__ ranges, const KeySource &src,
                                                      uint32_t *__restrict__ point_list, int count, const uint32_t *__restrict__ queue, u64 *keys,
                                                      int first, int stride) {
     const int tid = threadIdx.x, nt = blockDim.x;
     for (int q = first; q < count; q += stride) {
         const uint2 r = ranges[queue[q]];
         const int n = (int)(r.y - r.x);
-        if (n > skip_above) continue;
+        if (n <= take_from || n > take_upto) continue;
         if (n <= lds_cap) {
             for (int i = tid; i < n; i += nt) s_keys[i] = src.load(r.x + i);
             __syncthreads();
@@ -196,9 +197,10 @@ __device__ __forceinline__ void sort_queued_segments(u64 *s_keys, int lds_cap, i
 // One wave per tile (four tiles per workgroup); segments of more than CLASS_W entries are left to whole workgroups:
 //  * counting path (QUEUED): the tile-range scan has queued them already (binning.hip) and the LAST LONG_WGS workgroups
 //    of this very launch take them -- no launch of their own on every frame's critical path for a queue that is nearly
-//    always empty.  In LDS up to CLASS_L entries; beyond that in place on global memory, unless the host announces
-//    (big_follows) the 128 KiB-LDS kernel behind this one: it does so when an earlier frame on this device had such
-//    segments (a hint: results never depend on it);
+//    always empty -- in LDS up to CLASS_L entries, in place on global memory beyond.  When the previous frame on this
+//    device had such segments the host launches better-suited kernels behind this one (a wave per segment with 32 keys
+//    per lane up to CLASS_M entries, a 1024-thread workgroup on 128 KiB of LDS beyond) and tells the workgroups here which
+//    lengths are still theirs (take_from, take_upto).  A hint: results never depend on it;
 //  * radix path: queued here with one atomic each, sorted by the launch that follows.
 // tile_order (small grids, or null): the tiles by descending list length -- the waves of a workgroup then sort
 // segments of similar length, and the long ones start first.  Only tiles [t_lo, t_hi) are looked at (the band being
@@ -207,10 +209,10 @@ template <bool QUEUED>
 __global__ void __launch_bounds__(64 * SORT_WAVES) tile_depth_sort_wave_kernel(const uint2 *__restrict__ ranges, int t_lo, int t_hi, KeySource src,
                                                                     uint32_t *__restrict__ point_list, uint32_t *queue_count,
                                                                     uint32_t *__restrict__ queue, const uint32_t *__restrict__ tile_order,
-                                                                    u64 *keys, int sort_wgs, int big_follows) {
+                                                                    u64 *keys, int sort_wgs, int take_from, int take_upto) {
     __shared__ u64 s_long[QUEUED ? CLASS_L : 1];
     if (QUEUED && (int)blockIdx.x >= sort_wgs) {
-        sort_queued_segments(s_long, CLASS_L, big_follows ? CLASS_L : 0x7fffffff, ranges, src, point_list, (int)*queue_count, queue, keys,
+        sort_queued_segments(s_long, CLASS_L, take_from, take_upto, ranges, src, point_list, (int)*queue_count, queue, keys,
                              (int)blockIdx.x - sort_wgs, LONG_WGS);
         return;
     }
@@ -230,8 +232,23 @@ __global__ void __launch_bounds__(64 * SORT_WAVES) tile_depth_sort_wave_kernel(c
     else if (!QUEUED && lane == 0) queue[atomicAdd(queue_count, 1u)] = (uint32_t)tile;
 }
 
+// Queued segments of CLASS_W + 1 .. CLASS_M entries, one WAVE each with 32 keys per lane in registers -- the lists of a map
+// made of large Gaussians (500-2000 entries per tile) are mostly of this class, and a workgroup's LDS network takes five
+// times as long for them.  A kernel of its own because 32 keys per lane need twice the registers of the common case;
+// launched only when the previous frame on this device had such segments (the queue's length then sizes the grid).
+__global__ void __launch_bounds__(256) tile_depth_sort_mid_kernel(const uint2 *__restrict__ ranges, KeySource src, uint32_t *__restrict__ point_list,
+                                                                  const uint32_t *queue_count, const uint32_t *__restrict__ queue) {
+    const int lane = threadIdx.x & 63;
+    const int count = (int)*queue_count, waves = gridDim.x * 4;
+    for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < count; q += waves) {
+        const uint2 r = ranges[queue[q]];
+        const int n = (int)(r.y - r.x);
+        if (n > CLASS_W && n <= CLASS_M) wave_sort_segment<32>(src, r.x, point_list + r.x, n, lane);
+    }
+}
+
 // queued segments: in 128 KiB of LDS up to CLASS_B entries, in place on global memory beyond; segments of up to
-// `done_below` entries were sorted by the launch before
+// `done_below` entries were sorted by the launches before
 __global__ void __launch_bounds__(1024) tile_depth_sort_long_kernel(const uint2 *__restrict__ ranges, KeySource src,
                                                                     uint32_t *__restrict__ point_list, const uint32_t *long_count,
                                                                     const uint32_t *__restrict__ long_tiles, u64 *keys, int done_below) {
@@ -265,30 +282,39 @@ __global__ void __launch_bounds__(1024) tile_depth_sort_long_kernel(const uint2 
 }  // namespace
 
 int tile_sort_wave_limit() { return CLASS_W; }
-int tile_sort_in_launch_limit() { return CLASS_L; }
 
 int launch_tile_depth_sort(const ImageView &im, int num_tiles, int t_lo, int t_hi, const float *rec, uint32_t *point_list, void *keys64,
-                           bool keys_ready, bool big_segments_expected, int dbg, hipStream_t s) {
+                           bool keys_ready, int longest_expected, int queue_expected, int dbg, hipStream_t s) {
     if (num_tiles == 0 || t_hi <= t_lo) return LVDGS_OK;
     static unsigned char lds_done[16];
     if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&tile_depth_sort_long_kernel), CLASS_B * 8, lds_done)) return e;
     const KeySource src{rec, point_list, keys_ready ? (const u64 *)keys64 : nullptr};
     const int sort_wgs = cdiv(t_hi - t_lo, SORT_WAVES);
+    // longest_expected: the longest segment the previous frame on this device queued (0: none; negative: unknown, assume the
+    // worst).  Segments that turn up against the expectation are still sorted -- by the launch's own last workgroups.
+    const bool mid = keys_ready && longest_expected > CLASS_W, big = !keys_ready || longest_expected > CLASS_M || longest_expected < 0;
     {
         ProfScope ps("tile_sort", s);
         if (keys_ready)   // counting path: the queue is there already, the last workgroups of the launch take it
             hipLaunchKernelGGL(tile_depth_sort_wave_kernel<true>, dim3(sort_wgs + LONG_WGS), dim3(64 * SORT_WAVES), 0, s, (const uint2 *)im.ranges, t_lo, t_hi, src,
                                point_list, im.long_count, im.long_tiles, tile_order_in_use(num_tiles) ? im.long_tiles + num_tiles : nullptr,
-                               (u64 *)keys64, sort_wgs, big_segments_expected ? 1 : 0);
+                               (u64 *)keys64, sort_wgs, mid ? CLASS_M : CLASS_W, big ? CLASS_M : 0x7fffffff);
         else
             hipLaunchKernelGGL(tile_depth_sort_wave_kernel<false>, dim3(sort_wgs), dim3(64 * SORT_WAVES), 0, s, (const uint2 *)im.ranges, t_lo, t_hi, src,
-                               point_list, im.long_count, im.long_tiles, (const uint32_t *)nullptr, (u64 *)keys64, sort_wgs, 0);
+                               point_list, im.long_count, im.long_tiles, (const uint32_t *)nullptr, (u64 *)keys64, sort_wgs, 0, 0);
         LVDGS_LAUNCH_CHECK("tile_sort", dbg, s);
     }
-    if (!keys_ready || big_segments_expected) {
+    if (mid) {
+        ProfScope ps("tile_sort_mid", s);
+        const int wgs = min(4096, max(64, cdiv((int64_t)queue_expected * 5 / 4, 4)));
+        hipLaunchKernelGGL(tile_depth_sort_mid_kernel, dim3(wgs), dim3(256), 0, s, (const uint2 *)im.ranges, src, point_list,
+                           (const uint32_t *)im.long_count, (const uint32_t *)im.long_tiles);
+        LVDGS_LAUNCH_CHECK("tile_sort_mid", dbg, s);
+    }
+    if (big) {
         ProfScope ps("tile_sort_long", s);
         hipLaunchKernelGGL(tile_depth_sort_long_kernel, dim3(256), dim3(1024), CLASS_B * 8, s, (const uint2 *)im.ranges, src, point_list,
-                           (const uint32_t *)im.long_count, (const uint32_t *)im.long_tiles, (unsigned long long *)keys64, keys_ready ? CLASS_L : 0);
+                           (const uint32_t *)im.long_count, (const uint32_t *)im.long_tiles, (unsigned long long *)keys64, keys_ready ? CLASS_M : 0);
         LVDGS_LAUNCH_CHECK("tile_sort_long", dbg, s);
     }
     return LVDGS_OK;
