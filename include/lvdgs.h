@@ -181,6 +181,8 @@ typedef struct lvdgs_state_layout {
     size_t geom_tiles_touched; /* N x u32 */
     size_t geom_slot_base;     /* N x u32: exclusive scan of tiles_touched in id order (first pair of a Gaussian) */
     /* byte offsets into binning_state */
+    /* (binning_state is laid out by its SIZE: these offsets hold for a buffer of exactly lvdgs_binning_bytes(num_rendered) bytes;
+     *  point_list always starts the buffer) */
     size_t bin_point_list;     /* D x u32: Gaussian ids, (tile, depth, id) ordered */
     size_t bin_tile_keys;      /* D x u32: tile id of each entry of point_list -- written only on the radix
                                   path (images above 16384 tiles); otherwise derive it from img_ranges */

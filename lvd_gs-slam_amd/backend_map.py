@@ -41,7 +41,7 @@ from . import _lib
 
 from .fast_mapping import MapViewPass, _PARAM_FIELDS
 from .gaussian_renderer import render
-from .loss_utils import masked_mapping_loss
+from .loss_utils import masked_mapping_loss, masked_mapping_loss_and_grads
 from .pose_utils import update_pose
 from .slam_utils import get_loss_mapping
 
@@ -534,8 +534,13 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
                 first = {n: plan[k].view_as(p) for k, (n, p) in enumerate(zip(_PARAM_FIELDS, live))}
         for v, r0, r1 in mine:
             whole = (r0, r1) == (0, _tile_rows(views[v]))
-            if vpass is not None and MapViewPass.usable(backend, views[v]):
-                pkg, l = vpass.run(backend, views[v], first=first, band=None if whole else (r0, r1))
+            masked = v < n_window and getattr(views[v], "static_mask", None) is not None
+            if vpass is not None and MapViewPass.usable(backend, views[v], allow_static_mask=True):
+                # a window keyframe with a static mask: L1 + SSIM on the static pixels and the masked depth term (:196-261)
+                # bring their own gradient images; every other view: get_loss_mapping inside the backward blend pass
+                image_loss = None if not masked else (lambda color, depth, vp=views[v]: masked_mapping_loss_and_grads(
+                    color, depth, vp, backend.background, backend.opt_params.lambda_dssim, cfg["Training"].get("depth_lambda", 0.1)))
+                pkg, l = vpass.run(backend, views[v], first=first, band=None if whole else (r0, r1), image_loss=image_loss)
                 pkgs.append((v, r0, pkg))
                 loss_direct = l if loss_direct is None else loss_direct + l
                 continue

@@ -170,6 +170,19 @@ size_t bin_layout(int64_t D, BinView *v, void *base) {
     return off;
 }
 
+// Where the arrays lie is a function of the BUFFER's size, not of the pair count of the call: the forward pass lays the
+// buffer out for its pair capacity, the backward pass is told the frame's actual pair count -- and both must find
+// pair_valid (cleared by one, read by the other) in the same place.  The layout is the one of the largest pair count the
+// buffer holds; a buffer of exactly lvdgs_binning_bytes(D) bytes has the layout bin_layout(D) describes.
+int64_t bin_view(const lvdgs_args *a, BinView *v) {
+    if (!a->binning_state || a->binning_bytes < bin_layout(1, nullptr, nullptr)) { *v = BinView{}; return 0; }
+    int64_t p = (int64_t)((a->binning_bytes - 3 * 256 - 16) / 9);   // 4 + 4 + 1 bytes per pair, three 256-byte roundings
+    while (bin_layout(p + 1, nullptr, nullptr) <= a->binning_bytes) p++;
+    while (p > 1 && bin_layout(p, nullptr, nullptr) > a->binning_bytes) p--;
+    bin_layout(p, v, a->binning_state);
+    return p;
+}
+
 size_t image_layout(int W, int H, ImageView *v, void *base) {
     ImageView tmp;
     if (!v) v = &tmp;
@@ -339,7 +352,7 @@ int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipSt
     }
     bool grouped = false;
     if (cap > 0) {
-        bin_layout(cap, &b, a->binning_state);
+        if (bin_view(a, &b) < cap) { set_error("internal: binning_state smaller than the pair capacity"); return LVDGS_E_INVALID; }
         render_scratch_layout(N, cap, W, H, &w, a->scratch);
         if (use_counting_path(num_tiles)) {
             // counting path: no pair list is materialised, the tile ranges fall out of the counts
@@ -497,7 +510,7 @@ static int backward_impl(const lvdgs_args *a, const LossParams *fused, int propa
         }
         geom_layout(N, &g, a->geom_state);
         bwd_scratch_layout(N, D, &w, a->scratch);
-        if (D > 0) bin_layout(D, &b, a->binning_state);
+        if (D > 0) bin_view(a, &b);
     }
     // With the loss inside, the blend pass runs even over empty lists (a view that sees nothing, an empty map): it is what
     // evaluates the loss of the background image -- value and exposure gradients -- and no pair record is written.

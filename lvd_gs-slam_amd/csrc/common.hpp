@@ -212,6 +212,7 @@ struct BwdScratch {
 size_t geom_layout(int N, GeomView *v, void *base);
 size_t prep_scratch_layout(int N, PrepScratch *v, void *base);
 size_t bin_layout(int64_t D, BinView *v, void *base);
+int64_t bin_view(const lvdgs_args *a, BinView *v);   // the views of a->binning_state (laid out by its size); returns the pairs it holds
 size_t image_layout(int W, int H, ImageView *v, void *base);
 size_t render_scratch_layout(int N, int64_t D, int W, int H, RenderScratch *v, void *base);
 size_t bwd_scratch_layout(int N, int64_t D, BwdScratch *v, void *base);

@@ -400,7 +400,6 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
     // ---- sum every Gaussian's per-tile partial gradients (a contiguous run of 40-byte records, fixed order) ----
     // Records exist where blend_bwd wrote them (pair_valid): pairs behind their tile's last contributor have none.
     __shared__ float4 s_pg4[(PAIR_CHUNK + 2) * PAIR_FLOATS / 4 + 1];
-    __shared__ uint8_t s_valid[PAIR_CHUNK + 16];
     __shared__ uint32_t s_region[2];
     const float2 *s_pg = reinterpret_cast<const float2 *>(s_pg4);
     float A[10];
@@ -422,12 +421,21 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
         for (uint32_t c0 = r_lo; c0 < r_hi; c0 += PAIR_CHUNK) {
             const uint32_t n = min((uint32_t)PAIR_CHUNK, r_hi - c0);
             const uint32_t quads = (n * PAIR_FLOATS + 3) / 4, q0 = c0 / 2 * 5;   // c0 is even: record c0 starts at float4 c0 * 10 / 4
-            for (uint32_t k = threadIdx.x; k < quads; k += blockDim.x) s_pg4[k] = pg_all[(size_t)q0 + k];
-            for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) s_valid[k] = p.pair_valid[c0 + k];
+            // (a record blend_bwd did not write -- a pair behind its tile's last contributor -- is staged as zeros: the four
+            // floats of a load belong to at most two records)
+            for (uint32_t k = threadIdx.x; k < quads; k += blockDim.x) {
+                float4 v = pg_all[(size_t)q0 + k];
+                const uint32_t ra = (4 * k) / PAIR_FLOATS, rb = (4 * k + 3) / PAIR_FLOATS;
+                const bool va = p.pair_valid[c0 + min(ra, n - 1)] != 0, vb = p.pair_valid[c0 + min(rb, n - 1)] != 0;
+                v.x = va ? v.x : 0.f;
+                v.y = ((4 * k + 1) / PAIR_FLOATS == ra ? va : vb) ? v.y : 0.f;
+                v.z = ((4 * k + 2) / PAIR_FLOATS == ra ? va : vb) ? v.z : 0.f;
+                v.w = vb ? v.w : 0.f;
+                s_pg4[k] = v;
+            }
             __syncthreads();
             const uint32_t lo = max(first, c0), hi = min(last, c0 + n);
             for (uint32_t t = lo; t < hi; t++) {
-                if (!s_valid[t - c0]) continue;
                 const float2 *r = s_pg + 5 * (t - c0);
                 const float2 a0 = r[0], a1 = r[1], a2 = r[2], a3 = r[3], a4 = r[4];
                 A[0] += a0.x; A[1] += a0.y; A[2] += a1.x; A[3] += a1.y;

@@ -126,9 +126,10 @@ class MapViewPass:
         the sharded loop passes slices of its all-reduce bucket -- instead of the pass's own).  Returns the render package (fresh tensors, ``viewspace_points`` carries ``.grad``) and the
         loss (0-dim tensor).
 
-        ``image_loss(color) -> (loss, d_color)`` (optional) replaces ``get_loss_mapping``: a loss of the rendered colour
-        alone that brings its own gradient image -- colour refinement's ``(1 - l) L1 + l (1 - SSIM)`` from the fused
-        L1 + SSIM kernel -- after which the plain ``lvdgs_backward`` runs (no depth / exposure terms).
+        ``image_loss(color, depth) -> (loss, d_color[, d_depth])`` (optional) replaces ``get_loss_mapping``: a loss that
+        brings its own gradient images -- colour refinement's ``(1 - l) L1 + l (1 - SSIM)`` from the fused L1 + SSIM
+        kernel, the static-mask mapping loss with its masked depth term -- after which the plain ``lvdgs_backward`` runs
+        (no exposure terms: those losses do not use the exposure parameters).
 
         ``band = (row0, row1)``: only tile rows [row0, row1) of the view (``lvdgs_args.tile_row_begin / _end``): the band's
         pixels of the images, the band's share of the loss and of every gradient; ``radii`` are the whole view's,
@@ -218,13 +219,14 @@ class MapViewPass:
                 _lib.check(L.lvdgs_backward_fused_loss(C.byref(a), C.byref(la), 0, stream), "lvdgs_backward_fused_loss")
                 _lib.check(L.lvdgs_tracking_tail(C.byref(la), C.byref(a), None, _P(d_tau), 1, stream), "lvdgs_tracking_tail")
         if image_loss is not None:
-            loss, d_color = image_loss(color)
-            d_color = f32c(d_color)
-            keep.append(d_color)
-            a.dL_dout_color, a.dL_dout_depth, a.dL_dout_opacity, a.dL_dtau = _P(d_color), None, None, _P(d_tau)
+            res = image_loss(color, depth)
+            loss, d_color = res[0], f32c(res[1])
+            d_depth = f32c(res[2]) if len(res) > 2 and res[2] is not None else None
+            keep += [d_color, d_depth]
+            a.dL_dout_color, a.dL_dout_depth, a.dL_dout_opacity, a.dL_dtau = _P(d_color), _P(d_depth), None, _P(d_tau)
             with _lib.on_device(dev):
                 _lib.check(L.lvdgs_backward(C.byref(a), _lib.raw_stream(dev)), "lvdgs_backward")
-            a.dL_dout_color = a.dL_dtau = None
+            a.dL_dout_color = a.dL_dout_depth = a.dL_dtau = None
             initialization = True   # no exposure gradients from this loss
 
         # ---- hand the gradients over exactly where autograd would have put them ----

@@ -183,6 +183,41 @@ def masked_depth_l1(depth, mono_depth, static_mask=None, return_count=False):
     return (out[0], out[1].detach()) if return_count else out[0]
 
 
+def masked_mapping_loss_and_grads(image, depth, viewpoint, background, lambda_dssim, depth_lambda=0.1):
+    """``masked_mapping_loss`` without autograd: (loss, d loss / d image (3,H,W), d loss / d depth (1,H,W) or None) from the
+    fused L1 + SSIM launch (value and gradient image together) and the two masked-depth launches -- what a mapping view
+    with a ``static_mask`` hands to the plain ``lvdgs_backward`` (fast_mapping.MapViewPass, ``image_loss``)."""
+    L = _lib.lib()
+    dev = image.device
+    H, W = int(image.shape[-2]), int(image.shape[-1])
+    gt = viewpoint.original_image.to(dev)
+    mask = viewpoint.static_mask.to(dev)
+    keep = _mask_bytes(mask, H, W)
+    lam = float(lambda_dssim)
+    out, d_image = _launch(image.detach(), gt, keep, _c32(background), 1.0 - lam, -lam, True)
+    loss = (1.0 - lam) * out[0] - lam * out[1] + lam
+    d_depth = None
+    if depth is not None and getattr(viewpoint, "mono_depth", None) is not None:
+        d = _c32(_squeeze_hw(depth.detach()))
+        md = viewpoint.mono_depth
+        z = _c32(_squeeze_hw(md if torch.is_tensor(md) else torch.from_numpy(md)).to(dev))
+        if d.shape != z.shape or d.shape != (H, W):
+            raise ValueError("masked_mapping_loss_and_grads: depth, mono depth and image must have one size")
+        a = _lib.MaskedDepthArgs()
+        a.width, a.height = W, H
+        a.depth, a.gt_depth, a.static_mask = _p(d), _p(z), _p(keep)
+        scratch = torch.empty(int(L.lvdgs_masked_depth_scratch_bytes(W, H)), dtype=torch.uint8, device=dev)
+        res = torch.empty(2, dtype=torch.float32, device=dev)
+        weight = torch.full((1,), float(depth_lambda), dtype=torch.float32, device=dev)
+        d_depth = torch.empty(1, H, W, dtype=torch.float32, device=dev)
+        a.scratch, a.scratch_bytes, a.out, a.grad_loss, a.d_depth = _p(scratch), scratch.numel(), _p(res), _p(weight), _p(d_depth)
+        with _lib.on_device(dev):
+            _lib.check(L.lvdgs_masked_depth_l1_forward(C.byref(a), _raw_stream(dev)), "lvdgs_masked_depth_l1_forward")
+            _lib.check(L.lvdgs_masked_depth_l1_backward(C.byref(a), _raw_stream(dev)), "lvdgs_masked_depth_l1_backward")
+        loss = loss + float(depth_lambda) * res[0]
+    return loss, d_image, d_depth
+
+
 def masked_mapping_loss(image, depth, viewpoint, background, lambda_dssim, depth_lambda=0.1):
     """The mapping loss of a keyframe that carries a ``static_mask`` (utils/slam_backend.py:199-261):
     ``(1 - l) * L1 + l * (1 - SSIM)`` on the images with the dynamic pixels overwritten by the background colour,

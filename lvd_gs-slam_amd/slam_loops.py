@@ -83,7 +83,7 @@ def color_refinement(backend, iteration_total=26000, render_fn=render, loss_fn=N
         static_mask = getattr(viewpoint_cam, "static_mask", None)
         lam = float(backend.opt_params.lambda_dssim)
         if vpass is not None and G.get_xyz.shape[0] > 0 and type(vpass).usable(backend, viewpoint_cam, allow_static_mask=True):
-            def image_loss(color):
+            def image_loss(color, depth=None):
                 gt = viewpoint_cam.original_image.to(color.device)
                 keep_mask = _mask_bytes(static_mask, color.shape[1], color.shape[2])
                 bg = backend.background.detach().float().contiguous() if keep_mask is not None else None

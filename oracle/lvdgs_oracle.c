@@ -127,6 +127,19 @@ typedef struct {
 
 static void *zalloc(size_t n, size_t sz) { return calloc(n ? n : 1, sz); }
 
+/* OpenMP (liblvdgs_oracle_f32_omp.so only, built with -fopenmp -DORACLE_OMP): the same loops spread over the host's cores,
+ * for bench.py's cpu_baseline leg -- "the CPU path on all cores of the box".  The scalar builds, which the tests check
+ * the kernels against, do not see a single pragma or a single changed statement: every ORACLE_OMP difference below is a
+ * different ORDER of the same additions (per-tile partial sums, atomics), never a different formula. */
+#ifdef ORACLE_OMP
+#include <omp.h>
+#define OMP_PRAGMA(x) _Pragma(#x)
+int oracle_threads(void) { return omp_get_max_threads(); }
+#else
+#define OMP_PRAGMA(x)
+int oracle_threads(void) { return 1; }
+#endif
+
 /* ------------------------------------------------------------------------------------------ */
 /* per-Gaussian projection                                                                     */
 
@@ -250,6 +263,7 @@ static uint32_t depth_bits(real z) {
 /* stable merge sort of (key,id) pairs by key */
 static void merge_sort_pairs(uint64_t *k, uint32_t *v, uint64_t *tk, uint32_t *tv, int64_t n) {
     for (int64_t w = 1; w < n; w *= 2) {
+        OMP_PRAGMA(omp parallel for schedule(static))
         for (int64_t lo = 0; lo < n; lo += 2 * w) {
             int64_t mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
             int64_t i = lo, j = mid, o = lo;
@@ -283,6 +297,7 @@ int oracle_forward(oracle_ctx *c) {
 
     /* ---- per-Gaussian projection ---- */
     int64_t D = 0;
+    OMP_PRAGMA(omp parallel for reduction(+:D) schedule(static))
     for (int i = 0; i < N; i++) {
         const real *p = c->means3D + 3 * i;
         real pv[3], ph[4];
@@ -344,6 +359,22 @@ int oracle_forward(oracle_ctx *c) {
     /* ---- duplicate with keys, sort, ranges ---- */
     uint64_t *keys = zalloc(D, 8), *tk = zalloc(D, 8);
     uint32_t *ids = zalloc(D, 4), *tv = zalloc(D, 4);
+#ifdef ORACLE_OMP
+    int64_t *first = zalloc((size_t)N + 1, 8);
+    for (int i = 0; i < N; i++) first[i + 1] = first[i] + (c->radii[i] > 0 ? c->tiles_touched[i] : 0);
+    OMP_PRAGMA(omp parallel for schedule(static))
+    for (int i = 0; i < N; i++) {
+        if (c->radii[i] <= 0) continue;
+        const int32_t *r = c->rect + 4 * i;
+        int64_t off = first[i];
+        for (int y = r[1]; y < r[3]; y++)
+            for (int x = r[0]; x < r[2]; x++) {
+                keys[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | depth_bits(c->depths[i]);
+                ids[off++] = (uint32_t)i;
+            }
+    }
+    free(first);
+#else
     int64_t off = 0;
     for (int i = 0; i < N; i++) {
         if (c->radii[i] <= 0) continue;
@@ -354,6 +385,7 @@ int oracle_forward(oracle_ctx *c) {
                 ids[off++] = (uint32_t)i;
             }
     }
+#endif
     merge_sort_pairs(keys, ids, tk, tv, D);
     free(tk); free(tv);
     c->keys_sorted = keys; c->ids_sorted = ids;
@@ -364,6 +396,7 @@ int oracle_forward(oracle_ctx *c) {
     }
 
     /* ---- per-pixel front-to-back compositing ---- */
+    OMP_PRAGMA(omp parallel for collapse(2) schedule(dynamic, 4))
     for (int ty = 0; ty < gy; ty++)
         for (int tx = 0; tx < gx; tx++) {
             uint32_t beg = c->ranges[2 * (ty * gx + tx)], end = c->ranges[2 * (ty * gx + tx) + 1];
@@ -392,7 +425,10 @@ int oracle_forward(oracle_ctx *c) {
                         for (int ch = 0; ch < 3; ch++) C[ch] += c->rgb[3 * g + ch] * w;
                         Dp += c->depths[g] * w;
                         frag |= near_rel(test_T, T_TOUCH);
-                        if (test_T > T_TOUCH) c->n_touched[g]++;
+                        if (test_T > T_TOUCH) {
+                            OMP_PRAGMA(omp atomic)
+                            c->n_touched[g]++;
+                        }
                         T = test_T; last = contributor;
                     }
                     c->final_T[pix] = T; c->n_contrib[pix] = last; c->fragile[pix] = frag;
@@ -425,9 +461,21 @@ int oracle_backward(oracle_ctx *c) {
      * [5] d/d opacity, [6..8] d/d rgb, [9] d/d view depth */
     double *acc = zalloc(10 * (size_t)N, sizeof(double));
 
+#ifdef ORACLE_OMP
+    /* per tile: sums by list position in a buffer of the thread's own, added to the shared per-Gaussian sums once per
+     * (tile, Gaussian) with atomics */
+#define ACC(g, k, j) local[10 * (size_t)((k) - beg) + (j)]
+    OMP_PRAGMA(omp parallel for collapse(2) schedule(dynamic, 4))
+#else
+#define ACC(g, k, j) acc[10 * (size_t)(g) + (j)]
+#endif
     for (int ty = 0; ty < gy; ty++)
         for (int tx = 0; tx < gx; tx++) {
             uint32_t beg = c->ranges[2 * (ty * gx + tx)];
+#ifdef ORACLE_OMP
+            const uint32_t end_ = c->ranges[2 * (ty * gx + tx) + 1];
+            double *local = calloc(10 * (size_t)(end_ > beg ? end_ - beg : 1), sizeof(double));
+#endif
             for (int ly = 0; ly < TILE_Y; ly++)
                 for (int lx = 0; lx < TILE_X; lx++) {
                     int x = tx * TILE_X + lx, y = ty * TILE_Y + ly;
@@ -457,12 +505,12 @@ int oracle_backward(oracle_ctx *c) {
                             behind[ch] = last_alpha * last_c[ch] + ((real)1 - last_alpha) * behind[ch];
                             last_c[ch] = c->rgb[3 * g + ch];
                             dL_dalpha += (last_c[ch] - behind[ch]) * gC[ch];
-                            acc[10 * (size_t)g + 6 + ch] += w * gC[ch];
+                            ACC(g, k, 6 + ch) += w * gC[ch];
                         }
                         behind_d = last_alpha * last_d + ((real)1 - last_alpha) * behind_d;
                         last_d = c->depths[g];
                         dL_dalpha += (last_d - behind_d) * gD;
-                        acc[10 * (size_t)g + 9] += w * gD;
+                        ACC(g, k, 9) += w * gD;
                         dL_dalpha *= T;
                         last_alpha = alpha;
                         /* background and the opacity image both see alpha only through T_final */
@@ -470,21 +518,36 @@ int oracle_backward(oracle_ctx *c) {
                         /* UNPINNED: the published backward differentiates alpha = o*G and ignores the
                          * min(0.99, .) clamp (the gradient is not masked where the clamp is active). */
                         real dL_dG = co[3] * dL_dalpha;
-                        acc[10 * (size_t)g + 5] += G * dL_dalpha;
+                        ACC(g, k, 5) += G * dL_dalpha;
                         /* power = -1/2 (a dx^2 + c dy^2) - b dx dy, d = mean - pixel */
                         real dG_ddx = G * (-co[0] * dx - co[1] * dy), dG_ddy = G * (-co[2] * dy - co[1] * dx);
-                        acc[10 * (size_t)g + 0] += dL_dG * dG_ddx;
-                        acc[10 * (size_t)g + 1] += dL_dG * dG_ddy;
-                        acc[10 * (size_t)g + 2] += dL_dG * G * ((real)-0.5 * dx * dx);
-                        acc[10 * (size_t)g + 3] += dL_dG * G * (-dx * dy);
-                        acc[10 * (size_t)g + 4] += dL_dG * G * ((real)-0.5 * dy * dy);
+                        ACC(g, k, 0) += dL_dG * dG_ddx;
+                        ACC(g, k, 1) += dL_dG * dG_ddy;
+                        ACC(g, k, 2) += dL_dG * G * ((real)-0.5 * dx * dx);
+                        ACC(g, k, 3) += dL_dG * G * (-dx * dy);
+                        ACC(g, k, 4) += dL_dG * G * ((real)-0.5 * dy * dy);
                     }
                 }
+#ifdef ORACLE_OMP
+            for (uint32_t k = beg; k < end_; k++) {
+                const uint32_t g = c->ids_sorted[k];
+                for (int j = 0; j < 10; j++) {
+                    const double v = local[10 * (size_t)(k - beg) + j];
+                    if (v != 0) {
+                        OMP_PRAGMA(omp atomic)
+                        acc[10 * (size_t)g + j] += v;
+                    }
+                }
+            }
+            free(local);
+#endif
         }
+#undef ACC
 
     /* ---- per-Gaussian chain ---- */
     double tau[6] = {0, 0, 0, 0, 0, 0};
     const real *V = c->viewmatrix, *PM = c->projmatrix, *PR = c->projmatrix_raw;
+    OMP_PRAGMA(omp parallel for reduction(+:tau[:6]) schedule(static))
     for (int i = 0; i < N; i++) {
         if (c->radii[i] <= 0) continue;
         const double *A = acc + 10 * (size_t)i;

@@ -14,10 +14,10 @@ _LIBS = {}
 
 def build(force=False):
     out = os.path.join(HERE, "_build")
-    need = force or not all(os.path.exists(os.path.join(out, f"liblvdgs_oracle_{p}.so")) for p in ("f32", "f64"))
+    need = force or not all(os.path.exists(os.path.join(out, f"liblvdgs_oracle_{p}.so")) for p in ("f32", "f64", "f32_omp"))
     if not need:
         src = os.path.getmtime(os.path.join(HERE, "lvdgs_oracle.c"))
-        need = any(os.path.getmtime(os.path.join(out, f"liblvdgs_oracle_{p}.so")) < src for p in ("f32", "f64"))
+        need = any(os.path.getmtime(os.path.join(out, f"liblvdgs_oracle_{p}.so")) < src for p in ("f32", "f64", "f32_omp"))
     if need:
         subprocess.check_call(["make", "-C", HERE, "-s"])
 
@@ -53,7 +53,7 @@ def _lib(prec):
     if prec not in _LIBS:
         build()
         lib = C.CDLL(os.path.join(HERE, "_build", f"liblvdgs_oracle_{prec}.so"))
-        assert lib.oracle_real_bytes() == (4 if prec == "f32" else 8)
+        assert lib.oracle_real_bytes() == (8 if prec == "f64" else 4)
         _LIBS[prec] = lib
     return _LIBS[prec]
 
@@ -68,7 +68,9 @@ def _np(ptr, shape, dtype):
 class Oracle:
     """One forward (+ optional backward) of the CPU oracle on numpy inputs.
 
-    ``precision`` is "f32" (parity target of the HIP path) or "f64" (gradient pinning).
+    ``precision`` is "f32" (parity target of the HIP path), "f64" (gradient pinning) or "f32_omp" (the f32 restatement
+    spread over the host's cores with OpenMP -- bench.py's CPU baseline; its per-Gaussian sums are added in another order,
+    so it is not what the parity tests compare with).
     Inputs: means3D (N,3), opacities (N,), scales (N,3), rotations (N,4), shs (N,M,3) or
     colors_precomp (N,3), optional cov3D_precomp (N,6); viewmatrix/projmatrix/projmatrix_raw
     (4,4 row-vector layout as the reference's Camera produces them), campos (3,), bg (3,).
@@ -77,9 +79,10 @@ class Oracle:
     def __init__(self, precision="f32"):
         self.prec = precision
         self.lib = _lib(precision)
-        self.real = np.float32 if precision == "f32" else np.float64
-        self.creal = C.c_float if precision == "f32" else C.c_double
-        self.ctx = (_CtxF32 if precision == "f32" else _CtxF64)()
+        self.real = np.float64 if precision == "f64" else np.float32
+        self.creal = C.c_double if precision == "f64" else C.c_float
+        self.ctx = (_CtxF64 if precision == "f64" else _CtxF32)()
+        self.threads = int(self.lib.oracle_threads())
         self._keep = []
         self._live = False
 

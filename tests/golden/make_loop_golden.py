@@ -238,6 +238,45 @@ def main():
     out["track_median_depth"] = np.array(float(fe.median_depth))
     out["track_last_depth"] = pkg["depth"].detach().numpy()
 
+    # ------------------------------------------------------------------ FrontEnd.is_keyframe / add_to_window
+    # What the front end decides right after tracking (utils/slam_frontend.py:1579-1674), from the tracked frame's
+    # n_touched > 0 and the keyframes' occlusion-aware visibility -- both outputs of render().  The tracked frame joins
+    # the scene's seven keyframes as index 7; every keyframe's visibility row is what the back end stores for it
+    # ((n_touched > 0).long(), utils/slam_backend.py:311-315) on the same map.
+    with torch.no_grad():
+        cur_vis = (pkg["n_touched"] > 0)
+        occ = {i: (dense_render(c, fe.gaussians, fe.pipeline_params, fe.background)["n_touched"] > 0).long() for i, c in enumerate(sc["cameras"])}
+    fe.cameras = {i: c for i, c in enumerate(sc["cameras"])}
+    fe.cameras[7] = cam
+    fe.initialized = True
+    out["kf_cur_visibility"] = cur_vis.numpy()
+    for i, v in occ.items():
+        out[f"kf_occ_{i}"] = v.numpy()
+    out["kf_is_keyframe"] = np.array([bool(fe.is_keyframe(7, last, cur_vis, occ)) for last in range(7)])
+    # the same question at other scales of the scene (the thresholds are in units of the median depth)
+    decisions = []
+    for scale in (0.25, 1.0, 4.0, 16.0):
+        keep = fe.median_depth
+        fe.median_depth = keep * scale
+        decisions.append([bool(fe.is_keyframe(7, last, cur_vis, occ)) for last in range(7)])
+        fe.median_depth = keep
+    out["kf_is_keyframe_by_depth_scale"] = np.array(decisions)
+    windows = [[6, 5, 4, 3], [6, 5, 4], [6, 5, 4, 3, 2, 1], [3, 1, 6, 0, 5], [6]]
+    # a keyframe that sees little of what the new frame sees (its row thinned out) is the one the covisibility rule removes
+    occ_thin = dict(occ)
+    occ_thin[4] = occ[4] * (torch.arange(occ[4].numel()) % 7 == 0).long()
+    res = []
+    for w in windows:
+        for table, init in ((occ, True), (occ_thin, True), (occ_thin, False)):
+            fe.initialized = init
+            new_w, removed = fe.add_to_window(7, cur_vis, table, list(w))
+            res.append((w, init, table is occ_thin, new_w, removed))
+    fe.initialized = True
+    out["kf_windows_json"] = np.array(json.dumps([dict(window=w, initialized=i, thinned=t, new_window=[int(x) for x in nw],
+                                                      removed=None if r is None else int(r)) for w, i, t, nw, r in res]))
+    print("is_keyframe", out["kf_is_keyframe"].tolist(), "by scale", out["kf_is_keyframe_by_depth_scale"].tolist())
+    print("add_to_window", [(w, nw, r) for w, _, _, nw, r in res][:6])
+
     np.savez_compressed(os.path.join(HERE, "loops.npz"), **{k: v for k, v in out.items() if v is not None})
     print("wrote loops.npz:", {k: (v.shape if hasattr(v, "shape") else v) for k, v in list(out.items())[:12]}, "...")
     print("init losses", out["init_losses"][:3], "->", out["init_losses"][-1], "N", out["init_n_per_iter"])

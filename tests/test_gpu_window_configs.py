@@ -70,18 +70,41 @@ def test_kitti07_window_of_8_plus_2_random_keyframes():
 
 
 def test_2m_gaussians_with_dynamic_object_masks():
+    """Keyframes that carry a static mask: fused=True renders, scores and differentiates them without autograd (the
+    L1 + SSIM kernel's and the masked-depth kernels' gradient images into the plain lvdgs_backward, fast_mapping.MapViewPass
+    with ``image_loss``); fused=False is render() -> loss_utils.masked_mapping_loss -> backward() through the autograd
+    engine.  Same losses, same map after two iterations."""
     from lvdgs.backend_map import map_window
+    from lvdgs.fast_mapping import MapViewPass
     window = [2, 1]
-    be, N = _backend("cfg5_2m_1920x1280", 2, window, masks=True)
-    assert N == 2_000_000
-    stats = {}
-    map_window(be, window, iters=2, stats=stats)
-    torch.cuda.synchronize()
-    losses = [float(x) for x in stats["losses"]]
-    assert all(np.isfinite(losses)) and all(0.0 < v < 10.0 for v in losses)
-    # masked keyframes take the L1 + SSIM branch: their exposure parameters get no gradient and never move
+    out = {}
+    for fused in (True, False):
+        torch.manual_seed(0)
+        be, N = _backend("cfg5_2m_1920x1280", 2, window, masks=True)
+        assert N == 2_000_000
+        calls = []
+        run = MapViewPass.run
+        MapViewPass.run = lambda self, *a, **k: (calls.append(k.get("image_loss") is not None) or run(self, *a, **k))
+        stats = {}
+        try:
+            map_window(be, window, iters=2, stats=stats, fused=fused)
+        finally:
+            MapViewPass.run = run
+        torch.cuda.synchronize()
+        assert calls == ([True] * 4 if fused else [])        # two masked keyframes x two iterations, none through autograd
+        losses = [float(x) for x in stats["losses"]]
+        assert all(np.isfinite(losses)) and all(0.0 < v < 10.0 for v in losses)
+        # masked keyframes take the L1 + SSIM branch: their exposure parameters get no gradient and never move
+        for kf in window:
+            vp = be.viewpoints[kf]
+            assert float(vp.exposure_a.detach()) == 0.0 and float(vp.exposure_b.detach()) == 0.0
+            assert int(be.occ_aware_visibility[kf].sum()) > 50_000
+        assert be.gaussians.get_xyz.shape[0] == N and torch.isfinite(be.gaussians.get_xyz).all()
+        out[fused] = (losses, be.gaussians.get_xyz.detach().cpu().numpy(), be.gaussians._opacity.detach().cpu().numpy(),
+                      {kf: be.viewpoints[kf].T.cpu().numpy() for kf in window})
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=5e-5)
+    for k in (1, 2):
+        d = np.abs(out[True][k] - out[False][k])
+        assert (d > 1e-4 * np.abs(out[False][k]) + 1e-5).mean() < 3e-4 and d.max() < 3e-2, k
     for kf in window:
-        vp = be.viewpoints[kf]
-        assert float(vp.exposure_a.detach()) == 0.0 and float(vp.exposure_b.detach()) == 0.0
-        assert int(be.occ_aware_visibility[kf].sum()) > 50_000
-    assert be.gaussians.get_xyz.shape[0] == N and torch.isfinite(be.gaussians.get_xyz).all()
+        np.testing.assert_allclose(out[True][3][kf], out[False][3][kf], atol=2e-5)

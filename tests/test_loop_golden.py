@@ -185,6 +185,41 @@ def test_track_frame_replays_the_reference_tracking_loop(gold):
     _close([float(cam.exposure_a.detach()), float(cam.exposure_b.detach())], gold["track_end_exposure"], "exposure", rtol=1e-3, atol_scale=1e-3)
     assert abs(float(median_depth) - float(gold["track_median_depth"])) < 1e-4 * float(gold["track_median_depth"])
     _close(pkg["depth"].detach().numpy(), gold["track_last_depth"], "last rendered depth")
+    # ---- what the front end decides next (is_keyframe / add_to_window), on this run's own render outputs ----
+    check_keyframe_decisions(gold, cfg, sc, cam, pkg, median_depth, lambda c: dense_render(c, sc["gaussians"], sc["pipe"], sc["background"]), exact=True)
+
+
+def check_keyframe_decisions(gold, cfg, sc, cam, pkg, median_depth, render_keyframe, exact):
+    """``keyframe_utils.is_keyframe`` / ``add_to_window`` fed the product's outputs -- the tracked frame's n_touched > 0
+    and the keyframes' occlusion-aware visibility rows, (n_touched > 0).long() of their renders -- against what the
+    reference's own FrontEnd.is_keyframe / add_to_window (utils/slam_frontend.py:1579-1674) decided in the fixture."""
+    import json
+    from lvdgs.keyframe_utils import add_to_window, is_keyframe
+    with torch.no_grad():
+        cur_vis = (pkg["n_touched"] > 0).cpu()
+        occ = {i: (render_keyframe(c)["n_touched"] > 0).long().cpu() for i, c in enumerate(sc["cameras"])}
+    if exact:
+        np.testing.assert_array_equal(cur_vis.numpy(), gold["kf_cur_visibility"])
+        for i, v in occ.items():
+            np.testing.assert_array_equal(v.numpy(), gold[f"kf_occ_{i}"])
+    else:   # the HIP renderer may put a Gaussian on the other side of the "transmittance > 1/2" line at a pixel or two
+        assert (cur_vis.numpy() != gold["kf_cur_visibility"]).mean() < 0.02
+        for i, v in occ.items():
+            assert (v.numpy() != gold[f"kf_occ_{i}"]).mean() < 0.02, i
+    cameras = {i: c for i, c in enumerate(sc["cameras"])}
+    cameras[7] = cam
+    got = [is_keyframe(cfg, cameras, 7, last, cur_vis, occ, median_depth) for last in range(7)]
+    assert got == gold["kf_is_keyframe"].tolist()
+    assert any(got) and not all(got)
+    for scale, want in zip((0.25, 1.0, 4.0, 16.0), gold["kf_is_keyframe_by_depth_scale"].tolist()):
+        assert [is_keyframe(cfg, cameras, 7, last, cur_vis, occ, float(median_depth) * scale) for last in range(7)] == want, scale
+    occ_thin = dict(occ)
+    occ_thin[4] = occ[4] * (torch.arange(occ[4].numel()) % 7 == 0).long()
+    cases = json.loads(str(gold["kf_windows_json"]))
+    assert any(c["removed"] is not None for c in cases) and any(c["removed"] is None for c in cases)
+    for c in cases:
+        new_w, removed = add_to_window(cfg, cameras, 7, cur_vis, occ_thin if c["thinned"] else occ, c["window"], initialized=c["initialized"])
+        assert (list(new_w), removed) == (c["new_window"], c["removed"]), c
 
 
 def _cpu_refine_loss(image, gt_image, lambda_dssim, static_mask, background):

@@ -223,3 +223,29 @@ def test_empty_and_all_culled_inputs():
     assert not b["means3D"].any() and not b["tau"].any()
     assert not orc.mark_visible(g["means3D"].numpy(), cam.world_view_transform.numpy()).any()
     o.free()
+
+
+def test_openmp_build_equals_the_scalar_oracle():
+    """liblvdgs_oracle_f32_omp.so (bench.py's CPU baseline: the same loops over all host cores) gives the scalar build's
+    forward bit for bit and its gradients to the order of a few double-precision additions."""
+    W, H, N = 96, 64, 900
+    g, cam = _scene(N, W, H, seed=3)
+    g32 = {k: v.float() for k, v in g.items()}
+    bg = np.array([0.1, 0.2, 0.3])
+    gc, gd, go = _loss_weights(W, H, 5)
+    out = {}
+    for prec in ("f32", "f32_omp"):
+        o = orc.Oracle(prec)
+        f = o.forward(means3D=g32["means3D"].numpy(), opacities=g32["opacities"].numpy(), W=W, H=H, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+                      viewmatrix=cam.world_view_transform.numpy(), projmatrix=(cam.world_view_transform @ cam.projection_matrix).numpy(),
+                      projmatrix_raw=cam.projection_matrix.numpy(), campos=torch.linalg.inv(cam.world_view_transform)[3, :3].numpy(), bg=bg,
+                      scales=g32["scales"].numpy(), rotations=g32["rotations"].numpy(), colors_precomp=g32["colors"].numpy())
+        b = o.backward(gc.numpy(), gd.numpy(), go.numpy())
+        out[prec] = (f, b, o.threads)
+        o.free()
+    (f0, b0, t0), (f1, b1, t1) = out["f32"], out["f32_omp"]
+    assert t0 == 1 and t1 >= 1
+    for k in ("color", "depth", "opacity", "radii", "n_touched", "ids_sorted", "keys_sorted", "ranges", "n_contrib", "final_T"):
+        np.testing.assert_array_equal(f0[k], f1[k], err_msg=k)
+    for k in b0:
+        np.testing.assert_allclose(b1[k], b0[k], rtol=1e-6, atol=1e-6 * max(np.abs(b0[k]).max(), 1e-30), err_msg=k)
