@@ -176,7 +176,7 @@ size_t bin_layout(int64_t D, BinView *v, void *base) {
 // buffer holds; a buffer of exactly lvdgs_binning_bytes(D) bytes has the layout bin_layout(D) describes.
 int64_t bin_view(const lvdgs_args *a, BinView *v) {
     if (!a->binning_state || a->binning_bytes < bin_layout(1, nullptr, nullptr)) { *v = BinView{}; return 0; }
-    int64_t p = (int64_t)((a->binning_bytes - 3 * 256 - 16) / 9);   // 4 + 4 + 1 bytes per pair, three 256-byte roundings
+    int64_t p = a->binning_bytes > 2048 ? (int64_t)((a->binning_bytes - 3 * 256 - 16) / 9) : 1;   // 4 + 4 + 1 bytes per pair, three 256-byte roundings
     while (bin_layout(p + 1, nullptr, nullptr) <= a->binning_bytes) p++;
     while (p > 1 && bin_layout(p, nullptr, nullptr) > a->binning_bytes) p--;
     bin_layout(p, v, a->binning_state);
