@@ -257,10 +257,12 @@ int lvdgs_photometric_loss_partials(const lvdgs_loss_args *a, void *stream);
  * One launch = `pose_optimizer.step()` (torch.optim.Adam: betas, eps, one learning rate per group) on the frame's
  * cam_rot_delta, cam_trans_delta, exposure_a, exposure_b, then `update_pose`: T_w2c <- SE3_exp([trans, rot]) @ [R T],
  * deltas zeroed, and the matrices the next render reads (Camera.world_view_transform / full_proj_transform /
- * camera_center, utils/camera_utils.py:106-120).  `state` = 19 floats owned by the caller and zeroed before the first
- * step of a frame: Adam's (exp_avg, exp_avg_sq) of the 8 scalars, the step count, a STICKY converged flag
- * (||tau|| < converged_threshold at some step) and the number of steps applied.  Once the flag is set further calls
- * change nothing, so the host may enqueue iterations ahead and read the flag late. */
+ * camera_center, utils/camera_utils.py:106-120).  `state` = 24 floats owned by the caller and zeroed before the first
+ * step of a frame: [0..15] Adam's (exp_avg, exp_avg_sq) of the 8 scalars (rot xyz, trans xyz, exposure a, b), [16] calls
+ * applied, [17] a STICKY converged flag (||tau|| < converged_threshold at some step), [18] the number of steps applied,
+ * [19..22] the Adam step count of the rot / trans / exposure_a / exposure_b group (a group whose gradient pointer is NULL in
+ * a call is skipped, moments and count, as torch.optim.Adam skips parameters without .grad).  Once the flag is set further
+ * calls change nothing, so the host may enqueue iterations ahead and read the flag late. */
 typedef struct lvdgs_pose_step_args {
     float *R;                      /* 9, row-major world-to-camera rotation (in / out)                */
     float *T;                      /* 3 (in / out)                                                    */
@@ -271,7 +273,7 @@ typedef struct lvdgs_pose_step_args {
     const float *grad_tau;         /* 6: dL/d(trans, rot), as lvdgs_backward writes dL_dtau; NULL = 0 */
     const float *grad_exposure_a;  /* 1 or NULL                                                       */
     const float *grad_exposure_b;  /* 1 or NULL                                                       */
-    float *state;                  /* 19 floats, see above                                            */
+    float *state;                  /* 24 floats, see above                                            */
     double lr_rot, lr_trans, lr_exposure, beta1, beta2, eps;  /* doubles, like the Python floats torch.optim.Adam computes with */
     float converged_threshold;
     const float *projmatrix_raw;   /* 16: the camera's projection_matrix (row-vector layout) or NULL  */

@@ -291,7 +291,7 @@ class KeyframeStepper:
                 raise NotImplementedError("pose deltas in the optimiser of a keyframe that update_pose skips")
             dev = vp.exposure_a.device
             a = _lib.PoseStepArgs()
-            state = torch.zeros(19, dtype=torch.float32, device=dev)
+            state = torch.zeros(24, dtype=torch.float32, device=dev)
             keep = [state]
             if pose:
                 R = vp.R.detach().to(device=dev, dtype=torch.float32).contiguous().clone()
@@ -332,6 +332,22 @@ class KeyframeStepper:
                 return False
         owned = {id(getattr(vp, n, None)) for vp in viewpoints for n in _POSE_FIELDS}
         return all(id(p) in owned for gp in optimizer.param_groups for p in gp["params"]) and all(hasattr(vp, "update_RT") for vp in viewpoints)
+
+    def export_to_optimizer(self):
+        """Write the moments and step counts kept here into the torch optimiser's own state, so that a later
+        ``keyframe_optimizers.step()`` (``fused=False``, ``up_pose=False``) continues from them instead of from a stale or
+        empty state."""
+        groups = {"cam_rot_delta": (0, 19), "cam_trans_delta": (6, 20), "exposure_a": (12, 21), "exposure_b": (14, 22)}
+        for vp, a, pose, has, keep in self.items:
+            st = keep[0].detach().cpu()
+            for name, (off, cnt) in groups.items():
+                if not has[name] or float(st[cnt]) == 0.0:
+                    continue
+                p = getattr(vp, name)
+                n = p.numel()
+                mv = st[off:off + 2 * n].view(n, 2)
+                self.optimizer.state[p] = {"step": torch.tensor(float(st[cnt])), "exp_avg": mv[:, 0].clone().to(p.device).view_as(p),
+                                           "exp_avg_sq": mv[:, 1].clone().to(p.device).view_as(p)}
 
     def step(self):
         """All keyframes' steps in ONE launch (``lvdgs_pose_step_batch``; they touch disjoint cameras)."""
@@ -659,6 +675,10 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
                 if stepper is not None:
                     stepper.step()       # Adam + update_pose of every window keyframe, one launch each
                 else:
+                    stale = getattr(backend.keyframe_optimizers, "_lvdgs_stepper", None)
+                    if stale is not None:   # earlier iterations went through the stepper: hand its moments to torch's optimiser
+                        stale.export_to_optimizer()
+                        backend.keyframe_optimizers._lvdgs_stepper = None
                     backend.keyframe_optimizers.step()
                 backend.keyframe_optimizers.zero_grad(set_to_none=True)
             for v in views:   # exposure gradients of the random views are never stepped; do not let them pile up

@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256) isotropic_kernel(int N, const float *__re
     const int i = blockIdx.x * 256 + threadIdx.x;
     float acc = 0.f;
     if (i < N) {
-        const float s0 = __expf(raw[3 * (size_t)i]), s1 = __expf(raw[3 * (size_t)i + 1]), s2 = __expf(raw[3 * (size_t)i + 2]);
+        const float s0 = expf(raw[3 * (size_t)i]), s1 = expf(raw[3 * (size_t)i + 1]), s2 = expf(raw[3 * (size_t)i + 2]);   // (expf, like torch.exp and the projection kernel)
         const float m = (s0 + s1 + s2) / 3.f;
         const float d0 = s0 - m, d1 = s1 - m, d2 = s2 - m;
         acc = fabsf(d0) + fabsf(d1) + fabsf(d2);

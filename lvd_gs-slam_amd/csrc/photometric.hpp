@@ -30,7 +30,7 @@ struct LossConsts {   // per-launch values every pixel uses
     float ea, eb, Wr, Wd;
     bool has_d;
     __device__ __forceinline__ LossConsts(const LossParams &p, bool backward) {
-        ea = p.exposure_a ? __expf(p.exposure_a[0]) : 1.f;
+        ea = p.exposure_a ? expf(p.exposure_a[0]) : 1.f;   // (expf: what torch.exp(exposure_a) gives the autograd path)
         eb = p.exposure_b ? p.exposure_b[0] : 0.f;
         const float g = backward ? (p.grad_out ? p.grad_out[0] : 1.f) : 0.f;
         Wr = p.w_rgb / (3.f * (float)p.P) * g;

@@ -55,31 +55,65 @@ __device__ float adam_update(float p, float g, float *m, float *v, double lr, do
     return p - step_size * (m1 / denom);
 }
 
-__device__ void pose_step_body(const lvdgs_pose_step_args &a) {   // one thread
-    float *st = a.state;  // [0..15]: (m, v) of rot xyz, trans xyz, a, b ; [16]: step count ; [17]: converged (sticky) ; [18]: iterations applied
-    if (st[17] != 0.f) return;  // already converged: the host may have run ahead
-    const float step = st[16] + 1.f;
-    st[16] = step;
-    st[18] = step;
-    // beta^step by squaring (the step count is a small integer; the general pow() is several hundred dependent
-    // double-precision instructions on this one thread -- a third of the launch).  It can differ from Python's
-    // beta ** step in the last bits of the double, which the float32 step size and denominator never see.
-    const double bc1 = 1.0 - int_pow(a.beta1, (unsigned)step);
-    const double bc2_sqrt = sqrt(1.0 - int_pow(a.beta2, (unsigned)step));
-    // ---- Adam (a parameter without a gradient is skipped, moments included, as torch.optim.Adam does) ----
+// One wave.  Lanes 0..7 each take one of the eight scalars through Adam (rot xyz, trans xyz, exposure a, b) -- the bias
+// corrections are powers in double precision, a few hundred dependent instructions that used to run eight times in a row
+// on one lane -- then lane 0 does the retraction and the matrices with everything it needs already in registers (every
+// load of the step is issued before the first dependent instruction: the one-lane version paid a memory round trip per
+// statement, a third of the launch).
+// state: [0..15] (m, v) of the eight scalars; [16] calls applied; [17] converged (sticky); [18] iterations applied;
+// [19..22] Adam step count of the rot / trans / exposure_a / exposure_b group -- a group without a gradient in a call is
+// skipped, moments AND step count, as torch.optim.Adam skips parameters without .grad (bias corrections follow the group's
+// own count, not the number of calls).
+__device__ void pose_step_body(const lvdgs_pose_step_args &a) {   // the first wave of the workgroup, all 64 lanes
+    const int lane = threadIdx.x & 63;
+    float *st = a.state;
+    if (st[17] != 0.f) return;  // already converged: the host may have run ahead (uniform: every lane reads the same word)
+    // ---- everything the step reads, up front ----
+    const float calls = st[16];
     const float *g_rot = a.grad_tau ? a.grad_tau + 3 : a.grad_rot, *g_trans = a.grad_tau ? a.grad_tau : a.grad_trans;
-    float rot[3] = {0.f, 0.f, 0.f}, trans[3] = {0.f, 0.f, 0.f};
-    if (a.R) {
-        for (int k = 0; k < 3; k++) {
-            rot[k] = g_rot ? adam_update(a.cam_rot_delta[k], g_rot[k], st + 2 * k, st + 2 * k + 1, a.lr_rot, a.beta1, a.beta2, a.eps, bc1, bc2_sqrt)
-                           : a.cam_rot_delta[k];
-            trans[k] = g_trans ? adam_update(a.cam_trans_delta[k], g_trans[k], st + 6 + 2 * k, st + 6 + 2 * k + 1, a.lr_trans, a.beta1, a.beta2, a.eps, bc1, bc2_sqrt)
-                               : a.cam_trans_delta[k];
+    const int group = lane < 3 ? 0 : (lane < 6 ? 1 : (lane == 6 ? 2 : 3));
+    float *param = nullptr;
+    const float *grad = nullptr;
+    double lr = 0.0;
+    if (lane < 3) { if (a.R) { param = a.cam_rot_delta + lane; grad = g_rot ? g_rot + lane : nullptr; } lr = a.lr_rot; }
+    else if (lane < 6) { if (a.R) { param = a.cam_trans_delta + (lane - 3); grad = g_trans ? g_trans + (lane - 3) : nullptr; } lr = a.lr_trans; }
+    else if (lane == 6) { param = a.exposure_a; grad = a.exposure_a ? a.grad_exposure_a : nullptr; lr = a.lr_exposure; }
+    else if (lane == 7) { param = a.exposure_b; grad = a.exposure_b ? a.grad_exposure_b : nullptr; lr = a.lr_exposure; }
+    const bool mine = lane < 8 && param != nullptr;
+    const float p0 = mine ? *param : 0.f, g0 = (mine && grad) ? *grad : 0.f;
+    const float m0 = lane < 8 ? st[2 * lane] : 0.f, v0 = lane < 8 ? st[2 * lane + 1] : 0.f;
+    const float steps0 = lane < 8 ? st[19 + group] : 0.f;
+    float R0[9], T0[3], PR[16];
+    const bool lead = lane == 0 && a.R != nullptr;
+    if (lead) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) R0[i] = a.R[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) T0[i] = a.T[i];
+        if (a.projmatrix && a.projmatrix_raw) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) PR[i] = a.projmatrix_raw[i];
         }
     }
-    if (a.exposure_a && a.grad_exposure_a) *a.exposure_a = adam_update(*a.exposure_a, *a.grad_exposure_a, st + 12, st + 13, a.lr_exposure, a.beta1, a.beta2, a.eps, bc1, bc2_sqrt);
-    if (a.exposure_b && a.grad_exposure_b) *a.exposure_b = adam_update(*a.exposure_b, *a.grad_exposure_b, st + 14, st + 15, a.lr_exposure, a.beta1, a.beta2, a.eps, bc1, bc2_sqrt);
-    if (!a.R) return;  // exposure only
+    // ---- Adam, one scalar per lane ----
+    float p1 = p0;
+    if (mine && grad) {
+        const float step = steps0 + 1.f;
+        // beta^step by squaring (the step count is a small integer).  It can differ from Python's beta ** step in the last
+        // bits of the double, which the float32 step size and denominator never see.
+        const double bc1 = 1.0 - int_pow(a.beta1, (unsigned)step);
+        const double bc2_sqrt = sqrt(1.0 - int_pow(a.beta2, (unsigned)step));
+        float m = m0, v = v0;
+        p1 = adam_update(p0, g0, &m, &v, lr, a.beta1, a.beta2, a.eps, bc1, bc2_sqrt);
+        st[2 * lane] = m; st[2 * lane + 1] = v;
+        if (lane == 0 || lane == 3 || lane >= 6) st[19 + group] = step;
+        if (lane >= 6) *param = p1;
+    }
+    if (lane == 0) { st[16] = calls + 1.f; st[18] = calls + 1.f; }
+    float rot[3], trans[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { rot[k] = __shfl(p1, k, 64); trans[k] = __shfl(p1, 3 + k, 64); }
+    if (!lead) return;  // exposure only, or not the lane that holds the pose
     // ---- update_pose: T_w2c <- SE3_exp([trans, rot]) @ [R T] ----
     const float angle = sqrtf(rot[0] * rot[0] + rot[1] * rot[1] + rot[2] * rot[2]);
     float A, B, C;
@@ -95,9 +129,7 @@ __device__ void pose_step_body(const lvdgs_pose_step_args &a) {   // one thread
     }
     float dt[3];
     for (int i = 0; i < 3; i++) dt[i] = Vm[3 * i] * trans[0] + Vm[3 * i + 1] * trans[1] + Vm[3 * i + 2] * trans[2];
-    float R0[9], T0[3], R1[9], T1[3];
-    for (int i = 0; i < 9; i++) R0[i] = a.R[i];
-    for (int i = 0; i < 3; i++) T0[i] = a.T[i];
+    float R1[9], T1[3];
     mat3_mul(dR, R0, R1);
     for (int i = 0; i < 3; i++) T1[i] = dR[3 * i] * T0[0] + dR[3 * i + 1] * T0[1] + dR[3 * i + 2] * T0[2] + dt[i];
     for (int i = 0; i < 9; i++) a.R[i] = R1[i];
@@ -119,7 +151,7 @@ __device__ void pose_step_body(const lvdgs_pose_step_args &a) {   // one thread
         for (int i = 0; i < 4; i++)
             for (int j = 0; j < 4; j++) {
                 float s = 0.f;
-                for (int k = 0; k < 4; k++) s += view[4 * i + k] * a.projmatrix_raw[4 * k + j];
+                for (int k = 0; k < 4; k++) s += view[4 * i + k] * PR[4 * k + j];
                 a.projmatrix[4 * i + j] = s;
             }
     }
@@ -128,7 +160,7 @@ __device__ void pose_step_body(const lvdgs_pose_step_args &a) {   // one thread
 }
 
 __global__ void pose_step_kernel(PoseStepParams pp) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0) return;
     pose_step_body(pp.a);
 }
 
@@ -138,7 +170,6 @@ struct PoseBatchParams {
     lvdgs_pose_step_args a[POSE_BATCH_MAX];
 };
 __global__ void pose_step_batch_kernel(PoseBatchParams pp) {
-    if (threadIdx.x != 0) return;
     pose_step_body(pp.a[blockIdx.x]);
 }
 
@@ -187,12 +218,15 @@ __global__ void __launch_bounds__(THREADS) tracking_tail_kernel(TailParams t) {
         if (threadIdx.x >= 4) t.dL_dtau[threadIdx.x - 4] = v;
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    t.loss.loss[0] = t.loss.w_rgb * (s[0][0] / (3.f * (float)t.loss.P)) + t.loss.w_d * (s[1][0] / (float)t.loss.P);
-    if (t.loss.d_a) t.loss.d_a[0] = s[2][0];
-    if (t.loss.d_b) t.loss.d_b[0] = s[3][0];
+    if (threadIdx.x >= 64) return;
+    if (threadIdx.x == 0) {
+        t.loss.loss[0] = t.loss.w_rgb * (s[0][0] / (3.f * (float)t.loss.P)) + t.loss.w_d * (s[1][0] / (float)t.loss.P);
+        if (t.loss.d_a) t.loss.d_a[0] = s[2][0];
+        if (t.loss.d_b) t.loss.d_b[0] = s[3][0];
+    }
     if (!t.has_pose) return;
-    __threadfence_block();   // this thread reads dL_dtau (written by threads 4..9 before the barrier) and d_a / d_b back
+    __threadfence_block();   // the wave reads dL_dtau (written by threads 4..9 before the barrier) and d_a / d_b (lane 0, just now) back
+    __builtin_amdgcn_wave_barrier();
     pose_step_body(t.pose);
 }
 

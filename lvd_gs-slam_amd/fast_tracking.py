@@ -149,7 +149,7 @@ class TrackingSession:
 
         # ---- pose step (include/lvdgs.h: lvdgs_pose_step_args): torch.optim.Adam defaults, the front end's learning rates ----
         pa = self.pa = _lib.PoseStepArgs()
-        self.pose_state = torch.zeros(19, dtype=torch.float32, device=dev)
+        self.pose_state = torch.zeros(24, dtype=torch.float32, device=dev)
         pa.R, pa.T, pa.cam_rot_delta, pa.cam_trans_delta = _P(self.R), _P(self.T), _P(viewpoint.cam_rot_delta), _P(viewpoint.cam_trans_delta)
         pa.exposure_a, pa.exposure_b = _P(viewpoint.exposure_a), _P(viewpoint.exposure_b)
         pa.grad_tau, pa.grad_exposure_a, pa.grad_exposure_b, pa.state = _P(self.d_tau), _P(self.d_a), _P(self.d_b), _P(self.pose_state)

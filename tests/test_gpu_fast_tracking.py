@@ -38,7 +38,7 @@ def test_pose_step_equals_adam_plus_update_pose(grad_scale):
     L = _lib.lib()
     R, T = cam_k.R.clone().contiguous(), cam_k.T.clone().contiguous()
     view, proj, campos = torch.empty(4, 4, device="cuda"), torch.empty(4, 4, device="cuda"), torch.empty(3, device="cuda")
-    state = torch.zeros(19, device="cuda")
+    state = torch.zeros(24, device="cuda")
     gtau, ga, gb = torch.empty(6, device="cuda"), torch.empty(1, device="cuda"), torch.empty(1, device="cuda")
     pa = _lib.PoseStepArgs()
     P = lambda t: C.c_void_p(t.data_ptr())

@@ -20,7 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 # kernel symbol -> the name its launch is timed under in bench.py (ProfScope), where they differ
-ALIASES = {"blend_bwd2": "blend_bwd", "blend_bwd3": "blend_bwd", "blend_fwd2": "blend_fwd"}
+ALIASES = {"blend_bwd2": "blend_bwd", "blend_bwd3": "blend_bwd", "blend_fwd2": "blend_fwd", "preprocess_count": "preprocess_fwd",
+           "scatter_pairs": "group_scatter", "tile_depth_sort_wave": "tile_sort"}
 
 
 def short(name):
@@ -74,6 +75,10 @@ def main(tag, workload="cfg3_500k_1920x1080"):
                         "hbm_bytes_per_launch": int((2 * f + w) * 1024), "note": note}
             if "SQ_INSTS_VALU" in c:
                 entry[k]["valu_wave_instructions_per_launch"] = int(sum(c["SQ_INSTS_VALU"]) / len(c["SQ_INSTS_VALU"]))
+            for name, key in (("SQ_INSTS_SALU", "salu_wave_instructions_per_launch"), ("SQ_INSTS_LDS", "lds_wave_instructions_per_launch"),
+                              ("SQ_WAVES", "waves_per_launch")):
+                if name in c:
+                    entry[k][key] = int(sum(c[name]) / len(c[name]))
     if entry:
         entry["_source"] = f"gpurun_out/{tag} (tools/profile_round.sh), summarised by tools/summarize_profiles.py"
         traffic[workload] = entry
