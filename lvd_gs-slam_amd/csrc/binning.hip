@@ -248,6 +248,9 @@ __global__ void __launch_bounds__(1024) group_tilescan_kernel(int T, const uint3
 // SLOT_SCAN (lvdgs_forward): also makes slot_base[i] = exclusive scan of tiles_touched in id order (the backward's
 // gradient slots) from the pair totals the projection kernel left per chunk: every workgroup adds up the totals in front
 // of its chunk -- at most a few hundred values -- and scans its own Gaussians.  (The launch of a separate slot scan less.)
+#ifndef LVDGS_SCATTER_XCD
+#define LVDGS_SCATTER_XCD 1   // A/B builds: 0 = workgroup b takes chunk b
+#endif
 template <int PER, bool SLOT_SCAN>
 __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int gx, int T, const uint4 *__restrict__ rect,
                                                                      const uint32_t *__restrict__ hist,
@@ -261,13 +264,14 @@ __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int
     extern __shared__ uint32_t s_tile[];
     __shared__ uint32_t s_scan[33];
     __shared__ uint32_t s_slots[2];
-    const uint32_t *row = hist + (size_t)blockIdx.x * T;
+    const int chunk = LVDGS_SCATTER_XCD ? xcd_contiguous_chunk((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    const uint32_t *row = hist + (size_t)chunk * T;
     for (int t = threadIdx.x; t < T; t += GROUP_THREADS) s_tile[t] = ranges[t].x + row[t];  // (empty tiles are never visited)
     uint32_t slots_lo = 0, slots_hi = 0;   // the chunk's Gaussians' gradient slots: [lo, hi)
     if constexpr (SLOT_SCAN) {
         uint32_t before = 0;
-        for (int b = threadIdx.x; b < (int)blockIdx.x; b += GROUP_THREADS) before += chunk_sums[b];
-        const int base = blockIdx.x * GROUP_CHUNK + (int)threadIdx.x * PER;
+        for (int b = threadIdx.x; b < chunk; b += GROUP_THREADS) before += chunk_sums[b];
+        const int base = chunk * GROUP_CHUNK + (int)threadIdx.x * PER;
         uint32_t v[PER], mine = 0;
 #pragma unroll
         for (int k = 0; k < PER; k++) { v[k] = base + k < N ? tt[base + k] : 0u; mine += v[k]; }
@@ -284,7 +288,7 @@ __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int
         slots_lo = prefix; slots_hi = prefix + total;
     } else {
         if (threadIdx.x == 0) {
-            const int first = blockIdx.x * GROUP_CHUNK, last = min(N, first + GROUP_CHUNK) - 1;
+            const int first = chunk * GROUP_CHUNK, last = min(N, first + GROUP_CHUNK) - 1;
             s_slots[0] = slot_base[first]; s_slots[1] = slot_base[last] + tt[last];
         }
         __syncthreads();
@@ -302,7 +306,7 @@ __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < PER; k++) {
-        const int i = blockIdx.x * GROUP_CHUNK + k * GROUP_THREADS + (int)threadIdx.x;
+        const int i = chunk * GROUP_CHUNK + k * GROUP_THREADS + (int)threadIdx.x;
         const uint4 r = i < N ? rect[i] : make_uint4(0u, 0u, 0u, 0u);
         for_each_pair_of_rect(r, i, gx, [&](int tile, uint32_t id) {
             const uint32_t pos = atomicAdd(&s_tile[tile], 1u);

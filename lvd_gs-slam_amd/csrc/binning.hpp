@@ -8,11 +8,12 @@ namespace lvdgs {
 // A workgroup owns a chunk of consecutive Gaussians (1024 x PER) and keeps one counter per tile in LDS.
 constexpr int GROUP_THREADS = 1024;
 // Gaussians per workgroup = 1024 x PER.  Few, large chunks keep the [chunk][tile] count matrix and its scan small (2 M
-// Gaussians: 489 chunks of 4096); many, small ones spread the counting and scattering over the chip (200 k Gaussians
-// are 49 chunks of 4096 on 256 CUs, 98 of 2048, 196 of 1024).  Measured (same box, round 3, ms per tracking iteration with
-// chunks of 1024 / 2048 / 4096): KITTI geometry (200 k) 0.2557 / 0.2683 / -, config 3 (500 k) 0.5667 / 0.5678 / -,
-// 2 M / 1920x1280 - / 1.472 / 1.477.
-__host__ __device__ constexpr int group_per_thread_default(int N) { return N <= (1 << 18) ? 1 : (N <= (1 << 20) ? 2 : 4); }
+// Gaussians: 489 chunks of 4096); many, small ones spread the projection, counting and scattering over the chip and let
+// two workgroups share a CU (500 k Gaussians: 489 chunks of 1024 for 256 CUs).  Measured (same box, round 3, ms per
+// tracking iteration with chunks of 1024 / 2048 / 4096): KITTI geometry (200 k) 0.2557 / 0.2683 / -, config 3 (500 k)
+// 0.5587 / 0.5638 / - (with the scatter's chunks dealt XCD-contiguously; 0.5667 / 0.5678 before), 2 M / 1920x1280
+// - / 1.472 / 1.477.
+__host__ __device__ constexpr int group_per_thread_default(int N) { return N <= (1 << 19) ? 1 : (N <= (1 << 20) ? 2 : 4); }
 int group_per_thread_for(int N);   // binning.hip: the default, or LVDGS_GROUP_PER (1, 2 or 4; read once per process, for A/B measurements)
 constexpr int GROUP_MAX_TILES = 16384;  // 64 KiB of LDS counters
 constexpr int GROUP_BIG_RECT = 64;
@@ -47,6 +48,15 @@ __device__ __forceinline__ void for_each_pair_of_rect(const uint4 r, int i, int 
             if ((bm >> g.block_of(tx, ty)) & 1ull) visit((by0 + ty) * gx + bx0 + tx, bi);
         }
     }
+}
+
+// Workgroup b of n -> the chunk it takes, such that the workgroups of one XCD (b mod 8: workgroups are dealt round-robin over
+// the 8 XCDs) take CONSECUTIVE chunks.  Consecutive chunks place their pairs of a tile in neighbouring 8-byte slots of
+// the tile's segment; written from one XCD at about the same time, the slots of a 64-byte line meet in that XCD's L2 and
+// leave it as one full line instead of eight partial ones from eight L2s.
+__device__ __forceinline__ int xcd_contiguous_chunk(int b, int n) {
+    const int x = b & 7, k = b >> 3, q = n >> 3, r = n & 7;
+    return x * q + min(x, r) + k;
 }
 
 // Exclusive scan of one value per thread over a workgroup of 1024 threads (wave shifts, then the 16 wave totals by wave

@@ -377,7 +377,10 @@ struct BwdParams {
     float *tau_part;
 };
 
-constexpr int PAIR_CHUNK = 256;  // pair records staged per round: 10 KB of LDS
+#ifndef LVDGS_PAIR_CHUNK
+#define LVDGS_PAIR_CHUNK 256
+#endif
+constexpr int PAIR_CHUNK = LVDGS_PAIR_CHUNK;  // pair records staged per round: 10 KB of LDS at 256
 constexpr int BIG_RUN = 64;      // a Gaussian with more pairs than this is summed by its whole wave
 
 __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
