@@ -379,7 +379,8 @@ def main():
                                  "keyframe Adam, pose retraction; value = keyframes per second")),
                        "parallelism": ((f"10 views in pieces over {world} GPUs" if real_window else f"keyframe-per-gpu x{world}") if world > 1 else "single"),
                        "views_per_step": views_per_step, "comm_us_per_step": comm_us, "phases_us_per_step": phases,
-                       "autograd_api_iters_per_s": autograd_rate, "same_step_on_one_gpu_iters_per_s": same_step_single},
+                       "autograd_api_iters_per_s": autograd_rate, "same_step_on_one_gpu_iters_per_s": same_step_single,
+                       "same_step_on_one_gpu_value": None if same_step_single is None else round(same_step_single * views_per_step / (1 if real_window else world), 3)},
             **({"collective_backend": backend_name + " (functional check only, not a benchmark result)"} if world > 1 and backend_name != "nccl" else {}),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels_us_per_step": {k: round(v["us_per_step"], 2) for k, v in kernels.items()},
         }
