@@ -19,9 +19,14 @@ def _case(rng):
     r_min = float(rng.choice([0.3, 1.0, 4.0, 20.0]))
     r_max = r_min * float(rng.choice([1.5, 4.0, 12.0]))
     z_min = float(rng.choice([0.25, 1.0, 5.0]))
-    return dict(N=N, W=W, H=H, r_min=r_min, r_max=r_max, z_min=z_min, z_max=z_min * float(rng.choice([1.2, 10.0, 60.0])),
-                pose=None if rng.random() < 0.3 else int(rng.integers(0, 50)), opacity_scale=float(rng.choice([1.0, 0.3, 0.05])),
-                seed=int(rng.integers(0, 10_000)))
+    c = dict(N=N, W=W, H=H, r_min=r_min, r_max=r_max, z_min=z_min, z_max=z_min * float(rng.choice([1.2, 10.0, 60.0])),
+             pose=None if rng.random() < 0.3 else int(rng.integers(0, 50)), opacity_scale=float(rng.choice([1.0, 0.3, 0.05])),
+             seed=int(rng.integers(0, 10_000)))
+    # one case in five: opaque surfaces of large flat Gaussians (synthetic.make_surface_gaussians) -- rectangles of hundreds
+    # of tiles (block culling, wave-walked grouping, wave-summed gradients), lists beyond one wave's sort, saturating pixels
+    if rng.random() < 0.2:
+        c.update(kind="surface", N=int(rng.choice([40, 700, 2500, 6000])), r_min=float(rng.choice([2.0, 4.0, 8.0])), r_max=float(rng.choice([16.0, 64.0])))
+    return c
 
 
 @pytest.mark.parametrize("case_seed", list(range(int(os.environ.get("LVDGS_FUZZ_CASES", "24")))))  # more: set the variable
@@ -39,7 +44,10 @@ def test_wide_faint_gaussians_keep_every_quadrant_busy(opacity_scale):
 
 def _check_case(c):
     orc, hr, syn = tp._mods()
-    g = syn.make_gaussians(c["N"], c["W"], c["H"], seed=c["seed"], r_min=c["r_min"], r_max=c["r_max"], z_min=c["z_min"], z_max=c["z_max"])
+    if c.get("kind") == "surface":
+        g = syn.make_surface_gaussians(c["N"], c["W"], c["H"], seed=c["seed"], r_min=c["r_min"], r_max=c["r_max"])
+    else:
+        g = syn.make_gaussians(c["N"], c["W"], c["H"], seed=c["seed"], r_min=c["r_min"], r_max=c["r_max"], z_min=c["z_min"], z_max=c["z_max"])
     with torch.no_grad():
         g["opacities"].mul_(c["opacity_scale"])
     cam = syn.make_camera(c["W"], c["H"], pose_seed=c["pose"])
