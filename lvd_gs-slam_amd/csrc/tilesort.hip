@@ -1,22 +1,21 @@
 // Depth order inside every tile's list.
 //
-// The (Gaussian, tile) pairs are emitted in Gaussian-id order and grouped by tile with a stable radix sort on
-// the tile id alone, so each tile's segment of point_list arrives in id order.  This file sorts every segment by
-// the 64-bit key (view-depth bits << 32 | id): exactly the order a stable sort of (tile << 32 | depth) keys
-// over depth-presorted pairs gives (ties between equal depths go to the smaller id), without ever sorting the
-// N Gaussians globally -- that sort was 12 latency-bound launches (~115 us at 0.5 M Gaussians), while the
-// segments here are a few hundred entries each and sort independently in LDS.
+// The (Gaussian, tile) pairs are grouped by tile by counting (binning.hip; a stable radix sort on the tile id for images
+// of more than 16384 tiles), in arbitrary order inside a tile.  This file sorts every tile's segment by the 64-bit key
+// (view-depth bits << 32 | id): exactly the order a stable sort of (tile << 32 | depth) keys over id-ordered pairs gives
+// (ties between equal depths go to the smaller id), without ever sorting the N Gaussians or the D pairs globally -- the
+// segments are a few hundred entries each and sort independently.
 //
 // Size classes (bitonic networks throughout):
 //   <= 1024 entries: ONE WAVE per tile, keys in registers (4, 8 or 16 per lane): strides inside a lane are register
 //      compare-exchanges, strides across lanes one 64-bit lane shuffle per key; no LDS array, no barrier.  This
-//      is the common case by far (a few hundred entries per tile) and ~8x fewer instructions than a
-//      workgroup-wide LDS network, whose threads mostly wait at barriers;
-//   <= 16384 entries: queued, then one 1024-thread workgroup per segment on 128 KiB of LDS;
-//   longer: the same network in place on global memory (64-bit key scratch).
-// The queue is filled with one atomic per over-long segment and cleared together with the tile ranges.  (A middle
-// class -- 256 threads on 16 KiB for up to 2048 entries, fed by the first queue and feeding a second -- was one more
-// launch on every frame's critical path, ~6 us whether or not a single segment was that long.)
+//      is the common case by far and ~8x fewer instructions than a workgroup-wide LDS network, whose threads mostly wait
+//      at barriers;
+//   longer: queued -- by the tile-range scan on the counting path, by the wave kernel itself on the radix path -- and
+//      sorted by the LAST workgroups of the same launch (256 threads, LDS up to 2048 entries, in place on global memory
+//      beyond), or, when the previous frame on this device had such segments, by kernels launched behind the tile sort:
+//      one wave per segment with 32 keys per lane (<= 2048 entries), a 1024-thread workgroup on 128 KiB of LDS (<= 16384),
+//      global memory beyond.  (Round 2 launched the 1024-thread kernel on every frame: ~6 us for an empty queue.)
 #include "common.hpp"
 #include "device_utils.hpp"
 
