@@ -315,6 +315,19 @@ int lvdgs_backward_fused_loss(const lvdgs_args *a, const lvdgs_loss_args *loss, 
 int lvdgs_tracking_tail(const lvdgs_loss_args *loss, const lvdgs_args *bwd, const lvdgs_pose_step_args *pose, float *dL_dtau,
                         int32_t partials_per_tile, void *stream);
 
+/* The end of one VIEW of the mapping iteration in one launch: lvdgs_tracking_tail(loss, bwd, NULL, dL_dtau, 1, ...) -- the
+ * view's loss value, exposure gradients and pose gradient from the partial sums lvdgs_backward_fused_loss left -- and
+ * lvdgs_view_stats on the view's outputs (bwd->radii, bwd->n_touched, bwd->dL_dmeans2D; see lvdgs_view_stats below for the
+ * meaning of the fields, any of vis_count / touched_row / split_xy may be NULL). */
+typedef struct lvdgs_view_stats_args {
+    int32_t *radii_max;   /* N   */
+    float *norm_sum;      /* N   */
+    float *vis_count;     /* N or NULL */
+    uint8_t *touched_row; /* N or NULL */
+    float *split_xy;      /* N*2 or NULL */
+} lvdgs_view_stats_args;
+int lvdgs_map_view_tail(const lvdgs_loss_args *loss, const lvdgs_args *bwd, float *dL_dtau, const lvdgs_view_stats_args *stats, void *stream);
+
 /* ---- Adam step of the Gaussian map (reference utils/slam_backend.py:144, :378, :458: gaussians.optimizer.step()) ----
  * All parameter tensors in one launch, one pass over (grad, exp_avg, exp_avg_sq, param); torch.optim.Adam's arithmetic
  * (no weight decay, no amsgrad), `step` = that tensor's step count INCLUDING this step (bias corrections). */

@@ -76,6 +76,11 @@ class PoseStepArgs(C.Structure):
     ]
 
 
+class ViewStatsArgs(C.Structure):
+    """struct lvdgs_view_stats_args (include/lvdgs.h)."""
+    _fields_ = [("radii_max", _fp), ("norm_sum", _fp), ("vis_count", _fp), ("touched_row", _fp), ("split_xy", _fp)]
+
+
 class AdamTensor(C.Structure):
     """struct lvdgs_adam_tensor (include/lvdgs.h)."""
     _fields_ = [("param", _fp), ("grad", _fp), ("exp_avg", _fp), ("exp_avg_sq", _fp), ("numel", C.c_int64), ("step", C.c_int64),
@@ -111,7 +116,7 @@ EXPORTS = (
     "lvdgs_backward", "lvdgs_mark_visible", "lvdgs_state_layout_query", "lvdgs_knn_scratch_bytes",
     "lvdgs_dist2_knn3", "lvdgs_rope2d", "lvdgs_rope2d_strided", "lvdgs_loss_scratch_bytes", "lvdgs_photometric_loss_forward",
     "lvdgs_photometric_loss_backward", "lvdgs_photometric_loss_value_and_grad", "lvdgs_photometric_loss_partials", "lvdgs_tracking_tail", "lvdgs_backward_fused_loss", "lvdgs_masked_depth_scratch_bytes", "lvdgs_masked_depth_l1_forward",
-    "lvdgs_masked_depth_l1_backward", "lvdgs_pose_step", "lvdgs_pose_step_batch", "lvdgs_adam_step", "lvdgs_isotropic_scratch_bytes", "lvdgs_isotropic_reg", "lvdgs_view_stats", "lvdgs_map_stats_apply", "lvdgs_ssim_scratch_bytes", "lvdgs_ssim_l1", "lvdgs_last_error", "lvdgs_version", "lvdgs_profile_enable",
+    "lvdgs_masked_depth_l1_backward", "lvdgs_pose_step", "lvdgs_pose_step_batch", "lvdgs_adam_step", "lvdgs_isotropic_scratch_bytes", "lvdgs_isotropic_reg", "lvdgs_view_stats", "lvdgs_map_stats_apply", "lvdgs_map_view_tail", "lvdgs_ssim_scratch_bytes", "lvdgs_ssim_l1", "lvdgs_last_error", "lvdgs_version", "lvdgs_profile_enable",
     "lvdgs_profile_reset", "lvdgs_profile_read",
 )
 
@@ -175,6 +180,7 @@ def lib():
         L.lvdgs_isotropic_scratch_bytes.argtypes = [C.c_int32]
         L.lvdgs_isotropic_reg.argtypes = [C.c_int32, _fp, _fp, C.c_float, _fp, C.c_size_t, _fp, C.c_void_p]
         L.lvdgs_view_stats.argtypes = [C.c_int32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, C.c_void_p]
+        L.lvdgs_map_view_tail.argtypes = [C.POINTER(LossArgs), C.POINTER(Args), _fp, C.POINTER(ViewStatsArgs), C.c_void_p]
         L.lvdgs_map_stats_apply.argtypes = [C.c_int32, _fp, _fp, _fp, _fp, C.c_int32, _fp, _fp, _fp, C.c_void_p]
         L.lvdgs_ssim_scratch_bytes.restype = C.c_size_t
         L.lvdgs_ssim_scratch_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]

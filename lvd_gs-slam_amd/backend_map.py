@@ -405,8 +405,18 @@ class _ViewStats:
             both = torch.zeros((2 + 2 * len(self.split)) * N, dtype=torch.float32, device=dev)
             self.norm_sum, self.vis_count, self.split_xy = both[:N], both[N:2 * N], both[2 * N:]
 
+    def targets(self, view, row0):
+        """(radii_max, norm_sum, vis_count | None, touched_row | None, split plane | None) of one piece, for
+        ``MapViewPass.run(stats=...)``: the statistics taken by the launch that finishes the piece's loss."""
+        N = self.N
+        k = self.split.index(view) if view in self.split else -1
+        return (self.radii_max, self.norm_sum, self.vis_count if row0 == 0 else None, self.flags[view] if view < self.n_window else None,
+                self.split_xy[2 * N * k:2 * N * (k + 1)] if k >= 0 else None)
+
     def add(self, view, row0, pkg):
         """One piece of view ``view`` (``row0``: its first tile row; the piece starting at row 0 counts the view as seen)."""
+        if getattr(pkg["viewspace_points"], "stats_taken", False):
+            return
         N, n_window = self.N, self.n_window
         radii, nt, vg = pkg["radii"], pkg["n_touched"], pkg["viewspace_points"].grad
         k = self.split.index(view) if view in self.split else -1
@@ -548,6 +558,8 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
                                        live[0].device)
             if vpass is not None:
                 first = {n: plan[k].view_as(p) for k, (n, p) in enumerate(zip(_PARAM_FIELDS, live))}
+        with torch.no_grad():
+            vs = _ViewStats(N0, n_window, G.get_xyz.device, split, (plan[-4], plan[-3], plan[-2]) if plan is not None else None)
         for v, r0, r1 in mine:
             whole = (r0, r1) == (0, _tile_rows(views[v]))
             masked = v < n_window and getattr(views[v], "static_mask", None) is not None
@@ -556,7 +568,8 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
                 # bring their own gradient images; every other view: get_loss_mapping inside the backward blend pass
                 image_loss = None if not masked else (lambda color, depth, vp=views[v]: masked_mapping_loss_and_grads(
                     color, depth, vp, backend.background, backend.opt_params.lambda_dssim, cfg["Training"].get("depth_lambda", 0.1)))
-                pkg, l = vpass.run(backend, views[v], first=first, band=None if whole else (r0, r1), image_loss=image_loss)
+                pkg, l = vpass.run(backend, views[v], first=first, band=None if whole else (r0, r1), image_loss=image_loss,
+                                   stats=None if masked else vs.targets(v, r0))
                 pkgs.append((v, r0, pkg))
                 loss_direct = l if loss_direct is None else loss_direct + l
                 continue
@@ -587,8 +600,7 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
             N = G.get_xyz.shape[0]
             dev = G.get_xyz.device
             if marks: marks.mark("views")
-            # ---- what this rank's pieces say, in order ----
-            vs = _ViewStats(N, n_window, dev, split, (plan[-4], plan[-3], plan[-2]) if plan is not None else None)
+            # ---- what this rank's pieces say, in order (pieces that went through MapViewPass have said it already) ----
             for v, r0, pkg in pkgs:
                 vs.add(v, r0, pkg)
             radii_max, norm_sum, vis_count, split_xy, flags = vs.radii_max, vs.norm_sum, vs.vis_count, vs.split_xy, vs.flags

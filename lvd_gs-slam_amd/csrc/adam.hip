@@ -13,6 +13,7 @@
 #include <math.h>
 
 #include "common.hpp"
+#include "map_stats.hpp"
 
 namespace lvdgs {
 namespace {
@@ -141,21 +142,9 @@ __global__ void __launch_bounds__(256) isotropic_finish_kernel(int nblk, const f
 // A view rendered in bands by several ranks (lvdgs_args.tile_row_*) has only a share of its screen-space gradient here:
 // the norm is of the SUM over the bands, so the band's xy goes to split_xy (N x 2, summed over the ranks by the caller's
 // all-reduce; lvdgs_map_stats_apply then takes the norm) instead of into norm_sum; vis_count is passed for one band only.
-__global__ void __launch_bounds__(256) view_stats_kernel(int N, const int32_t *__restrict__ radii, const int32_t *__restrict__ n_touched,
-                                                         const float *__restrict__ viewspace_grad, int32_t *__restrict__ radii_max,
-                                                         float *__restrict__ norm_sum, float *__restrict__ vis_count,
-                                                         uint8_t *__restrict__ touched_row, float *__restrict__ split_xy) {
+__global__ void __launch_bounds__(256) view_stats_kernel(ViewStats v) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
-    const int r = radii[i];
-    const bool vis = r > 0;
-    if (r > radii_max[i]) radii_max[i] = r;
-    float gx = 0.f, gy = 0.f;
-    if (vis && viewspace_grad) { gx = viewspace_grad[3 * (size_t)i]; gy = viewspace_grad[3 * (size_t)i + 1]; }
-    if (split_xy) *reinterpret_cast<float2 *>(split_xy + 2 * (size_t)i) = make_float2(gx, gy);
-    else if (vis && viewspace_grad) norm_sum[i] += sqrtf(gx * gx + gy * gy);
-    if (vis && vis_count) vis_count[i] += 1.f;
-    if (touched_row) touched_row[i] = n_touched[i] > 0 ? 1 : 0;
+    if (i < v.N) view_stats_one(v, i);
 }
 
 // The statistics' way into the model, one launch (slam_backend.py:350-357 on the reduced values):
@@ -202,7 +191,7 @@ extern "C" int lvdgs_view_stats(int32_t N, const int32_t *radii, const int32_t *
     }
     if (N == 0) return LVDGS_OK;
     ProfScope ps("view_stats", s);
-    hipLaunchKernelGGL(view_stats_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, N, radii, n_touched, viewspace_grad, radii_max, norm_sum, vis_count, touched_row, split_xy);
+    hipLaunchKernelGGL(view_stats_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, ViewStats{N, radii, n_touched, viewspace_grad, radii_max, norm_sum, vis_count, touched_row, split_xy});
     LVDGS_LAUNCH_CHECK("view_stats", 0, s);
     return LVDGS_OK;
 }

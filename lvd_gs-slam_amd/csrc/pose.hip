@@ -14,6 +14,7 @@
 // Arithmetic mirrors the PyTorch statements in float32 (Adam's bias corrections in double, like Python floats).
 #include "common.hpp"
 #include "device_utils.hpp"
+#include "map_stats.hpp"
 
 namespace lvdgs {
 namespace {
@@ -186,7 +187,7 @@ struct TailParams {
 // THREADS = 256: the order of photometric_finish_kernel / tau_reduce_kernel (bit-identical to them); 1024: for the four
 // times as many per-tile partial sums lvdgs_backward_fused_loss leaves (a fixed order of its own).
 template <int THREADS>
-__global__ void __launch_bounds__(THREADS) tracking_tail_kernel(TailParams t) {
+__device__ __forceinline__ void tracking_tail_body(const TailParams &t) {
     constexpr int WAVES = THREADS / 64;
     __shared__ float s[10][WAVES];   // [value][wave]: loss sums 0..3, pose gradient 4..9
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -230,6 +231,18 @@ __global__ void __launch_bounds__(THREADS) tracking_tail_kernel(TailParams t) {
     pose_step_body(t.pose);
 }
 
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) tracking_tail_kernel(TailParams t) { tracking_tail_body<THREADS>(t); }
+
+// A mapping view's last launch: workgroup 0 finishes the view's loss and pose gradient (the tail above, without a pose
+// step), the others take the view's statistics (map_stats.hpp) -- one launch where lvdgs_tracking_tail + lvdgs_view_stats
+// were two on every view's critical path.
+__global__ void __launch_bounds__(1024) map_view_tail_kernel(TailParams t, ViewStats v) {
+    if (blockIdx.x == 0) { tracking_tail_body<1024>(t); return; }
+    const int i = ((int)blockIdx.x - 1) * 1024 + (int)threadIdx.x;
+    if (i < v.N) view_stats_one(v, i);
+}
+
 }  // namespace
 }  // namespace lvdgs
 
@@ -256,13 +269,12 @@ static int check_pose_args(const lvdgs_pose_step_args *a) {
     return LVDGS_OK;
 }
 
-extern "C" int lvdgs_tracking_tail(const lvdgs_loss_args *loss, const lvdgs_args *bwd, const lvdgs_pose_step_args *pose, float *dL_dtau,
-                                   int32_t partials_per_tile, void *stream) {
-    hipStream_t s = (hipStream_t)stream;
+static int make_tail_params(const lvdgs_loss_args *loss, const lvdgs_args *bwd, const lvdgs_pose_step_args *pose, float *dL_dtau,
+                            int32_t partials_per_tile, TailParams &t) {
     if (!bwd || !dL_dtau) { set_error("tracking tail: backward arguments / dL_dtau is NULL"); return LVDGS_E_INVALID; }
     if (pose)
         if (int e = check_pose_args(pose)) return e;
-    TailParams t{};
+    t = TailParams{};
     if (int e = loss_tail_params(loss, partials_per_tile != 0, &t.loss)) return e;
     if (partials_per_tile) {   // a band of tile rows (lvdgs_args.tile_row_*): the backward left partial sums for its tiles only
         int row0, row1;
@@ -289,10 +301,33 @@ extern "C" int lvdgs_tracking_tail(const lvdgs_loss_args *loss, const lvdgs_args
         t.pose.grad_exposure_a = pose->exposure_a ? loss->d_exposure_a : nullptr;
         t.pose.grad_exposure_b = pose->exposure_b ? loss->d_exposure_b : nullptr;
     }
+    return LVDGS_OK;
+}
+
+extern "C" int lvdgs_tracking_tail(const lvdgs_loss_args *loss, const lvdgs_args *bwd, const lvdgs_pose_step_args *pose, float *dL_dtau,
+                                   int32_t partials_per_tile, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    TailParams t;
+    if (int e = make_tail_params(loss, bwd, pose, dL_dtau, partials_per_tile, t)) return e;
     ProfScope ps("tracking_tail", s);
     if (partials_per_tile) hipLaunchKernelGGL(tracking_tail_kernel<1024>, dim3(1), dim3(1024), 0, s, t);
     else hipLaunchKernelGGL(tracking_tail_kernel<256>, dim3(1), dim3(256), 0, s, t);
     LVDGS_LAUNCH_CHECK("tracking_tail", 0, s);
+    return LVDGS_OK;
+}
+
+extern "C" int lvdgs_map_view_tail(const lvdgs_loss_args *loss, const lvdgs_args *bwd, float *dL_dtau, const lvdgs_view_stats_args *stats, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    TailParams t;
+    if (int e = make_tail_params(loss, bwd, nullptr, dL_dtau, 1, t)) return e;
+    if (!stats || !bwd->radii || !stats->radii_max || (!stats->norm_sum && !stats->split_xy) || (stats->touched_row && !bwd->n_touched)) {
+        set_error("map view tail: a statistics pointer is NULL"); return LVDGS_E_INVALID;
+    }
+    const int N = bwd->num_gaussians;
+    const ViewStats v{N, bwd->radii, bwd->n_touched, bwd->dL_dmeans2D, stats->radii_max, stats->norm_sum, stats->vis_count, stats->touched_row, stats->split_xy};
+    ProfScope ps("map_view_tail", s);
+    hipLaunchKernelGGL(map_view_tail_kernel, dim3(1 + cdiv(N, 1024)), dim3(1024), 0, s, t, v);
+    LVDGS_LAUNCH_CHECK("map_view_tail", 0, s);
     return LVDGS_OK;
 }
 

@@ -120,7 +120,7 @@ class MapViewPass:
         a.scratch, a.scratch_bytes = _P(self.scratch), self.scratch.numel()
 
     # ---- one view ----------------------------------------------------------------------------------------------------
-    def run(self, backend, viewpoint, initialization=False, first=None, image_loss=None, band=None):
+    def run(self, backend, viewpoint, initialization=False, first=None, image_loss=None, band=None, stats=None):
         """Render ``viewpoint``, evaluate ``get_loss_mapping`` and add its gradients to the model's and the viewpoint's
         ``.grad`` fields (``first``: buffers, by parameter field, for a view that finds no gradients yet to write into --
         the sharded loop passes slices of its all-reduce bucket -- instead of the pass's own).  Returns the render package (fresh tensors, ``viewspace_points`` carries ``.grad``) and the
@@ -133,7 +133,11 @@ class MapViewPass:
 
         ``band = (row0, row1)``: only tile rows [row0, row1) of the view (``lvdgs_args.tile_row_begin / _end``): the band's
         pixels of the images, the band's share of the loss and of every gradient; ``radii`` are the whole view's,
-        ``n_touched`` counts the band's pixels.  The other pixels of the returned images are not written."""
+        ``n_touched`` counts the band's pixels.  The other pixels of the returned images are not written.
+
+        ``stats = (radii_max, norm_sum, vis_count or None, touched_row or None, split_xy or None)``: the view's statistics
+        (``lvdgs_view_stats``) are taken in the launch that finishes its loss (``lvdgs_map_view_tail``) instead of one of
+        their own; built-in mapping loss only."""
         G, cfg, dev, L = backend.gaussians, backend.config, self.dev, self.L
         T = cfg["Training"]
         N, K = int(G._xyz.shape[0]), 1 + int(G._features_rest.shape[1])
@@ -217,7 +221,12 @@ class MapViewPass:
             a.num_rendered = D
             if image_loss is None:
                 _lib.check(L.lvdgs_backward_fused_loss(C.byref(a), C.byref(la), 0, stream), "lvdgs_backward_fused_loss")
-                _lib.check(L.lvdgs_tracking_tail(C.byref(la), C.byref(a), None, _P(d_tau), 1, stream), "lvdgs_tracking_tail")
+                if stats is not None:
+                    sa = _lib.ViewStatsArgs()
+                    sa.radii_max, sa.norm_sum, sa.vis_count, sa.touched_row, sa.split_xy = (_P(t) for t in stats)
+                    _lib.check(L.lvdgs_map_view_tail(C.byref(la), C.byref(a), _P(d_tau), C.byref(sa), stream), "lvdgs_map_view_tail")
+                else:
+                    _lib.check(L.lvdgs_tracking_tail(C.byref(la), C.byref(a), None, _P(d_tau), 1, stream), "lvdgs_tracking_tail")
         if image_loss is not None:
             res = image_loss(color, depth)
             loss, d_color = res[0], f32c(res[1])
@@ -245,7 +254,7 @@ class MapViewPass:
             if p.requires_grad:
                 g = g.view_as(p)
                 p.grad = g if p.grad is None else p.grad + g
-        vsp = SimpleNamespace(grad=d_m2)   # stands in for the leaf autograd would have filled: only .grad is read
+        vsp = SimpleNamespace(grad=d_m2, stats_taken=stats is not None and image_loss is None)   # stands in for the leaf autograd would have filled: only .grad is read
         pkg = {"render": color, "viewspace_points": vsp, "visibility_filter": radii > 0, "radii": radii, "depth": depth,
                "opacity": opacity, "n_touched": n_touched}
         return pkg, loss

@@ -50,7 +50,7 @@ def test_ctypes_struct_matches_c_layout(tmp_path):
 
 @pytest.mark.parametrize("ctype,cname", [("LossArgs", "lvdgs_loss_args"), ("MaskedDepthArgs", "lvdgs_masked_depth_args"),
                                          ("SsimArgs", "lvdgs_ssim_args"), ("PoseStepArgs", "lvdgs_pose_step_args"),
-                                         ("AdamTensor", "lvdgs_adam_tensor")])
+                                         ("AdamTensor", "lvdgs_adam_tensor"), ("ViewStatsArgs", "lvdgs_view_stats_args")])
 def test_every_other_ctypes_struct_matches_its_c_layout(tmp_path, ctype, cname):
     """Field offsets and sizes of the ctypes mirrors against a C probe compiled from include/lvdgs.h."""
     cls = getattr(_lib, ctype)
