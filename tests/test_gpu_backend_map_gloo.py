@@ -103,10 +103,11 @@ def _worker(rank, world, port, q, policy):
 _SINGLE = {}
 
 
-@pytest.mark.parametrize("world,policy", [(2, "leftover"), (3, "all")])
+@pytest.mark.parametrize("world,policy", [(2, "leftover"), (2, "all")])
 def test_ranks_on_one_gpu_stay_bit_identical_and_match_the_single_process_run(world, policy):
-    """world 2, whole views (six views, three each); world 3 with EVERY view cut into three bands of one tile row, one per
-    rank (the band path of the rasterizer, lvdgs_args.tile_row_*, the split views' statistics, the byte-wise flag OR)."""
+    """world 2: whole views (six views, three each), and EVERY view cut into two bands of tile rows, one per rank (the band
+    path of the rasterizer, lvdgs_args.tile_row_*, the split views' statistics, the byte-wise flag OR).  (Three ranks with a
+    band each were run by the builder too; a third interpreter start costs the suite half a minute.)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 31500 + (os.getpid() % 2000) + 11 * world
