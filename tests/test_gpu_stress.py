@@ -119,7 +119,8 @@ def test_radix_grouping_gives_the_same_lists_as_the_counting_path():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, LVDGS_FORCE_RADIX_GROUPING="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu", "-x",
-                        "-k", "test_forward_and_backward_match_oracle or overflow or more_than_64_tiles", "-p", "no:cacheprovider"],
+                        "-k", "test_forward_and_backward_match_oracle or overflow or more_than_64_tiles", "-p", "no:cacheprovider", "--durations=8"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    print(r.stdout[-1500:])   # (shown with -s: where the child's time went)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
