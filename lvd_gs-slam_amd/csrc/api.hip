@@ -119,10 +119,12 @@ static bool use_counting_path(int num_tiles) {
 
 // Small grids (a KITTI frame: 1848 tiles for 2048 places) are resident all at once, so nothing rebalances the CUs while
 // they run: the blend kernels then take their tiles longest list first, dealt round-robin (binning.hip writes the order
-// into the second half of long_tiles).  LVDGS_TILE_ORDER_MAX_TILES overrides the bound (0: never).
+// into the second half of long_tiles).
+#ifndef LVDGS_TILE_ORDER_MAX_TILES
+#define LVDGS_TILE_ORDER_MAX_TILES 4096   // A/B builds: 0 = never
+#endif
 bool tile_order_in_use(int num_tiles) {
-    static const int max_tiles = [] { const char *e = getenv("LVDGS_TILE_ORDER_MAX_TILES"); return e ? atoi(e) : 4096; }();
-    return use_counting_path(num_tiles) && num_tiles <= max_tiles && num_tiles > 0;
+    return use_counting_path(num_tiles) && num_tiles <= LVDGS_TILE_ORDER_MAX_TILES && num_tiles > 0;
 }
 
 // ---------------------------------------------------------------- layouts

@@ -329,10 +329,10 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t *__rest
 
 }  // namespace
 
-int group_per_thread_for(int N) {
-    static const int forced = [] { const char *e = getenv("LVDGS_GROUP_PER"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 0; }();
-    return forced ? forced : group_per_thread_default(N);
-}
+#ifndef LVDGS_GROUP_PER
+#define LVDGS_GROUP_PER 0   // A/B builds: 1, 2 or 4 Gaussians per thread of a grouping workgroup whatever the map's size
+#endif
+int group_per_thread_for(int N) { return LVDGS_GROUP_PER ? LVDGS_GROUP_PER : group_per_thread_default(N); }
 int group_max_tiles() { return GROUP_MAX_TILES; }
 size_t group_chunks(int N) { return (size_t)cdiv(N > 0 ? N : 1, GROUP_THREADS * group_per_thread_for(N)); }
 size_t group_hist_entries(int N, int num_tiles) {

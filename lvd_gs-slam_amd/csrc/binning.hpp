@@ -14,7 +14,7 @@ constexpr int GROUP_THREADS = 1024;
 // 0.5587 / 0.5638 / - (with the scatter's chunks dealt XCD-contiguously; 0.5667 / 0.5678 before), 2 M / 1920x1280
 // - / 1.472 / 1.477.
 __host__ __device__ constexpr int group_per_thread_default(int N) { return N <= (1 << 19) ? 1 : (N <= (1 << 20) ? 2 : 4); }
-int group_per_thread_for(int N);   // binning.hip: the default, or LVDGS_GROUP_PER (1, 2 or 4; read once per process, for A/B measurements)
+int group_per_thread_for(int N);   // binning.hip: the default, or a -DLVDGS_GROUP_PER=1/2/4 build (A/B measurements)
 constexpr int GROUP_MAX_TILES = 16384;  // 64 KiB of LDS counters
 constexpr int GROUP_BIG_RECT = 64;
 static_assert(GROUP_BIG_RECT == RECT_MASK_TILES, "rectangles walked by the whole wave are the ones without a tile mask");

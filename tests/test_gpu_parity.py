@@ -175,6 +175,20 @@ def test_config2_100k_640x480_forward_backward():
     _check_backward(b_hip, b_ora, ["means3D", "means2D", "opacities", "scales", "rotations", "colors", "tau"], f_ora, W, H)
 
 
+def test_a_map_between_half_a_million_and_a_million_gaussians():
+    """The grouping kernels take one Gaussian per thread up to 2^19, four above 2^20 (binning.hpp:
+    group_per_thread_default); BASELINE's sizes (100k / 200k / 500k / 2M) never land on the two in between."""
+    orc, hr, syn = _mods()
+    W, H, N = 640, 480, (1 << 19) + 20_000
+    g, cam = _scene(syn, N, W, H, 3)
+    bg = torch.zeros(3)
+    grads = syn.make_image_grads(W, H, 3)
+    f_hip, b_hip = hr.run_hip(g, cam, W, H, bg, grads=grads)
+    f_ora, b_ora = hr.run_oracle(orc, g, cam, W, H, bg, grads=grads)
+    _check_forward(f_hip, f_ora, W, H)
+    _check_backward(b_hip, b_ora, ["means3D", "means2D", "opacities", "scales", "rotations", "colors", "tau"], f_ora, W, H)
+
+
 @pytest.mark.parametrize("deg", [0, 1, 2, 3])
 def test_spherical_harmonics_degrees(deg):
     orc, hr, syn = _mods()
