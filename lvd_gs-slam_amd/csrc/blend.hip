@@ -302,8 +302,11 @@ __device__ __forceinline__ float fma_rotated(float g, float w, float acc) {  // 
     return acc;
 }
 
+#ifndef LVDGS_BWD_NB
+#define LVDGS_BWD_NB 8   // survivors per batch of the backward pass: 8 or 4 (A/B builds)
+#endif
 struct Bwd3Shared {
-    static constexpr int NB = 8;
+    static constexpr int NB = LVDGS_BWD_NB;
     float4 a[BR];                        // x, y, a, b
     float4 b[BR];                        // -c/2*log2e, opacity, depth, -a/2*log2e
     float4 c[BR];                        // r, g, b, -b*log2e
@@ -320,7 +323,10 @@ struct Bwd3Shared {
 // DEPTH_GRAD = false: the loss has no depth term / the caller passed no gradient of the depth image (monocular tracking):
 // the depth image's gradient is identically zero and its terms (one multiply-add per survivor in each pass) are left out.
 template <bool FUSED_LOSS, bool DEPTH_GRAD = true>
-__global__ void __launch_bounds__(256, 5) blend_bwd3_kernel(BlendParams p) {
+#ifndef LVDGS_BWD_WGS
+#define LVDGS_BWD_WGS 5   // workgroups per CU the backward blend is compiled for (A/B builds)
+#endif
+__global__ void __launch_bounds__(256, LVDGS_BWD_WGS) blend_bwd3_kernel(BlendParams p) {
     constexpr int NB = Bwd3Shared::NB;
     __shared__ Bwd3Shared sh;
 
@@ -459,13 +465,19 @@ __global__ void __launch_bounds__(256, 5) blend_bwd3_kernel(BlendParams p) {
                     for (int s = 0; s < NB; s++) js[s] = next_entry();
                     Rec r0 = fetch(js[0]), r1 = fetch(js[1]), r2 = fetch(js[2]);
                     entry(std::integral_constant<int, 0>{}, js[0], r0); r0 = fetch(js[3]);
-                    entry(std::integral_constant<int, 1>{}, js[1], r1); r1 = fetch(js[4]);
-                    entry(std::integral_constant<int, 2>{}, js[2], r2); r2 = fetch(js[5]);
-                    entry(std::integral_constant<int, 3>{}, js[3], r0); r0 = fetch(js[6]);
-                    entry(std::integral_constant<int, 4>{}, js[4], r1); r1 = fetch(js[7]);
-                    entry(std::integral_constant<int, 5>{}, js[5], r2);
-                    entry(std::integral_constant<int, 6>{}, js[6], r0);
-                    entry(std::integral_constant<int, 7>{}, js[7], r1);
+                    if constexpr (NB == 8) {
+                        entry(std::integral_constant<int, 1>{}, js[1], r1); r1 = fetch(js[4]);
+                        entry(std::integral_constant<int, 2>{}, js[2], r2); r2 = fetch(js[5]);
+                        entry(std::integral_constant<int, 3>{}, js[3], r0); r0 = fetch(js[6]);
+                        entry(std::integral_constant<int, 4>{}, js[4], r1); r1 = fetch(js[NB - 1]);
+                        entry(std::integral_constant<int, 5>{}, js[5], r2);
+                        entry(std::integral_constant<int, 6>{}, js[6], r0);
+                        entry(std::integral_constant<int, NB - 1>{}, js[NB - 1], r1);
+                    } else {
+                        entry(std::integral_constant<int, 1>{}, js[1], r1);
+                        entry(std::integral_constant<int, 2>{}, js[2], r2);
+                        entry(std::integral_constant<int, 3>{}, js[3], r0);
+                    }
                 } else {
                     for (int s = 0; s < nb; s++) {
                         const int j = next_entry();
@@ -485,9 +497,9 @@ __global__ void __launch_bounds__(256, 5) blend_bwd3_kernel(BlendParams p) {
                 float Sx = 0.f, Sy = 0.f, Sxx = 0.f, Sxy = 0.f, Syy = 0.f, Su = 0.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, CD = 0.f;
                 // all eight (u, w) reads go out first: their addresses are known, and at 5 waves per SIMD a read issued
                 // one step ahead is still on its way when it is needed
-                float2 uw8[8];
+                float2 uw8[NB];
 #pragma unroll
-                for (int s8 = 0; s8 < 8; s8++) uw8[s8] = Mrow[(col - s8) & 15];
+                for (int s8 = 0; s8 < NB; s8++) uw8[s8] = Mrow[(col - s8) & 15];
 #define LVDGS_SPLAT_STEP(S)                                                                          \
                 {                                                                                    \
                     const float2 uw = uw8[S];                                                        \
@@ -501,15 +513,16 @@ __global__ void __launch_bounds__(256, 5) blend_bwd3_kernel(BlendParams p) {
                     if constexpr (DEPTH_GRAD) CD = fma_rotated<S>(gD, uw.y, CD);                     \
                 }
                 LVDGS_SPLAT_STEP(0) LVDGS_SPLAT_STEP(1) LVDGS_SPLAT_STEP(2) LVDGS_SPLAT_STEP(3)
-                LVDGS_SPLAT_STEP(4) LVDGS_SPLAT_STEP(5) LVDGS_SPLAT_STEP(6) LVDGS_SPLAT_STEP(7)
+                if constexpr (NB == 8) { LVDGS_SPLAT_STEP(NB - 4) LVDGS_SPLAT_STEP(NB - 3) LVDGS_SPLAT_STEP(NB - 2) LVDGS_SPLAT_STEP(NB - 1) }
 #undef LVDGS_SPLAT_STEP
                 // fold the 8 partial sums of every slot: rows first (two pairwise folds, ten registers -> three) ...
                 float q0 = fold16(fold32(Sx, Sy), fold32(Sxx, Sxy));   // rows: Sx Sxx Sy Sxy
                 float q1 = fold16(fold32(Syy, Su), fold32(C0, C1));    // rows: Syy C0 Su C1
                 float q2 = fold16(fold32(C2, CD), C1);                  // rows: C2 x CD x
-                q0 += row_rotate<8>(q0);  // ... then the two half-rows that share a slot
+                q0 += row_rotate<8>(q0);  // ... then the two half-rows (NB = 4: four quarter-rows) that share a slot
                 q1 += row_rotate<8>(q1);
                 q2 += row_rotate<8>(q2);
+                if constexpr (NB == 4) { q0 += row_rotate<4>(q0); q1 += row_rotate<4>(q1); q2 += row_rotate<4>(q2); }
                 if (valid && col < NB) {
                     // value index held by this row: q0 -> {Sx, Sxx, Sy, Sxy}, q1 -> {Syy, C0, Su, C1}, q2 -> {C2, -, CD, -}
                     const int i0 = row == 0 ? 0 : (row == 1 ? 2 : (row == 2 ? 1 : 3));
