@@ -135,7 +135,7 @@ def _single_process(half_blind):
     return _SINGLE[half_blind]
 
 
-@pytest.mark.parametrize("world,policy,half_blind", [(2, "leftover", False), (4, "leftover", False), (3, "all", True)]   # (two ranks with every view in bands: the GPU twin of this test))
+@pytest.mark.parametrize("world,policy,half_blind", [(2, "leftover", False), (4, "leftover", False), (3, "all", True)])   # (two ranks, every view in bands: the GPU twin of this test)
 def test_ranks_stay_bit_identical_and_match_the_single_process_run(world, policy, half_blind):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
