@@ -149,6 +149,16 @@ __device__ __forceinline__ void sh_basis_grad(int deg, const float d[3], float G
 // kernels (exp / sigmoid / normalise and their backward) before and after the rasterizer.
 constexpr int ACT_EXP_SCALES = 1, ACT_NORMALIZE_ROT = 2, ACT_SIGMOID_OPACITY = 4;
 
+// the activations of raw scales / rotations (s, q hold the raw values on entry)
+__device__ __forceinline__ void activate_scale_rot(int act, float s[3], float q[4], float &qnorm) {
+    if (act & ACT_EXP_SCALES) { s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]); }
+    qnorm = 1.f;
+    if (act & ACT_NORMALIZE_ROT) {
+        qnorm = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
+        q[0] /= qnorm; q[1] /= qnorm; q[2] /= qnorm; q[3] /= qnorm;
+    }
+}
+
 __device__ __forceinline__ void load_scale_rot(const float *__restrict__ scales, const float *__restrict__ rotations, int i,
                                                int act, float s[3], float q[4], float &qnorm) {
 #pragma unroll
@@ -377,19 +387,59 @@ struct BwdParams {
     float *tau_part;
 };
 
-#ifndef LVDGS_PAIR_CHUNK
-#define LVDGS_PAIR_CHUNK 256
+#ifndef LVDGS_WAVE_CHUNK
+#define LVDGS_WAVE_CHUNK 192
 #endif
-constexpr int PAIR_CHUNK = LVDGS_PAIR_CHUNK;  // pair records staged per round: 10 KB of LDS at 256
+constexpr int WAVE_CHUNK = LVDGS_WAVE_CHUNK;  // pair records a wave stages per round (a multiple of 4): 7.5 KB of LDS per wave at 192, five workgroups per CU
 constexpr int BIG_RUN = 64;      // a Gaussian with more pairs than this is summed by its whole wave
 
-__global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
+#ifndef LVDGS_PBWD_WGS
+#define LVDGS_PBWD_WGS 5
+#endif
+#ifndef LVDGS_PBWD_ABLATE
+#define LVDGS_PBWD_ABLATE 0   // diagnostic builds: 1 = no pair sums, 2 = no per-Gaussian chain
+#endif
+__global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(BwdParams p) {
     __shared__ float s_tau[4][6];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const Cam &c = p.cam;
-    const float *V = c.view, *PM = c.proj, *PR = c.proj_raw;
+    // The camera's matrices, read once into scalar registers (the compiler reads them with vector loads where they are
+    // used -- the pointers are not known to be invariant -- and such a load's first use would end the overlap below).
+    float V[16];
+    {
+        auto uniform = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+#pragma unroll
+        for (int k = 0; k < 16; k++) V[k] = uniform(c.view[k]);
+    }
+    const float *Vg = c.view, *PMg = c.proj, *PRg = c.proj_raw;   // (after the sums: read where they are used, as before)
     float tau[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const bool live = i < p.N && p.radii[i] > 0;
+    // One round of ordinary loads, all of them waited for before the records are requested: the compiler waits for
+    // EVERYTHING outstanding (vmcnt(0)) at the first use of an ordinary load's result while LDS-DMA loads are in flight,
+    // so nothing loaded the ordinary way may be used for the first time between the request and the sums.  (Parameters of
+    // Gaussians that turn out invisible are read for nothing: 44 bytes each.)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool in_map = i < p.N;
+    int32_t radius_i = 0;
+    uint32_t slot_i = 0u, tiles_i = 0u;
+    float pos[3] = {0.f, 0.f, 0.f}, opac_raw = 0.f, c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sc[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f};
+    if (in_map) {
+        radius_i = p.radii[i]; slot_i = p.slot_base[i]; tiles_i = p.tiles_touched[i];
+        pos[0] = p.means3D[3 * i]; pos[1] = p.means3D[3 * i + 1]; pos[2] = p.means3D[3 * i + 2];
+        opac_raw = p.opacities[i];
+        if (p.cov3D_precomp) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) c6[k] = p.cov3D_precomp[6 * (size_t)i + k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; k++) sc[k] = p.scales[3 * (size_t)i + k];
+#pragma unroll
+            for (int k = 0; k < 4; k++) q[k] = p.rotations[4 * (size_t)i + k];
+        }
+    }
+    asm volatile("" : "+v"(radius_i), "+v"(slot_i), "+v"(tiles_i), "+v"(pos[0]), "+v"(pos[1]), "+v"(pos[2]), "+v"(opac_raw));
+    asm volatile("" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
+    asm volatile("" : "+v"(c6[0]), "+v"(c6[1]), "+v"(c6[2]), "+v"(c6[3]), "+v"(c6[4]), "+v"(c6[5]));
+    const bool live = in_map && radius_i > 0;
     if (i < p.N && !live) {
 #pragma unroll
         for (int k = 0; k < 3; k++) { p.dmeans3D[3 * (size_t)i + k] = 0.f; p.dmeans2D[3 * (size_t)i + k] = 0.f; }
@@ -402,53 +452,97 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
     }
     // ---- sum every Gaussian's per-tile partial gradients (a contiguous run of 40-byte records, fixed order) ----
     // Records exist where blend_bwd wrote them (pair_valid): pairs behind their tile's last contributor have none.
-    __shared__ float4 s_pg4[(PAIR_CHUNK + 2) * PAIR_FLOATS / 4 + 1];
-    __shared__ uint32_t s_region[2];
-    const float2 *s_pg = reinterpret_cast<const float2 *>(s_pg4);
+    //
+    // The runs of a wave's 64 Gaussians follow each other in memory (slots are in id order), so the wave streams that
+    // region through its own piece of LDS with coalesced 16-byte loads and every lane then picks its own records out of
+    // it -- instead of 64 lanes walking 64 different runs with one gather each per step, which moved 2.2x the bytes
+    // (r01 / r02_a counters).  The loads of the first chunk (at config 3 the only one for most waves) are issued BEFORE
+    // the part of the per-Gaussian arithmetic that does not depend on the sums -- projection, covariance, the EWA matrices,
+    // the rotation matrix -- and land while it runs: with the workgroup-wide staging of before (two workgroup barriers per
+    // chunk) the kernel was the sum of a memory phase and an arithmetic phase, every resident workgroup in the same one
+    // (ablation builds: 26.7 us without the arithmetic, 28.9 without the sums, 49.5 together).
+    __shared__ float4 s_pg4[4][WAVE_CHUNK * PAIR_FLOATS / 4];   // (the last load instruction of a chunk is masked to the lanes inside it)
+    __shared__ uint32_t s_valid4[4][WAVE_CHUNK / 4];
     float A[10];
 #pragma unroll
     for (int k = 0; k < 10; k++) A[k] = 0.f;
-    const uint32_t first = live ? p.slot_base[i] : 0u, npairs = live ? p.tiles_touched[i] : 0u, last = first + npairs;
+    const uint32_t first = live ? slot_i : 0u, npairs = live ? tiles_i : 0u, last = first + npairs;
     const bool big = npairs > BIG_RUN;
-    if (!__syncthreads_or(big)) {
-        // The runs of a workgroup's 256 Gaussians follow each other in memory (slots are in id order), so the workgroup
-        // streams that region through LDS in chunks with coalesced 16-byte loads and every lane picks its own records out
-        // of the chunk -- instead of 64 lanes walking 64 different runs with one gather each per step, which moved
-        // 2.2x the bytes (r01 / r02_a counters).  Same additions in the same order as before.
-        // (A chunk starts at an even record, i.e. on a 16-byte boundary: 2 records = 80 bytes = 5 loads.)
-        const int blk_first = blockIdx.x * blockDim.x, blk_last = min(p.N, blk_first + (int)blockDim.x) - 1;
-        if (threadIdx.x == 0) { s_region[0] = p.slot_base[blk_first] & ~1u; s_region[1] = p.slot_base[blk_last] + p.tiles_touched[blk_last]; }
-        __syncthreads();
-        const uint32_t r_lo = s_region[0], r_hi = s_region[1];
-        const float4 *pg_all = reinterpret_cast<const float4 *>(p.pair_grads);
-        for (uint32_t c0 = r_lo; c0 < r_hi; c0 += PAIR_CHUNK) {
-            const uint32_t n = min((uint32_t)PAIR_CHUNK, r_hi - c0);
-            const uint32_t quads = (n * PAIR_FLOATS + 3) / 4, q0 = c0 / 2 * 5;   // c0 is even: record c0 starts at float4 c0 * 10 / 4
-            // (a record blend_bwd did not write -- a pair behind its tile's last contributor -- is staged as zeros: the four
-            // floats of a load belong to at most two records)
-            for (uint32_t k = threadIdx.x; k < quads; k += blockDim.x) {
-                float4 v = pg_all[(size_t)q0 + k];
-                const uint32_t ra = (4 * k) / PAIR_FLOATS, rb = (4 * k + 3) / PAIR_FLOATS;
-                const bool va = p.pair_valid[c0 + min(ra, n - 1)] != 0, vb = p.pair_valid[c0 + min(rb, n - 1)] != 0;
-                v.x = va ? v.x : 0.f;
-                v.y = ((4 * k + 1) / PAIR_FLOATS == ra ? va : vb) ? v.y : 0.f;
-                v.z = ((4 * k + 2) / PAIR_FLOATS == ra ? va : vb) ? v.z : 0.f;
-                v.w = vb ? v.w : 0.f;
-                s_pg4[k] = v;
-            }
-            __syncthreads();
-            const uint32_t lo = max(first, c0), hi = min(last, c0 + n);
-            for (uint32_t t = lo; t < hi; t++) {
-                const float2 *r = s_pg + 5 * (t - c0);
-                const float2 a0 = r[0], a1 = r[1], a2 = r[2], a3 = r[3], a4 = r[4];
-                A[0] += a0.x; A[1] += a0.y; A[2] += a1.x; A[3] += a1.y;
-                A[4] += a2.x; A[5] += a2.y; A[6] += a3.x; A[7] += a3.y;
-                A[8] += a4.x; A[9] += a4.y;
-            }
-            __syncthreads();
+    const bool stream = __ballot(big) == 0ull;   // (wave-uniform)
+    // the wave's region: from the first slot of its first Gaussian to the end of its last one's (slot_base is the running
+    // sum of tiles_touched over ALL Gaussians, visible or not)
+    uint32_t r_lo = 0u, r_hi = 0u;
+    if (stream && i - lane < p.N) {
+        const int last_lane = min(63, p.N - 1 - (i - lane));
+        r_lo = (uint32_t)__shfl((int)slot_i, 0, 64) & ~3u;   // a chunk starts at a multiple of 4 records: on a 16-byte boundary of the records and a word of flags
+        r_hi = (uint32_t)__shfl((int)(slot_i + tiles_i), last_lane, 64);
+    }
+    const float4 *pg_all = reinterpret_cast<const float4 *>(p.pair_grads);
+    const uint32_t *valid_all = reinterpret_cast<const uint32_t *>(p.pair_valid);
+    constexpr int QUADS_PER_LANE = (WAVE_CHUNK * PAIR_FLOATS / 4 + 63) / 64;
+    // global -> LDS directly (global_load_lds: the wave's lanes land side by side, 1 KiB per instruction; no registers held
+    // while the chunk is on its way): one chunk of records and their flags
+    auto request = [&](uint32_t c0) {
+        const uint32_t n = min((uint32_t)WAVE_CHUNK, r_hi - c0);
+        const uint32_t quads = (n * PAIR_FLOATS + 3) / 4, q0 = c0 / 2 * 5;   // c0 is even: record c0 starts at float4 c0 * 10 / 4
+#pragma unroll
+        for (int u = 0; u < QUADS_PER_LANE; u++) {
+            const uint32_t k = (uint32_t)lane + 64u * (uint32_t)u;
+            if (k < quads) __builtin_amdgcn_global_load_lds(pg_all + (size_t)q0 + k, &s_pg4[wave][64 * u], 16, 0, 0);
+        }
+        if ((uint32_t)lane * 4u < n) __builtin_amdgcn_global_load_lds(valid_all + c0 / 4 + (uint32_t)lane, &s_valid4[wave][0], 4, 0, 0);
+    };
+    auto consume = [&](uint32_t c0) {   // LDS -> every lane's own records, in slot order
+        const uint32_t n = min((uint32_t)WAVE_CHUNK, r_hi - c0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const float2 *s_pg = reinterpret_cast<const float2 *>(s_pg4[wave]);
+        const uint8_t *s_valid = reinterpret_cast<const uint8_t *>(s_valid4[wave]);
+        const uint32_t lo = max(first, c0), hi = min(last, c0 + n);
+        for (uint32_t t = lo; t < hi; t++) {
+            if (!s_valid[t - c0]) continue;   // (a record blend_bwd did not write: a pair behind its tile's last contributor)
+            const float2 *r = s_pg + 5 * (t - c0);
+            const float2 a0 = r[0], a1 = r[1], a2 = r[2], a3 = r[3], a4 = r[4];
+            A[0] += a0.x; A[1] += a0.y; A[2] += a1.x; A[3] += a1.y;
+            A[4] += a2.x; A[5] += a2.y; A[6] += a3.x; A[7] += a3.y;
+            A[8] += a4.x; A[9] += a4.y;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+#if LVDGS_PBWD_ABLATE != 1
+    if (r_lo < r_hi) request(r_lo);
+#endif
+
+    // ---- the part of the per-Gaussian arithmetic that needs no sums (the first chunk is on its way) ----
+    float pv[3] = {0.f, 0.f, 1.f}, qnorm = 1.f;
+    Ewa e{};
+    float Q00 = 0.f, Q01 = 0.f, Q11 = 0.f;
+#if LVDGS_PBWD_ABLATE != 2
+    if (live) {
+        xform3(pos, V, pv);
+        if (!p.cov3D_precomp) {
+            activate_scale_rot(p.act, sc, q, qnorm);
+            cov3d_of(sc, c.scale_mod, q, c6);
+        }
+        ewa_setup(pv, V, c, e);
+        float ca, cb, cc;
+        cov2d_of(e, c6, ca, cb, cc);
+        const float det = ca * cc - cb * cb, di = 1.f / det;
+        Q00 = cc * di; Q01 = -cb * di; Q11 = ca * di;
+    }
+#endif
+
+#if LVDGS_PBWD_ABLATE != 1
+    if (stream) {
+        for (uint32_t c0 = r_lo; c0 < r_hi; c0 += WAVE_CHUNK) {
+            if (c0 != r_lo) request(c0);
+            consume(c0);
         }
     } else {
-        // A workgroup that holds large-footprint Gaussians (hundreds of pairs each: the stuff opaque surfaces are made of):
+        // A wave that holds large-footprint Gaussians (hundreds of pairs each: the stuff opaque surfaces are made of):
         // one lane summing 800 records while 63 wait was 1.5 ms of this kernel at 100 k such Gaussians.  The small ones
         // walk their own few records straight from memory; every large one is summed by its whole wave -- lane l takes
         // records l, l + 64, ... -- and the 64 partial sums are folded in a fixed order.
@@ -463,7 +557,6 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
         if (!big)
             for (uint32_t t = first; t < last; t++)
                 if (p.pair_valid[t]) add(A, t);
-        const int lane = threadIdx.x & 63;
         for (uint64_t todo = __ballot(big); todo; todo &= todo - 1) {
             const int src = __builtin_ctzll(todo);
             const uint32_t f = (uint32_t)__shfl((int)first, src, 64), l = (uint32_t)__shfl((int)last, src, 64);
@@ -480,17 +573,18 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
             }
         }
     }
+#endif
+#if LVDGS_PBWD_ABLATE == 2
+    if (live) { p.dmeans2D[3 * (size_t)i] = ((A[0] + A[1]) + (A[2] + A[3])) + ((A[4] + A[5]) + (A[6] + A[7])) + (A[8] + A[9]); }
+    if (false) {
+#else
     if (live) {
+#endif
         // A: [0,1] d/d pixel mean, [2..4] d/d conic a,b,c, [5] d/d opacity, [6..8] d/d rgb, [9] d/d view depth
-        const float pos[3] = {p.means3D[3 * i], p.means3D[3 * i + 1], p.means3D[3 * i + 2]};
-        float pv[3], ph[3];
-        xform3(pos, V, pv);
-        xform3(pos, PM, ph);
-        const float phw = xform_w(pos, PM);
         {
             // d/d(logit) = d/d(opacity) * o (1 - o) when the sigmoid is fused (o re-evaluated with the forward's expression: the
             // record holds it too, but reading 4 bytes of a 64-byte record per Gaussian moved 20 MB for 2)
-            float o = p.opacities[i];
+            float o = opac_raw;
             if (p.act & ACT_SIGMOID_OPACITY) { o = 1.f / (1.f + expf(-o)); p.dopac[i] = A[5] * o * (1.f - o); }
             else p.dopac[i] = A[5];
         }
@@ -543,26 +637,11 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
                 const float g_d = (g_u[a] - u[a] * dot) / len;
                 g_world[a] += g_d;
 #pragma unroll
-                for (int j = 0; j < 3; j++) tau[j] += V[4 * a + j] * g_d;
+                for (int j = 0; j < 3; j++) tau[j] += Vg[4 * a + j] * g_d;
             }
         }
 
         // ---- conic -> cov2D -> (cov3D, T) ----
-        float c6[6];
-        float sc[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f}, qnorm = 1.f;
-        if (p.cov3D_precomp) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) c6[k] = p.cov3D_precomp[6 * (size_t)i + k];
-        } else {
-            load_scale_rot(p.scales, p.rotations, i, p.act, sc, q, qnorm);
-            cov3d_of(sc, c.scale_mod, q, c6);
-        }
-        Ewa e;
-        ewa_setup(pv, V, c, e);
-        float ca, cb, cc;
-        cov2d_of(e, c6, ca, cb, cc);
-        const float det = ca * cc - cb * cb, di = 1.f / det;
-        const float Q00 = cc * di, Q01 = -cb * di, Q11 = ca * di;
         const float G00 = A[2], G01 = 0.5f * A[3], G11 = A[4];
         const float QG00 = Q00 * G00 + Q01 * G01, QG01 = Q00 * G01 + Q01 * G11;
         const float QG10 = Q01 * G00 + Q11 * G01, QG11 = Q01 * G01 + Q11 * G11;
@@ -601,7 +680,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
         float g_W[3][3];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            const float w0 = V[4 * k + 0], w1 = V[4 * k + 1], w2 = V[4 * k + 2];
+            const float w0 = Vg[4 * k + 0], w1 = Vg[4 * k + 1], w2 = Vg[4 * k + 2];
             g_J00 += g_T[0][k] * w0; g_J02 += g_T[0][k] * w2;
             g_J11 += g_T[1][k] * w1; g_J12 += g_T[1][k] * w2;
             g_W[0][k] = j00 * g_T[0][k];
@@ -614,17 +693,20 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
                       (2.f * c.fy * e.t[1] / tz3) * g_J12;
 
         // ---- projected mean through the full projection (world) and the raw projection (pose) ----
+        float ph[3];
+        xform3(pos, PMg, ph);
+        const float phw = xform_w(pos, PMg);
         const float pw = 1.f / (phw + HOMOG_EPS);
         const float gh0 = g_ndc[0] * pw, gh1 = g_ndc[1] * pw, gh3 = -(g_ndc[0] * ph[0] + g_ndc[1] * ph[1]) * pw * pw;
         float g_pview_proj[3];
 #pragma unroll
         for (int a = 0; a < 3; a++) {
-            g_world[a] += PM[4 * a + 0] * gh0 + PM[4 * a + 1] * gh1 + PM[4 * a + 3] * gh3;
-            g_pview_proj[a] = PR[4 * a + 0] * gh0 + PR[4 * a + 1] * gh1 + PR[4 * a + 3] * gh3;
+            g_world[a] += PMg[4 * a + 0] * gh0 + PMg[4 * a + 1] * gh1 + PMg[4 * a + 3] * gh3;
+            g_pview_proj[a] = PRg[4 * a + 0] * gh0 + PRg[4 * a + 1] * gh1 + PRg[4 * a + 3] * gh3;
         }
 #pragma unroll
         for (int a = 0; a < 3; a++) {
-            g_world[a] += V[4 * a + 0] * g_pview[0] + V[4 * a + 1] * g_pview[1] + V[4 * a + 2] * g_pview[2];
+            g_world[a] += Vg[4 * a + 0] * g_pview[0] + Vg[4 * a + 1] * g_pview[1] + Vg[4 * a + 2] * g_pview[2];
             p.dmeans3D[3 * (size_t)i + a] = g_world[a];
         }
 
@@ -636,7 +718,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
         tau[5] = pv[0] * gv[1] - pv[1] * gv[0];
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            const float w0 = V[4 * k + 0], w1 = V[4 * k + 1], w2 = V[4 * k + 2];
+            const float w0 = Vg[4 * k + 0], w1 = Vg[4 * k + 1], w2 = Vg[4 * k + 2];
             tau[3] += w1 * g_W[2][k] - w2 * g_W[1][k];
             tau[4] += w2 * g_W[0][k] - w0 * g_W[2][k];
             tau[5] += w0 * g_W[1][k] - w1 * g_W[0][k];
@@ -677,7 +759,6 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(BwdParams p) {
         }
     }
     // ---- workgroup sum of the pose gradient -> one partial per workgroup (no atomics) ----
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         const float s = wave_sum_to_lane63(tau[k]);
