@@ -266,6 +266,16 @@ __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int
     __shared__ uint32_t s_slots[2];
     const int chunk = LVDGS_SCATTER_XCD ? xcd_contiguous_chunk((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     const uint32_t *row = hist + (size_t)chunk * T;
+    // this thread's Gaussians: requested before anything else (their first use is behind several workgroup barriers, which
+    // the compiler does not move loads across: the round trip would otherwise start after the slot scan)
+    uint4 my_rect[PER];
+    uint32_t my_depth[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int i = chunk * GROUP_CHUNK + k * GROUP_THREADS + (int)threadIdx.x;
+        my_rect[k] = i < N ? rect[i] : make_uint4(0u, 0u, 0u, 0u);
+        my_depth[k] = i < N ? depth_bits[i] : 0u;
+    }
     for (int t = threadIdx.x; t < T; t += GROUP_THREADS) s_tile[t] = ranges[t].x + row[t];  // (empty tiles are never visited)
     uint32_t slots_lo = 0, slots_hi = 0;   // the chunk's Gaussians' gradient slots: [lo, hi)
     if constexpr (SLOT_SCAN) {
@@ -307,12 +317,13 @@ __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         const int i = chunk * GROUP_CHUNK + k * GROUP_THREADS + (int)threadIdx.x;
-        const uint4 r = i < N ? rect[i] : make_uint4(0u, 0u, 0u, 0u);
+        const uint4 r = my_rect[k];
         for_each_pair_of_rect(r, i, gx, [&](int tile, uint32_t id) {
             const uint32_t pos = atomicAdd(&s_tile[tile], 1u);
             // the tile sort's key, so that it need not gather depths; beyond the caller's capacity: dropped (the caller
-            // is told and re-runs)
-            if (pos < capacity) keys64[pos] = ((unsigned long long)depth_bits[id] << 32) | (unsigned long long)id;
+            // is told and re-runs).  (id is this thread's own Gaussian, or the one its wave walks together.)
+            const uint32_t d = id == (uint32_t)i ? my_depth[k] : depth_bits[id];
+            if (pos < capacity) keys64[pos] = ((unsigned long long)d << 32) | (unsigned long long)id;
         });
     }
 }
