@@ -159,20 +159,6 @@ __device__ __forceinline__ void activate_scale_rot(int act, float s[3], float q[
     }
 }
 
-__device__ __forceinline__ void load_scale_rot(const float *__restrict__ scales, const float *__restrict__ rotations, int i,
-                                               int act, float s[3], float q[4], float &qnorm) {
-#pragma unroll
-    for (int k = 0; k < 3; k++) s[k] = scales[3 * (size_t)i + k];
-#pragma unroll
-    for (int k = 0; k < 4; k++) q[k] = rotations[4 * (size_t)i + k];
-    if (act & ACT_EXP_SCALES) { s[0] = expf(s[0]); s[1] = expf(s[1]); s[2] = expf(s[2]); }
-    qnorm = 1.f;
-    if (act & ACT_NORMALIZE_ROT) {
-        qnorm = fmaxf(sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), 1e-12f);
-        q[0] /= qnorm; q[1] /= qnorm; q[2] /= qnorm; q[3] /= qnorm;
-    }
-}
-
 struct FwdParams {
     Cam cam;
     int N, act;
@@ -186,14 +172,39 @@ struct FwdParams {
     uint32_t *blocksums;   // per workgroup: sum of tiles_touched (first level of the slot scan, sortscan.hip)
 };
 
-__device__ __forceinline__ void preprocess_one(const FwdParams &p, int i, uint32_t &tiles_out, uint4 &rect_out);
+// What the projection reads of one Gaussian whatever becomes of it, requested in ONE round of loads (position, then --
+// only if in front of the camera -- scale and rotation, then -- only if on the image -- opacity and colour were three
+// dependent round trips, each of them exposed: the kernels below run as a single resident round of workgroups, every
+// wave in the same phase).  Gaussians that turn out culled have 44 bytes read for nothing.
+struct RawGaussian {
+    float pos[3], sc[3], q[4], opac, col[3];   // raw (not activated) values; col: colors_precomp or the SH DC coefficients
+};
+__device__ __forceinline__ RawGaussian load_raw(const FwdParams &p, int i) {
+    RawGaussian r;
+#pragma unroll
+    for (int k = 0; k < 3; k++) r.pos[k] = p.means3D[3 * (size_t)i + k];
+    if (!p.cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) r.sc[k] = p.scales[3 * (size_t)i + k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) r.q[k] = p.rotations[4 * (size_t)i + k];
+    } else {
+        r.sc[0] = r.sc[1] = r.sc[2] = 0.f; r.q[0] = 1.f; r.q[1] = r.q[2] = r.q[3] = 0.f;
+    }
+    r.opac = p.opacities[i];
+    const float *col = p.colors_precomp ? p.colors_precomp + 3 * (size_t)i : p.shs + (size_t)i * p.cam.M * 3;
+#pragma unroll
+    for (int k = 0; k < 3; k++) r.col[k] = col[k];
+    return r;
+}
+__device__ __forceinline__ void preprocess_one(const FwdParams &p, int i, const RawGaussian &raw, uint32_t &tiles_out, uint4 &rect_out);
 
 __global__ void __launch_bounds__(256) preprocess_fwd_kernel(FwdParams p) {
     __shared__ uint32_t s_sum[4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t tiles = 0;
     uint4 rect;
-    if (i < p.N) preprocess_one(p, i, tiles, rect);
+    if (i < p.N) preprocess_one(p, i, load_raw(p, i), tiles, rect);
     // the workgroup's pair count: the slot scan starts from these sums instead of re-reading tiles_touched in a launch of its own
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) tiles += (uint32_t)__shfl_xor((int)tiles, off, 64);
@@ -213,6 +224,10 @@ __global__ void __launch_bounds__(GROUP_THREADS, 8) preprocess_count_kernel(FwdP
                                                                         uint32_t *__restrict__ queue_counts) {
     extern __shared__ uint32_t s_tile[];
     __shared__ uint32_t s_sum[GROUP_THREADS / 64];
+    // the first Gaussian's values are on their way while the counters are cleared
+    const int i_first = blockIdx.x * (GROUP_THREADS * PER) + (int)threadIdx.x;
+    RawGaussian raw{};
+    if (i_first < p.N) raw = load_raw(p, i_first);
     for (int t = threadIdx.x; t < T; t += GROUP_THREADS) s_tile[t] = 0u;
     if (blockIdx.x == 0 && threadIdx.x < 64) queue_counts[threadIdx.x] = 0u;
     __syncthreads();
@@ -223,7 +238,8 @@ __global__ void __launch_bounds__(GROUP_THREADS, 8) preprocess_count_kernel(FwdP
         uint32_t tiles = 0;
         uint4 rect = make_uint4(0u, 0u, 0u, 0u);
         if (i < p.N) {
-            preprocess_one(p, i, tiles, rect);
+            if (k > 0) raw = load_raw(p, i);
+            preprocess_one(p, i, raw, tiles, rect);
             n_touched[i] = 0;
         }
         mine += tiles;
@@ -243,14 +259,14 @@ __global__ void __launch_bounds__(GROUP_THREADS, 8) preprocess_count_kernel(FwdP
     for (int t = threadIdx.x; t < T; t += GROUP_THREADS) row[t] = s_tile[t];
 }
 
-__device__ __forceinline__ void preprocess_one(const FwdParams &p, int i, uint32_t &tiles_out, uint4 &rect_out) {
+__device__ __forceinline__ void preprocess_one(const FwdParams &p, int i, const RawGaussian &raw, uint32_t &tiles_out, uint4 &rect_out) {
     const Cam &c = p.cam;
     // culled unless proven visible
     int radius = 0;
     uint32_t tiles = 0;
     uint4 rect = make_uint4(0u, 0u, 0u, 0u);
     uint32_t depth_bits = 0u;
-    float pos[3] = {p.means3D[3 * i], p.means3D[3 * i + 1], p.means3D[3 * i + 2]};
+    const float pos[3] = {raw.pos[0], raw.pos[1], raw.pos[2]};
     float pv[3];
     xform3(pos, c.view, pv);
     if (pv[2] > NEAR_CULL) {
@@ -264,8 +280,8 @@ __device__ __forceinline__ void preprocess_one(const FwdParams &p, int i, uint32
 #pragma unroll
             for (int k = 0; k < 6; k++) c6[k] = p.cov3D_precomp[6 * (size_t)i + k];
         } else {
-            float s[3], q[4], qn;
-            load_scale_rot(p.scales, p.rotations, i, p.act, s, q, qn);
+            float s[3] = {raw.sc[0], raw.sc[1], raw.sc[2]}, q[4] = {raw.q[0], raw.q[1], raw.q[2], raw.q[3]}, qn;
+            activate_scale_rot(p.act, s, q, qn);
             cov3d_of(s, c.scale_mod, q, c6);
         }
         Ewa e;
@@ -297,7 +313,7 @@ __device__ __forceinline__ void preprocess_one(const FwdParams &p, int i, uint32
             if (on_image) {
                 float rgb[3];
                 if (p.colors_precomp) {
-                    rgb[0] = p.colors_precomp[3 * i]; rgb[1] = p.colors_precomp[3 * i + 1]; rgb[2] = p.colors_precomp[3 * i + 2];
+                    rgb[0] = raw.col[0]; rgb[1] = raw.col[1]; rgb[2] = raw.col[2];
                 } else {
                     float d[3] = {pos[0] - c.campos[0], pos[1] - c.campos[1], pos[2] - c.campos[2]};
                     const float inv = 1.f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
@@ -306,16 +322,16 @@ __device__ __forceinline__ void preprocess_one(const FwdParams &p, int i, uint32
                     sh_basis(c.sh_degree, d, B);
                     const int nb = (c.sh_degree + 1) * (c.sh_degree + 1);
                     const float *sh = p.shs + (size_t)i * c.M * 3;
-                    rgb[0] = rgb[1] = rgb[2] = 0.f;
+                    rgb[0] = 0.f + B[0] * raw.col[0]; rgb[1] = 0.f + B[0] * raw.col[1]; rgb[2] = 0.f + B[0] * raw.col[2];
 #pragma unroll
-                    for (int k = 0; k < 16; k++)
+                    for (int k = 1; k < 16; k++)
                         if (k < nb) {
                             rgb[0] += B[k] * sh[3 * k]; rgb[1] += B[k] * sh[3 * k + 1]; rgb[2] += B[k] * sh[3 * k + 2];
                         }
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) { rgb[ch] += 0.5f; rgb[ch] = rgb[ch] < 0.f ? 0.f : rgb[ch]; }
                 }
-                float opac = p.opacities[i];
+                float opac = raw.opac;
                 if (p.act & ACT_SIGMOID_OPACITY) opac = 1.f / (1.f + expf(-opac));
                 // the tiles of the rectangle the Gaussian can reach with alpha >= 1/255 (common.hpp: rect_keeps)
                 uint64_t mask = ~0ull;
