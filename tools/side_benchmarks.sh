@@ -15,4 +15,4 @@ python3 bench.py --step mapping --steps 50 --warmup 5 --no-cpu-baseline --worklo
 python3 bench.py --step mapping --window weak --steps 100 --warmup 10 --no-cpu-baseline > "$OUT/bench_mapping_single_view_cfg3.json" 2>/dev/null
 python3 tools/map_bench.py > "$OUT/map_bench.txt" 2>&1
 python3 tools/track_bench.py > "$OUT/track_bench.txt" 2>&1
-tail -3 "$OUT/map_bench.txt" "$OUT/track_bench.txt"
+tail -n 3 "$OUT/map_bench.txt"; tail -n 3 "$OUT/track_bench.txt"
