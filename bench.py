@@ -222,31 +222,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Everything built so far (torch, the scene) leaves the garbage collector's generations BEFORE the warm-up: a full
+    # collection over that heap is one stall of about 40 ms, which otherwise lands somewhere in the first hundred iterations
+    # of whichever loop allocates Python objects (tools/autograd_variance.py) -- and taken between the warm-up and the timed
+    # region it let the GPU fall idle (and its clocks drop) right before the measurement.  The collector stays on.
+    gc.collect()
+    gc.freeze()
     rasterizer.KEEP_DEBUG_STATE = True
     for _ in range(max(args.warmup, 1)):
         radii = step()
+    debug_pairs = int(rasterizer._DEBUG_LAST.get("num_rendered", 0))   # (a Python int the autograd API left: no GPU work)
+    rasterizer.KEEP_DEBUG_STATE = False
+    rasterizer._DEBUG_LAST.clear()
+    # Nothing sits between the warm-up and the timed region but the barrier: a pause of a millisecond here (reading the
+    # scene's statistics back used to be done at this point) lets the GPU drop its clocks, and the next ~17 ms -- 30
+    # iterations -- then run 12 % slower (tools/short_region.py: per-step times after a synchronisation).
     sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        radii = step()
+    sync()
+    elapsed = time.perf_counter() - t0
     if session is not None:
         stats["D"] = int(session.num_rendered)
     elif backend is not None and getattr(backend, "_lvdgs_view_pass", None) is not None:
         stats["D"] = int(backend._lvdgs_view_pass.a.num_rendered)   # the mapping views bypass the autograd rasterizer
     else:
-        stats["D"] = int(rasterizer._DEBUG_LAST.get("num_rendered", 0))
+        stats["D"] = debug_pairs
     stats["V"] = int((radii > 0).sum().item()) if radii is not None else int((backend.gaussians.max_radii2D > 0).sum().item())
-    rasterizer.KEEP_DEBUG_STATE = False
-    rasterizer._DEBUG_LAST.clear()
-
-    # Everything built so far (torch, the scene, the warm-up's leftovers) leaves the garbage collector's generations: a
-    # full collection over that heap is one stall of about 40 ms, which otherwise lands somewhere in the first hundred
-    # iterations of whichever loop allocates Python objects (tools/autograd_variance.py).  The collector stays on.
-    gc.collect()
-    gc.freeze()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -255,6 +258,8 @@ def main():
     # ---- per-kernel durations: the same steps again with HIP events around every launch ----
     roofline = None
     kernels = {}
+    for _ in range(max(args.warmup, 1)):   # (the read-backs above let the GPU idle: back to the timed region's clocks first)
+        step()
     if rank == 0:
         _lib.profile_reset()
         _lib.profile_enable(True)
@@ -382,6 +387,10 @@ def main():
                        "autograd_api_iters_per_s": autograd_rate, "same_step_on_one_gpu_iters_per_s": same_step_single,
                        "same_step_on_one_gpu_value": None if same_step_single is None else round(same_step_single * views_per_step / (1 if real_window else world), 3)},
             **({"collective_backend": backend_name + " (functional check only, not a benchmark result)"} if world > 1 and backend_name != "nccl" else {}),
+            **({"timing_note": "warm-up + timed region last under ~40 ms: after start-up idle this GPU needs ~17 ms of load to reach its clocks, "
+                               "and every kernel runs 5-12 % slower until then (tools/short_region.py; 20 steps after 60 of warm-up read the "
+                               "same per-step time as 200 after 20)"}
+               if (max(args.warmup, 1) + args.steps) * elapsed / args.steps < 0.040 else {}),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "kernels_us_per_step": {k: round(v["us_per_step"], 2) for k, v in kernels.items()},
         }
         print(json.dumps(out))
