@@ -205,7 +205,10 @@ __device__ __forceinline__ void sort_queued_segments(u64 *s_keys, int lds_cap, i
 // segments of similar length, and the long ones start first.  Only tiles [t_lo, t_hi) are looked at (the band being
 // rendered).
 template <bool QUEUED>
-__global__ void __launch_bounds__(64 * SORT_WAVES) tile_depth_sort_wave_kernel(const uint2 *__restrict__ ranges, int t_lo, int t_hi, KeySource src,
+#ifndef LVDGS_SORT_OCC
+#define LVDGS_SORT_OCC 1
+#endif
+__global__ void __launch_bounds__(64 * SORT_WAVES, LVDGS_SORT_OCC) tile_depth_sort_wave_kernel(const uint2 *__restrict__ ranges, int t_lo, int t_hi, KeySource src,
                                                                     uint32_t *__restrict__ point_list, uint32_t *queue_count,
                                                                     uint32_t *__restrict__ queue, const uint32_t *__restrict__ tile_order,
                                                                     u64 *keys, int sort_wgs, int take_from, int take_upto) {
