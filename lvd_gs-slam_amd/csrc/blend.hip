@@ -91,6 +91,21 @@ __device__ __forceinline__ int tile_of_workgroup(int b, int n) {
     return ((k / TILE_RUN) * 8 + xcd) * TILE_RUN + k % TILE_RUN;
 }
 
+// Small grids (every workgroup resident at once: tile_order, longest list first): which entry of the order workgroup b
+// takes.  Workgroups b and b + 256 land on the same CU (dealt round-robin over 8 XCDs x 32 CUs), so taking the order
+// as it comes gives CU 0 the longest list of every stratum of 256 and CU 255 the shortest of every one; walking the odd
+// strata backwards evens the sums out.  Bijective for any count (the last, partial stratum is mirrored on itself).
+#ifndef LVDGS_TILE_SNAKE
+#define LVDGS_TILE_SNAKE 1
+#endif
+__device__ __forceinline__ int order_slot_of_workgroup(int b, int n) {
+    if (!LVDGS_TILE_SNAKE) return b;
+    const int k = b >> 8, j = b & 255;
+    if ((k & 1) == 0) return b;
+    const int m = min(256, n - (k << 8));   // entries in this stratum
+    return (k << 8) + (m - 1 - j);
+}
+
 // ------------------------------------------------------------------------------------------
 // One survivor of the quadrant test against the wave's 64 pixels, hand-scheduled: the hit lanes run the compositing
 // under EXEC instead of through selects (the compiler's form of the same statements is 31 vector + 17 scalar
@@ -170,7 +185,7 @@ __global__ void __launch_bounds__(256) blend_fwd2_kernel(BlendParams p) {
     float *const s_d = s_recs.d;   // raw conic c
     __shared__ int s_touch[256]; // pixels of this tile each staged Gaussian "touched" (T after it > 0.5)
 
-    const int tile = (p.tile_order && *p.order_valid) ? (int)p.tile_order[blockIdx.x] : p.tile_base + tile_of_workgroup(blockIdx.x, p.num_tiles);
+    const int tile = (p.tile_order && *p.order_valid) ? (int)p.tile_order[order_slot_of_workgroup(blockIdx.x, p.num_tiles)] : p.tile_base + tile_of_workgroup(blockIdx.x, p.num_tiles);
     const int tx = tile % p.gx, ty = tile / p.gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;
@@ -330,7 +345,7 @@ __global__ void __launch_bounds__(256, LVDGS_BWD_WGS) blend_bwd3_kernel(BlendPar
     constexpr int NB = Bwd3Shared::NB;
     __shared__ Bwd3Shared sh;
 
-    const int tile = (p.tile_order && *p.order_valid) ? (int)p.tile_order[blockIdx.x] : p.tile_base + tile_of_workgroup(blockIdx.x, p.num_tiles);
+    const int tile = (p.tile_order && *p.order_valid) ? (int)p.tile_order[order_slot_of_workgroup(blockIdx.x, p.num_tiles)] : p.tile_base + tile_of_workgroup(blockIdx.x, p.num_tiles);
     const int tx = tile % p.gx, ty = tile / p.gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;
