@@ -455,7 +455,9 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(Bwd
     asm volatile("" : "+v"(radius_i), "+v"(slot_i), "+v"(tiles_i), "+v"(pos[0]), "+v"(pos[1]), "+v"(pos[2]), "+v"(opac_raw));
     asm volatile("" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
     asm volatile("" : "+v"(c6[0]), "+v"(c6[1]), "+v"(c6[2]), "+v"(c6[3]), "+v"(c6[4]), "+v"(c6[5]));
-    const bool live = in_map && radius_i > 0;
+    // (a visible Gaussian without a listed pair -- none of its tiles in the band being rendered, or every tile ruled out by the
+    // reach test -- has all-zero sums, and every output is linear in them: zeros are written and the arithmetic left out)
+    const bool live = in_map && radius_i > 0 && tiles_i > 0u;
     if (i < p.N && !live) {
 #pragma unroll
         for (int k = 0; k < 3; k++) { p.dmeans3D[3 * (size_t)i + k] = 0.f; p.dmeans2D[3 * (size_t)i + k] = 0.f; }
