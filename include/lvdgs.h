@@ -137,9 +137,14 @@ typedef struct lvdgs_args {
 
 /* lvdgs_args.flags */
 enum {
-    LVDGS_FLAG_LIST_ALL_TILES = 1  /* list every tile of a Gaussian's 3-sigma rectangle -- the reference's pair list, bit
+    LVDGS_FLAG_LIST_ALL_TILES = 1, /* list every tile of a Gaussian's 3-sigma rectangle -- the reference's pair list, bit
                                       for bit (num_rendered, point_list, ranges, n_contrib) -- instead of only the tiles
                                       on which it can reach alpha >= 1/255 (outputs are the same either way) */
+    LVDGS_FLAG_ACCUMULATE_PARAM_GRADS = 2 /* B: the gradients w.r.t. the Gaussian parameters (dL_dmeans3D, dL_dopacities,
+                                      dL_dscales, dL_drotations, dL_dcov3D, dL_dshs / dL_dcolors) are ADDED to what their
+                                      buffers hold -- a later view of a mapping iteration, whose losses are summed before one
+                                      backward (reference utils/slam_backend.py:180-306) -- instead of written; dL_dmeans2D
+                                      and dL_dtau (per view) are written as always */
 };
 
 /* ---- sizes ---- */

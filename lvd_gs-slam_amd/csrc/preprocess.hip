@@ -401,6 +401,7 @@ struct BwdParams {
     const uint8_t *pair_valid;   // 1 where blend_bwd wrote the pair's record (pairs behind their tile's last contributor have none)
     float *dmeans3D, *dmeans2D, *dopac, *dscales, *drot, *dcov3D, *dshs, *dcolors;
     float *tau_part;
+    int accumulate;   // LVDGS_FLAG_ACCUMULATE_PARAM_GRADS: the parameter gradients are added to what their buffers hold
 };
 
 #ifndef LVDGS_WAVE_CHUNK
@@ -458,15 +459,22 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(Bwd
     // (a visible Gaussian without a listed pair -- none of its tiles in the band being rendered, or every tile ruled out by the
     // reach test -- has all-zero sums, and every output is linear in them: zeros are written and the arithmetic left out)
     const bool live = in_map && radius_i > 0 && tiles_i > 0u;
+    // gradients w.r.t. the parameters: written, or (a later view of a mapping iteration) added to what is there
+    const bool accumulate = p.accumulate != 0;
+    auto put = [accumulate](float *dst, float v) { *dst = accumulate ? *dst + v : v; };
     if (i < p.N && !live) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) { p.dmeans3D[3 * (size_t)i + k] = 0.f; p.dmeans2D[3 * (size_t)i + k] = 0.f; }
-        p.dopac[i] = 0.f;
-        if (p.dscales) { for (int k = 0; k < 3; k++) p.dscales[3 * (size_t)i + k] = 0.f; }
-        if (p.drot) { for (int k = 0; k < 4; k++) p.drot[4 * (size_t)i + k] = 0.f; }
-        if (p.dcov3D) { for (int k = 0; k < 6; k++) p.dcov3D[6 * (size_t)i + k] = 0.f; }
-        if (p.dcolors) { for (int k = 0; k < 3; k++) p.dcolors[3 * (size_t)i + k] = 0.f; }
-        if (p.dshs) { for (int k = 0; k < 3 * c.M; k++) p.dshs[(size_t)i * 3 * c.M + k] = 0.f; }
+        for (int k = 0; k < 3; k++) p.dmeans2D[3 * (size_t)i + k] = 0.f;
+        if (!accumulate) {   // (adding zero: nothing to do)
+#pragma unroll
+            for (int k = 0; k < 3; k++) p.dmeans3D[3 * (size_t)i + k] = 0.f;
+            p.dopac[i] = 0.f;
+            if (p.dscales) { for (int k = 0; k < 3; k++) p.dscales[3 * (size_t)i + k] = 0.f; }
+            if (p.drot) { for (int k = 0; k < 4; k++) p.drot[4 * (size_t)i + k] = 0.f; }
+            if (p.dcov3D) { for (int k = 0; k < 6; k++) p.dcov3D[6 * (size_t)i + k] = 0.f; }
+            if (p.dcolors) { for (int k = 0; k < 3; k++) p.dcolors[3 * (size_t)i + k] = 0.f; }
+            if (p.dshs) { for (int k = 0; k < 3 * c.M; k++) p.dshs[(size_t)i * 3 * c.M + k] = 0.f; }
+        }
     }
     // ---- sum every Gaussian's per-tile partial gradients (a contiguous run of 40-byte records, fixed order) ----
     // Records exist where blend_bwd wrote them (pair_valid): pairs behind their tile's last contributor have none.
@@ -603,8 +611,8 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(Bwd
             // d/d(logit) = d/d(opacity) * o (1 - o) when the sigmoid is fused (o re-evaluated with the forward's expression: the
             // record holds it too, but reading 4 bytes of a 64-byte record per Gaussian moved 20 MB for 2)
             float o = opac_raw;
-            if (p.act & ACT_SIGMOID_OPACITY) { o = 1.f / (1.f + expf(-o)); p.dopac[i] = A[5] * o * (1.f - o); }
-            else p.dopac[i] = A[5];
+            if (p.act & ACT_SIGMOID_OPACITY) { o = 1.f / (1.f + expf(-o)); put(&p.dopac[i], A[5] * o * (1.f - o)); }
+            else put(&p.dopac[i], A[5]);
         }
         const float g_ndc[2] = {A[0] * 0.5f * (float)c.W, A[1] * 0.5f * (float)c.H};
         p.dmeans2D[3 * (size_t)i] = g_ndc[0]; p.dmeans2D[3 * (size_t)i + 1] = g_ndc[1]; p.dmeans2D[3 * (size_t)i + 2] = 0.f;
@@ -616,7 +624,7 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(Bwd
         // ---- colour ----
         if (p.colors_precomp) {
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) p.dcolors[3 * (size_t)i + ch] = g_rgb[ch];
+            for (int ch = 0; ch < 3; ch++) put(&p.dcolors[3 * (size_t)i + ch], g_rgb[ch]);
         } else {
             float d[3] = {pos[0] - c.campos[0], pos[1] - c.campos[1], pos[2] - c.campos[2]};
             const float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
@@ -640,12 +648,13 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(Bwd
                 if (k < nb) {
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) {
-                        dsh[3 * k + ch] = B[k] * g_rgb[ch];
+                        put(&dsh[3 * k + ch], B[k] * g_rgb[ch]);
                         const float sg = sh[3 * k + ch] * g_rgb[ch];
                         g_u[0] += G[k][0] * sg; g_u[1] += G[k][1] * sg; g_u[2] += G[k][2] * sg;
                     }
                 }
-            for (int k = nb; k < c.M; k++) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
+            if (!accumulate)
+                for (int k = nb; k < c.M; k++) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
             // The view direction d = mean - camera centre moves with the mean and with the camera: C = -R^T T, and under
             // T_w2c <- Exp(tau) T_w2c dC/drho = -R^T, dC/dtheta = 0 at tau = 0, so dL/drho += R g_d (oracle: same statement,
             // pinned against the dense autograd formulation in float64).  Zero at SH degree 0.
@@ -680,8 +689,8 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(Bwd
             }
         if (p.dcov3D) {
             float *o = p.dcov3D + 6 * (size_t)i;
-            o[0] = g_S[0][0]; o[1] = 2.f * g_S[0][1]; o[2] = 2.f * g_S[0][2];
-            o[3] = g_S[1][1]; o[4] = 2.f * g_S[1][2]; o[5] = g_S[2][2];
+            put(o + 0, g_S[0][0]); put(o + 1, 2.f * g_S[0][1]); put(o + 2, 2.f * g_S[0][2]);
+            put(o + 3, g_S[1][1]); put(o + 4, 2.f * g_S[1][2]); put(o + 5, g_S[2][2]);
         }
         float TS[2][3], g_T[2][3];
 #pragma unroll
@@ -725,7 +734,7 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(Bwd
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             g_world[a] += Vg[4 * a + 0] * g_pview[0] + Vg[4 * a + 1] * g_pview[1] + Vg[4 * a + 2] * g_pview[2];
-            p.dmeans3D[3 * (size_t)i + a] = g_world[a];
+            put(&p.dmeans3D[3 * (size_t)i + a], g_world[a]);
         }
 
         // ---- camera pose: T' = Exp(tau) T ----
@@ -758,7 +767,7 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(Bwd
                     g_R[a][b] = gm * sm[b];
                 }
                 // fused exp: d/d(log s) = d/ds * s
-                p.dscales[3 * (size_t)i + b] = v * c.scale_mod * ((p.act & ACT_EXP_SCALES) ? sc[b] : 1.f);
+                put(&p.dscales[3 * (size_t)i + b], v * c.scale_mod * ((p.act & ACT_EXP_SCALES) ? sc[b] : 1.f));
             }
             const float r = q[0], x = q[1], y = q[2], z = q[3];
             float dq[4];
@@ -773,7 +782,7 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(Bwd
                 for (int k = 0; k < 4; k++) dq[k] = (dq[k] - q[k] * dot) / qnorm;
             }
 #pragma unroll
-            for (int k = 0; k < 4; k++) p.drot[4 * (size_t)i + k] = dq[k];
+            for (int k = 0; k < 4; k++) put(&p.drot[4 * (size_t)i + k], dq[k]);
         }
     }
     // ---- workgroup sum of the pose gradient -> one partial per workgroup (no atomics) ----
@@ -883,7 +892,7 @@ int launch_preprocess_bwd(const lvdgs_args &a, const GeomView &g, const BwdScrat
         p.rec = g.rec; p.tiles_touched = g.tiles_touched; p.slot_base = g.slot_base; p.pair_grads = b.pair_grads; p.pair_valid = pair_valid;
         p.dmeans3D = a.dL_dmeans3D; p.dmeans2D = a.dL_dmeans2D; p.dopac = a.dL_dopacities; p.dscales = a.dL_dscales;
         p.drot = a.dL_drotations; p.dcov3D = a.cov3D_precomp ? a.dL_dcov3D : nullptr; p.dshs = a.dL_dshs;
-        p.dcolors = a.dL_dcolors; p.tau_part = b.tau_part;
+        p.dcolors = a.dL_dcolors; p.tau_part = b.tau_part; p.accumulate = (a.flags & LVDGS_FLAG_ACCUMULATE_PARAM_GRADS) ? 1 : 0;
         ProfScope ps("preprocess_bwd", s);
         hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(256), 0, s, p);
         LVDGS_LAUNCH_CHECK("preprocess_bwd", a.debug, s);

@@ -179,9 +179,16 @@ class MapViewPass:
         has = [getattr(G, n).grad is not None for n in fields]
         if any(has) and not all(has):
             raise _lib.LvdgsError("MapViewPass: some of the model's parameters carry a gradient and some do not")
-        into = self.more if has[0] else (self.first if first is None or K > 1 else first)
         if has[0] and any(not _gpu_f32c(getattr(G, n).grad, dev) for n in fields):
             raise _lib.LvdgsError("MapViewPass: the model's existing gradients are not contiguous float32 tensors on the GPU")
+        # A later view of the iteration ADDS its parameter gradients to the ones that are there, inside the backward's last
+        # kernel (LVDGS_FLAG_ACCUMULATE_PARAM_GRADS) -- instead of writing a second set that a multi-tensor add folds in
+        # (three passes over N x 14 floats per view).  With SH coefficients beyond degree 0 the kernel's one colour gradient
+        # maps onto two parameters: the second set and the add stay.
+        accumulate = has[0] and K == 1
+        into = ({n: getattr(G, n).grad for n in fields} if accumulate else
+                (self.more if has[0] else (self.first if first is None or K > 1 else first)))
+        a.flags = (a.flags & ~_lib.FLAG_ACCUMULATE_PARAM_GRADS) | (_lib.FLAG_ACCUMULATE_PARAM_GRADS if accumulate else 0)
         d_sh = into["sh"] if K > 1 else into["_features_dc"]
         a.dL_dmeans3D, a.dL_dopacities, a.dL_dscales = _P(into["_xyz"]), _P(into["_opacity"]), _P(into["_scaling"])
         a.dL_drotations, a.dL_dshs = _P(into["_rotation"]), _P(d_sh)
@@ -242,7 +249,9 @@ class MapViewPass:
         if K > 1:
             into["_features_dc"].copy_(d_sh[:, :1])
             into["_features_rest"].copy_(d_sh[:, 1:])
-        if has[0]:
+        if accumulate:
+            pass   # (added in place by the backward)
+        elif has[0]:
             torch._foreach_add_([getattr(G, n).grad for n in fields], [into[n] for n in fields])
         else:
             for n in fields:

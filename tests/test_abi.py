@@ -30,6 +30,15 @@ def test_every_declared_symbol_is_exported():
         assert hasattr(L, name), name
 
 
+def test_flag_and_status_values_match_the_header():
+    text = open(HEADER).read()
+    enums = {k: int(v) for k, v in re.findall(r"\b(LVDGS_[A-Z_]+)\s*=\s*(\d+)", text)}
+    assert enums["LVDGS_FLAG_LIST_ALL_TILES"] == _lib.FLAG_LIST_ALL_TILES
+    assert enums["LVDGS_FLAG_ACCUMULATE_PARAM_GRADS"] == _lib.FLAG_ACCUMULATE_PARAM_GRADS
+    assert (enums["LVDGS_OK"], enums["LVDGS_E_INVALID"], enums["LVDGS_E_HIP"], enums["LVDGS_E_RANGE"], enums["LVDGS_E_CAPACITY"]) == \
+        (_lib.OK, _lib.E_INVALID, _lib.E_HIP, _lib.E_RANGE, _lib.E_CAPACITY)
+
+
 def test_ctypes_struct_matches_c_layout(tmp_path):
     src = tmp_path / "probe.c"
     fields = [f for f, _ in _lib.Args._fields_]

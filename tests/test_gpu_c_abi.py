@@ -77,6 +77,20 @@ def test_two_call_forward_and_backward_through_ctypes():
     np.testing.assert_array_equal(out["tau"].cpu().numpy(), b_ref["tau"].reshape(-1))
     assert b"lvdgs" in L.lvdgs_version()
 
+    # LVDGS_FLAG_ACCUMULATE_PARAM_GRADS: the same backward ADDS the parameter gradients to what the buffers hold (a later
+    # view of a mapping iteration) -- one addition per element, so exactly x + g -- and writes dL_dmeans2D / dL_dtau as always
+    gen = torch.Generator().manual_seed(9)
+    start = {k: torch.randn(out[k].shape, generator=gen).to(dev) for k in out}
+    acc = {k: start[k].clone() for k in out}
+    a.dL_dmeans3D, a.dL_dmeans2D, a.dL_dopacities = _p(acc["means3D"]), _p(acc["means2D"]), _p(acc["opacities"])
+    a.dL_dscales, a.dL_drotations, a.dL_dcolors, a.dL_dtau = _p(acc["scales"]), _p(acc["rotations"]), _p(acc["colors"]), _p(acc["tau"])
+    a.flags = _lib.FLAG_ACCUMULATE_PARAM_GRADS
+    _lib.check(L.lvdgs_backward(C.byref(a), stream), "backward (accumulating)")
+    torch.cuda.synchronize()
+    for k in ("means3D", "opacities", "scales", "rotations", "colors"):
+        assert torch.equal(acc[k], start[k] + out[k]), k
+    assert torch.equal(acc["means2D"], out["means2D"]) and torch.equal(acc["tau"], out["tau"])
+
 
 def test_errors_are_reported_not_thrown():
     from lvdgs import _lib
