@@ -547,6 +547,7 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
 
         loss_mapping = 0      # pieces that go through autograd (a graph)
         loss_direct = None    # pieces rendered, scored and differentiated by MapViewPass (values only)
+        direct_losses = []    # (summed once: an addition per view is a launch per view)
         pkgs = []
         # sharded: the first piece's backward writes the parameter gradients straight into their slices of the float
         # bucket the all-reduce works on (no packing copy); the statistics' float pieces live there too
@@ -571,7 +572,7 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
                 pkg, l = vpass.run(backend, views[v], first=first, band=None if whole else (r0, r1), image_loss=image_loss,
                                    stats=None if masked else vs.targets(v, r0))
                 pkgs.append((v, r0, pkg))
-                loss_direct = l if loss_direct is None else loss_direct + l
+                direct_losses.append(l)
                 continue
             pkg = render_fn(views[v], G, backend.pipeline_params, backend.background)
             pkgs.append((v, r0, pkg))
@@ -587,6 +588,8 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
         if torch.is_tensor(loss_mapping):
             loss_mapping.backward()
             loss_mapping = loss_mapping.detach()
+        if direct_losses:
+            loss_direct = direct_losses[0] if len(direct_losses) == 1 else torch.stack(direct_losses).sum()
         if loss_direct is not None:
             loss_mapping = loss_mapping + loss_direct
         if fuse_iso:

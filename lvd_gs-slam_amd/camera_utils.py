@@ -36,7 +36,7 @@ class Camera(nn.Module):
             setattr(self, name, nn.Parameter(torch.zeros(3, device=device)))
         for name in _EXPOSURE_PARAMS:
             setattr(self, name, nn.Parameter(torch.zeros(1, device=device)))
-        self.projection_matrix = projection_matrix.to(device=device)
+        self.projection_matrix = projection_matrix.to(device=device).contiguous()   # (callers pass a transposed view: copy it once here, not at every render)
         self._derived_key = None
         self._derived = None
 
@@ -63,7 +63,7 @@ class Camera(nn.Module):
         k = self._derived_key
         if (k is None or k[0] is not R or k[1] != R._version or k[2] is not T or k[3] != T._version
                 or k[4] is not P or k[5] != P._version):
-            view = getWorld2View2(R, T).transpose(0, 1)          # row-vector convention
+            view = getWorld2View2(R, T).transpose(0, 1).contiguous()   # row-vector convention (contiguous: the renderer takes its pointer)
             full = view.unsqueeze(0).bmm(P.unsqueeze(0)).squeeze(0)
             centre = view.inverse()[3, :3]
             self._derived, self._derived_key = (view, full, centre), (R, R._version, T, T._version, P, P._version)

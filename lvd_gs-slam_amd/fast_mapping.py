@@ -264,6 +264,7 @@ class MapViewPass:
                 g = g.view_as(p)
                 p.grad = g if p.grad is None else p.grad + g
         vsp = SimpleNamespace(grad=d_m2, stats_taken=stats is not None and image_loss is None)   # stands in for the leaf autograd would have filled: only .grad is read
-        pkg = {"render": color, "viewspace_points": vsp, "visibility_filter": radii > 0, "radii": radii, "depth": depth,
+        # (visibility_filter: a launch of its own; a caller that had the statistics taken by the tail launch does not read it)
+        pkg = {"render": color, "viewspace_points": vsp, "visibility_filter": (radii > 0) if not vsp.stats_taken else None, "radii": radii, "depth": depth,
                "opacity": opacity, "n_touched": n_touched}
         return pkg, loss
