@@ -27,8 +27,8 @@
  *    scratch buffers, with the sizes the lvdgs_*_bytes functions report, and keeps the state
  *    buffers alive until backward (PyTorch: ctx.save_for_backward);
  *  - no global mutable state that results depend on: besides the optional profiling counters, lvdgs_forward keeps a
- *    per-thread, per-device block of pinned words (the pair count it returns, and the previous frame's longest tile
- *    segment, which only selects the sort kernels the next frame launches); the environment is looked at once per
+ *    per-thread, per-device block of pinned, device-visible words (the tile-scan kernel writes the pair count lvdgs_forward
+ *    returns there, and the frame's longest tile segment, which only selects the sort kernels the next frame launches); the environment is looked at once per
  *    process for the test hook LVDGS_FORCE_RADIX_GROUPING;
  *  - all float tensors are float32, contiguous, row-major; matrices are 4x4 in the
  *    row-vector layout the reference's Camera produces (world_view_transform =

@@ -9,6 +9,8 @@
 
 #include <cstdlib>
 
+#include <chrono>
+
 #include "common.hpp"
 #include "photometric.hpp"
 
@@ -298,7 +300,9 @@ int lvdgs_state_layout_query(int32_t N, int64_t D, int32_t W, int32_t H, lvdgs_s
 namespace {
 struct PairProbe {
     int device = -1;
-    uint32_t *pinned = nullptr;   // [0] pair count, [1] longest queued tile segment of the frame, [2] length of that queue
+    uint32_t *pinned = nullptr;   // [0] pair count, [1] longest queued tile segment of the frame, [2] length of that queue, [3] sequence number of the call that wrote them
+    uint32_t *pinned_dev = nullptr;   // the same words as the device addresses them
+    uint32_t seq = 0;             // of the last single-call forward on this thread and device
     hipEvent_t ready = nullptr;
     int longest = 0, queued = 0;  // of the previous frame on this device: which kernels for long segments the next frame
     int keep = 0;                 // launches behind its tile sort (a hint, never a result); kept for a few frames
@@ -311,7 +315,9 @@ int get_probe(PairProbe **out) {
     PairProbe &p = g_probe[dev & 15];
     if (p.device != dev || !p.pinned) {
         p.device = dev;
-        if (int e = check_hip(hipHostMalloc((void **)&p.pinned, 64, hipHostMallocDefault), "pinned pair count")) return e;
+        if (int e = check_hip(hipHostMalloc((void **)&p.pinned, 64, hipHostMallocMapped | hipHostMallocCoherent), "pinned pair count")) return e;
+        for (int k = 0; k < 16; k++) p.pinned[k] = 0u;
+        if (int e = check_hip(hipHostGetDevicePointer((void **)&p.pinned_dev, p.pinned, 0), "device address of the pinned pair count")) return e;
         if (int e = check_hip(hipEventCreateWithFlags(&p.ready, hipEventDisableTiming), "pair count event")) return e;
     }
     *out = &p;
@@ -325,6 +331,23 @@ int enqueue_prepare(const lvdgs_args *a, const GeomView &g, hipStream_t s) {
     prep_scratch_layout(N, &w, a->scratch);
     if (int e = launch_preprocess_fwd(*a, g, w.blocksums, s)) return e;
     return launch_slot_scan(g.tiles_touched, g.slot_base, w.blocksums, g.total, N, a->debug, s);
+}
+
+// The tile scan of this call has written the pinned words when their fourth holds the call's sequence number.
+int wait_for_sequence(PairProbe *probe) {
+    volatile uint32_t *flag = probe->pinned + 3;
+    const uint32_t want = probe->seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 0;; spins++) {
+        if (__atomic_load_n(const_cast<uint32_t *>(flag), __ATOMIC_ACQUIRE) == want) return LVDGS_OK;
+        if ((spins & 0xffffu) == 0xffffu) {
+            if (int e = check_hip(hipGetLastError(), "while waiting for the pair count")) return e;
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
+                set_error("timed out waiting for the pair count (the kernels before it never finished)");
+                return LVDGS_E_HIP;
+            }
+        }
+    }
 }
 
 int enqueue_count_probe(PairProbe *probe, const uint32_t *total, hipStream_t s) {
@@ -360,9 +383,9 @@ int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipSt
             // counting path: no pair list is materialised, the tile ranges fall out of the counts
             if (!counted)
                 if (int e = launch_group_count(*a, g, im, w, s)) return e;
-            if (int e = launch_group_scan(*a, im, w, cap, counted ? g.total : nullptr, s)) return e;
-            if (counted && probe)
-                if (int e = enqueue_count_probe(probe, g.total, s)) return e;
+            // (single-call forward: the tile scan writes the pair count and the hints into the caller thread's pinned words itself)
+            if (int e = launch_group_scan(*a, im, w, cap, counted ? g.total : nullptr, s, counted && probe ? probe->pinned_dev : nullptr,
+                                          counted && probe ? probe->seq : 0u)) return e;
             if (int e = launch_group_scatter(*a, g, im, w, (unsigned long long *)w.keys, cap, counted, b.pair_valid, s)) return e;
             grouped = true;
         } else {
@@ -473,8 +496,11 @@ int lvdgs_forward(const lvdgs_args *a, int64_t *num_rendered, void *stream) {
     }
     // Everything after the count is enqueued BEFORE the host waits for it: the GPU keeps working on
     // the tile sort and the blend while the host learns whether the capacity was enough.
+    if (counted) { probe->seq++; if (probe->seq == 0u) probe->seq = 1u; }
     if (int e = enqueue_render(a, cap, true, s, counted, probe)) return e;
-    if (int e = check_hip(hipEventSynchronize(probe->ready), "wait for pair count")) return e;
+    if (counted) {
+        if (int e = wait_for_sequence(probe)) return e;
+    } else if (int e = check_hip(hipEventSynchronize(probe->ready), "wait for pair count")) return e;
     const uint32_t total = probe->pinned[0];
     if (counted) {   // what the next frames expect: this frame's long segments, or a recent frame's for a while (views alternate)
         const int longest = (int)probe->pinned[1], queued = (int)probe->pinned[2];

@@ -135,9 +135,10 @@ __global__ void __launch_bounds__(1024) group_colscan_kernel(int T, int nchunks,
 __global__ void __launch_bounds__(1024) group_tilescan_kernel(int T, const uint32_t *__restrict__ totals, uint32_t capacity,
                                                               uint2 *__restrict__ ranges, uint32_t *__restrict__ total_out,
                                                               uint32_t long_limit, uint32_t *__restrict__ queue_count, uint32_t *__restrict__ queue,
-                                                              uint32_t *__restrict__ tile_order, int t_lo, int t_hi, uint32_t *__restrict__ order_valid) {
+                                                              uint32_t *__restrict__ tile_order, int t_lo, int t_hi, uint32_t *__restrict__ order_valid,
+                                                              uint32_t *host_out, uint32_t host_seq) {
     __shared__ uint32_t s_scan[1024];
-    __shared__ uint32_t s_q, s_longest;
+    __shared__ uint32_t s_q, s_longest, s_total;
     constexpr int PER = GROUP_MAX_TILES / 1024;
     static_assert(PER == 16, "four 16-byte loads, eight 16-byte stores per thread");
     uint32_t v[PER], sum = 0;
@@ -181,7 +182,10 @@ __global__ void __launch_bounds__(1024) group_tilescan_kernel(int T, const uint3
     }
     __syncthreads();
     inc += wave ? s_scan[16 + wave - 1] : 0u;
-    if (threadIdx.x == 1023 && total_out) total_out[0] = inc;   // the frame's pair count (before clamping)
+    if (threadIdx.x == 1023) {
+        s_total = inc;
+        if (total_out) total_out[0] = inc;   // the frame's pair count (before clamping)
+    }
     uint32_t run = inc - sum;
     uint32_t longest = 0;
 #pragma unroll
@@ -203,6 +207,14 @@ __global__ void __launch_bounds__(1024) group_tilescan_kernel(int T, const uint3
     if (threadIdx.x == 0) {
         *queue_count = s_q;
         if (total_out) { total_out[1] = s_longest; total_out[2] = s_q; }   // longest queued segment (0: none) and the queue's length, read back with the pair count
+        // The host's copy, written straight into its (pinned, device-visible) memory: the pair count and the two hints, then --
+        // behind a system-scope fence -- the sequence number of the call, which is what the host spins on.  (A device-to-host
+        // copy enqueued behind this kernel is a blit kernel of its own: 3.6 us on every frame's critical path.)
+        if (host_out) {
+            host_out[0] = s_total; host_out[1] = s_longest; host_out[2] = s_q;
+            __threadfence_system();
+            __hip_atomic_store(host_out + 3, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     if (!tile_order) return;
     // counting sort of the tiles by bucket 1023 - min(length / 8, 1023): bucket 0 holds the longest lists
@@ -371,7 +383,8 @@ int launch_group_count(const lvdgs_args &a, const GeomView &g, const ImageView &
 }
 
 // colscan + tilescan: tile ranges, the pair count (total_out, may be null), the tile sort's queue, the tile order
-int launch_group_scan(const lvdgs_args &a, const ImageView &im, const RenderScratch &w, int64_t capacity, uint32_t *total_out, hipStream_t s) {
+int launch_group_scan(const lvdgs_args &a, const ImageView &im, const RenderScratch &w, int64_t capacity, uint32_t *total_out, hipStream_t s,
+                      uint32_t *host_out, uint32_t host_seq) {
     const int N = a.num_gaussians;
     const int gx = (a.image_width + TILE - 1) / TILE, gy = (a.image_height + TILE - 1) / TILE, T = gx * gy;
     if (N == 0 || T == 0) return LVDGS_OK;
@@ -387,7 +400,7 @@ int launch_group_scan(const lvdgs_args &a, const ImageView &im, const RenderScra
     else hipLaunchKernelGGL(group_colscan_kernel<0>, dim3(wg_tiles), dim3(1024), 0, s, T, nchunks, w.group_hist, w.group_totals);
     hipLaunchKernelGGL(group_tilescan_kernel, dim3(1), dim3(1024), 0, s, T, (const uint32_t *)w.group_totals, (uint32_t)capacity, im.ranges,
                        total_out, (uint32_t)tile_sort_wave_limit(), im.long_count, im.long_tiles,
-                       tile_order_in_use(T) ? im.long_tiles + T : nullptr, row0 * gx, row1 * gx, im.long_count + 1);
+                       tile_order_in_use(T) ? im.long_tiles + T : nullptr, row0 * gx, row1 * gx, im.long_count + 1, host_out, host_seq);
     LVDGS_LAUNCH_CHECK("group_scan", a.debug, s);
     return LVDGS_OK;
 }

@@ -258,7 +258,8 @@ size_t group_chunks(int N);
 int launch_preprocess_count(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, hipStream_t s);
 int launch_group_count(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, hipStream_t s);
 // prefixes over the chunks, tile ranges, the pair count (*total_out, may be null), the queue of over-long segments
-int launch_group_scan(const lvdgs_args &a, const ImageView &im, const RenderScratch &w, int64_t capacity, uint32_t *total_out, hipStream_t s);
+int launch_group_scan(const lvdgs_args &a, const ImageView &im, const RenderScratch &w, int64_t capacity, uint32_t *total_out, hipStream_t s,
+                      uint32_t *host_out = nullptr, uint32_t host_seq = 0);   // host_out: pinned words the tile scan writes the pair count + hints + host_seq to
 // slot_scan: also makes slot_base from tiles_touched and w.chunk_sums (launch_preprocess_count's leftovers)
 int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, unsigned long long *keys64,
                          int64_t capacity, bool slot_scan, uint8_t *pair_valid, hipStream_t s);
