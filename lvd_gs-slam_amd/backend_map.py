@@ -628,7 +628,6 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
             if marks: marks.mark("collectives")
             if stats is not None:
                 stats.setdefault("iterations", []).append(dict(views=[v for v, _, _ in mine], pieces=list(mine), phases=marks))
-            seen_by_any = vis_count > 0   # (every view is counted by exactly one rank: a sum that reduces correctly)
 
             # ---- bookkeeping of reference :309-389 on the reduced values ----
             backend.occ_aware_visibility = {}
@@ -675,7 +674,8 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
                                     backend.size_threshold)
                 gaussian_split = True
             if (backend.iteration_count % backend.gaussian_reset) == 0 and (not update_gaussian):
-                G.reset_opacity_nonvisible([seen_by_any])
+                # seen by any view of the iteration: every view is counted by exactly one rank, a sum that reduces correctly
+                G.reset_opacity_nonvisible([vis_count > 0])
                 gaussian_split = True
 
             if stats is not None and callable(stats.get("before_steps")):
