@@ -18,5 +18,5 @@ done
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --output-format csv -d "$OUT/pmc_SQ" -o run -- python3 "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline > "$OUT/pmc_SQ.log" 2>&1
 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d "$OUT/pmc_SQ2" -o run -- python3 "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline > "$OUT/pmc_SQ2.log" 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_GRBM" -o run -- python3 "$ROOT/bench.py" --steps 3 --warmup 2 --no-cpu-baseline > "$OUT/pmc_GRBM.log" 2>&1
-python3 "$ROOT/bench.py" --steps 100 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
+python3 "$ROOT/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"   # (the defaults: 200 steps after 20 of warm-up)
 ls -R "$OUT" | head -40
