@@ -38,6 +38,74 @@ def _backend(workload, n_keyframes, window, masks=False):
     return be, N
 
 
+def test_a_mapping_view_at_kitti_size_matches_the_cpu_chain_end_to_end():
+    """One view of the KITTI-sized window through MapViewPass (lvdgs_forward -> lvdgs_backward_fused_loss -> the view's tail)
+    against the chain it stands for, on the CPU: the C oracle's forward -> get_loss_mapping as PyTorch statements ->
+    autograd of the loss w.r.t. the images -> the oracle's backward -> the chain rule through the parameters' activations.
+    (The window tests below compare two implementations of the product; this one has the oracle on the other side.)"""
+    import math
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bench
+    import test_gpu_parity as tp
+    from lvdgs.fast_mapping import MapViewPass
+    from lvdgs.slam_utils import get_loss_mapping
+    orc, _, _ = tp._mods()
+    dev = torch.device("cuda", 0)
+    model, _, _, (N, W, H) = bench.build_scene("kitti07_geom", 0, dev)
+    be, window = bench.build_window("kitti07_geom", 2, dev, model)
+    G, view = be.gaussians, be.viewpoints[window[0]]
+    with torch.no_grad():   # a view with exposure parameters that matter
+        view.exposure_a.fill_(0.03); view.exposure_b.fill_(-0.02)
+    for p in G.parameters():
+        p.grad = None
+    assert MapViewPass.usable(be, view)
+    pkg, loss = MapViewPass(dev).run(be, view)
+    torch.cuda.synchronize()
+
+    cpu = lambda t: t.detach().cpu().contiguous()
+    o = orc.Oracle("f32")
+    f_ora = o.forward(means3D=cpu(G.get_xyz).numpy(), opacities=cpu(G.get_opacity).numpy(), W=W, H=H,
+                      tanfovx=math.tan(view.FoVx * 0.5), tanfovy=math.tan(view.FoVy * 0.5),
+                      viewmatrix=cpu(view.world_view_transform).numpy(), projmatrix=cpu(view.full_proj_transform).numpy(),
+                      projmatrix_raw=cpu(view.projection_matrix).numpy(), campos=cpu(view.camera_center).numpy(), bg=np.zeros(3, np.float32),
+                      scales=cpu(G.get_scaling).numpy(), rotations=cpu(G.get_rotation).numpy(), shs=cpu(G.get_features).numpy(), sh_degree=0)
+    color = torch.from_numpy(np.ascontiguousarray(f_ora["color"])).reshape(3, H, W).requires_grad_(True)
+    depth = torch.from_numpy(np.ascontiguousarray(f_ora["depth"])).reshape(1, H, W).requires_grad_(True)
+    cpu_view = SimpleNamespace(original_image=cpu(view.original_image), mono_depth=view.mono_depth,
+                               exposure_a=cpu(view.exposure_a).requires_grad_(True), exposure_b=cpu(view.exposure_b).requires_grad_(True))
+    loss_cpu = get_loss_mapping(be.config, color, cpu_view, depth=depth, monodepth=True)
+    loss_cpu.backward()
+    b_ora = o.backward(color.grad.numpy(), depth.grad.numpy(), None)
+    o.free()
+    assert abs(float(loss) - float(loss_cpu.detach())) <= 1e-5 * abs(float(loss_cpu.detach())), (float(loss), float(loss_cpu.detach()))
+
+    # the oracle's gradients (w.r.t. activated values) carried to the raw parameters
+    s = cpu(G.get_scaling).numpy().astype(np.float64)
+    op = cpu(G.get_opacity).numpy().astype(np.float64)
+    raw_q = cpu(G._rotation).numpy().astype(np.float64)
+    qn = np.linalg.norm(raw_q, axis=1, keepdims=True)
+    q = raw_q / qn
+    g_q = b_ora["rotations"].astype(np.float64)
+    ref = {"means3D": b_ora["means3D"], "scales": b_ora["scales"] * s, "opacities": b_ora["opacities"].reshape(op.shape) * op * (1.0 - op),
+           "rotations": (g_q - q * (q * g_q).sum(1, keepdims=True)) / qn, "shs": b_ora["shs"], "tau": b_ora["tau"]}
+    got = {"means3D": cpu(G._xyz.grad).numpy(), "scales": cpu(G._scaling.grad).numpy(), "opacities": cpu(G._opacity.grad).numpy(),
+           "rotations": cpu(G._rotation.grad).numpy(), "shs": cpu(G._features_dc.grad).numpy(),
+           "tau": np.concatenate([cpu(view.cam_trans_delta.grad).numpy().reshape(-1), cpu(view.cam_rot_delta.grad).numpy().reshape(-1)])}
+    ref = {k: np.asarray(v, np.float32) for k, v in ref.items()}
+    # The loss is an L1: where a rendered value sits within rounding of its target the two pipelines can take different signs,
+    # and that pixel's whole contribution (1 / (3 H W) of the loss's weight) flips -- a handful of pixels per frame.  So: the
+    # tensors as wholes to 2e-4, every element to 1 % of the tensor's scale (the fixed-gradient parity cases are the strict ones).
+    for n in ("means3D", "opacities", "scales", "rotations", "shs", "tau"):
+        st = tp.parity_stats_record("mapping view, grad " + n, got[n].reshape(ref[n].shape), ref[n])
+        scale = max(float(np.abs(ref[n]).max()), 1e-30)
+        assert st["rel_l2"] <= 2e-4, (n, st)
+        assert float(np.abs(got[n].reshape(ref[n].shape) - ref[n]).max()) <= 1e-2 * scale, (n, st)
+    for n in ("exposure_a", "exposure_b"):
+        a, b = float(getattr(view, n).grad), float(getattr(cpu_view, n).grad)
+        assert abs(a - b) <= 2e-4 * max(abs(b), 1e-6), (n, a, b)
+
+
 def test_kitti07_window_of_8_plus_2_random_keyframes():
     from lvdgs.backend_map import map_window
     window = list(range(12, 4, -1))          # 8 newest of 12 keyframes; 1..4 are the older ones
