@@ -243,6 +243,73 @@ def test_map_window_with_fused_steps_equals_the_pytorch_statements():
     assert all(not d.any() for d in a["deltas"])
 
 
+def test_a_tracking_iteration_at_kitti_size_matches_the_cpu_chain_end_to_end():
+    """One TrackingSession.step (lvdgs_forward -> lvdgs_backward_fused_loss -> lvdgs_tracking_tail) at KITTI-07's geometry
+    against the chain it stands for, on the CPU: the C oracle's forward -> get_loss_tracking as PyTorch statements (opacity
+    image detached, edge mask, exposure) -> autograd of the loss w.r.t. the image -> the oracle's backward: the loss, the
+    pose gradient the optimiser step consumed, the exposure gradients and every Gaussian gradient."""
+    import math
+    from types import SimpleNamespace
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
+    import bench
+    import test_gpu_parity as tp
+    from lvdgs.fast_tracking import TrackingSession
+    from lvdgs.slam_utils import get_loss_tracking
+    orc, _, _ = tp._mods()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    model, cam, g, (N, W, H) = bench.build_scene("kitti07_geom", 2, dev)   # (rank 2: a camera off the origin)
+    with torch.no_grad():
+        cam.exposure_a.fill_(0.04); cam.exposure_b.fill_(-0.03)
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False)
+    s = TrackingSession(cam, model, bench.CONFIG, pipe, torch.zeros(3, device=dev))
+    cpu = lambda t: t.detach().cpu().contiguous().clone()
+    view, proj, proj_raw, campos = cpu(s.view), cpu(s.proj), cpu(s.proj_raw), cpu(s.campos)   # the camera the step renders from
+    exp_a, exp_b = cpu(cam.exposure_a), cpu(cam.exposure_b)
+    s.step()
+    torch.cuda.synchronize()
+
+    G = model
+    o = orc.Oracle("f32")
+    f_ora = o.forward(means3D=cpu(G.get_xyz).numpy(), opacities=cpu(G.get_opacity).numpy(), W=W, H=H,
+                      tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), viewmatrix=view.numpy(), projmatrix=proj.numpy(),
+                      projmatrix_raw=proj_raw.numpy(), campos=campos.numpy(), bg=np.zeros(3, np.float32), scales=cpu(G.get_scaling).numpy(),
+                      rotations=cpu(G.get_rotation).numpy(), shs=cpu(G.get_features).numpy(), sh_degree=0)
+    color = torch.from_numpy(np.ascontiguousarray(f_ora["color"])).reshape(3, H, W).requires_grad_(True)
+    depth = torch.from_numpy(np.ascontiguousarray(f_ora["depth"])).reshape(1, H, W)
+    opacity = torch.from_numpy(np.ascontiguousarray(f_ora["opacity"])).reshape(1, H, W)
+    cpu_view = SimpleNamespace(original_image=cpu(cam.original_image), grad_mask=cpu(cam.grad_mask), mono_depth=cam.mono_depth,
+                               exposure_a=exp_a.requires_grad_(True), exposure_b=exp_b.requires_grad_(True))
+    loss_cpu = get_loss_tracking(bench.CONFIG, color, depth, opacity, cpu_view)
+    loss_cpu.backward()
+    b_ora = o.backward(color.grad.numpy(), None, None)
+    o.free()
+    assert abs(float(s.loss) - float(loss_cpu.detach())) <= 1e-5 * abs(float(loss_cpu.detach())), (float(s.loss), float(loss_cpu.detach()))
+
+    sc = cpu(G.get_scaling).numpy().astype(np.float64)
+    op = cpu(G.get_opacity).numpy().astype(np.float64)
+    raw_q = cpu(G._rotation).numpy().astype(np.float64)
+    qn = np.linalg.norm(raw_q, axis=1, keepdims=True)
+    q = raw_q / qn
+    g_q = b_ora["rotations"].astype(np.float64)
+    ref = {"means3D": b_ora["means3D"], "scales": b_ora["scales"] * sc, "opacities": b_ora["opacities"].reshape(op.shape) * op * (1.0 - op),
+           "rotations": (g_q - q * (q * g_q).sum(1, keepdims=True)) / qn, "shs": b_ora["shs"], "tau": b_ora["tau"]}
+    got = {"means3D": cpu(s.d_m3).numpy(), "scales": cpu(s.d_sc).numpy(), "opacities": cpu(s.d_op).numpy(), "rotations": cpu(s.d_rot).numpy(),
+           "shs": cpu(s.d_sh).numpy(), "tau": cpu(s.d_tau).numpy()}
+    # (an L1 loss: at pixels within rounding of their target the two pipelines may take different signs -- a handful per frame;
+    # the tensors as wholes to 2e-4, elements to 1 % of the tensor's scale; the fixed-gradient parity cases are the strict ones)
+    for n in ("means3D", "opacities", "scales", "rotations", "shs", "tau"):
+        r = np.asarray(ref[n], np.float32)
+        a = got[n].reshape(r.shape)
+        st = tp.parity_stats_record("tracking iteration, grad " + n, a, r)
+        scale = max(float(np.abs(r).max()), 1e-30)
+        assert st["rel_l2"] <= 2e-4, (n, st)
+        assert float(np.abs(a - r).max()) <= 1e-2 * scale, (n, st)
+    for got_e, ref_e, n in ((s.d_a, cpu_view.exposure_a.grad, "exposure_a"), (s.d_b, cpu_view.exposure_b.grad, "exposure_b")):
+        a, b = float(got_e), float(ref_e)
+        assert abs(a - b) <= 2e-4 * max(abs(b), 1e-6), (n, a, b)
+
+
 def test_map_view_pass_equals_render_loss_backward_through_autograd():
     """fast_mapping.MapViewPass.run against render() -> get_loss_mapping() -> backward() on the same view: the loss, the
     images, the gradients of the six parameter tensors, of the pose deltas and of the exposure, and the screen-space
