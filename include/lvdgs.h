@@ -294,8 +294,16 @@ typedef struct lvdgs_pose_step_args {
      * steps the exposure only (keyframes outside the pose window).  converged_threshold < 0 never raises the flag. */
     const float *grad_rot;         /* 3 or NULL */
     const float *grad_trans;       /* 3 or NULL */
+    /* Optional: 2 floats of pinned host memory as the DEVICE addresses them (lvdgs_host_device_pointer), zeroed by the caller
+     * before a frame's first step.  Every step stores state[18] (steps applied) to [1] and, when it raises the converged flag,
+     * 1 to [0]: the host watches the optimisation without enqueuing a device-to-host copy per iteration (on this stack such a
+     * copy is a blit kernel of its own). */
+    float *host_flags;
 } lvdgs_pose_step_args;
 int lvdgs_pose_step(const lvdgs_pose_step_args *a, void *stream);
+/* The address under which the device sees `host` (page-locked, mapped host memory, e.g. a pinned PyTorch tensor); fails with
+ * LVDGS_E_HIP when the memory is not mapped into the device's address space. */
+int lvdgs_host_device_pointer(void *host, void **device);
 /* `count` independent steps (distinct cameras: the keyframes of a mapping window) in one launch instead of `count`. */
 int lvdgs_pose_step_batch(const lvdgs_pose_step_args *steps, int32_t count, void *stream);
 

@@ -73,7 +73,7 @@ class PoseStepArgs(C.Structure):
         ("lr_rot", C.c_double), ("lr_trans", C.c_double), ("lr_exposure", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
         ("eps", C.c_double), ("converged_threshold", C.c_float),
         ("projmatrix_raw", _fp), ("viewmatrix", _fp), ("projmatrix", _fp), ("campos", _fp),
-        ("grad_rot", _fp), ("grad_trans", _fp),
+        ("grad_rot", _fp), ("grad_trans", _fp), ("host_flags", _fp),
     ]
 
 
@@ -117,7 +117,7 @@ EXPORTS = (
     "lvdgs_backward", "lvdgs_mark_visible", "lvdgs_state_layout_query", "lvdgs_knn_scratch_bytes",
     "lvdgs_dist2_knn3", "lvdgs_rope2d", "lvdgs_rope2d_strided", "lvdgs_loss_scratch_bytes", "lvdgs_photometric_loss_forward",
     "lvdgs_photometric_loss_backward", "lvdgs_photometric_loss_value_and_grad", "lvdgs_photometric_loss_partials", "lvdgs_tracking_tail", "lvdgs_backward_fused_loss", "lvdgs_masked_depth_scratch_bytes", "lvdgs_masked_depth_l1_forward",
-    "lvdgs_masked_depth_l1_backward", "lvdgs_pose_step", "lvdgs_pose_step_batch", "lvdgs_adam_step", "lvdgs_isotropic_scratch_bytes", "lvdgs_isotropic_reg", "lvdgs_view_stats", "lvdgs_map_stats_apply", "lvdgs_map_view_tail", "lvdgs_ssim_scratch_bytes", "lvdgs_ssim_l1", "lvdgs_last_error", "lvdgs_version", "lvdgs_profile_enable",
+    "lvdgs_masked_depth_l1_backward", "lvdgs_pose_step", "lvdgs_host_device_pointer", "lvdgs_pose_step_batch", "lvdgs_adam_step", "lvdgs_isotropic_scratch_bytes", "lvdgs_isotropic_reg", "lvdgs_view_stats", "lvdgs_map_stats_apply", "lvdgs_map_view_tail", "lvdgs_ssim_scratch_bytes", "lvdgs_ssim_l1", "lvdgs_last_error", "lvdgs_version", "lvdgs_profile_enable",
     "lvdgs_profile_reset", "lvdgs_profile_read",
 )
 
@@ -155,6 +155,7 @@ def lib():
         L.lvdgs_forward.argtypes = [C.POINTER(Args), C.POINTER(C.c_int64), C.c_void_p]
         L.lvdgs_backward.argtypes = [C.POINTER(Args), C.c_void_p]
         L.lvdgs_mark_visible.argtypes = [C.c_int32, _fp, _fp, _fp, _fp, C.c_void_p]
+        L.lvdgs_host_device_pointer.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.lvdgs_state_layout_query.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(StateLayout)]
         L.lvdgs_knn_scratch_bytes.restype = C.c_size_t
         L.lvdgs_knn_scratch_bytes.argtypes = [C.c_int32]

@@ -110,7 +110,7 @@ __device__ void pose_step_body(const lvdgs_pose_step_args &a) {   // the first w
         if (lane == 0 || lane == 3 || lane >= 6) st[19 + group] = step;
         if (lane >= 6) *param = p1;
     }
-    if (lane == 0) { st[16] = calls + 1.f; st[18] = calls + 1.f; }
+    if (lane == 0) { st[16] = calls + 1.f; st[18] = calls + 1.f; if (a.host_flags) a.host_flags[1] = calls + 1.f; }
     float rot[3], trans[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) { rot[k] = __shfl(p1, k, 64); trans[k] = __shfl(p1, 3 + k, 64); }
@@ -136,7 +136,7 @@ __device__ void pose_step_body(const lvdgs_pose_step_args &a) {   // the first w
     for (int i = 0; i < 9; i++) a.R[i] = R1[i];
     for (int i = 0; i < 3; i++) a.T[i] = T1[i];
     const float tau_norm = sqrtf(trans[0] * trans[0] + trans[1] * trans[1] + trans[2] * trans[2] + rot[0] * rot[0] + rot[1] * rot[1] + rot[2] * rot[2]);
-    if (tau_norm < a.converged_threshold) st[17] = 1.f;
+    if (tau_norm < a.converged_threshold) { st[17] = 1.f; if (a.host_flags) a.host_flags[0] = 1.f; }
     for (int k = 0; k < 3; k++) { a.cam_rot_delta[k] = 0.f; a.cam_trans_delta[k] = 0.f; }
     // ---- derived matrices (row-vector layout, utils/camera_utils.py:106-120) ----
     // world_view_transform = [[R, T], [0, 1]]^T ; full_proj_transform = world_view_transform @ projection_matrix ;
@@ -258,6 +258,12 @@ extern "C" int lvdgs_pose_step(const lvdgs_pose_step_args *a, void *stream) {
     hipLaunchKernelGGL(pose_step_kernel, dim3(1), dim3(64), 0, s, pp);
     LVDGS_LAUNCH_CHECK("pose_step", 0, s);
     return LVDGS_OK;
+}
+
+extern "C" int lvdgs_host_device_pointer(void *host, void **device) {
+    if (!host || !device) { set_error("host_device_pointer: NULL argument"); return LVDGS_E_INVALID; }
+    *device = nullptr;
+    return check_hip(hipHostGetDevicePointer(device, host, 0), "hipHostGetDevicePointer (is the memory page-locked and mapped?)");
 }
 
 static int check_pose_args(const lvdgs_pose_step_args *a) {

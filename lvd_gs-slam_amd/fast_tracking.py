@@ -157,8 +157,19 @@ class TrackingSession:
         pa.beta1, pa.beta2, pa.eps, pa.converged_threshold = 0.9, 0.999, 1e-8, float(converged_threshold)
         pa.projmatrix_raw, pa.viewmatrix, pa.projmatrix, pa.campos = _P(self.proj_raw), _P(self.view), _P(self.proj), _P(self.campos)
 
-        # ring of pinned words + events for the late, non-blocking reads of the converged flag
-        self._ring = [(torch.cuda.Event(), torch.zeros(2, dtype=torch.float32).pin_memory()) for _ in range(8)]
+        # The converged flag and the count of applied steps, where the host can see them without asking: two pinned words the
+        # tail launch stores to (lvdgs_pose_step_args.host_flags).  Where pinned memory is not mapped into the device's
+        # address space: a ring of pinned words + events for late, non-blocking copies of the flag (a copy per iteration is a
+        # blit kernel per iteration).
+        self.host_flags = None
+        try:
+            flags = torch.zeros(2, dtype=torch.float32).pin_memory()
+            dptr = C.c_void_p()
+            if self.L.lvdgs_host_device_pointer(C.c_void_p(flags.data_ptr()), C.byref(dptr)) == _lib.OK and dptr.value:
+                self.host_flags, pa.host_flags = flags, dptr
+        except RuntimeError:
+            pass
+        self._ring = None if self.host_flags is not None else [(torch.cuda.Event(), torch.zeros(2, dtype=torch.float32).pin_memory()) for _ in range(8)]
         self._asked, self._answered = 0, 0
         self.iterations_enqueued = 0
         self.num_rendered = 0
@@ -200,6 +211,8 @@ class TrackingSession:
         """True once the device's sticky flag has been SEEN set.  Non-blocking: a copy of the flag is requested at every
         call, and requests made at least ``lag`` calls ago are read if their copy has landed (the oldest one is waited
         for only when the ring of 8 outstanding requests is full)."""
+        if self.host_flags is not None:
+            return float(self.host_flags[0]) != 0.0
         if self._asked - self._answered == len(self._ring):
             self._ring[self._answered % len(self._ring)][0].synchronize()
         ev, buf = self._ring[self._asked % len(self._ring)]
@@ -219,7 +232,7 @@ class TrackingSession:
         """Synchronise, write the pose back into the viewpoint, return the number of iterations the reference's loop
         would have run (it breaks at the first converged one)."""
         torch.cuda.synchronize(self.dev)
-        applied = int(self.pose_state[18].item())
+        applied = int(self.host_flags[1]) if self.host_flags is not None else int(self.pose_state[18].item())
         self.vp.update_RT(self.R.clone(), self.T.clone())
         return applied
 
