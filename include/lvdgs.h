@@ -18,10 +18,11 @@
  *  - plain C: raw device pointers, sizes, a hipStream_t passed as void*; no C++ exceptions
  *    cross the boundary; every entry point returns an lvdgs_status (0 = ok) and
  *    lvdgs_last_error() returns a thread-local message for the last failure;
- *  - all work is enqueued on the given stream and is ordered with it; the only host
- *    synchronisation is inside lvdgs_forward_prepare (it returns the number of
- *    (Gaussian, tile) pairs so the caller can size the binning buffer -- the same
- *    device->host read upstream performs);
+ *  - all work is enqueued on the given stream and is ordered with it; the host waits for the
+ *    device in two places only, both for the number of (Gaussian, tile) pairs the caller sizes
+ *    the binning buffer with (the device->host read upstream performs): lvdgs_forward_prepare
+ *    synchronises the stream, lvdgs_forward waits -- with everything else of the frame already
+ *    enqueued -- until the tile-scan kernel has stored the count into pinned host memory;
  *  - the library owns no device memory: the caller allocates the three state buffers
  *    (geometry, binning, image -- upstream's geomBuffer / binningBuffer / imgBuffer) and the
  *    scratch buffers, with the sizes the lvdgs_*_bytes functions report, and keeps the state
@@ -140,6 +141,16 @@ enum {
     LVDGS_FLAG_LIST_ALL_TILES = 1, /* list every tile of a Gaussian's 3-sigma rectangle -- the reference's pair list, bit
                                       for bit (num_rendered, point_list, ranges, n_contrib) -- instead of only the tiles
                                       on which it can reach alpha >= 1/255 (outputs are the same either way) */
+    LVDGS_FLAG_POSE_ONLY = 4,      /* B: only the camera-pose gradient (dL_dtau, or its partial sums for lvdgs_tracking_tail) and --
+                                      lvdgs_backward_fused_loss -- the loss value and exposure gradients are produced.  The
+                                      reference's tracking optimiser holds the pose and the exposure alone
+                                      (utils/slam_frontend.py:1468-1490, stepped at :1520); the Gaussian gradients autograd
+                                      computes beside them are dropped.  With this flag they are not computed: the dL_d*
+                                      outputs other than dL_dtau are ignored (may be NULL) and NOT written, the backward blend
+                                      pass leaves out the sums that feed only colours and opacities, the per-Gaussian pass
+                                      neither reads opacities / SH coefficients nor writes N x 14 gradients.  dL_dtau is bit for
+                                      bit the full backward's.  Needs sh_degree 0 or colors_precomp (a view-dependent colour
+                                      feeds the pose gradient through the colour gradient): LVDGS_E_INVALID otherwise */
     LVDGS_FLAG_ACCUMULATE_PARAM_GRADS = 2 /* B: the gradients w.r.t. the Gaussian parameters (dL_dmeans3D, dL_dopacities,
                                       dL_dscales, dL_drotations, dL_dcov3D, dL_dshs / dL_dcolors) are ADDED to what their
                                       buffers hold -- a later view of a mapping iteration, whose losses are summed before one

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("LVDGS_LIB") or os.path.join(_HERE, "lib", "liblvdgs.s
 OK, E_INVALID, E_HIP, E_RANGE, E_CAPACITY = 0, 1, 2, 3, 4
 FLAG_LIST_ALL_TILES = 1
 FLAG_ACCUMULATE_PARAM_GRADS = 2   # lvdgs_args.flags
+FLAG_POSE_ONLY = 4
 
 _fp = C.c_void_p
 

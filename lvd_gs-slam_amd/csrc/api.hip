@@ -525,12 +525,19 @@ static int backward_impl(const lvdgs_args *a, const LossParams *fused, int propa
     if (!a->image_state || a->image_bytes < lvdgs_image_bytes(W, H)) { set_error("image_state is NULL or too small"); return LVDGS_E_INVALID; }
     GeomView g{}; BinView b{}; ImageView im; BwdScratch w{};
     image_layout(W, H, &im, a->image_state);
+    const bool pose_only = (a->flags & LVDGS_FLAG_POSE_ONLY) != 0;
     if (N > 0) {
-        if ((!fused && !a->dL_dout_color) || !a->dL_dmeans3D || !a->dL_dmeans2D || !a->dL_dopacities || !a->projmatrix_raw || !a->radii) {
-            set_error("a required backward pointer is NULL"); return LVDGS_E_INVALID;
+        if ((!fused && !a->dL_dout_color) || !a->projmatrix_raw || !a->radii) { set_error("a required backward pointer is NULL"); return LVDGS_E_INVALID; }
+        if (pose_only) {
+            // a view-dependent colour moves with the camera centre: its gradient feeds dL/dtau (preprocess.hip), and the
+            // pose-only passes do not make it
+            if (a->shs && a->sh_degree > 0) { set_error("LVDGS_FLAG_POSE_ONLY needs sh_degree 0 or colors_precomp"); return LVDGS_E_INVALID; }
+            if (a->flags & LVDGS_FLAG_ACCUMULATE_PARAM_GRADS) { set_error("LVDGS_FLAG_POSE_ONLY writes no parameter gradients: nothing to accumulate"); return LVDGS_E_INVALID; }
+        } else {
+            if (!a->dL_dmeans3D || !a->dL_dmeans2D || !a->dL_dopacities) { set_error("a required backward pointer is NULL"); return LVDGS_E_INVALID; }
+            if (a->cov3D_precomp ? !a->dL_dcov3D : (!a->dL_dscales || !a->dL_drotations)) { set_error("covariance gradient output is NULL"); return LVDGS_E_INVALID; }
+            if (a->shs ? !a->dL_dshs : !a->dL_dcolors) { set_error("colour gradient output is NULL"); return LVDGS_E_INVALID; }
         }
-        if (a->cov3D_precomp ? !a->dL_dcov3D : (!a->dL_dscales || !a->dL_drotations)) { set_error("covariance gradient output is NULL"); return LVDGS_E_INVALID; }
-        if (a->shs ? !a->dL_dshs : !a->dL_dcolors) { set_error("colour gradient output is NULL"); return LVDGS_E_INVALID; }
         if (!a->geom_state || !a->scratch || (D > 0 && !a->binning_state)) { set_error("a state / scratch buffer is NULL"); return LVDGS_E_INVALID; }
         if (a->geom_bytes < lvdgs_geom_bytes(N) || (D > 0 && a->binning_bytes < lvdgs_binning_bytes(D)) ||
             a->scratch_bytes < lvdgs_backward_scratch_bytes(N, D)) {

@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int N, int gx, const ui
 // not serialise thousands of atomics on one lane.
 
 // (Two-call API: clears what the later kernels of the frame accumulate into, n_touched and the tile-sort queue.)
-template <int PER>
+template <int GROUP_THREADS, int PER>
 __global__ void __launch_bounds__(GROUP_THREADS) count_pairs_kernel(int N, int gx, int T, const uint4 *__restrict__ rect,
                                                                    uint32_t *__restrict__ hist, int32_t *__restrict__ n_touched,
                                                                    uint32_t *__restrict__ queue_counts) {
@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(1024) group_tilescan_kernel(int T, const uint3
 #ifndef LVDGS_SCATTER_XCD
 #define LVDGS_SCATTER_XCD 1   // A/B builds: 0 = workgroup b takes chunk b
 #endif
-template <int PER, bool SLOT_SCAN>
+template <int GROUP_THREADS, int PER, bool SLOT_SCAN>
 __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int gx, int T, const uint4 *__restrict__ rect,
                                                                      const uint32_t *__restrict__ hist,
                                                                      const uint2 *__restrict__ ranges, uint32_t capacity,
@@ -271,7 +271,6 @@ __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int
                                                                      unsigned long long *__restrict__ keys64,
                                                                      const uint32_t *__restrict__ tt, const uint32_t *__restrict__ chunk_sums,
                                                                      uint32_t *__restrict__ slot_base, uint8_t *__restrict__ pair_valid) {
-    static_assert(GROUP_THREADS == 1024, "scan_1024");
     constexpr int GROUP_CHUNK = GROUP_THREADS * PER;
     extern __shared__ uint32_t s_tile[];
     __shared__ uint32_t s_scan[33];
@@ -298,10 +297,10 @@ __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int
 #pragma unroll
         for (int k = 0; k < PER; k++) { v[k] = base + k < N ? tt[base + k] : 0u; mine += v[k]; }
         uint32_t prefix;
-        scan_1024(before, s_scan, &prefix);  // only the total is of interest
+        scan_workgroup<GROUP_THREADS>(before, s_scan, &prefix);  // only the total is of interest
         __syncthreads();                     // s_scan is used again
         uint32_t total;
-        uint32_t run = scan_1024(mine, s_scan, &total) + prefix;
+        uint32_t run = scan_workgroup<GROUP_THREADS>(mine, s_scan, &total) + prefix;
 #pragma unroll
         for (int k = 0; k < PER; k++) {
             if (base + k < N) slot_base[base + k] = run;
@@ -352,32 +351,33 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t *__rest
 
 }  // namespace
 
-#ifndef LVDGS_GROUP_PER
-#define LVDGS_GROUP_PER 0   // A/B builds: 1, 2 or 4 Gaussians per thread of a grouping workgroup whatever the map's size
+#ifndef LVDGS_GROUP_CHUNK
+#define LVDGS_GROUP_CHUNK 0   // A/B builds: 256, 512, 1024, 2048 or 4096 Gaussians per grouping workgroup whatever the map's size
 #endif
-int group_per_thread_for(int N) { return LVDGS_GROUP_PER ? LVDGS_GROUP_PER : group_per_thread_default(N); }
-int group_max_tiles() { return GROUP_MAX_TILES; }
-size_t group_chunks(int N) { return (size_t)cdiv(N > 0 ? N : 1, GROUP_THREADS * group_per_thread_for(N)); }
-size_t group_hist_entries(int N, int num_tiles) {
-    return (size_t)cdiv(N > 0 ? N : 1, GROUP_THREADS * group_per_thread_for(N)) * (size_t)num_tiles;
+GroupShape group_shape_for(int N) {
+    if (LVDGS_GROUP_CHUNK) return LVDGS_GROUP_CHUNK <= 1024 ? GroupShape{LVDGS_GROUP_CHUNK, 1} : GroupShape{1024, LVDGS_GROUP_CHUNK / 1024};
+    return group_shape_default(N);
 }
+int group_max_tiles() { return GROUP_MAX_TILES; }
+static int chunk_of(int N) { const GroupShape g = group_shape_for(N); return g.threads * g.per; }
+size_t group_chunks(int N) { return (size_t)cdiv(N > 0 ? N : 1, chunk_of(N)); }
+size_t group_hist_entries(int N, int num_tiles) { return group_chunks(N) * (size_t)num_tiles; }
 
 int launch_group_count(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, hipStream_t s) {
     const int N = a.num_gaussians;
     const int gx = (a.image_width + TILE - 1) / TILE, gy = (a.image_height + TILE - 1) / TILE, T = gx * gy;
     if (N == 0 || T == 0) return LVDGS_OK;
-    const int per = group_per_thread_for(N), nchunks = cdiv(N, GROUP_THREADS * per);
+    const int nchunks = (int)group_chunks(N);
     const size_t lds = (size_t)T * sizeof(uint32_t);
-    static unsigned char done[3][16];
+    static unsigned char done[GROUP_SHAPES][16];
     ProfScope ps("group_count", s);
-#define LVDGS_COUNT(PER_, D_)                                                                                                      \
-    {                                                                                                                              \
-        if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&count_pairs_kernel<PER_>), GROUP_MAX_TILES * 4, done[D_])) return e; \
-        hipLaunchKernelGGL(count_pairs_kernel<PER_>, dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint4 *)g.rect, w.group_hist, \
-                           a.n_touched, im.long_count);                                                                            \
-    }
-    if (per == 1) LVDGS_COUNT(1, 0) else if (per == 2) LVDGS_COUNT(2, 1) else LVDGS_COUNT(4, 2)
-#undef LVDGS_COUNT
+    if (int e = group_dispatch(group_shape_for(N), [&](auto threads_, auto per_, int d) {
+            constexpr int THREADS = decltype(threads_)::value, PER = decltype(per_)::value;
+            if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&count_pairs_kernel<THREADS, PER>), GROUP_MAX_TILES * 4, done[d])) return e;
+            hipLaunchKernelGGL((count_pairs_kernel<THREADS, PER>), dim3(nchunks), dim3(THREADS), lds, s, N, gx, T, (const uint4 *)g.rect, w.group_hist,
+                               a.n_touched, im.long_count);
+            return (int)LVDGS_OK;
+        })) return e;
     LVDGS_LAUNCH_CHECK("group_count", a.debug, s);
     return LVDGS_OK;
 }
@@ -388,7 +388,7 @@ int launch_group_scan(const lvdgs_args &a, const ImageView &im, const RenderScra
     const int N = a.num_gaussians;
     const int gx = (a.image_width + TILE - 1) / TILE, gy = (a.image_height + TILE - 1) / TILE, T = gx * gy;
     if (N == 0 || T == 0) return LVDGS_OK;
-    const int per = group_per_thread_for(N), nchunks = cdiv(N, GROUP_THREADS * per);
+    const int nchunks = (int)group_chunks(N);
     int row0, row1;
     tile_row_band(a, &row0, &row1);
     ProfScope ps("group_scan", s);
@@ -410,24 +410,21 @@ int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView
     const int N = a.num_gaussians;
     const int gx = (a.image_width + TILE - 1) / TILE, gy = (a.image_height + TILE - 1) / TILE, T = gx * gy;
     if (N == 0 || T == 0) return LVDGS_OK;
-    const int per = group_per_thread_for(N), nchunks = cdiv(N, GROUP_THREADS * per);
+    const int nchunks = (int)group_chunks(N);
     const size_t lds = (size_t)T * sizeof(uint32_t);
-    static unsigned char done[6][16];
+    static unsigned char done[2 * GROUP_SHAPES][16];
     ProfScope ps("group_scatter", s);
-#define LVDGS_SCATTER(PER_, SS_, D_)                                                                                               \
-    {                                                                                                                              \
-        if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&scatter_pairs_kernel<PER_, SS_>), GROUP_MAX_TILES * 4, done[D_])) return e; \
-        hipLaunchKernelGGL((scatter_pairs_kernel<PER_, SS_>), dim3(nchunks), dim3(GROUP_THREADS), lds, s, N, gx, T, (const uint4 *)g.rect,         \
-                           (const uint32_t *)w.group_hist, (const uint2 *)im.ranges, (uint32_t)capacity, (const uint32_t *)g.depth_bits, keys64, \
-                           (const uint32_t *)g.tiles_touched, (const uint32_t *)w.chunk_sums, g.slot_base, pair_valid);            \
-    }
-    if (per == 1 && slot_scan) LVDGS_SCATTER(1, true, 4)
-    else if (per == 1) LVDGS_SCATTER(1, false, 5)
-    else if (per == 2 && slot_scan) LVDGS_SCATTER(2, true, 0)
-    else if (per == 2) LVDGS_SCATTER(2, false, 1)
-    else if (slot_scan) LVDGS_SCATTER(4, true, 2)
-    else LVDGS_SCATTER(4, false, 3)
-#undef LVDGS_SCATTER
+    auto launch = [&](auto kernel, int d, int threads) {
+        if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(kernel), GROUP_MAX_TILES * 4, done[d])) return e;
+        hipLaunchKernelGGL(kernel, dim3(nchunks), dim3(threads), lds, s, N, gx, T, (const uint4 *)g.rect, (const uint32_t *)w.group_hist,
+                           (const uint2 *)im.ranges, (uint32_t)capacity, (const uint32_t *)g.depth_bits, keys64, (const uint32_t *)g.tiles_touched,
+                           (const uint32_t *)w.chunk_sums, g.slot_base, pair_valid);
+        return (int)LVDGS_OK;
+    };
+    if (int e = group_dispatch(group_shape_for(N), [&](auto threads_, auto per_, int d) {
+            constexpr int THREADS = decltype(threads_)::value, PER = decltype(per_)::value;
+            return slot_scan ? launch(&scatter_pairs_kernel<THREADS, PER, true>, 2 * d, THREADS) : launch(&scatter_pairs_kernel<THREADS, PER, false>, 2 * d + 1, THREADS);
+        })) return e;
     LVDGS_LAUNCH_CHECK("group_scatter", a.debug, s);
     return LVDGS_OK;
 }

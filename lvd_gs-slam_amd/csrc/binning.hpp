@@ -5,16 +5,35 @@
 
 namespace lvdgs {
 
-// A workgroup owns a chunk of consecutive Gaussians (1024 x PER) and keeps one counter per tile in LDS.
-constexpr int GROUP_THREADS = 1024;
-// Gaussians per workgroup = 1024 x PER.  Few, large chunks keep the [chunk][tile] count matrix and its scan small (2 M
-// Gaussians: 489 chunks of 4096); many, small ones spread the projection, counting and scattering over the chip and let
-// two workgroups share a CU (500 k Gaussians: 489 chunks of 1024 for 256 CUs).  Measured (same box, round 3, ms per
-// tracking iteration with chunks of 1024 / 2048 / 4096): KITTI geometry (200 k) 0.2557 / 0.2683 / -, config 3 (500 k)
-// 0.5587 / 0.5638 / - (with the scatter's chunks dealt XCD-contiguously; 0.5667 / 0.5678 before), 2 M / 1920x1280
-// - / 1.472 / 1.477.
-__host__ __device__ constexpr int group_per_thread_default(int N) { return N <= (1 << 19) ? 1 : (N <= (1 << 20) ? 2 : 4); }
-int group_per_thread_for(int N);   // binning.hip: the default, or a -DLVDGS_GROUP_PER=1/2/4 build (A/B measurements)
+// A workgroup owns a chunk of consecutive Gaussians (THREADS x PER) and keeps one counter per tile in LDS.
+// Few, large chunks keep the [chunk][tile] count matrix and its scan small (2 M Gaussians: 489 chunks of 4096); many, small
+// ones spread the projection, counting and scattering over the chip (500 k Gaussians: 489 chunks of 1024 for 256 CUs).
+// Measured (same box, round 3, ms per tracking iteration with chunks of 1024 / 2048 / 4096): KITTI geometry (200 k) 0.2557 /
+// 0.2683 / -, config 3 (500 k) 0.5587 / 0.5638 / - (with the scatter's chunks dealt XCD-contiguously; 0.5667 / 0.5678
+// before), 2 M / 1920x1280 - / 1.472 / 1.477.
+// Small maps take smaller workgroups (round 4): 100 k Gaussians in chunks of 1024 are 98 workgroups for 256 CUs, and when the
+// Gaussians are the large flat ones real maps are made of -- 80 listed tiles each on the opaque-surface workload -- the
+// projection's reach tests, the counting and the scatter are all work per Gaussian on a chip 60 % idle.  The chunk is chosen so
+// that a map of up to 2^19 Gaussians makes 256-512 workgroups (the scan of the count matrix holds up to 512 rows in registers).
+constexpr int GROUP_THREADS_MAX = 1024;
+template <int V> struct template_int { static constexpr int value = V; };
+struct GroupShape { int threads, per; };   // Gaussians per workgroup = threads x per
+__host__ __device__ constexpr GroupShape group_shape_default(int N) {
+    return N <= (1 << 17) ? GroupShape{256, 1} : N <= (1 << 18) ? GroupShape{512, 1} : N <= (1 << 19) ? GroupShape{1024, 1}
+         : N <= (1 << 20) ? GroupShape{1024, 2} : GroupShape{1024, 4};
+}
+GroupShape group_shape_for(int N);   // binning.hip: the default, or a -DLVDGS_GROUP_CHUNK=256/512/1024/2048/4096 build (A/B measurements)
+// the instantiations of the grouping kernels: f(THREADS, PER as integral constants, index of the instantiation)
+template <typename F>
+inline int group_dispatch(GroupShape g, F &&f) {
+    template_int<1> one; template_int<2> two; template_int<4> four;
+    if (g.threads == 256) return f(template_int<256>{}, one, 0);
+    if (g.threads == 512) return f(template_int<512>{}, one, 1);
+    if (g.per == 1) return f(template_int<1024>{}, one, 2);
+    if (g.per == 2) return f(template_int<1024>{}, two, 3);
+    return f(template_int<1024>{}, four, 4);
+}
+constexpr int GROUP_SHAPES = 5;
 constexpr int GROUP_MAX_TILES = 16384;  // 64 KiB of LDS counters
 constexpr int GROUP_BIG_RECT = 64;
 static_assert(GROUP_BIG_RECT == RECT_MASK_TILES, "rectangles walked by the whole wave are the ones without a tile mask");
@@ -59,9 +78,12 @@ __device__ __forceinline__ int xcd_contiguous_chunk(int b, int n) {
     return x * q + min(x, r) + k;
 }
 
-// Exclusive scan of one value per thread over a workgroup of 1024 threads (wave shifts, then the 16 wave totals by wave
-// 0: two barriers); *total = sum over the workgroup.  s_scan: 33 words.
-__device__ __forceinline__ uint32_t scan_1024(uint32_t v, uint32_t *s_scan, uint32_t *total) {
+// Exclusive scan of one value per thread over a workgroup of THREADS threads (wave shifts, then the up to 16 wave totals by
+// wave 0: two barriers); *total = sum over the workgroup.  s_scan: 33 words.
+template <int THREADS>
+__device__ __forceinline__ uint32_t scan_workgroup(uint32_t v, uint32_t *s_scan, uint32_t *total) {
+    constexpr int WAVES = THREADS / 64;
+    static_assert(WAVES >= 1 && WAVES <= 16 && THREADS % 64 == 0, "up to 16 whole waves");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t inc = v;
 #pragma unroll
@@ -72,7 +94,7 @@ __device__ __forceinline__ uint32_t scan_1024(uint32_t v, uint32_t *s_scan, uint
     if (lane == 63) s_scan[wave] = inc;
     __syncthreads();
     if (wave == 0) {
-        uint32_t w = lane < 16 ? s_scan[lane] : 0u;
+        uint32_t w = lane < WAVES ? s_scan[lane] : 0u;
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) {
             const uint32_t x = (uint32_t)__shfl_up((int)w, off, 64);
@@ -81,7 +103,7 @@ __device__ __forceinline__ uint32_t scan_1024(uint32_t v, uint32_t *s_scan, uint
         if (lane < 16) s_scan[16 + lane] = w;   // inclusive over the waves
     }
     __syncthreads();
-    *total = s_scan[31];
+    *total = s_scan[16 + WAVES - 1];
     return inc - v + (wave ? s_scan[16 + wave - 1] : 0u);
 }
 

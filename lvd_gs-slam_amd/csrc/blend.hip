@@ -320,30 +320,46 @@ __device__ __forceinline__ float fma_rotated(float g, float w, float acc) {  // 
 #ifndef LVDGS_BWD_NB
 #define LVDGS_BWD_NB 8   // survivors per batch of the backward pass: 8 or 4 (A/B builds)
 #endif
+#ifdef LVDGS_DIAG_FILL
+// diagnostic build (tools/fill_diag.py): survivors, splat batches, full batches, (wave, round) pairs with survivors, summed over launches
+__device__ unsigned long long g_fill_diag[4];
+#endif
+// POSE_ONLY (LVDGS_FLAG_POSE_ONLY: the tracking loop, which consumes only dL/dtau and the exposure gradients): the sums that feed
+// nothing but the colour and opacity gradients (Su, C0..C2) are left out -- six accumulators per (wave, entry) instead of
+// ten, and without a depth gradient the (u, w) matrix holds u alone.
+template <bool POSE_ONLY, bool DEPTH_GRAD>
 struct Bwd3Shared {
     static constexpr int NB = LVDGS_BWD_NB;
+    static constexpr int ACC = POSE_ONLY ? 6 : ACC_STRIDE;   // POSE_ONLY: Sx Sy Sxx Sxy Syy CD
+    using MT = std::conditional_t<POSE_ONLY && !DEPTH_GRAD, float, float2>;
     float4 a[BR];                        // x, y, a, b
     float4 b[BR];                        // -c/2*log2e, opacity, depth, -a/2*log2e
     float4 c[BR];                        // r, g, b, -b*log2e
     float craw[BR];                      // c
     uint32_t slot[BR];
-    float acc[4][BR * ACC_STRIDE];       // per wave: Sx Sy Sxx Sxy Syy Su C0 C1 C2 CD of every entry it accumulated
+    float acc[4][BR * ACC];              // per wave: Sx Sy Sxx Sxy Syy Su C0 C1 C2 CD of every entry it accumulated
     unsigned long long mask[4];
     uint32_t wmax[4], wall[4];           // per wave: deepest list position its pixels reached, among pixels with a gradient / among all
     float loss_sum[4][4];                // fused loss: [sum][wave]
-    float2 M[4][NB][64];                 // per wave: (u, w) of [batch slot][pixel]
+    MT M[4][NB][64];                     // per wave: (u, w) of [batch slot][pixel]
     uint32_t bj[4][NB];                  // per wave: entry (position in the round) of every batch slot
 };
 
 // DEPTH_GRAD = false: the loss has no depth term / the caller passed no gradient of the depth image (monocular tracking):
 // the depth image's gradient is identically zero and its terms (one multiply-add per survivor in each pass) are left out.
-template <bool FUSED_LOSS, bool DEPTH_GRAD = true>
 #ifndef LVDGS_BWD_WGS
 #define LVDGS_BWD_WGS 5   // workgroups per CU the backward blend is compiled for (A/B builds)
 #endif
-__global__ void __launch_bounds__(256, LVDGS_BWD_WGS) blend_bwd3_kernel(BlendParams p) {
-    constexpr int NB = Bwd3Shared::NB;
-    __shared__ Bwd3Shared sh;
+#ifndef LVDGS_BWD_WGS_POSE
+#define LVDGS_BWD_WGS_POSE 7   // ... and its pose-only form (18.2 KB of LDS, 74 VGPRs; 26.4 KB with a depth gradient: six). Same box, config 3 / KITTI geometry: 5: 240.9 / 92.0 us, 6: 240.4 / 92.1, 7: 233.7 / 92.6, 8: 233.6 / 95.8
+#endif
+template <bool FUSED_LOSS, bool DEPTH_GRAD = true, bool POSE_ONLY = false>
+__global__ void __launch_bounds__(256, POSE_ONLY ? (DEPTH_GRAD ? 6 : LVDGS_BWD_WGS_POSE) : LVDGS_BWD_WGS) blend_bwd3_kernel(BlendParams p) {
+    using Shared = Bwd3Shared<POSE_ONLY, DEPTH_GRAD>;
+    constexpr int NB = Shared::NB, ACC = Shared::ACC;
+    constexpr bool U_ONLY = POSE_ONLY && !DEPTH_GRAD;   // the matrix holds u alone
+    using MT = typename Shared::MT;
+    __shared__ Shared sh;
 
     const int tile = (p.tile_order && *p.order_valid) ? (int)p.tile_order[order_slot_of_workgroup(blockIdx.x, p.num_tiles)] : p.tile_base + tile_of_workgroup(blockIdx.x, p.num_tiles);
     const int tx = tile % p.gx, ty = tile / p.gx;
@@ -414,10 +430,13 @@ __global__ void __launch_bounds__(256, LVDGS_BWD_WGS) blend_bwd3_kernel(BlendPar
     // splat pass: this lane's slot in the batch and its 16-lane row; at step s it looks at the pixel of lane (col - s) mod 16
     const int row = lane >> 4, col = lane & 15;
     const int my_slot = col & (NB - 1);
-    const float2 *Mrow = &sh.M[wave][my_slot][row * 16];
-    float2 *const Mmine = &sh.M[wave][0][lane];
+    const MT *Mrow = &sh.M[wave][my_slot][row * 16];
+    MT *const Mmine = &sh.M[wave][0][lane];
 
     const int rounds = (todo + BR - 1) / BR;
+#ifdef LVDGS_DIAG_FILL
+    unsigned diag_surv = 0, diag_batches = 0, diag_full = 0, diag_rounds = 0;
+#endif
     for (int r = rounds - 1; r >= 0; r--) {
         const int base = r * BR;
         const int cnt = min(BR, todo - base);
@@ -442,10 +461,16 @@ __global__ void __launch_bounds__(256, LVDGS_BWD_WGS) blend_bwd3_kernel(BlendPar
             uint64_t live = __ballot(keep);
             const uint32_t rel_last = my_last > (uint32_t)base ? my_last - (uint32_t)base : 0u;  // entries below this position composited
             wrote = live;
+#ifdef LVDGS_DIAG_FILL
+            diag_surv += (unsigned)__popcll(live); diag_rounds += live ? 1u : 0u;
+#endif
             while (live) {
                 // ---------------- pixel pass: the next NB survivors, back to front ----------------
                 const uint64_t before = live;
                 const int nb = min(NB, (int)__popcll(live));
+#ifdef LVDGS_DIAG_FILL
+                diag_batches++; diag_full += nb == NB ? 1u : 0u;
+#endif
                 struct Rec { float4 A, B, Cc; };
                 auto next_entry = [&]() {
                     const int j = 63 - __builtin_clzll(live);
@@ -471,7 +496,8 @@ __global__ void __launch_bounds__(256, LVDGS_BWD_WGS) blend_bwd3_kernel(BlendPar
                     const float w = alpha_h * T;
                     const float dL_dalpha = fmaf(k, T, -(R * inv));
                     R = fmaf(k, w, R);
-                    Mmine[(int)slot * 64] = make_float2(G_h * dL_dalpha, w);
+                    if constexpr (U_ONLY) Mmine[(int)slot * 64] = G_h * dL_dalpha;
+                    else Mmine[(int)slot * 64] = make_float2(G_h * dL_dalpha, w);
                 };
                 if (nb == NB) {
                     // straight-line; the records of entries s + 1 and s + 2 are on their way while entry s is evaluated
@@ -514,7 +540,10 @@ __global__ void __launch_bounds__(256, LVDGS_BWD_WGS) blend_bwd3_kernel(BlendPar
                 // one step ahead is still on its way when it is needed
                 float2 uw8[NB];
 #pragma unroll
-                for (int s8 = 0; s8 < NB; s8++) uw8[s8] = Mrow[(col - s8) & 15];
+                for (int s8 = 0; s8 < NB; s8++) {
+                    if constexpr (U_ONLY) uw8[s8] = make_float2(Mrow[(col - s8) & 15], 0.f);
+                    else uw8[s8] = Mrow[(col - s8) & 15];
+                }
 #define LVDGS_SPLAT_STEP(S)                                                                          \
                 {                                                                                    \
                     const float2 uw = uw8[S];                                                        \
@@ -522,9 +551,11 @@ __global__ void __launch_bounds__(256, LVDGS_BWD_WGS) blend_bwd3_kernel(BlendPar
                     const float t1 = uw.x * dx, t2 = uw.x * dy;                                      \
                     Sx += t1; Sy += t2;                                                              \
                     Sxx = fmaf(t1, dx, Sxx); Sxy = fmaf(t1, dy, Sxy); Syy = fmaf(t2, dy, Syy);       \
-                    Su += uw.x;                                                                      \
-                    C0 = fma_rotated<S>(gC0, uw.y, C0); C1 = fma_rotated<S>(gC1, uw.y, C1);          \
-                    C2 = fma_rotated<S>(gC2, uw.y, C2);                                              \
+                    if constexpr (!POSE_ONLY) {                                                      \
+                        Su += uw.x;                                                                  \
+                        C0 = fma_rotated<S>(gC0, uw.y, C0); C1 = fma_rotated<S>(gC1, uw.y, C1);      \
+                        C2 = fma_rotated<S>(gC2, uw.y, C2);                                          \
+                    }                                                                                \
                     if constexpr (DEPTH_GRAD) CD = fma_rotated<S>(gD, uw.y, CD);                     \
                 }
                 LVDGS_SPLAT_STEP(0) LVDGS_SPLAT_STEP(1) LVDGS_SPLAT_STEP(2) LVDGS_SPLAT_STEP(3)
@@ -532,19 +563,26 @@ __global__ void __launch_bounds__(256, LVDGS_BWD_WGS) blend_bwd3_kernel(BlendPar
 #undef LVDGS_SPLAT_STEP
                 // fold the 8 partial sums of every slot: rows first (two pairwise folds, ten registers -> three) ...
                 float q0 = fold16(fold32(Sx, Sy), fold32(Sxx, Sxy));   // rows: Sx Sxx Sy Sxy
-                float q1 = fold16(fold32(Syy, Su), fold32(C0, C1));    // rows: Syy C0 Su C1
-                float q2 = fold16(fold32(C2, CD), C1);                  // rows: C2 x CD x
+                // (POSE_ONLY: Syy and CD take the places -- and so the summation trees -- they have in the full form: the
+                // pose gradient comes out bit for bit the same)
+                float q1 = POSE_ONLY ? fold16(fold32(Syy, CD), Syy) : fold16(fold32(Syy, Su), fold32(C0, C1));    // rows: Syy C0 Su C1 | Syy x CD x
+                float q2 = POSE_ONLY ? 0.f : fold16(fold32(C2, CD), C1);                                             // rows: C2 x CD x
                 q0 += row_rotate<8>(q0);  // ... then the two half-rows (NB = 4: four quarter-rows) that share a slot
                 q1 += row_rotate<8>(q1);
-                q2 += row_rotate<8>(q2);
+                if constexpr (!POSE_ONLY) q2 += row_rotate<8>(q2);
                 if constexpr (NB == 4) { q0 += row_rotate<4>(q0); q1 += row_rotate<4>(q1); q2 += row_rotate<4>(q2); }
                 if (valid && col < NB) {
                     // value index held by this row: q0 -> {Sx, Sxx, Sy, Sxy}, q1 -> {Syy, C0, Su, C1}, q2 -> {C2, -, CD, -}
                     const int i0 = row == 0 ? 0 : (row == 1 ? 2 : (row == 2 ? 1 : 3));
-                    const int i1 = row == 0 ? 4 : (row == 1 ? 6 : (row == 2 ? 5 : 7));
-                    float *o = &sh.acc[wave][jj * ACC_STRIDE];
-                    o[i0] = q0; o[i1] = q1;
-                    if ((row & 1) == 0) o[row == 0 ? 8 : 9] = q2;
+                    float *o = &sh.acc[wave][jj * ACC];
+                    o[i0] = q0;
+                    if constexpr (POSE_ONLY) {
+                        if ((row & 1) == 0) o[row == 0 ? 4 : 5] = q1;   // Syy, CD
+                    } else {
+                        const int i1 = row == 0 ? 4 : (row == 1 ? 6 : (row == 2 ? 5 : 7));
+                        o[i1] = q1;
+                        if ((row & 1) == 0) o[row == 0 ? 8 : 9] = q2;
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -553,32 +591,41 @@ __global__ void __launch_bounds__(256, LVDGS_BWD_WGS) blend_bwd3_kernel(BlendPar
         if (lane == 0) sh.mask[wave] = wrote;
         __syncthreads();
         if (tid < cnt) {
-            float acc[ACC_STRIDE];
+            float acc[ACC];
 #pragma unroll
-            for (int k = 0; k < ACC_STRIDE; k++) acc[k] = 0.f;
+            for (int k = 0; k < ACC; k++) acc[k] = 0.f;
             const unsigned long long bit = 1ull << tid;
 #pragma unroll
             for (int w = 0; w < 4; w++)
                 if (sh.mask[w] & bit) {
-                    const float2 *o = reinterpret_cast<const float2 *>(&sh.acc[w][tid * ACC_STRIDE]);
+                    const float2 *o = reinterpret_cast<const float2 *>(&sh.acc[w][tid * ACC]);
 #pragma unroll
-                    for (int k = 0; k < 5; k++) { const float2 t = o[k]; acc[2 * k] += t.x; acc[2 * k + 1] += t.y; }
+                    for (int k = 0; k < ACC / 2; k++) { const float2 t = o[k]; acc[2 * k] += t.x; acc[2 * k + 1] += t.y; }
                 }
-            // acc: Sx Sy Sxx Sxy Syy Su C0 C1 C2 CD (sums of u, not yet of h = opacity * u)
+            // acc: Sx Sy Sxx Sxy Syy Su C0 C1 C2 CD (sums of u, not yet of h = opacity * u); POSE_ONLY: Sx Sy Sxx Sxy Syy CD
             const float4 A = sh.a[tid];
             const float op = sh.b[tid].y;
             const float sx = op * acc[0], sy = op * acc[1];
-            // the pair's record: ten floats, 40 bytes (8-byte aligned: five 8-byte stores), and its "written" flag
+            // the pair's record: ten floats, 40 bytes (8-byte aligned: five 8-byte stores), and its "written" flag;
+            // POSE_ONLY: d/d(mean, conic, view depth) alone, six floats at the same 8-byte alignment
             p.pair_valid[sh.slot[tid]] = 1;
-            float2 *dst = reinterpret_cast<float2 *>(p.pair_grads + (size_t)sh.slot[tid] * PAIR_FLOATS);
+            float2 *dst = reinterpret_cast<float2 *>(p.pair_grads + (size_t)sh.slot[tid] * (POSE_ONLY ? PAIR_FLOATS_POSE : PAIR_FLOATS));
             dst[0] = make_float2(-fmaf(A.z, sx, A.w * sy), -fmaf(sh.craw[tid], sy, A.w * sx));
             dst[1] = make_float2(-0.5f * (op * acc[2]), -(op * acc[3]));
             dst[2] = make_float2(-0.5f * (op * acc[4]), acc[5]);
-            dst[3] = make_float2(acc[6], acc[7]);
-            dst[4] = make_float2(acc[8], acc[9]);
+            if constexpr (!POSE_ONLY) {
+                dst[3] = make_float2(acc[6], acc[7]);
+                dst[4] = make_float2(acc[8], acc[9]);
+            }
         }
         __syncthreads();
     }
+#ifdef LVDGS_DIAG_FILL
+    if (lane == 0) {
+        atomicAdd(&g_fill_diag[0], (unsigned long long)diag_surv); atomicAdd(&g_fill_diag[1], (unsigned long long)diag_batches);
+        atomicAdd(&g_fill_diag[2], (unsigned long long)diag_full); atomicAdd(&g_fill_diag[3], (unsigned long long)diag_rounds);
+    }
+#endif
 }
 
 BlendParams make_params(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im) {
@@ -616,7 +663,10 @@ int launch_blend_bwd(const lvdgs_args &a, const GeomView &g, const BinView &b, c
     p.pair_grads = w.pair_grads; p.pair_valid = b.pair_valid;
     if (p.num_tiles == 0) return LVDGS_OK;
     ProfScope ps("blend_bwd", s);
-    if (LVDGS_BWD_DEPTH_ALWAYS || p.dL_ddepth) hipLaunchKernelGGL((blend_bwd3_kernel<false, true>), dim3(p.num_tiles), dim3(256), 0, s, p);
+    const bool depth = LVDGS_BWD_DEPTH_ALWAYS || p.dL_ddepth, pose_only = (a.flags & LVDGS_FLAG_POSE_ONLY) != 0;
+    if (pose_only && depth) hipLaunchKernelGGL((blend_bwd3_kernel<false, true, true>), dim3(p.num_tiles), dim3(256), 0, s, p);
+    else if (pose_only) hipLaunchKernelGGL((blend_bwd3_kernel<false, false, true>), dim3(p.num_tiles), dim3(256), 0, s, p);
+    else if (depth) hipLaunchKernelGGL((blend_bwd3_kernel<false, true>), dim3(p.num_tiles), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((blend_bwd3_kernel<false, false>), dim3(p.num_tiles), dim3(256), 0, s, p);
     LVDGS_LAUNCH_CHECK("blend_bwd", a.debug, s);
     return LVDGS_OK;
@@ -630,10 +680,24 @@ int launch_blend_bwd_fused_loss(const lvdgs_args &a, const GeomView &g, const Bi
     p.loss_propagate_opacity = propagate_opacity;
     if (p.num_tiles == 0) return LVDGS_OK;
     ProfScope ps("blend_bwd", s);
-    if (LVDGS_BWD_DEPTH_ALWAYS || (loss.depth && loss.gt_depth && loss.w_d != 0.f)) hipLaunchKernelGGL((blend_bwd3_kernel<true, true>), dim3(p.num_tiles), dim3(256), 0, s, p);
+    const bool depth = LVDGS_BWD_DEPTH_ALWAYS || (loss.depth && loss.gt_depth && loss.w_d != 0.f), pose_only = (a.flags & LVDGS_FLAG_POSE_ONLY) != 0;
+    if (pose_only && depth) hipLaunchKernelGGL((blend_bwd3_kernel<true, true, true>), dim3(p.num_tiles), dim3(256), 0, s, p);
+    else if (pose_only) hipLaunchKernelGGL((blend_bwd3_kernel<true, false, true>), dim3(p.num_tiles), dim3(256), 0, s, p);
+    else if (depth) hipLaunchKernelGGL((blend_bwd3_kernel<true, true>), dim3(p.num_tiles), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((blend_bwd3_kernel<true, false>), dim3(p.num_tiles), dim3(256), 0, s, p);
     LVDGS_LAUNCH_CHECK("blend_bwd", a.debug, s);
     return LVDGS_OK;
 }
 
 }  // namespace lvdgs
+
+#ifdef LVDGS_DIAG_FILL
+extern "C" int lvdgs_diag_fill(unsigned long long *out4, int reset) {
+    if (out4 && hipMemcpyFromSymbol(out4, HIP_SYMBOL(lvdgs::g_fill_diag), 4 * sizeof(unsigned long long)) != hipSuccess) return LVDGS_E_HIP;
+    if (reset) {
+        const unsigned long long z[4] = {0ull, 0ull, 0ull, 0ull};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(lvdgs::g_fill_diag), z, sizeof(z)) != hipSuccess) return LVDGS_E_HIP;
+    }
+    return LVDGS_OK;
+}
+#endif

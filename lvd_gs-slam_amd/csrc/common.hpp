@@ -30,6 +30,7 @@ constexpr int WAVE = 64;
 constexpr int REC_FLOATS = LVDGS_REC_FLOATS;
 static_assert(REC_FLOATS == 12 || REC_FLOATS == 16, "12: the record without the rectangle copy (A/B builds)");
 constexpr int PAIR_FLOATS = 10;  // per-(Gaussian, tile) partial gradient record: 40 bytes (48 with two pad floats until round 3)
+constexpr int PAIR_FLOATS_POSE = 6;  // ... of a pose-only backward (LVDGS_FLAG_POSE_ONLY): d/d(2-D mean, conic, view depth), 24 bytes
 
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_IPT = 16;                       // elements per thread per radix pass
@@ -160,17 +161,24 @@ __device__ __forceinline__ uint32_t rect_rank(const uint4 r, int k, int area) {
     const int w = (int)(r.x >> 16) - (int)(r.x & 0xffffu);
     const RectBlocks g(w, area / w);
     const int tx = k % w, ty = k / w, b = g.block_of(tx, ty);
-    uint32_t rank = (uint32_t)((ty % g.bh) * g.width(b) + tx % g.bw);
-    for (uint64_t below = m & ((1ull << b) - 1ull); below; below &= below - 1) {
-        const int q = __builtin_ctzll(below);
-        rank += (uint32_t)(g.width(q) * g.height(q));
-    }
-    return rank;
+    // The tiles of the kept blocks in front of block b, in closed form (until round 4: a walk over the up to 63 mask bits below
+    // b, which the backward blend pass paid for every staged entry of a large-footprint Gaussian).  Blocks are bw x bh tiles
+    // except in the grid's last column (wl wide) and last row; every block row in front of b's is a full-height one.
+    const int bc = b & 7, br = b >> 3;
+    const int ncols = (g.w + g.bw - 1) / g.bw, wl = g.w - (ncols - 1) * g.bw;          // columns of the grid, width of the last one
+    const uint64_t rows_before = br ? (~0ull >> (64 - 8 * br)) : 0ull;                // every bit of the block rows in front of br
+    const uint64_t last_col = 0x0101010101010101ull << (ncols - 1);
+    const uint64_t full_cols = (0x0101010101010101ull * (uint64_t)((1u << (ncols - 1)) - 1u));
+    const uint32_t row_bits = (uint32_t)(m >> (8 * br)) & ((1u << bc) - 1u);           // kept blocks of b's row in front of it: full width
+    const uint32_t before = (uint32_t)g.bh * ((uint32_t)g.bw * (uint32_t)__popcll(m & rows_before & full_cols) +
+                                              (uint32_t)wl * (uint32_t)__popcll(m & rows_before & last_col)) +
+                            (uint32_t)g.height(b) * (uint32_t)g.bw * (uint32_t)__popc(row_bits);
+    return before + (uint32_t)((ty % g.bh) * g.width(b) + tx % g.bw);
 }
 
 // ---- state layouts ----
 struct GeomView {
-    float *rec;              // N*12
+    float *rec;              // N * REC_FLOATS (16)
     uint32_t *tiles_touched; // N: tiles of the rectangle the Gaussian can reach (= pairs listed for it)
     uint32_t *depth_bits;    // N: view depth as ordered bits (positive floats compare like unsigned integers)
     uint4 *rect;             // N: tile rectangle x0 | x1 << 16, y0 | y1 << 16 (empty for culled Gaussians) and the kept-tile mask

@@ -213,12 +213,12 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(FwdParams p) {
     if (threadIdx.x == 0) p.blocksums[blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
 }
 
-// The projection that also counts: a workgroup owns the chunk of 1024 x PER consecutive Gaussians the grouping kernels
+// The projection that also counts: a workgroup owns the chunk of GROUP_THREADS x PER consecutive Gaussians the grouping kernels
 // (binning.hip) work in, keeps the per-tile pair counters of that chunk in LDS while it projects, and leaves the chunk's
 // row of the [chunk][tile] count matrix and the chunk's pair total -- the grouping's first kernel and its re-read of
 // every rectangle are gone from the single-call forward (lvdgs_forward).  Also clears what the later kernels of the
 // frame accumulate into (n_touched, the tile-sort queue counters).
-template <int PER>
+template <int GROUP_THREADS, int PER>
 __global__ void __launch_bounds__(GROUP_THREADS, 8) preprocess_count_kernel(FwdParams p, int T, uint32_t *__restrict__ hist,
                                                                         uint32_t *__restrict__ chunk_sums, int32_t *__restrict__ n_touched,
                                                                         uint32_t *__restrict__ queue_counts) {
@@ -416,7 +416,21 @@ constexpr int BIG_RUN = 64;      // a Gaussian with more pairs than this is summ
 #ifndef LVDGS_PBWD_ABLATE
 #define LVDGS_PBWD_ABLATE 0   // diagnostic builds: 1 = no pair sums, 2 = no per-Gaussian chain
 #endif
-__global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(BwdParams p) {
+// The values are in their registers -- their loads waited for -- at this point of the program.
+__device__ __forceinline__ void wait_for_vector_memory() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void loads_complete_here(int32_t &radius, uint32_t &slot, uint32_t &tiles, float (&pos)[3], float &opac, float (&sc)[3],
+                                                    float (&q)[4], float (&c6)[6]) {
+    asm volatile("" : "+v"(radius), "+v"(slot), "+v"(tiles), "+v"(pos[0]), "+v"(pos[1]), "+v"(pos[2]), "+v"(opac));
+    asm volatile("" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
+    asm volatile("" : "+v"(c6[0]), "+v"(c6[1]), "+v"(c6[2]), "+v"(c6[3]), "+v"(c6[4]), "+v"(c6[5]));
+}
+
+// POSE_ONLY (LVDGS_FLAG_POSE_ONLY): the pose gradient alone -- six-float pair records (d/d 2-D mean, conic, view depth), no
+// opacity / colour reads, no parameter-gradient stores, no scale / quaternion chain.  The statements that make dL/dtau are the
+// same ones in the same order: the partial sums are bit for bit those of the full form.
+template <bool POSE_ONLY>
+__device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p) {
+    constexpr int PF = POSE_ONLY ? PAIR_FLOATS_POSE : PAIR_FLOATS;   // floats per pair record
     __shared__ float s_tau[4][6];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const Cam &c = p.cam;
@@ -442,7 +456,7 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(Bwd
     if (in_map) {
         radius_i = p.radii[i]; slot_i = p.slot_base[i]; tiles_i = p.tiles_touched[i];
         pos[0] = p.means3D[3 * i]; pos[1] = p.means3D[3 * i + 1]; pos[2] = p.means3D[3 * i + 2];
-        opac_raw = p.opacities[i];
+        if constexpr (!POSE_ONLY) opac_raw = p.opacities[i];
         if (p.cov3D_precomp) {
 #pragma unroll
             for (int k = 0; k < 6; k++) c6[k] = p.cov3D_precomp[6 * (size_t)i + k];
@@ -453,16 +467,14 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(Bwd
             for (int k = 0; k < 4; k++) q[k] = p.rotations[4 * (size_t)i + k];
         }
     }
-    asm volatile("" : "+v"(radius_i), "+v"(slot_i), "+v"(tiles_i), "+v"(pos[0]), "+v"(pos[1]), "+v"(pos[2]), "+v"(opac_raw));
-    asm volatile("" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
-    asm volatile("" : "+v"(c6[0]), "+v"(c6[1]), "+v"(c6[2]), "+v"(c6[3]), "+v"(c6[4]), "+v"(c6[5]));
+    loads_complete_here(radius_i, slot_i, tiles_i, pos, opac_raw, sc, q, c6);
     // (a visible Gaussian without a listed pair -- none of its tiles in the band being rendered, or every tile ruled out by the
     // reach test -- has all-zero sums, and every output is linear in them: zeros are written and the arithmetic left out)
     const bool live = in_map && radius_i > 0 && tiles_i > 0u;
     // gradients w.r.t. the parameters: written, or (a later view of a mapping iteration) added to what is there
     const bool accumulate = p.accumulate != 0;
     auto put = [accumulate](float *dst, float v) { *dst = accumulate ? *dst + v : v; };
-    if (i < p.N && !live) {
+    if (!POSE_ONLY && i < p.N && !live) {
 #pragma unroll
         for (int k = 0; k < 3; k++) p.dmeans2D[3 * (size_t)i + k] = 0.f;
         if (!accumulate) {   // (adding zero: nothing to do)
@@ -487,7 +499,7 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(Bwd
     // the rotation matrix -- and land while it runs: with the workgroup-wide staging of before (two workgroup barriers per
     // chunk) the kernel was the sum of a memory phase and an arithmetic phase, every resident workgroup in the same one
     // (ablation builds: 26.7 us without the arithmetic, 28.9 without the sums, 49.5 together).
-    __shared__ float4 s_pg4[4][WAVE_CHUNK * PAIR_FLOATS / 4];   // (the last load instruction of a chunk is masked to the lanes inside it)
+    __shared__ float4 s_pg4[4][WAVE_CHUNK * PF / 4];   // (the last load instruction of a chunk is masked to the lanes inside it)
     __shared__ uint32_t s_valid4[4][WAVE_CHUNK / 4];
     float A[10];
 #pragma unroll
@@ -505,12 +517,12 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(Bwd
     }
     const float4 *pg_all = reinterpret_cast<const float4 *>(p.pair_grads);
     const uint32_t *valid_all = reinterpret_cast<const uint32_t *>(p.pair_valid);
-    constexpr int QUADS_PER_LANE = (WAVE_CHUNK * PAIR_FLOATS / 4 + 63) / 64;
+    constexpr int QUADS_PER_LANE = (WAVE_CHUNK * PF / 4 + 63) / 64;
     // global -> LDS directly (global_load_lds: the wave's lanes land side by side, 1 KiB per instruction; no registers held
     // while the chunk is on its way): one chunk of records and their flags
     auto request = [&](uint32_t c0) {
         const uint32_t n = min((uint32_t)WAVE_CHUNK, r_hi - c0);
-        const uint32_t quads = (n * PAIR_FLOATS + 3) / 4, q0 = c0 / 2 * 5;   // c0 is even: record c0 starts at float4 c0 * 10 / 4
+        const uint32_t quads = (n * PF + 3) / 4, q0 = c0 / 4 * PF;   // c0 is a multiple of 4: record c0 starts at float4 c0 * PF / 4
 #pragma unroll
         for (int u = 0; u < QUADS_PER_LANE; u++) {
             const uint32_t k = (uint32_t)lane + 64u * (uint32_t)u;
@@ -520,7 +532,7 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(Bwd
     };
     auto consume = [&](uint32_t c0) {   // LDS -> every lane's own records, in slot order
         const uint32_t n = min((uint32_t)WAVE_CHUNK, r_hi - c0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_for_vector_memory();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -529,11 +541,14 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(Bwd
         const uint32_t lo = max(first, c0), hi = min(last, c0 + n);
         for (uint32_t t = lo; t < hi; t++) {
             if (!s_valid[t - c0]) continue;   // (a record blend_bwd did not write: a pair behind its tile's last contributor)
-            const float2 *r = s_pg + 5 * (t - c0);
-            const float2 a0 = r[0], a1 = r[1], a2 = r[2], a3 = r[3], a4 = r[4];
-            A[0] += a0.x; A[1] += a0.y; A[2] += a1.x; A[3] += a1.y;
-            A[4] += a2.x; A[5] += a2.y; A[6] += a3.x; A[7] += a3.y;
-            A[8] += a4.x; A[9] += a4.y;
+            const float2 *r = s_pg + (PF / 2) * (t - c0);
+            const float2 a0 = r[0], a1 = r[1], a2 = r[2];
+            A[0] += a0.x; A[1] += a0.y; A[2] += a1.x; A[3] += a1.y; A[4] += a2.x;
+            if constexpr (POSE_ONLY) A[9] += a2.y;
+            else {
+                const float2 a3 = r[3], a4 = r[4];
+                A[5] += a2.y; A[6] += a3.x; A[7] += a3.y; A[8] += a4.x; A[9] += a4.y;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -574,11 +589,14 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(Bwd
         // records l, l + 64, ... -- and the 64 partial sums are folded in a fixed order.
         const float2 *pg = reinterpret_cast<const float2 *>(p.pair_grads);
         auto add = [&](float (&S)[10], uint32_t t) {
-            const float2 *r = pg + (size_t)5 * t;
-            const float2 a0 = r[0], a1 = r[1], a2 = r[2], a3 = r[3], a4 = r[4];
-            S[0] += a0.x; S[1] += a0.y; S[2] += a1.x; S[3] += a1.y;
-            S[4] += a2.x; S[5] += a2.y; S[6] += a3.x; S[7] += a3.y;
-            S[8] += a4.x; S[9] += a4.y;
+            const float2 *r = pg + (size_t)(PF / 2) * t;
+            const float2 a0 = r[0], a1 = r[1], a2 = r[2];
+            S[0] += a0.x; S[1] += a0.y; S[2] += a1.x; S[3] += a1.y; S[4] += a2.x;
+            if constexpr (POSE_ONLY) S[9] += a2.y;
+            else {
+                const float2 a3 = r[3], a4 = r[4];
+                S[5] += a2.y; S[6] += a3.x; S[7] += a3.y; S[8] += a4.x; S[9] += a4.y;
+            }
         };
         if (!big)
             for (uint32_t t = first; t < last; t++)
@@ -607,7 +625,7 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(Bwd
     if (live) {
 #endif
         // A: [0,1] d/d pixel mean, [2..4] d/d conic a,b,c, [5] d/d opacity, [6..8] d/d rgb, [9] d/d view depth
-        {
+        if constexpr (!POSE_ONLY) {
             // d/d(logit) = d/d(opacity) * o (1 - o) when the sigmoid is fused (o re-evaluated with the forward's expression: the
             // record holds it too, but reading 4 bytes of a 64-byte record per Gaussian moved 20 MB for 2)
             float o = opac_raw;
@@ -615,14 +633,15 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(Bwd
             else put(&p.dopac[i], A[5]);
         }
         const float g_ndc[2] = {A[0] * 0.5f * (float)c.W, A[1] * 0.5f * (float)c.H};
-        p.dmeans2D[3 * (size_t)i] = g_ndc[0]; p.dmeans2D[3 * (size_t)i + 1] = g_ndc[1]; p.dmeans2D[3 * (size_t)i + 2] = 0.f;
+        if constexpr (!POSE_ONLY) { p.dmeans2D[3 * (size_t)i] = g_ndc[0]; p.dmeans2D[3 * (size_t)i + 1] = g_ndc[1]; p.dmeans2D[3 * (size_t)i + 2] = 0.f; }
 
         float g_rgb[3] = {A[6], A[7], A[8]};
         float g_pview[3] = {0.f, 0.f, A[9]};
         float g_world[3] = {0.f, 0.f, 0.f};
 
-        // ---- colour ----
-        if (p.colors_precomp) {
+        // ---- colour ---- (POSE_ONLY: colours without view dependence only -- api.hip -- which give the pose nothing)
+        if constexpr (POSE_ONLY) {
+        } else if (p.colors_precomp) {
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) put(&p.dcolors[3 * (size_t)i + ch], g_rgb[ch]);
         } else {
@@ -687,7 +706,7 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(Bwd
                     for (int s = 0; s < 2; s++) v += e.T[r][a] * Gs[r][s] * e.T[s][b];
                 g_S[a][b] = v;
             }
-        if (p.dcov3D) {
+        if (!POSE_ONLY && p.dcov3D) {
             float *o = p.dcov3D + 6 * (size_t)i;
             put(o + 0, g_S[0][0]); put(o + 1, 2.f * g_S[0][1]); put(o + 2, 2.f * g_S[0][2]);
             put(o + 3, g_S[1][1]); put(o + 4, 2.f * g_S[1][2]); put(o + 5, g_S[2][2]);
@@ -734,7 +753,7 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(Bwd
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             g_world[a] += Vg[4 * a + 0] * g_pview[0] + Vg[4 * a + 1] * g_pview[1] + Vg[4 * a + 2] * g_pview[2];
-            put(&p.dmeans3D[3 * (size_t)i + a], g_world[a]);
+            if constexpr (!POSE_ONLY) put(&p.dmeans3D[3 * (size_t)i + a], g_world[a]);
         }
 
         // ---- camera pose: T' = Exp(tau) T ----
@@ -752,7 +771,7 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(Bwd
         }
 
         // ---- Sigma3 -> scale, quaternion ----
-        if (!p.cov3D_precomp) {
+        if (!POSE_ONLY && !p.cov3D_precomp) {
             float R[3][3];
             quat_rot(q, R);
             const float sm[3] = {c.scale_mod * sc[0], c.scale_mod * sc[1], c.scale_mod * sc[2]};
@@ -796,6 +815,14 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(Bwd
         p.tau_part[(size_t)blockIdx.x * 6 + threadIdx.x] =
             ((s_tau[0][threadIdx.x] + s_tau[1][threadIdx.x]) + s_tau[2][threadIdx.x]) + s_tau[3][threadIdx.x];
 }
+
+// (two plain kernels around the body: a kernel TEMPLATE with this body loses its host stub -- "substitution failure" -- on this
+// toolchain)
+__global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(BwdParams p) { preprocess_bwd_body<false>(p); }
+#ifndef LVDGS_PBWD_WGS_POSE
+#define LVDGS_PBWD_WGS_POSE 6
+#endif
+__global__ void __launch_bounds__(256, LVDGS_PBWD_WGS_POSE) preprocess_bwd_pose_kernel(BwdParams p) { preprocess_bwd_body<true>(p); }
 
 // fixed-order reduction of the per-workgroup pose partials (strided per-thread sums, then a wave fold and a four-term sum:
 // two barriers fewer than an LDS tree, the order of the additions fixed by the code either way)
@@ -865,18 +892,17 @@ int launch_preprocess_count(const lvdgs_args &a, const GeomView &g, const ImageV
     if (N == 0) return LVDGS_OK;
     FwdParams p = make_fwd_params(a, g);
     const int T = p.cam.gx * p.cam.gy;
-    const int per = group_per_thread_for(N), nchunks = cdiv(N, GROUP_THREADS * per);
+    const int nchunks = (int)group_chunks(N);
     const size_t lds = (size_t)T * sizeof(uint32_t);
-    static unsigned char done[3][16];
+    static unsigned char done[GROUP_SHAPES][16];
     ProfScope ps("preprocess_fwd", s);
-#define LVDGS_PCOUNT(PER_, D_)                                                                                                     \
-    {                                                                                                                              \
-        if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&preprocess_count_kernel<PER_>), GROUP_MAX_TILES * 4, done[D_])) return e; \
-        hipLaunchKernelGGL(preprocess_count_kernel<PER_>, dim3(nchunks), dim3(GROUP_THREADS), lds, s, p, T, w.group_hist, w.chunk_sums, a.n_touched, \
-                           im.long_count);                                                                                         \
-    }
-    if (per == 1) LVDGS_PCOUNT(1, 0) else if (per == 2) LVDGS_PCOUNT(2, 1) else LVDGS_PCOUNT(4, 2)
-#undef LVDGS_PCOUNT
+    if (int e = group_dispatch(group_shape_for(N), [&](auto threads_, auto per_, int d) {
+            constexpr int THREADS = decltype(threads_)::value, PER = decltype(per_)::value;
+            if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&preprocess_count_kernel<THREADS, PER>), GROUP_MAX_TILES * 4, done[d])) return e;
+            hipLaunchKernelGGL((preprocess_count_kernel<THREADS, PER>), dim3(nchunks), dim3(THREADS), lds, s, p, T, w.group_hist, w.chunk_sums, a.n_touched,
+                               im.long_count);
+            return (int)LVDGS_OK;
+        })) return e;
     LVDGS_LAUNCH_CHECK("preprocess_count", a.debug, s);
     return LVDGS_OK;
 }
@@ -894,7 +920,8 @@ int launch_preprocess_bwd(const lvdgs_args &a, const GeomView &g, const BwdScrat
         p.drot = a.dL_drotations; p.dcov3D = a.cov3D_precomp ? a.dL_dcov3D : nullptr; p.dshs = a.dL_dshs;
         p.dcolors = a.dL_dcolors; p.tau_part = b.tau_part; p.accumulate = (a.flags & LVDGS_FLAG_ACCUMULATE_PARAM_GRADS) ? 1 : 0;
         ProfScope ps("preprocess_bwd", s);
-        hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(256), 0, s, p);
+        if (a.flags & LVDGS_FLAG_POSE_ONLY) hipLaunchKernelGGL(preprocess_bwd_pose_kernel, dim3(nblk), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(256), 0, s, p);
         LVDGS_LAUNCH_CHECK("preprocess_bwd", a.debug, s);
     }
     if (a.dL_dtau) {   // NULL: the partials stay in the scratch for lvdgs_tracking_tail

@@ -26,8 +26,13 @@ pose untouched (``lvdgs_pose_step``), so the final pose, exposure and iteration 
 at the converged iteration.  (The images left in the session after such a late stop are a re-render at the converged
 pose, not the render that preceded the last step; they differ by a pose change below the convergence threshold.)
 
-Gradients w.r.t. the Gaussians are still produced by ``lvdgs_backward`` (the reference's tracking computes and never
-uses them either); they are written to scratch the session owns, the model's ``.grad`` fields are not touched.
+Gradients w.r.t. the Gaussians: the reference's tracking optimiser holds the pose and the exposure alone
+(utils/slam_frontend.py:1468-1490, stepped at :1520); autograd computes the Gaussians' gradients beside them and drops them.
+The session does not compute them (``LVDGS_FLAG_POSE_ONLY``: the backward blend pass without the colour / opacity sums,
+the per-Gaussian pass without parameter reads it does not need or any N x 14 gradient stores; dL/dtau and the exposure
+gradients are bit for bit those of the full backward) unless asked to with ``gaussian_gradients=True`` -- they then land in
+scratch the session owns (``d_m3`` ...), the model's ``.grad`` fields are not touched -- or unless the colours depend on
+the view direction (active SH degree > 0: the colour gradient then feeds the pose gradient).
 """
 import ctypes as C
 
@@ -52,7 +57,7 @@ class TrackingSession:
     """State of one frame's pose optimisation.  ``step()`` enqueues one iteration; ``finish()`` writes the result back
     into the viewpoint (``R``, ``T`` via ``update_RT``; exposure and the zeroed deltas were updated in place)."""
 
-    def __init__(self, viewpoint, gaussians, config, pipeline_params, background, converged_threshold=1e-4):
+    def __init__(self, viewpoint, gaussians, config, pipeline_params, background, converged_threshold=1e-4, gaussian_gradients=False):
         import math
         dev = gaussians.get_xyz.device
         if dev.type != "cuda":
@@ -96,6 +101,9 @@ class TrackingSession:
             scales, rotations, opacity = gaussians.get_scaling, gaussians.get_rotation, gaussians.get_opacity
             a.activations = 0
         a.flags = _lib.FLAG_LIST_ALL_TILES if _rz.LIST_ALL_TILES else 0
+        self.pose_only = not gaussian_gradients and int(gaussians.active_sh_degree) == 0
+        if self.pose_only:
+            a.flags |= _lib.FLAG_POSE_ONLY
         m3, sc, rot, op, shs = (_f32c(t, dev) for t in (gaussians.get_xyz, scales, rotations, opacity, gaussians.get_features))
         keep += [m3, sc, rot, op, shs]
         a.num_gaussians, a.sh_coeffs = N, int(shs.shape[1])
@@ -112,9 +120,12 @@ class TrackingSession:
         key = dev.index if dev.index is not None else torch.cuda.current_device()
         self.cap = max(_rz._PAIR_CAPACITY.get(key, 0), _rz._MIN_PAIR_CAPACITY, _rz._PAIRS_PER_GAUSSIAN_GUESS * N, 1)
         self._size_for_pairs(self.cap)
-        # gradient outputs of lvdgs_backward (scratch: only dL/dtau is consumed)
-        self.d_m3, self.d_m2, self.d_op = e(N, 3), e(N, 3), e(*op.shape)
-        self.d_sc, self.d_rot, self.d_sh, self.d_tau = e(N, 3), e(N, 4), e(*shs.shape), e(6)
+        # gradient outputs of lvdgs_backward (only dL/dtau is consumed; the Gaussians' go to scratch when they are asked for)
+        self.d_tau = e(6)
+        self.d_m3 = self.d_m2 = self.d_op = self.d_sc = self.d_rot = self.d_sh = None
+        if not self.pose_only:
+            self.d_m3, self.d_m2, self.d_op = e(N, 3), e(N, 3), e(*op.shape)
+            self.d_sc, self.d_rot, self.d_sh = e(N, 3), e(N, 4), e(*shs.shape)
         a.dL_dmeans3D, a.dL_dmeans2D, a.dL_dopacities = _P(self.d_m3), _P(self.d_m2), _P(self.d_op)
         a.dL_dscales, a.dL_drotations, a.dL_dshs = _P(self.d_sc), _P(self.d_rot), _P(self.d_sh)
         a.dL_dtau = None   # the backward leaves its partial sums, lvdgs_tracking_tail reduces them into self.d_tau

@@ -35,6 +35,9 @@ def test_flag_and_status_values_match_the_header():
     enums = {k: int(v) for k, v in re.findall(r"\b(LVDGS_[A-Z_]+)\s*=\s*(\d+)", text)}
     assert enums["LVDGS_FLAG_LIST_ALL_TILES"] == _lib.FLAG_LIST_ALL_TILES
     assert enums["LVDGS_FLAG_ACCUMULATE_PARAM_GRADS"] == _lib.FLAG_ACCUMULATE_PARAM_GRADS
+    assert enums["LVDGS_FLAG_POSE_ONLY"] == _lib.FLAG_POSE_ONLY
+    flags = [v for k, v in enums.items() if k.startswith("LVDGS_FLAG_")]
+    assert len(set(flags)) == len(flags) and all(v & (v - 1) == 0 for v in flags)   # distinct single bits
     assert (enums["LVDGS_OK"], enums["LVDGS_E_INVALID"], enums["LVDGS_E_HIP"], enums["LVDGS_E_RANGE"], enums["LVDGS_E_CAPACITY"]) == \
         (_lib.OK, _lib.E_INVALID, _lib.E_HIP, _lib.E_RANGE, _lib.E_CAPACITY)
 

@@ -91,6 +91,37 @@ def test_two_call_forward_and_backward_through_ctypes():
         assert torch.equal(acc[k], start[k] + out[k]), k
     assert torch.equal(acc["means2D"], out["means2D"]) and torch.equal(acc["tau"], out["tau"])
 
+    # LVDGS_FLAG_POSE_ONLY: the pose gradient alone -- bit for bit the full backward's -- with every other gradient pointer NULL,
+    # and nothing written through the ones that are given
+    tau_only = torch.full((6,), float("nan"), device=dev)
+    a.flags = _lib.FLAG_POSE_ONLY
+    a.dL_dmeans3D = a.dL_dmeans2D = a.dL_dopacities = a.dL_dscales = a.dL_drotations = a.dL_dcolors = None
+    a.dL_dtau = _p(tau_only)
+    _lib.check(L.lvdgs_backward(C.byref(a), stream), "backward (pose only)")
+    torch.cuda.synchronize()
+    assert torch.equal(tau_only, out["tau"])
+    sentinel = {k: torch.full(out[k].shape, 7.0, device=dev) for k in out if k != "tau"}
+    a.dL_dmeans3D, a.dL_dmeans2D, a.dL_dopacities = _p(sentinel["means3D"]), _p(sentinel["means2D"]), _p(sentinel["opacities"])
+    a.dL_dscales, a.dL_drotations, a.dL_dcolors = _p(sentinel["scales"]), _p(sentinel["rotations"]), _p(sentinel["colors"])
+    a.dL_dout_depth = a.dL_dout_opacity = None     # (the form without a depth gradient: another kernel instantiation)
+    _lib.check(L.lvdgs_backward(C.byref(a), stream), "backward (pose only, colour gradient alone)")
+    a.flags = 0
+    a.dL_dtau = _p(acc["tau"])
+    _lib.check(L.lvdgs_backward(C.byref(a), stream), "backward (colour gradient alone)")
+    torch.cuda.synchronize()
+    assert torch.equal(tau_only, acc["tau"]) and bool(tau_only.any())
+    # (the full call has just written the sentinels' buffers: pose-only before it must not have)
+    a.flags = _lib.FLAG_POSE_ONLY
+    for v in sentinel.values():
+        v.fill_(7.0)
+    _lib.check(L.lvdgs_backward(C.byref(a), stream), "backward (pose only)")
+    torch.cuda.synchronize()
+    assert all(bool((v == 7.0).all()) for v in sentinel.values())
+    # a view-dependent colour feeds the pose gradient through the colour gradient: refused, with a message
+    shs = torch.zeros(N, 4, 3, device=dev)
+    a.colors_precomp, a.shs, a.sh_coeffs, a.sh_degree = None, _p(shs), 4, 1
+    assert L.lvdgs_backward(C.byref(a), stream) == _lib.E_INVALID and b"POSE_ONLY" in L.lvdgs_last_error()
+
 
 def test_errors_are_reported_not_thrown():
     from lvdgs import _lib

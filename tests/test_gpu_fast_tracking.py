@@ -262,7 +262,7 @@ def test_a_tracking_iteration_at_kitti_size_matches_the_cpu_chain_end_to_end():
     with torch.no_grad():
         cam.exposure_a.fill_(0.04); cam.exposure_b.fill_(-0.03)
     pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False)
-    s = TrackingSession(cam, model, bench.CONFIG, pipe, torch.zeros(3, device=dev))
+    s = TrackingSession(cam, model, bench.CONFIG, pipe, torch.zeros(3, device=dev), gaussian_gradients=True)
     cpu = lambda t: t.detach().cpu().contiguous().clone()
     view, proj, proj_raw, campos = cpu(s.view), cpu(s.proj), cpu(s.proj_raw), cpu(s.campos)   # the camera the step renders from
     exp_a, exp_b = cpu(cam.exposure_a), cpu(cam.exposure_b)
@@ -446,7 +446,7 @@ def test_tracking_tail_and_fused_loss_backward_equal_the_separate_launches():
     cfg = {k: (dict(v) if isinstance(v, dict) else v) for k, v in bench.CONFIG.items()}
     cfg["Training"]["monocular"] = False   # depth term on: all four partial sums are in play
     pipe = type("P", (), dict(convert_SHs_python=False, compute_cov3D_python=False))()
-    sess = TrackingSession(cam, model, cfg, pipe, torch.zeros(3, device=dev))
+    sess = TrackingSession(cam, model, cfg, pipe, torch.zeros(3, device=dev), gaussian_gradients=True)
     sess.step(); sess.step()   # a state with non-zero Adam moments
     torch.cuda.synchronize()
     L, a, la, pa = sess.L, sess.a, sess.la, sess.pa
