@@ -410,7 +410,8 @@ int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipSt
         if (int e = launch_tile_depth_sort(im, num_tiles, row0 * gx, row1 * gx, g.rec, b.point_list, w.keys, grouped, probe ? probe->longest : -1,
                                            probe ? probe->queued : 0, a->debug, s)) return e;
     }
-    return launch_blend_fwd(*a, g, b, im, s);
+    // (tile lists beyond what one wave sorts on recent frames: the blend kernel built for deep lists)
+    return launch_blend_fwd(*a, g, b, im, probe && probe->longest > 0, s);
 }
 
 int check_render_buffers(const lvdgs_args *a, int64_t cap) {

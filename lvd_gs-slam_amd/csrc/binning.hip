@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(GROUP_THREADS) count_pairs_kernel(int N, int g
         const int i = blockIdx.x * GROUP_CHUNK + k * GROUP_THREADS + (int)threadIdx.x;
         if (i < N) n_touched[i] = 0;
         const uint4 r = i < N ? rect[i] : make_uint4(0u, 0u, 0u, 0u);
-        for_each_pair_of_rect(r, i, gx, [&](int tile, uint32_t) { atomicAdd(&s_tile[tile], 1u); });
+        for_each_pair_of_rect(r, i, gx, 0u, [&](int tile, uint32_t, uint32_t) { atomicAdd(&s_tile[tile], 1u); });
     }
     __syncthreads();
     uint32_t *row = hist + (size_t)blockIdx.x * T;
@@ -329,12 +329,11 @@ __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int
     for (int k = 0; k < PER; k++) {
         const int i = chunk * GROUP_CHUNK + k * GROUP_THREADS + (int)threadIdx.x;
         const uint4 r = my_rect[k];
-        for_each_pair_of_rect(r, i, gx, [&](int tile, uint32_t id) {
+        for_each_pair_of_rect(r, i, gx, my_depth[k], [&](int tile, uint32_t id, uint32_t depth) {
             const uint32_t pos = atomicAdd(&s_tile[tile], 1u);
             // the tile sort's key, so that it need not gather depths; beyond the caller's capacity: dropped (the caller
-            // is told and re-runs).  (id is this thread's own Gaussian, or the one its wave walks together.)
-            const uint32_t d = id == (uint32_t)i ? my_depth[k] : depth_bits[id];
-            if (pos < capacity) keys64[pos] = ((unsigned long long)d << 32) | (unsigned long long)id;
+            // is told and re-runs).  (id, depth: this thread's own Gaussian, or the one its wave walks together.)
+            if (pos < capacity) keys64[pos] = ((unsigned long long)depth << 32) | (unsigned long long)id;
         });
     }
 }

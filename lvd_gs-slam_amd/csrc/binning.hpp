@@ -38,12 +38,14 @@ constexpr int GROUP_MAX_TILES = 16384;  // 64 KiB of LDS counters
 constexpr int GROUP_BIG_RECT = 64;
 static_assert(GROUP_BIG_RECT == RECT_MASK_TILES, "rectangles walked by the whole wave are the ones without a tile mask");
 
-// visit(tile, id) for every listed (Gaussian, tile) pair of the rectangles the wave's lanes hold (r: the lane's rect[],
-// all zero for a lane without a Gaussian).  Must be reached by all lanes of the wave: rectangles of more than 64 tiles
-// (one mask bit per block of tiles, common.hpp: RectBlocks) are walked by the whole wave, so that one screen-filling
-// Gaussian does not serialise thousands of LDS atomics on one lane.
+// visit(tile, id, payload) for every listed (Gaussian, tile) pair of the rectangles the wave's lanes hold (r: the lane's
+// rect[], all zero for a lane without a Gaussian; payload: a word of the lane's Gaussian that travels with its pairs -- the
+// scatter's depth bits).  Must be reached by all lanes of the wave: rectangles of more than 64 tiles (one mask bit per block of
+// tiles, common.hpp: RectBlocks) are walked by the whole wave, so that one screen-filling Gaussian does not serialise thousands
+// of LDS atomics on one lane -- the owner's payload is handed to the 64 lanes with its rectangle (until round 4 the scatter
+// re-read the depth from memory in every one of those rounds: a dependent load per 64 pairs).
 template <typename F>
-__device__ __forceinline__ void for_each_pair_of_rect(const uint4 r, int i, int gx, F visit) {
+__device__ __forceinline__ void for_each_pair_of_rect(const uint4 r, int i, int gx, uint32_t payload, F visit) {
     const int lane = threadIdx.x & 63;
     const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
     const int w = x1 - x0, area = w * (y1 - y0);
@@ -52,19 +54,21 @@ __device__ __forceinline__ void for_each_pair_of_rect(const uint4 r, int i, int 
         uint64_t m = (uint64_t)r.z | ((uint64_t)r.w << 32);
         for (int y = y0; y < y1; y++)
             for (int x = x0; x < x1; x++, m >>= 1)
-                if (m & 1ull) visit(y * gx + x, (uint32_t)i);
+                if (m & 1ull) visit(y * gx + x, (uint32_t)i, payload);
     }
     uint64_t big = __ballot(area > GROUP_BIG_RECT);
     while (big) {
         const int src = __builtin_ctzll(big);
         big &= big - 1;
         const int bx0 = __shfl(x0, src, 64), by0 = __shfl(y0, src, 64), bw = __shfl(w, src, 64), barea = __shfl(area, src, 64);
-        const uint32_t bi = (uint32_t)__shfl(i, src, 64);
+        const uint32_t bi = (uint32_t)__shfl(i, src, 64), bp = (uint32_t)__shfl((int)payload, src, 64);
         const uint64_t bm = (uint64_t)(uint32_t)__shfl((int)r.z, src, 64) | ((uint64_t)(uint32_t)__shfl((int)r.w, src, 64) << 32);
         const RectBlocks g(bw, barea / bw);
+        const float inv_w = __builtin_amdgcn_rcpf((float)bw), inv_gw = __builtin_amdgcn_rcpf((float)g.bw), inv_gh = __builtin_amdgcn_rcpf((float)g.bh);
         for (int t = lane; t < barea; t += 64) {
-            const int tx = t % bw, ty = t / bw;
-            if ((bm >> g.block_of(tx, ty)) & 1ull) visit((by0 + ty) * gx + bx0 + tx, bi);
+            const int ty = div_by(t, bw, inv_w), tx = t - ty * bw;
+            const int block = div_by(ty, g.bh, inv_gh) * 8 + div_by(tx, g.bw, inv_gw);   // = g.block_of(tx, ty)
+            if ((bm >> block) & 1ull) visit((by0 + ty) * gx + bx0 + tx, bi, bp);
         }
     }
 }

@@ -175,7 +175,14 @@ __device__ __forceinline__ int composite_one(const float4 A, const float2 B, con
 #ifndef LVDGS_FWD_BATCH
 #define LVDGS_FWD_BATCH 8
 #endif
-__global__ void __launch_bounds__(256) blend_fwd2_kernel(BlendParams p) {
+#ifndef LVDGS_FWD_QUADRANT_EXIT
+#define LVDGS_FWD_QUADRANT_EXIT 1   // A/B builds: 0 = a finished quadrant walks to the end of the round of 256 staged entries
+#endif
+// DEEP_LISTS: a build for frames whose tile lists run to a thousand entries and more, of which the pixels composite the first
+// tenth (opaque surfaces): a quadrant looks after every batch of eight whether any of its pixels is still open.  Same results;
+// which of the two kernels runs is decided by the previous frame's longest list (a hint, api.hip).
+template <bool DEEP_LISTS>
+__device__ __forceinline__ void blend_fwd2_body(const BlendParams &p) {
     // one shared object, so that the three reads of a survivor share one address register; laid out so that they are
     // a 16-, an 8- and a 16-byte read (4 + 2 + 4 LDS cycles per wave; a 12-byte read alone costs 8)
     __shared__ struct { float4 a[256], b[256], c[256]; float d[256]; } s_recs;
@@ -223,6 +230,10 @@ __global__ void __launch_bounds__(256) blend_fwd2_kernel(BlendParams p) {
         __syncthreads();
         if (__ballot(!done) != 0ull) {
             for (int c0 = 0; c0 < cnt; c0 += 64) {
+                // A quadrant whose 64 pixels are all finished (opaque surfaces: after a tenth of the list) sits the rest of the
+                // round out: no test, no walk.  (Until round 4 it went on testing and walking -- every step with EXEC = 0 -- to
+                // the end of the 256 staged entries.)
+                if (LVDGS_FWD_QUADRANT_EXIT && __ballot(pxe != FAR_AWAY) == 0ull) break;
                 // ---- lane -> Gaussian: which of these 64 can touch this wave's quadrant? ----
                 const int jl = c0 + lane;
                 bool keep = false;
@@ -261,6 +272,8 @@ __global__ void __launch_bounds__(256) blend_fwd2_kernel(BlendParams p) {
                 while (__popcll(live) >= LVDGS_FWD_BATCH) {
 #pragma unroll
                     for (int u = 0; u < LVDGS_FWD_BATCH; u++) one(std::false_type{});
+                    // (at config 3, whose pixels rarely finish, this look was +4 us)
+                    if (DEEP_LISTS && __ballot(pxe != FAR_AWAY) == 0ull) live = 0ull;   // ... nor the rest of this chunk
                 }
                 while (live) one(std::false_type{});
                 if (vcnt) atomicAdd(&s_touch[c0 + lane], vcnt);
@@ -284,6 +297,9 @@ __global__ void __launch_bounds__(256) blend_fwd2_kernel(BlendParams p) {
         p.out_opacity[pix] = 1.f - T;
     }
 }
+
+__global__ void __launch_bounds__(256) blend_fwd2_kernel(BlendParams p) { blend_fwd2_body<false>(p); }
+__global__ void __launch_bounds__(256, 8) blend_fwd2_deep_kernel(BlendParams p) { blend_fwd2_body<true>(p); }
 
 // ------------------------------------------------------------------------------------------
 constexpr int ACC_STRIDE = 10;  // floats per (wave, entry) accumulator slot
@@ -645,11 +661,12 @@ BlendParams make_params(const lvdgs_args &a, const GeomView &g, const BinView &b
 
 }  // namespace
 
-int launch_blend_fwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, hipStream_t s) {
+int launch_blend_fwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, bool deep_lists, hipStream_t s) {
     BlendParams p = make_params(a, g, b, im);
     if (p.num_tiles == 0) return LVDGS_OK;
     ProfScope ps("blend_fwd", s);
-    hipLaunchKernelGGL(blend_fwd2_kernel, dim3(p.num_tiles), dim3(256), 0, s, p);
+    if (deep_lists) hipLaunchKernelGGL(blend_fwd2_deep_kernel, dim3(p.num_tiles), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(blend_fwd2_kernel, dim3(p.num_tiles), dim3(256), 0, s, p);
     LVDGS_LAUNCH_CHECK("blend_fwd", a.debug, s);
     return LVDGS_OK;
 }

@@ -140,6 +140,15 @@ struct TileReach {
 // unchanged.  A Gaussian's pairs are numbered 0 .. tiles_touched - 1 (its gradient slots behind slot_base[i]): row-major
 // over the kept tiles, resp. kept blocks in bit order and row-major inside a block (rect_rank).
 constexpr int RECT_MASK_TILES = 64;
+// n / d for 0 <= n < 2^23, 0 < d, with inv_d = 1 / (float)d to an ulp: the float quotient is off by at most one, one
+// correction step makes it exact.  (The compiler's unsigned division is some 25 instructions; the walks over large
+// rectangles divide three times per pair.)
+__device__ __forceinline__ int div_by(int n, int d, float inv_d) {
+    int q = (int)((float)n * inv_d);
+    const int r = n - q * d;
+    q += (r >= d) - (r < 0);
+    return q;
+}
 struct RectBlocks {   // the block grid of a rectangle of more than RECT_MASK_TILES tiles
     int w, h, bw, bh;
     __device__ __forceinline__ RectBlocks(int w_, int h_) : w(w_), h(h_), bw((w_ + 7) >> 3), bh((h_ + 7) >> 3) {}
@@ -284,7 +293,7 @@ int launch_tile_depth_sort(const ImageView &im, int num_tiles, int t_lo, int t_h
 int launch_tile_ranges(const uint32_t *tile_keys, int64_t D, const uint32_t *D_dev, const ImageView &im, int num_tiles, int dbg,
                        hipStream_t s);
 
-int launch_blend_fwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, hipStream_t s);
+int launch_blend_fwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, bool deep_lists, hipStream_t s);   // deep_lists: a hint (which build of the kernel), never a result
 int launch_blend_bwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, const BwdScratch &w,
                      hipStream_t s);
 

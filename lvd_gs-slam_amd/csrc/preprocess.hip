@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(GROUP_THREADS, 8) preprocess_count_kernel(FwdP
             n_touched[i] = 0;
         }
         mine += tiles;
-        for_each_pair_of_rect(rect, i, p.cam.gx, [&](int tile, uint32_t) { atomicAdd(&s_tile[tile], 1u); });
+        for_each_pair_of_rect(rect, i, p.cam.gx, 0u, [&](int tile, uint32_t, uint32_t) { atomicAdd(&s_tile[tile], 1u); });
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mine += (uint32_t)__shfl_xor((int)mine, off, 64);
@@ -409,6 +409,10 @@ struct BwdParams {
 #endif
 constexpr int WAVE_CHUNK = LVDGS_WAVE_CHUNK;  // pair records a wave stages per round (a multiple of 4): 7.5 KB of LDS per wave at 192, five workgroups per CU
 constexpr int BIG_RUN = 64;      // a Gaussian with more pairs than this is summed by its whole wave
+#ifndef LVDGS_PBWD_BIG_UNROLL
+#define LVDGS_PBWD_BIG_UNROLL 2
+#endif
+constexpr int BIG_UNROLL = LVDGS_PBWD_BIG_UNROLL;   // ... LVDGS_PBWD_BIG_UNROLL records per lane and trip
 
 #ifndef LVDGS_PBWD_WGS
 #define LVDGS_PBWD_WGS 5
@@ -423,6 +427,165 @@ __device__ __forceinline__ void loads_complete_here(int32_t &radius, uint32_t &s
     asm volatile("" : "+v"(radius), "+v"(slot), "+v"(tiles), "+v"(pos[0]), "+v"(pos[1]), "+v"(pos[2]), "+v"(opac));
     asm volatile("" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
     asm volatile("" : "+v"(c6[0]), "+v"(c6[1]), "+v"(c6[2]), "+v"(c6[3]), "+v"(c6[4]), "+v"(c6[5]));
+}
+
+// The pair sums of a wave that holds large-footprint Gaussians (a function of its own so that it can be built as a call,
+// LVDGS_PBWD_INLINE_BIG = 0: measured, slower).
+// s_mem: the wave's LDS staging area.
+struct PairSums { float A[10]; };
+#ifndef LVDGS_PBWD_INLINE_BIG
+#define LVDGS_PBWD_INLINE_BIG 1   // A/B builds: 0 = a function call (same box, config 3 / opaque surfaces: 50.5 / 96 us against 44.5 / 74.3 inlined: the spills around the call cost more than the separate register allocation returns)
+#endif
+#if LVDGS_PBWD_INLINE_BIG
+#define LVDGS_BIG_PATH_ATTR __forceinline__
+#else
+#define LVDGS_BIG_PATH_ATTR __attribute__((noinline))
+#endif
+template <bool POSE_ONLY>
+__device__ LVDGS_BIG_PATH_ATTR PairSums sum_region_compacted(const float *__restrict__ pair_grads, const uint8_t *__restrict__ pair_valid, char *s_mem,
+                                                                   uint32_t first, uint32_t last, uint32_t w_first, uint32_t w_hi) {
+    constexpr int PF = POSE_ONLY ? PAIR_FLOATS_POSE : PAIR_FLOATS;
+    const int lane = threadIdx.x & 63;
+    float A[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) A[k] = 0.f;
+    {
+        // A wave that holds large-footprint Gaussians (hundreds of pairs each: the stuff opaque surfaces are made of).  Of their
+        // records only those in front of their tiles' last contributors exist -- a tenth on opaque surfaces -- and a lane that
+        // walks its own run (flag, record, flag, record ...: two dependent round trips per slot) while 63 wait was 1.5 ms of this
+        // kernel at 100 k such Gaussians; round 3's "the whole wave sums one large Gaussian after the other" still was a chain of
+        // two round trips per Gaussian and 64 slots (76 us of 88 on that workload).  Now the wave sweeps its whole region -- the
+        // runs of its 64 Gaussians follow each other in memory -- 512 slots at a time:
+        //   1. the segment's FLAGS, eight per lane in one load (the next segment's are requested before this one is worked on),
+        //      compacted into a list of the slots that hold a record (wave scan of the per-lane counts);
+        //   2. just those records, gathered densely into the wave's LDS, BIG_UNROLL per lane in flight;
+        //   3. every lane adds up ITS Gaussian's records of the pass from LDS, in slot order (the order of the streaming path);
+        //      a Gaussian with more than 64 records in the pass is summed by the whole wave (lane l: records l, l + 64, ...) and
+        //      folded in a fixed order.
+        constexpr uint32_t SEG = 512u;
+        constexpr int AUX_BYTES = (int)SEG * 2 + 64 * 2 + 64;                                   // list, per-lane prefix, per-lane flag bits
+        constexpr uint32_t CAP = 128u;   // records per pass: the same number in both forms of the kernel, so that both add in the same order
+        static_assert(CAP * PF * 4 + AUX_BYTES <= WAVE_CHUNK * PF * 4, "fits the wave's staging area");
+        float2 *const s_rec = reinterpret_cast<float2 *>(s_mem);
+        uint16_t *const s_list = reinterpret_cast<uint16_t *>(s_mem + CAP * PF * 4);   // offsets (in the segment) of the slots with a record
+        uint16_t *const s_before = s_list + SEG;                                                  // records of the segment in front of lane l's eight slots
+        uint8_t *const s_bits = reinterpret_cast<uint8_t *>(s_before + 64);                       // lane l's eight flags
+        const float2 *pg = reinterpret_cast<const float2 *>(pair_grads);
+        const uint32_t w_lo = w_first & ~7u;   // w_first rounded down to the flags' 8-byte loads
+        auto flags_of = [&](uint32_t seg) {   // (pair_valid is padded by 16 bytes)
+            const uint32_t s0 = seg + 8u * (uint32_t)lane;
+            return s0 < w_hi ? *reinterpret_cast<const uint2 *>(pair_valid + s0) : make_uint2(0u, 0u);
+        };
+        uint2 fl_next = w_lo < w_hi ? flags_of(w_lo) : make_uint2(0u, 0u);
+        for (uint32_t seg = w_lo; seg < w_hi; seg += SEG) {
+            const uint2 fl = fl_next;
+            if (seg + SEG < w_hi) fl_next = flags_of(seg + SEG);
+            // ---- 1. which of the segment's slots hold a record ----
+            uint32_t mine = 0;   // bit b: slot seg + 8 lane + b
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                if ((fl.x >> (8 * b)) & 0xffu) mine |= 1u << b;
+                if ((fl.y >> (8 * b)) & 0xffu) mine |= 16u << b;
+            }
+            {   // slots outside the wave's region are other waves' (or, behind the frame's last pair, nobody's: their flags are stale)
+                const uint32_t s0 = seg + 8u * (uint32_t)lane;
+                const uint32_t keep_hi = s0 >= w_hi ? 0u : (w_hi - s0 >= 8u ? 0xffu : (1u << (w_hi - s0)) - 1u);
+                const uint32_t keep_lo = s0 >= w_first ? 0xffu : (w_first - s0 >= 8u ? 0u : (0xffu << (w_first - s0)) & 0xffu);
+                mine &= keep_hi & keep_lo;
+            }
+            const uint32_t cnt = (uint32_t)__popc(mine);
+            uint32_t inc = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t x = (uint32_t)__shfl_up((int)inc, off, 64);
+                if (lane >= off) inc += x;
+            }
+            const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
+            {
+                uint32_t at = inc - cnt;
+                s_before[lane] = (uint16_t)at;
+                s_bits[lane] = (uint8_t)mine;
+                for (uint32_t m = mine; m; m &= m - 1u) s_list[at++] = (uint16_t)(8u * (uint32_t)lane + (uint32_t)__builtin_ctz(m));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // this lane's Gaussian: its records are entries [lo, hi) of the segment's list
+            auto records_before = [&](uint32_t slot) {   // slot in [seg, seg + SEG]
+                const uint32_t o = slot - seg;
+                if (o >= SEG) return total;
+                return (uint32_t)s_before[o >> 3] + (uint32_t)__popc((uint32_t)s_bits[o >> 3] & ((1u << (o & 7u)) - 1u));
+            };
+            uint32_t lo = 0u, hi = 0u;
+            if (first < last && first < seg + SEG && last > seg) { lo = records_before(max(first, seg)); hi = records_before(min(last, seg + SEG)); }
+            for (uint32_t p0 = 0; p0 < total; p0 += CAP) {
+                const uint32_t n = min(CAP, total - p0);
+                // ---- 2. the pass's records, densely into LDS ----
+                for (uint32_t j0 = (uint32_t)lane; j0 < n; j0 += 64u * BIG_UNROLL) {
+                    float2 v[BIG_UNROLL][PF / 2];
+#pragma unroll
+                    for (int u = 0; u < BIG_UNROLL; u++) {
+                        const uint32_t j = j0 + 64u * (uint32_t)u;
+                        const float2 *r = pg + (size_t)(PF / 2) * (seg + (uint32_t)s_list[p0 + min(j, n - 1u)]);
+#pragma unroll
+                        for (int k = 0; k < PF / 2; k++) v[u][k] = r[k];
+                    }
+#pragma unroll
+                    for (int u = 0; u < BIG_UNROLL; u++) {
+                        const uint32_t j = j0 + 64u * (uint32_t)u;
+                        if (j < n) {
+#pragma unroll
+                            for (int k = 0; k < PF / 2; k++) s_rec[(PF / 2) * j + k] = v[u][k];
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // ---- 3. every Gaussian's share of the pass ----
+                const uint32_t a = max(lo, p0), b = min(hi, p0 + n);   // (empty when a >= b)
+                const bool wide = b > a && b - a > 64u;
+                auto take = [&](float (&S)[10], uint32_t t) {
+                    const float2 *r = s_rec + (PF / 2) * (t - p0);
+                    const float2 a0 = r[0], a1 = r[1], a2 = r[2];
+                    S[0] += a0.x; S[1] += a0.y; S[2] += a1.x; S[3] += a1.y; S[4] += a2.x;
+                    if constexpr (POSE_ONLY) S[9] += a2.y;
+                    else {
+                        const float2 a3 = r[3], a4 = r[4];
+                        S[5] += a2.y; S[6] += a3.x; S[7] += a3.y; S[8] += a4.x; S[9] += a4.y;
+                    }
+                };
+                if (!wide)
+                    for (uint32_t t = a; t < b; t++) take(A, t);
+                for (uint64_t todo = __ballot(wide); todo; todo &= todo - 1) {
+                    const int src = __builtin_ctzll(todo);
+                    const uint32_t wa = (uint32_t)__shfl((int)a, src, 64), wb = (uint32_t)__shfl((int)b, src, 64);
+                    float S[10];
+#pragma unroll
+                    for (int k = 0; k < 10; k++) S[k] = 0.f;
+                    for (uint32_t t = wa + (uint32_t)lane; t < wb; t += 64u) take(S, t);
+                    // the 64 partial sums of every value, folded in a fixed order: halves of the wave, pairs of rows, then inside the rows
+                    float b0 = fold16(fold32(S[0], S[1]), fold32(S[2], S[3]));   // rows: S0 S2 S1 S3
+                    float b1 = fold16(fold32(S[4], S[5]), fold32(S[6], S[7]));   // rows: S4 S6 S5 S7
+                    const float e89 = fold32(S[8], S[9]);
+                    float b2 = fold16(e89, e89);                                 // rows: S8 S8 S9 S9
+                    row_sums3(b0, b1, b2);                                       // lane 15 of a row: the row's total
+                    auto at_lane = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+                    const float tot[10] = {at_lane(b0, 15), at_lane(b0, 47), at_lane(b0, 31), at_lane(b0, 63), at_lane(b1, 15), at_lane(b1, 47),
+                                           at_lane(b1, 31), at_lane(b1, 63), at_lane(b2, 15), at_lane(b2, 47)};
+#pragma unroll
+                    for (int k = 0; k < 10; k++)
+                        if (lane == src) A[k] += tot[k];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    PairSums out;
+#pragma unroll
+    for (int k = 0; k < 10; k++) out.A[k] = A[k];
+    return out;
 }
 
 // POSE_ONLY (LVDGS_FLAG_POSE_ONLY): the pose gradient alone -- six-float pair records (d/d 2-D mean, conic, view depth), no
@@ -583,39 +746,16 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p) {
             consume(c0);
         }
     } else {
-        // A wave that holds large-footprint Gaussians (hundreds of pairs each: the stuff opaque surfaces are made of):
-        // one lane summing 800 records while 63 wait was 1.5 ms of this kernel at 100 k such Gaussians.  The small ones
-        // walk their own few records straight from memory; every large one is summed by its whole wave -- lane l takes
-        // records l, l + 64, ... -- and the 64 partial sums are folded in a fixed order.
-        const float2 *pg = reinterpret_cast<const float2 *>(p.pair_grads);
-        auto add = [&](float (&S)[10], uint32_t t) {
-            const float2 *r = pg + (size_t)(PF / 2) * t;
-            const float2 a0 = r[0], a1 = r[1], a2 = r[2];
-            S[0] += a0.x; S[1] += a0.y; S[2] += a1.x; S[3] += a1.y; S[4] += a2.x;
-            if constexpr (POSE_ONLY) S[9] += a2.y;
-            else {
-                const float2 a3 = r[3], a4 = r[4];
-                S[5] += a2.y; S[6] += a3.x; S[7] += a3.y; S[8] += a4.x; S[9] += a4.y;
-            }
-        };
-        if (!big)
-            for (uint32_t t = first; t < last; t++)
-                if (p.pair_valid[t]) add(A, t);
-        for (uint64_t todo = __ballot(big); todo; todo &= todo - 1) {
-            const int src = __builtin_ctzll(todo);
-            const uint32_t f = (uint32_t)__shfl((int)first, src, 64), l = (uint32_t)__shfl((int)last, src, 64);
-            float S[10];
-#pragma unroll
-            for (int k = 0; k < 10; k++) S[k] = 0.f;
-            for (uint32_t t = f + (uint32_t)lane; t < l; t += 64)
-                if (p.pair_valid[t]) add(S, t);
-#pragma unroll
-            for (int k = 0; k < 10; k++) {
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) S[k] += __shfl_xor(S[k], off, 64);
-                if (lane == src) A[k] = S[k];
-            }
+        // A wave that holds large-footprint Gaussians: sum_region_compacted (above)
+        uint32_t w_first = 0u, w_hi = 0u;   // the wave's region
+        if (i - lane < p.N) {
+            const int last_lane = min(63, p.N - 1 - (i - lane));
+            w_first = (uint32_t)__shfl((int)slot_i, 0, 64);
+            w_hi = (uint32_t)__shfl((int)(slot_i + tiles_i), last_lane, 64);
         }
+        const PairSums sums = sum_region_compacted<POSE_ONLY>(p.pair_grads, p.pair_valid, reinterpret_cast<char *>(s_pg4[wave]), first, last, w_first, w_hi);
+#pragma unroll
+        for (int k = 0; k < 10; k++) A[k] = sums.A[k];
     }
 #endif
 #if LVDGS_PBWD_ABLATE == 2
