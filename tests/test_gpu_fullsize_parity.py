@@ -48,7 +48,8 @@ def test_full_size_forward_and_backward_match_oracle(name, pose_seed):
     f_ora, b_ora = hr.run_oracle(orc, g, cam, W, H, bg, grads=grads)
     assert f_ora["num_rendered"] > 2 * N
     tp._check_forward(f_hip, f_ora, W, H)
-    tp._check_backward(b_hip, b_ora, GRADS, f_ora, W, H)
+    # every gradient of EVERY Gaussian and the pose to the strict tolerances, on the problem without the fragile pixels
+    tp._check_backward(b_hip, b_ora, GRADS, f_ora, W, H, rerun=tp.masked_rerun(hr, orc, g, cam, W, H, bg, grads))
     if name == "cfg5_2m_1920x1280":
         return
     # The index state at BASELINE's sizes, bit for bit: with LVDGS_FLAG_LIST_ALL_TILES (every tile of the 3-sigma rectangle
@@ -85,19 +86,11 @@ def test_opaque_surfaces_of_large_gaussians_match_oracle(name):
     assert f_ora["n_contrib"].mean() < 0.25 * lists.mean()          # pixels saturate early
     assert f_hip["num_rendered"] < 0.9 * f_ora["num_rendered"]      # block + tile culling together (opaque blobs reach most of their square)
     tp._check_forward(f_hip, f_ora, W, H)
-    tp._check_backward(b_hip, b_ora, [n for n in GRADS if n != "tau"], f_ora, W, H)
-    # The pose gradient is six sums over every Gaussian of terms that are large here (opaque, large footprints) and cancel:
-    # float32 itself cannot hold them to 1e-5 of the largest component in whatever order they are added.  What float32 can
-    # deliver is what the float32 oracle delivers against the float64 one; the kernels must be no farther from the float64
-    # result than that (x 1.5, plus the strict tolerance) -- the rule of tests/test_gpu_fuzz.py.
-    try:
-        tp._close(b_hip["tau"], b_ora["tau"], what="grad tau", rel_l2=1e-4)
-    except AssertionError:
-        _, b_64 = hr.run_oracle(orc, g, cam, W, H, bg, grads=grads, prec="f64")
-        t64 = np.asarray(b_64["tau"], np.float64)
-        strict = 1e-4 * np.abs(t64) + 1e-5 * np.abs(t64).max()
-        err_hip, err_f32 = np.abs(b_hip["tau"] - t64), np.abs(np.asarray(b_ora["tau"], np.float64) - t64)
-        assert (err_hip <= 1.5 * err_f32 + strict).all(), (err_hip, err_f32, strict)
+    # Every gradient of every Gaussian, and the pose gradient -- here six sums over every Gaussian of terms that are large
+    # (opaque, large footprints) and cancel: float32 itself cannot hold them to 1e-5 of the largest component in whatever
+    # order they are added, and such a tensor must be no farther from the FLOAT64 oracle than the float32 oracle is (x 1.5, plus
+    # the strict tolerance): tp._check_backward with the fragile pixels' image gradients zeroed on both sides.
+    tp._check_backward(b_hip, b_ora, GRADS, f_ora, W, H, rerun=tp.masked_rerun(hr, orc, g, cam, W, H, bg, grads))
     f_all, _ = hr.run_hip(g, cam, W, H, bg, tile_cull=False)
     assert f_all["num_rendered"] == f_ora["num_rendered"]
     np.testing.assert_array_equal(f_all["point_list"], f_ora["ids_sorted"])

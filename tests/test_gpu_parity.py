@@ -111,25 +111,76 @@ def gaussians_away_from_fragile_pixels(f_ora, W, H):
     return (n == 0) | (f_ora["radii"] <= 0)
 
 
-def _check_backward(b_hip, b_ora, names, f_ora=None, W=None, H=None):
-    """Every gradient within the tolerances of _close.  With the oracle's forward results given, per-Gaussian gradients
-    are held to them on the Gaussians no fragile pixel can reach; on the others (and on the pose gradient, a sum over
-    all of them) the perturbation of a fragile pixel -- alpha ~ 4e-3 of one pixel's contribution -- is allowed for."""
+def masked_rerun(hr, orc, g, cam, W, H, bg, grads, **run_kw):
+    """For _check_backward(rerun=...): both sides again with the image gradients of the given pixels zeroed -- returns
+    (HIP backward, float32-oracle backward, a function that runs the float64 oracle on the same problem when asked)."""
+    def rerun(solid):
+        keep = torch.from_numpy(np.ascontiguousarray(solid.reshape(H, W)))[None]
+        masked = tuple(None if t is None else torch.where(keep, t, torch.zeros_like(t)) for t in grads)
+        _, bh = hr.run_hip(g, cam, W, H, bg, grads=masked, **run_kw)
+        _, bo = hr.run_oracle(orc, g, cam, W, H, bg, grads=masked, **{k: v for k, v in run_kw.items() if k in ("use_sh", "sh_degree", "cov_precomp")})
+        ora_kw = {k: v for k, v in run_kw.items() if k in ("use_sh", "sh_degree", "cov_precomp")}
+        return bh, bo, lambda: hr.run_oracle(orc, g, cam, W, H, bg, grads=masked, prec="f64", **ora_kw)[1]
+    return rerun
+
+
+def _no_farther_from_float64_than_the_float32_oracle(n, hip, ref32, ref64, why):
+    """The rule of tests/test_gpu_fuzz.py for sums float32 cannot hold to the strict bounds (large cancelling terms): the
+    kernels are no farther from the float64 result than the float32 restatement is (x 1.5), plus the strict tolerance."""
+    import parity_stats
+    hip, ref32, ref64 = (np.asarray(x, np.float64).reshape(np.shape(hip)) for x in (hip, ref32, ref64))
+    norm = max(np.linalg.norm(ref64), 1e-300)
+    scale = max(np.abs(ref64).max(), 1e-300)
+    e_hip, e_ora = np.linalg.norm(hip - ref64) / norm, np.linalg.norm(ref32 - ref64) / norm
+    m_hip, m_ora = np.abs(hip - ref64).max(), np.abs(ref32 - ref64).max()
+    parity_stats.record(f"grad {n} vs the FLOAT64 oracle (float32 oracle: rel_l2 {e_ora:.2e}, max {m_ora / scale:.2e} of scale)", hip, ref64)
+    assert e_hip <= 2e-5 + 1.5 * e_ora, f"{n}: kernels {e_hip:.3e} from float64, float32 oracle {e_ora:.3e} | strict check said: {why}"
+    strict = 1e-4 * np.abs(ref64) + 1e-5 * scale
+    assert (np.abs(hip - ref64) <= 1.5 * m_ora + strict).all(), f"{n}: max error {m_hip:.3e} vs the float32 oracle's {m_ora:.3e} (scale {scale:.3e}) | {why}"
+
+
+def _check_backward(b_hip, b_ora, names, f_ora=None, W=None, H=None, rerun=None):
+    """Every gradient within the tolerances of _close.
+
+    Fragile pixels (the oracle saw a threshold comparison within 1e-5 relative: exp() rounding may composite one faint
+    Gaussian on one side and not on the other) perturb the contribution of THEIR pixel to every Gaussian composited there by
+    alpha ~ 4e-3 of it.  With `rerun` (masked_rerun: the full-size cases) the statement that holds for EVERY Gaussian and the
+    pose is made on the problem without them: the image gradients of the fragile pixels are zeroed, both sides run again,
+    and every tensor must agree to the strict tolerances (1e-4 elementwise + 1e-5 of scale, 2e-5 relative L2; a tensor float32
+    cannot hold to them -- the pose gradient of an opaque-surface scene, six sums of large cancelling terms -- must be no farther
+    from the FLOAT64 oracle than the float32 oracle is, x 1.5).  On the problem as given: strict on the Gaussians no fragile
+    pixel can reach, the perturbation's size on the others."""
     clean = None if f_ora is None else gaussians_away_from_fragile_pixels(f_ora, W, H)
+    if rerun is not None and clean is not None and not clean.all():
+        bh, bo, float64 = rerun(f_ora["fragile"] == 0)
+        b64 = None
+        for n in names:
+            ref = bo[n].reshape(bh[n].shape)
+            try:
+                # (relative L2 asserted at five times what the full-size cases achieve, profiles/r04_parity_report.txt:
+                # <= 1e-6 per-Gaussian tensors, <= 2.8e-6 the pose gradient)
+                _close(bh[n], ref, what="grad " + n + " (image gradients of the fragile pixels zeroed: EVERY Gaussian)", rel_l2=1.5e-5 if n == "tau" else 5e-6)
+            except AssertionError as why:
+                b64 = float64() if b64 is None else b64
+                _no_farther_from_float64_than_the_float32_oracle(n, bh[n], ref, b64[n], why)
     for n in names:
         ref = b_ora[n].reshape(b_hip[n].shape)
         if clean is None or clean.all():
             _close(b_hip[n], ref, what="grad " + n)
             continue
         if n == "tau":  # six sums over every Gaussian, the ones fragile pixels reach included
-            _close(b_hip[n], ref, what="grad tau", rel_l2=1e-4)
+            if rerun is None:
+                _close(b_hip[n], ref, what="grad tau", rel_l2=1e-4)
+            else:   # (held strictly on the masked problem above; here to the size of the fragile pixels' perturbation)
+                st = parity_stats_record("grad tau (fragile pixels included)", b_hip[n], ref)
+                assert st["rel_l2"] <= 1e-3, st
             continue
         if clean.any():
             # (the other Gaussians take the reference's values, so the error of the clean ones is measured against the
             # norm and scale of the whole gradient, whatever the subset happens to contain)
             sel = clean.reshape((-1,) + (1,) * (ref.ndim - 1))
             _close(np.where(sel, b_hip[n], ref), ref, what="grad " + n + " (away from fragile pixels)")
-        st = parity_stats_record("grad " + n + " (all Gaussians)", b_hip[n], ref)
+        st = parity_stats_record("grad " + n + " (all Gaussians, fragile pixels included)", b_hip[n], ref)
         scale = max(np.abs(ref).max(), 1e-30)
         assert st["rel_l2"] <= 2e-4, (n, st)
         assert np.abs(b_hip[n] - ref).max() <= 2e-2 * scale, (n, st)

@@ -38,6 +38,13 @@ def _backend(workload, n_keyframes, window, masks=False):
     return be, N
 
 
+# bounds of the end-to-end comparison below: relative L2 error and largest element error (of the tensor's scale) per gradient
+# (five times what the run achieves -- 9.2e-7 / 9.9e-7 at worst, the quaternion gradient; round 3, with the L1 loss's coin tosses
+# in: 2e-4 and 1e-2)
+MAPPING_VIEW_REL_L2 = {n: 5e-6 for n in ("means3D", "opacities", "scales", "rotations", "shs", "tau")}
+MAPPING_VIEW_MAX = {n: 5e-6 for n in ("means3D", "opacities", "scales", "rotations", "shs", "tau")}
+
+
 def test_a_mapping_view_at_kitti_size_matches_the_cpu_chain_end_to_end():
     """One view of the KITTI-sized window through MapViewPass (lvdgs_forward -> lvdgs_backward_fused_loss -> the view's tail)
     against the chain it stands for, on the CPU: the C oracle's forward -> get_loss_mapping as PyTorch statements ->
@@ -57,6 +64,21 @@ def test_a_mapping_view_at_kitti_size_matches_the_cpu_chain_end_to_end():
     G, view = be.gaussians, be.viewpoints[window[0]]
     with torch.no_grad():   # a view with exposure parameters that matter
         view.exposure_a.fill_(0.03); view.exposure_b.fill_(-0.02)
+    # The loss is an L1: where a rendered value sits within rounding of its target, two pipelines that agree to 1e-5 can still take
+    # different signs, and that pixel's whole contribution flips.  The targets are moved off such pixels (by 1e-3 where a
+    # residual is below 2e-4, a few dozen values per frame), so that what is compared is the arithmetic, not a coin toss.
+    from lvdgs.gaussian_renderer import render
+    with torch.no_grad():
+        pre = render(view, G, be.pipeline_params, be.background)
+        shown = torch.exp(view.exposure_a) * pre["render"] + view.exposure_b
+        r = shown - view.original_image
+        near = r.abs() < 2e-4
+        view.original_image = torch.where(near, shown - 1e-3 * torch.where(r >= 0, 1.0, -1.0), view.original_image).contiguous()
+        md = torch.from_numpy(view.mono_depth).to(dev)
+        rd = pre["depth"][0] - md
+        neard = rd.abs() < 2e-4 * md.clamp_min(1.0)
+        view.mono_depth = torch.where(neard, pre["depth"][0] - 1e-3 * md.clamp_min(1.0) * torch.where(rd >= 0, 1.0, -1.0), md).cpu().numpy()
+        moved = int(near.sum()) + int(neard.sum())
     for p in G.parameters():
         p.grad = None
     assert MapViewPass.usable(be, view)
@@ -93,14 +115,15 @@ def test_a_mapping_view_at_kitti_size_matches_the_cpu_chain_end_to_end():
            "rotations": cpu(G._rotation.grad).numpy(), "shs": cpu(G._features_dc.grad).numpy(),
            "tau": np.concatenate([cpu(view.cam_trans_delta.grad).numpy().reshape(-1), cpu(view.cam_rot_delta.grad).numpy().reshape(-1)])}
     ref = {k: np.asarray(v, np.float32) for k, v in ref.items()}
-    # The loss is an L1: where a rendered value sits within rounding of its target the two pipelines can take different signs,
-    # and that pixel's whole contribution (1 / (3 H W) of the loss's weight) flips -- a handful of pixels per frame.  So: the
-    # tensors as wholes to 2e-4, every element to 1 % of the tensor's scale (the fixed-gradient parity cases are the strict ones).
+    # (no residual of the loss sits within rounding of zero -- see above -- so what is left between the two chains is the rasterizer's
+    # own float32 latitude: the fragile pixels of tests/test_gpu_parity.py.  Asserted at five times what the run achieves,
+    # profiles/r04_parity_report.txt.)
+    assert moved < 20000, moved   # (of 1.8 M residuals)
     for n in ("means3D", "opacities", "scales", "rotations", "shs", "tau"):
         st = tp.parity_stats_record("mapping view, grad " + n, got[n].reshape(ref[n].shape), ref[n])
         scale = max(float(np.abs(ref[n]).max()), 1e-30)
-        assert st["rel_l2"] <= 2e-4, (n, st)
-        assert float(np.abs(got[n].reshape(ref[n].shape) - ref[n]).max()) <= 1e-2 * scale, (n, st)
+        assert st["rel_l2"] <= MAPPING_VIEW_REL_L2[n], (n, st)
+        assert float(np.abs(got[n].reshape(ref[n].shape) - ref[n]).max()) <= MAPPING_VIEW_MAX[n] * scale, (n, st)
     for n in ("exposure_a", "exposure_b"):
         a, b = float(getattr(view, n).grad), float(getattr(cpu_view, n).grad)
         assert abs(a - b) <= 2e-4 * max(abs(b), 1e-6), (n, a, b)
