@@ -199,6 +199,8 @@ def main():
     make_window = (lambda m: build_window(args.workload, 12, dev, m, n_window=8)) if real_window else (lambda m: build_window(args.workload, world, dev, m))
     if not tracking:
         backend, window = make_window(model)
+        if world > 1:   # the two small MAX collectives on a communicator of their own: in flight under the gradient all-reduce
+            backend.shard_aux_group = dist.new_group(backend=backend_name if backend_name != "nccl" else None)
     elif use_session:
         from lvdgs.fast_tracking import TrackingSession
         # BASELINE configs[2] names the full pose + map backward: the headline computes every Gaussian gradient.  (The product's

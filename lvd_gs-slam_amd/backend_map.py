@@ -235,8 +235,9 @@ class FlatReducer:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         return list(flat.split(list(sizes)))
 
-    def max_ints(self, tensors: Sequence[torch.Tensor], device, group=None):
-        """int32 tensors, all-reduce MAX, views of the reduced pieces."""
+    def max_ints(self, tensors: Sequence[torch.Tensor], device, group=None, async_op=False):
+        """int32 tensors, all-reduce MAX, views of the reduced pieces (``async_op``: and the collective's work handle, to be
+        waited for before the views are read -- None on one rank)."""
         sizes = [int(t.numel()) for t in tensors]
         total = int(sum(sizes))
         self.ibuf = self._fit(self.ibuf, total, torch.int32, device)
@@ -246,18 +247,21 @@ class FlatReducer:
         if tensors and not in_place:   # (pieces a producer laid out with plan_ints are where they belong already)
             torch.cat([t.reshape(-1) for t in tensors], out=flat)
         _, world = _world(group)
+        work = None
         if world > 1:
-            dist.all_reduce(flat, op=dist.ReduceOp.MAX, group=group)
-        return list(flat.split(sizes))
+            work = dist.all_reduce(flat, op=dist.ReduceOp.MAX, group=group, async_op=async_op)
+        return (list(flat.split(sizes)), work) if async_op else list(flat.split(sizes))
 
 
-def _max_bytes(flags: torch.Tensor, group=None):
+def _max_bytes(flags: torch.Tensor, group=None, async_op=False):
     """uint8 all-reduce MAX in place: the byte-wise OR of 0 / 1 flags.  (Packed into int32 words and reduced with MAX --
-    round 2 -- a word's high byte decided for all four: flags of other ranks were dropped.)"""
+    round 2 -- a word's high byte decided for all four: flags of other ranks were dropped.)  ``async_op``: returns the
+    collective's work handle (None when there is nothing to reduce) instead of the flags."""
     _, world = _world(group)
+    work = None
     if world > 1 and flags.numel():
-        dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group)
-    return flags
+        work = dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group, async_op=async_op)
+    return work if async_op else flags
 
 
 _P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
@@ -499,16 +503,28 @@ def view_loss(backend, viewpoint, pkg):
 
 
 def map_window(backend, current_window, prune=False, iters=1, up_pose=True, group=None, reducer: Optional[FlatReducer] = None,
-               render_fn=render, view_loss_fn=None, stats: Optional[Dict] = None, fused=True):
+               render_fn=render, view_loss_fn=None, stats: Optional[Dict] = None, fused=True, aux_group=None, bands_ok: Optional[bool] = None):
     """``BackEnd.map(current_window, prune, iters, up_pose)`` (reference utils/slam_backend.py:153-390) with the
     iteration's views sharded over ``group``.  Returns ``gaussian_split`` of the last iteration like the reference.
     ``stats`` (optional dict) receives per-iteration records: loss, views of this rank, collective time.
     ``render_fn`` / ``view_loss_fn`` default to the HIP renderer and the fused losses; the CPU tests of the loop logic
     pass the dense renderer and the float64 loss statements instead.  ``fused`` (GPU only): the isotropic regulariser,
     the per-view statistics and the keyframes' Adam + ``update_pose`` run as single launches (``lvdgs_isotropic_reg``,
-    ``lvdgs_view_stats``, ``lvdgs_pose_step``) instead of PyTorch statements; ``fused=False`` keeps the statements."""
+    ``lvdgs_view_stats``, ``lvdgs_pose_step``) instead of PyTorch statements; ``fused=False`` keeps the statements.
+    ``aux_group``: a second process group over the same ranks (``dist.new_group()``, made once by the caller -- creating a
+    group is itself a collective of the whole job): the two small MAX collectives (radii, visibility flags) are started on it
+    BEFORE the float SUM is issued on ``group`` and waited for after it -- with RCCL a communicator and stream of their own, so
+    that their latency (two dependent ~30 us collectives at eight ranks) lies under the gradient all-reduce instead of behind
+    it.  Without it they are started on ``group`` itself (same results, no overlap).  ``backend.shard_aux_group`` is read when
+    the argument is None.
+    ``bands_ok``: may window views be cut into bands of tile rows (several ranks)?  Only a loss that is a sum over pixels gated
+    by the target's own validity masks survives that (``_BandView``): ``get_loss_mapping`` is one, so the default is True for the
+    default ``view_loss_fn`` -- keyframes with a static mask excepted, as always -- and False for a caller's own, which then
+    says so itself (the CPU tests' float64 statement of the same loss does)."""
     if len(current_window) == 0:
         return
+    if bands_ok is None:
+        bands_ok = view_loss_fn is None or view_loss_fn is view_loss
     view_loss_fn = view_loss if view_loss_fn is None else view_loss_fn
     rank, world = _world(group)
     reducer = reducer if reducer is not None else getattr(backend, "_lvdgs_reducer", None) or FlatReducer()
@@ -540,7 +556,8 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
         vpass = _view_pass(backend) if (fused and render_fn is render and view_loss_fn is view_loss) else None
         # a view renders in bands when its loss is a sum over pixels: get_loss_mapping, i.e. no static mask (L1 + SSIM and a
         # count-normalised depth term are not); window views without MapViewPass take the _BandView route through autograd
-        splittable = [getattr(v, "static_mask", None) is None or i >= n_window for i, v in enumerate(views)]
+        # (the random views always score with get_loss_mapping; a caller's own window loss splits only if the caller says so)
+        splittable = [(bands_ok and getattr(v, "static_mask", None) is None) or i >= n_window for i, v in enumerate(views)]
         pieces = plan_pieces([_tile_rows(v) for v in views], world, backend.iteration_count, splittable)
         split = sorted({v for v, r0, r1, _ in pieces if (r0, r1) != (0, _tile_rows(views[v]))})
         mine = [(v, r0, r1) for v, r0, r1, o in pieces if o == rank]
@@ -576,6 +593,8 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
                 continue
             pkg = render_fn(views[v], G, backend.pipeline_params, backend.background)
             pkgs.append((v, r0, pkg))
+            if not whole and not cfg["Training"]["rgb_boundary_threshold"] >= 0:
+                raise ValueError("a view in bands needs rgb_boundary_threshold >= 0: pixels outside the band are masked out by their zeroed target")
             target = views[v] if whole else _BandView(views[v], 16 * r0, min(16 * r1, int(views[v].image_height)))
             if v < n_window:
                 loss_mapping = loss_mapping + view_loss_fn(backend, target, pkg)
@@ -610,6 +629,13 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
             # ---- the collectives (a pruning pass reduces the flags only, see below) ----
             params = G.parameters()
             if marks: marks.mark("statistics")
+            # the two small MAX collectives first (on the auxiliary communicator when there is one): they are in flight while
+            # the float bucket is reduced
+            small_works = []
+            if world > 1:
+                small_group = aux_group if aux_group is not None else (getattr(backend, "shard_aux_group", None) or group)
+                (radii_red,), w_radii = reducer.max_ints([radii_max], dev, small_group, async_op=True)
+                small_works = [w for w in (w_radii, _max_bytes(flags, small_group, async_op=True)) if w is not None]
             if not prune and world > 1:
                 tensors = [p.grad for p in params] + [p.grad for p in kf_params] + [norm_sum, vis_count, split_xy,
                            loss_mapping.detach().reshape(1).float() if torch.is_tensor(loss_mapping) else None]
@@ -623,8 +649,9 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
             elif stats is not None and torch.is_tensor(loss_mapping):
                 stats.setdefault("losses", []).append(loss_mapping.detach().reshape(1).float())
             if world > 1:
-                radii_max = reducer.max_ints([radii_max], dev, group)[0]
-                flags = _max_bytes(flags, group)
+                for w in small_works:
+                    w.wait()
+                radii_max = radii_red
             if marks: marks.mark("collectives")
             if stats is not None:
                 stats.setdefault("iterations", []).append(dict(views=[v for v, _, _ in mine], pieces=list(mine), phases=marks))

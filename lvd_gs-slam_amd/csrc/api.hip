@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 #include <chrono>
+#include <thread>
 
 #include "common.hpp"
 #include "photometric.hpp"
@@ -338,8 +339,13 @@ int wait_for_sequence(PairProbe *probe) {
     volatile uint32_t *flag = probe->pinned + 3;
     const uint32_t want = probe->seq;
     const auto t0 = std::chrono::steady_clock::now();
+    // The count arrives some tens of microseconds after the call got here (the projection and the two scans); the wait is a
+    // spin on a pinned word, polite to the core's sibling thread (pause) and, past ~20 us, to the scheduler (yield) -- the
+    // reference's front end and back end are two processes that each sit in this wait once per render.
     for (uint64_t spins = 0;; spins++) {
         if (__atomic_load_n(const_cast<uint32_t *>(flag), __ATOMIC_ACQUIRE) == want) return LVDGS_OK;
+        if (spins < 2000) __builtin_ia32_pause();
+        else std::this_thread::yield();
         if ((spins & 0xffffu) == 0xffffu) {
             if (int e = check_hip(hipGetLastError(), "while waiting for the pair count")) return e;
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) {
@@ -350,8 +356,10 @@ int wait_for_sequence(PairProbe *probe) {
     }
 }
 
+// (radix path: the slot scan leaves the pair count alone -- ONE word is copied; the words behind it are the counting path's
+// hints and the sequence number lvdgs_forward's wait spins on, which a copy of uninitialised device words must not touch)
 int enqueue_count_probe(PairProbe *probe, const uint32_t *total, hipStream_t s) {
-    if (int e = check_hip(hipMemcpyAsync(probe->pinned, total, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read pair count")) return e;
+    if (int e = check_hip(hipMemcpyAsync(probe->pinned, total, sizeof(uint32_t), hipMemcpyDeviceToHost, s), "read pair count")) return e;
     return check_hip(hipEventRecord(probe->ready, s), "record pair count event");
 }
 

@@ -326,10 +326,11 @@ extern "C" int lvdgs_map_view_tail(const lvdgs_loss_args *loss, const lvdgs_args
     hipStream_t s = (hipStream_t)stream;
     TailParams t;
     if (int e = make_tail_params(loss, bwd, nullptr, dL_dtau, 1, t)) return e;
-    if (!stats || !bwd->radii || !stats->radii_max || (!stats->norm_sum && !stats->split_xy) || (stats->touched_row && !bwd->n_touched)) {
+    const int N = bwd->num_gaussians;
+    // (an empty map has no statistics to take: only workgroup 0 -- the loss and the pose gradient -- runs, as the header says)
+    if (!stats || (N > 0 && (!bwd->radii || !stats->radii_max || (!stats->norm_sum && !stats->split_xy) || (stats->touched_row && !bwd->n_touched)))) {
         set_error("map view tail: a statistics pointer is NULL"); return LVDGS_E_INVALID;
     }
-    const int N = bwd->num_gaussians;
     const ViewStats v{N, bwd->radii, bwd->n_touched, bwd->dL_dmeans2D, stats->radii_max, stats->norm_sum, stats->vis_count, stats->touched_row, stats->split_xy};
     ProfScope ps("map_view_tail", s);
     hipLaunchKernelGGL(map_view_tail_kernel, dim3(1 + cdiv(N, 1024)), dim3(1024), 0, s, t, v);

@@ -217,11 +217,29 @@ class TrackingSession:
             if record_loss is not None:
                 record_loss.copy_(self.loss)
         self.iterations_enqueued += 1
+        self._drained = False
+
+    def close(self):
+        """Wait for everything the session has enqueued.  The tail launch of every step stores into ``host_flags`` -- pinned
+        memory PyTorch's host allocator owns and knows nothing of that use: were the tensor released with steps still in
+        flight (the design lets the host run ahead of the device), a late store would land in whoever got the block next.
+        ``finish()`` synchronises already; this is for a session that is dropped without it (also called on deletion)."""
+        if getattr(self, "iterations_enqueued", 0) and not getattr(self, "_drained", False):
+            torch.cuda.synchronize(self.dev)
+            self._drained = True
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # (interpreter shutdown: nothing left to protect)
+            pass
 
     def converged_lagging(self, lag=2):
-        """True once the device's sticky flag has been SEEN set.  Non-blocking: a copy of the flag is requested at every
-        call, and requests made at least ``lag`` calls ago are read if their copy has landed (the oldest one is waited
-        for only when the ring of 8 outstanding requests is full)."""
+        """True once the device's sticky flag has been SEEN set.  Non-blocking.  With ``host_flags`` (pinned words the tail
+        launch itself stores to, the normal case) that is a read of host memory: the flag is seen as soon as the step that
+        raised it has run, ``lag`` plays no part.  Without them: a copy of the flag is requested at every call, and
+        requests made at least ``lag`` calls ago are read if their copy has landed (the oldest one is waited for only when
+        the ring of 8 outstanding requests is full)."""
         if self.host_flags is not None:
             return float(self.host_flags[0]) != 0.0
         if self._asked - self._answered == len(self._ring):
@@ -243,6 +261,7 @@ class TrackingSession:
         """Synchronise, write the pose back into the viewpoint, return the number of iterations the reference's loop
         would have run (it breaks at the first converged one)."""
         torch.cuda.synchronize(self.dev)
+        self._drained = True
         applied = int(self.host_flags[1]) if self.host_flags is not None else int(self.pose_state[18].item())
         self.vp.update_RT(self.R.clone(), self.T.clone())
         return applied

@@ -76,8 +76,11 @@ def make_keyframe_optimizer(viewpoints, window, cfg):
     return torch.optim.Adam(opt_params)
 
 
-def build_scene(device="cpu", camera_cls=None):
+def build_scene(device="cpu", camera_cls=None, n_cameras=N_CAMERAS, window=None):
+    """``n_cameras`` / ``window``: a larger set of keyframes than the fixtures' seven (the eight-rank test of the reference's
+    8 + 2 window); the defaults are the scene the golden fixtures were generated on, draw for draw."""
     from dense_render import dense_render
+    N_CAMERAS = n_cameras   # (shadows the module's constant below)
     if camera_cls is None:
         from lvdgs.camera_utils import Camera as camera_cls
     g = synthetic.make_gaussians(N_TRUE, W, H, seed=21, r_min=3.0, r_max=9.0, z_min=2.0, z_max=6.0)
@@ -118,5 +121,5 @@ def build_scene(device="cpu", camera_cls=None):
     model.init_lr(6.0)
     model.training_setup(OPT)
     return dict(gaussians=model, cameras=cameras, track_camera=track_camera, track_mono_depth=cams[N_CAMERAS][1],
-                background=bg.to(device), pipe=pipe, window=list(WINDOW), map_iters=MAP_ITERS,
+                background=bg.to(device), pipe=pipe, window=list(WINDOW if window is None else window), map_iters=MAP_ITERS,
                 make_keyframe_optimizer=make_keyframe_optimizer, opt=dict(OPT))

@@ -47,8 +47,10 @@ def _half_blind(render_fn):
     return render
 
 
-def _run(group_world, policy="leftover", half_blind=False):
-    """One run of ITERS iterations + the pruning pass; returns a dict of numpy results."""
+def _run(group_world, policy="leftover", half_blind=False, real_window=False, aux_group=None):
+    """One run of ITERS iterations + the pruning pass; returns a dict of numpy results.  ``real_window``: the reference's
+    window instead of the fixtures' -- 8 keyframes + 2 random older ones of 12 (configs/mono/KITTI/base_config.yaml:37,
+    utils/slam_backend.py:275), two iterations, the first of them through the opacity reset of the non-visible."""
     _paths()
     import test_loop_golden as tl
     from dense_render import dense_render
@@ -60,9 +62,12 @@ def _run(group_world, policy="leftover", half_blind=False):
     cfg = loop_config()
     if half_blind:   # reach the opacity reset of the non-visible inside the run (iteration 3; densification at 2 and 6)
         cfg["Training"]["gaussian_reset"] = 3
-    sc = build_scene("cpu")
+    if real_window:
+        cfg["Training"].update(window_size=8, gaussian_reset=1, gaussian_update_every=1000, gaussian_update_offset=999)
+    sc = build_scene("cpu", n_cameras=12, window=list(range(11, 3, -1))) if real_window else build_scene("cpu")
     be = tl._backend(sc, cfg)
     be.initialized = True
+    be.shard_aux_group = aux_group
     for i, cam in enumerate(sc["cameras"]):
         be.viewpoints[i] = cam
     window = sc["window"]
@@ -76,12 +81,16 @@ def _run(group_world, policy="leftover", half_blind=False):
         bm.random_view_indices = lambda n, k, it, world, seed=0: keyed(n, k, it, 2, seed)
     stats = {}
     try:
-        bm.map_window(be, window, iters=ITERS, render_fn=dense_render, view_loss_fn=tl._cpu_view_loss, stats=stats)
+        bm.map_window(be, window, iters=2 if real_window else ITERS, render_fn=dense_render, view_loss_fn=tl._cpu_view_loss, stats=stats, bands_ok=True)
         n_mid = be.gaussians.get_xyz.shape[0]
-        bm.map_window(be, window, prune=True, render_fn=dense_render, view_loss_fn=tl._cpu_view_loss)
+        if real_window:
+            raise _Done
+        bm.map_window(be, window, prune=True, render_fn=dense_render, view_loss_fn=tl._cpu_view_loss, bands_ok=True)
         # one more iteration after the pruning pass: its (unreduced) gradients must have been dropped with the
         # replaced parameters, or carried consistently
-        bm.map_window(be, window, iters=1, render_fn=dense_render, view_loss_fn=tl._cpu_view_loss)
+        bm.map_window(be, window, iters=1, render_fn=dense_render, view_loss_fn=tl._cpu_view_loss, bands_ok=True)
+    except _Done:
+        pass
     finally:
         if group_world == 1:
             bm.random_view_indices = keyed
@@ -94,6 +103,7 @@ def _run(group_world, policy="leftover", half_blind=False):
             out["v_" + gp["name"]] = st["exp_avg_sq"].numpy().copy()
     out.update(max_radii2D=G.max_radii2D.numpy().copy(), accum=G.xyz_gradient_accum.numpy().copy(), denom=G.denom.numpy().copy(),
                n_obs=G.n_obs.numpy().copy(), kf_ids=G.unique_kfIDs.numpy().copy(), counts=np.array(counts), n_mid=np.array(n_mid))
+    out["pieces_first_iteration"] = np.array([[v, r0, r1] for v, r0, r1 in stats["iterations"][0]["pieces"]], dtype=np.int64).reshape(-1, 3)
     for i, cam in enumerate(sc["cameras"]):
         out[f"R{i}"], out[f"T{i}"] = cam.R.numpy().copy(), cam.T.numpy().copy()
         out[f"exp{i}"] = np.array([float(cam.exposure_a.detach()), float(cam.exposure_b.detach())])
@@ -104,22 +114,33 @@ def _run(group_world, policy="leftover", half_blind=False):
     return out
 
 
+class _Done(Exception):
+    pass
+
+
+_PER_RANK = ("views_per_iteration", "rows_per_iteration", "pieces_first_iteration")
+
+
 def _digest(res):
     h = hashlib.sha256()
     for k in sorted(res):
-        if k not in ("views_per_iteration", "rows_per_iteration"):
+        if k not in _PER_RANK:
             h.update(k.encode())
             h.update(np.ascontiguousarray(res[k]).tobytes())
     return h.hexdigest()
 
 
-def _worker(rank, world, port, q, policy, half_blind):
+def _worker(rank, world, port, q, policy, half_blind, real_window=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if world >= 8:
+        torch.set_num_threads(1)   # eight ranks on the test box's eight cores
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.manual_seed(100 + rank)   # the ranks' global generators differ on purpose: nothing may depend on them
-        res = _run(world, policy, half_blind)
+        # the small MAX collectives on a communicator of their own (map_window's aux_group), in the runs with >= 4 ranks
+        aux = dist.new_group() if world >= 4 else None
+        res = _run(world, policy, half_blind, real_window, aux)
         q.put((rank, _digest(res), res))
     finally:
         dist.destroy_process_group()
@@ -151,7 +172,7 @@ def test_ranks_stay_bit_identical_and_match_the_single_process_run(world, policy
     # (1) replicas: bit-identical, everything
     for _, dk, rk in results[1:]:
         for k in r0:
-            if k not in ("views_per_iteration", "rows_per_iteration"):
+            if k not in _PER_RANK:
                 np.testing.assert_array_equal(r0[k], rk[k], err_msg=k)
         assert d0 == dk
     # the six views of an iteration (4 window + 2 random), three tile rows each: the same number of rows on every rank
@@ -167,7 +188,52 @@ def test_ranks_stay_bit_identical_and_match_the_single_process_run(world, policy
     np.testing.assert_array_equal(ref["counts"], r0["counts"])
     assert int(ref["n_mid"]) == int(r0["n_mid"]) and len(set(ref["counts"].tolist())) > 1   # a densification happened
     for k in ref:
-        if k in ("views_per_iteration", "rows_per_iteration", "counts", "n_mid"):
+        if k in _PER_RANK + ("counts", "n_mid"):
+            continue
+        a, b = np.asarray(r0[k], np.float64), np.asarray(ref[k], np.float64)
+        assert a.shape == b.shape, k
+        if a.size:
+            tol = 5e-4 * np.abs(b) + 5e-5 * max(np.abs(b).max(), 1e-30)
+            assert (np.abs(a - b) <= tol).all(), (k, np.abs(a - b).max(), np.abs(b).max())
+
+
+def test_the_reference_window_of_ten_views_on_eight_ranks():
+    """The target shape of the sharded iteration, executed (not only planned): 8 window keyframes + 2 random older ones on
+    EIGHT ranks -- every rank one whole keyframe, the two other views in bands of tile rows -- for two iterations, the first
+    of them through the opacity reset of the non-visible (the "seen by any view" statistic across ranks).  Replicas end
+    bit-identical and equal to the single-process run to float rounding."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33100 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "leftover", False, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=1500) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    _, d0, r0 = results[0]
+    for _, dk, rk in results[1:]:
+        for k in r0:
+            if k not in _PER_RANK:
+                np.testing.assert_array_equal(r0[k], rk[k], err_msg=k)
+        assert d0 == dk
+    # the plan, as executed: rank r holds window keyframe r whole; the two random views' 2 x 3 tile rows are dealt as bands
+    pieces = {rank: res["pieces_first_iteration"].tolist() for rank, _, res in results}
+    for rank in range(world):
+        assert [rank, 0, 3] in pieces[rank], (rank, pieces[rank])
+    bands = sorted(tuple(p) for ps in pieces.values() for p in ps if p[0] >= 8)
+    assert sorted(r1 - r0 for _, r0, r1 in bands) and sum(r1 - r0 for _, r0, r1 in bands) == 6
+    for v in (8, 9):
+        cover = sorted((r0, r1) for w, r0, r1 in bands if w == v)
+        assert cover[0][0] == 0 and cover[-1][1] == 3 and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+    assert len({rank for rank, ps in pieces.items() if any(p[0] >= 8 for p in ps)}) >= 4   # the bands are spread over the ranks
+    torch.manual_seed(7)
+    ref = _run(1, "leftover", False, True)
+    assert (ref["views_per_iteration"] == 10).all()
+    for k in ref:
+        if k in _PER_RANK + ("counts", "n_mid"):
             continue
         a, b = np.asarray(r0[k], np.float64), np.asarray(ref[k], np.float64)
         assert a.shape == b.shape, k
