@@ -319,7 +319,30 @@ class KeyframeStepper:
             any_p = next(getattr(vp, n) for n in _POSE_FIELDS if has[n])
             (a.beta1, a.beta2), a.eps = lr_of[id(any_p)][1], lr_of[id(any_p)][2]
             a.state, a.converged_threshold = _P(state), -1.0
+            self._import_state(optimizer, vp, has, state)
             self.items.append((vp, a, pose, has, keep))
+
+    _STATE_SLOTS = {"cam_rot_delta": (0, 19), "cam_trans_delta": (6, 20), "exposure_a": (12, 21), "exposure_b": (14, 22)}   # (moments, step count) in `state`
+
+    @classmethod
+    def _import_state(cls, optimizer, vp, has, state):
+        """Moments and step counts the torch optimiser already holds for this keyframe (iterations that went through
+        ``keyframe_optimizers.step()`` -- ``fused=False``, ``up_pose=False`` -- before the stepper took over) continue here;
+        a fresh optimiser has none and the state stays zero.  The counterpart of ``export_to_optimizer``."""
+        host = None
+        for name, (off, cnt) in cls._STATE_SLOTS.items():
+            p = getattr(vp, name, None)
+            st = optimizer.state.get(p) if (has[name] and p is not None) else None
+            if not st or "exp_avg" not in st:
+                continue
+            host = torch.zeros(24, dtype=torch.float32) if host is None else host
+            n = p.numel()
+            mv = host[off:off + 2 * n].view(n, 2)
+            mv[:, 0] = st["exp_avg"].detach().reshape(-1).float().cpu()
+            mv[:, 1] = st["exp_avg_sq"].detach().reshape(-1).float().cpu()
+            host[cnt] = float(st["step"])
+        if host is not None:
+            state.copy_(host.to(state.device))
 
     @staticmethod
     def _sig(optimizer):
@@ -341,10 +364,9 @@ class KeyframeStepper:
         """Write the moments and step counts kept here into the torch optimiser's own state, so that a later
         ``keyframe_optimizers.step()`` (``fused=False``, ``up_pose=False``) continues from them instead of from a stale or
         empty state."""
-        groups = {"cam_rot_delta": (0, 19), "cam_trans_delta": (6, 20), "exposure_a": (12, 21), "exposure_b": (14, 22)}
         for vp, a, pose, has, keep in self.items:
             st = keep[0].detach().cpu()
-            for name, (off, cnt) in groups.items():
+            for name, (off, cnt) in self._STATE_SLOTS.items():
                 if not has[name] or float(st[cnt]) == 0.0:
                     continue
                 p = getattr(vp, name)

@@ -637,6 +637,20 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p) {
     // gradients w.r.t. the parameters: written, or (a later view of a mapping iteration) added to what is there
     const bool accumulate = p.accumulate != 0;
     auto put = [accumulate](float *dst, float v) { *dst = accumulate ? *dst + v : v; };
+    // a Gaussian's three / four values as ONE 12- / 16-byte access per lane: the wave's stores are whole runs of memory
+    // instead of three or four passes of every-third-word stores over the same sectors
+    struct f3 { float x, y, z; };
+    struct f4 { float x, y, z, w; };
+    auto put3 = [accumulate](float *dst, float a, float b, float c) {
+        f3 *d = reinterpret_cast<f3 *>(dst);
+        if (accumulate) { const f3 o = *d; a += o.x; b += o.y; c += o.z; }
+        *d = f3{a, b, c};
+    };
+    auto put4 = [accumulate](float *dst, float a, float b, float c, float e) {
+        f4 *d = reinterpret_cast<f4 *>(dst);
+        if (accumulate) { const f4 o = *d; a += o.x; b += o.y; c += o.z; e += o.w; }
+        *d = f4{a, b, c, e};
+    };
     if (!POSE_ONLY && i < p.N && !live) {
 #pragma unroll
         for (int k = 0; k < 3; k++) p.dmeans2D[3 * (size_t)i + k] = 0.f;
@@ -773,7 +787,7 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p) {
             else put(&p.dopac[i], A[5]);
         }
         const float g_ndc[2] = {A[0] * 0.5f * (float)c.W, A[1] * 0.5f * (float)c.H};
-        if constexpr (!POSE_ONLY) { p.dmeans2D[3 * (size_t)i] = g_ndc[0]; p.dmeans2D[3 * (size_t)i + 1] = g_ndc[1]; p.dmeans2D[3 * (size_t)i + 2] = 0.f; }
+        if constexpr (!POSE_ONLY) *reinterpret_cast<f3 *>(&p.dmeans2D[3 * (size_t)i]) = f3{g_ndc[0], g_ndc[1], 0.f};
 
         float g_rgb[3] = {A[6], A[7], A[8]};
         float g_pview[3] = {0.f, 0.f, A[9]};
@@ -782,8 +796,7 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p) {
         // ---- colour ---- (POSE_ONLY: colours without view dependence only -- api.hip -- which give the pose nothing)
         if constexpr (POSE_ONLY) {
         } else if (p.colors_precomp) {
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) put(&p.dcolors[3 * (size_t)i + ch], g_rgb[ch]);
+            put3(&p.dcolors[3 * (size_t)i], g_rgb[0], g_rgb[1], g_rgb[2]);
         } else {
             float d[3] = {pos[0] - c.campos[0], pos[1] - c.campos[1], pos[2] - c.campos[2]};
             const float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
@@ -805,9 +818,9 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p) {
 #pragma unroll
             for (int k = 0; k < 16; k++)
                 if (k < nb) {
+                    put3(&dsh[3 * k], B[k] * g_rgb[0], B[k] * g_rgb[1], B[k] * g_rgb[2]);
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) {
-                        put(&dsh[3 * k + ch], B[k] * g_rgb[ch]);
                         const float sg = sh[3 * k + ch] * g_rgb[ch];
                         g_u[0] += G[k][0] * sg; g_u[1] += G[k][1] * sg; g_u[2] += G[k][2] * sg;
                     }
@@ -893,8 +906,8 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p) {
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             g_world[a] += Vg[4 * a + 0] * g_pview[0] + Vg[4 * a + 1] * g_pview[1] + Vg[4 * a + 2] * g_pview[2];
-            if constexpr (!POSE_ONLY) put(&p.dmeans3D[3 * (size_t)i + a], g_world[a]);
         }
+        if constexpr (!POSE_ONLY) put3(&p.dmeans3D[3 * (size_t)i], g_world[0], g_world[1], g_world[2]);
 
         // ---- camera pose: T' = Exp(tau) T ----
         const float gv[3] = {g_pview[0] + g_pview_proj[0], g_pview[1] + g_pview_proj[1], g_pview[2] + g_pview_proj[2]};
@@ -915,7 +928,7 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p) {
             float R[3][3];
             quat_rot(q, R);
             const float sm[3] = {c.scale_mod * sc[0], c.scale_mod * sc[1], c.scale_mod * sc[2]};
-            float g_R[3][3];
+            float g_R[3][3], g_sc[3];
 #pragma unroll
             for (int b = 0; b < 3; b++) {
                 float v = 0.f;
@@ -926,8 +939,9 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p) {
                     g_R[a][b] = gm * sm[b];
                 }
                 // fused exp: d/d(log s) = d/ds * s
-                put(&p.dscales[3 * (size_t)i + b], v * c.scale_mod * ((p.act & ACT_EXP_SCALES) ? sc[b] : 1.f));
+                g_sc[b] = v * c.scale_mod * ((p.act & ACT_EXP_SCALES) ? sc[b] : 1.f);
             }
+            put3(&p.dscales[3 * (size_t)i], g_sc[0], g_sc[1], g_sc[2]);
             const float r = q[0], x = q[1], y = q[2], z = q[3];
             float dq[4];
             dq[0] = 2.f * (-z * g_R[0][1] + y * g_R[0][2] + z * g_R[1][0] - x * g_R[1][2] - y * g_R[2][0] + x * g_R[2][1]);
@@ -940,8 +954,7 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) dq[k] = (dq[k] - q[k] * dot) / qnorm;
             }
-#pragma unroll
-            for (int k = 0; k < 4; k++) put(&p.drot[4 * (size_t)i + k], dq[k]);
+            put4(&p.drot[4 * (size_t)i], dq[0], dq[1], dq[2], dq[3]);
         }
     }
     // ---- workgroup sum of the pose gradient -> one partial per workgroup (no atomics) ----
@@ -960,7 +973,7 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p) {
 // toolchain)
 __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(BwdParams p) { preprocess_bwd_body<false>(p); }
 #ifndef LVDGS_PBWD_WGS_POSE
-#define LVDGS_PBWD_WGS_POSE 6
+#define LVDGS_PBWD_WGS_POSE 5   // (6: 80 VGPRs with 7 spilled; same box 25.1 against 24.1 us at config 3)
 #endif
 __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS_POSE) preprocess_bwd_pose_kernel(BwdParams p) { preprocess_bwd_body<true>(p); }
 

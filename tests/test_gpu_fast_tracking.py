@@ -243,6 +243,40 @@ def test_map_window_with_fused_steps_equals_the_pytorch_statements():
     assert all(not d.any() for d in a["deltas"])
 
 
+def test_the_keyframe_stepper_continues_from_the_torch_optimisers_state_and_hands_it_back():
+    """Iterations may change hands between ``keyframe_optimizers.step()`` (fused=False) and the device-side stepper: two
+    iterations through torch's Adam, two through the stepper (which IMPORTS the moments and step counts it finds), two through
+    torch's again (the stepper EXPORTS) must leave the keyframes where six iterations of either alone leave them."""
+    sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
+    import test_loop_golden as tl
+    from loop_scene import build_scene, loop_config
+    from lvdgs.backend_map import map_window
+    cfg = loop_config()
+    cfg["Training"].update(gaussian_update_every=1000, gaussian_update_offset=999, gaussian_reset=1000)   # the map's size stays
+    res = {}
+    for plan in ((False,) * 6, (False, False, True, True, False, False)):
+        torch.manual_seed(1)
+        sc = build_scene("cuda")
+        be = tl._backend(sc, cfg)
+        be.initialized = True
+        for i, cam in enumerate(sc["cameras"]):
+            be.viewpoints[i] = cam
+        window = sc["window"]
+        be.current_window = window
+        be.keyframe_optimizers = sc["make_keyframe_optimizer"](be.viewpoints, window, cfg)
+        for fused in plan:
+            map_window(be, window, iters=1, fused=fused)
+        res[plan] = [(c.R.cpu().numpy(), c.T.cpu().numpy(), float(c.exposure_a.detach()), float(c.exposure_b.detach())) for c in sc["cameras"]]
+    (a, b) = res.values()
+    moved = 0
+    for (Ra, Ta, ea, fa), (Rb, Tb, eb, fb) in zip(a, b):
+        np.testing.assert_allclose(Ra, Rb, atol=5e-6)
+        np.testing.assert_allclose(Ta, Tb, atol=5e-6)
+        assert abs(ea - eb) < 1e-5 and abs(fa - fb) < 1e-5
+        moved += int(abs(ea) > 1e-3)
+    assert moved >= 3   # (Adam's sixth step from imported moments differs from a first step by far more than the tolerance)
+
+
 def test_a_tracking_iteration_at_kitti_size_matches_the_cpu_chain_end_to_end():
     """One TrackingSession.step (lvdgs_forward -> lvdgs_backward_fused_loss -> lvdgs_tracking_tail) at KITTI-07's geometry
     against the chain it stands for, on the CPU: the C oracle's forward -> get_loss_tracking as PyTorch statements (opacity
