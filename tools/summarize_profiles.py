@@ -20,8 +20,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 # kernel symbol -> the name its launch is timed under in bench.py (ProfScope), where they differ
-ALIASES = {"blend_bwd2": "blend_bwd", "blend_bwd3": "blend_bwd", "blend_fwd2": "blend_fwd", "preprocess_count": "preprocess_fwd",
-           "scatter_pairs": "group_scatter", "tile_depth_sort_wave": "tile_sort"}
+ALIASES = {"blend_bwd2": "blend_bwd", "blend_bwd3": "blend_bwd", "blend_fwd2": "blend_fwd", "blend_fwd2_deep": "blend_fwd", "preprocess_count": "preprocess_fwd",
+           "preprocess_bwd_pose": "preprocess_bwd", "scatter_pairs": "group_scatter", "tile_depth_sort_wave": "tile_sort"}
 
 
 def short(name):
@@ -30,20 +30,23 @@ def short(name):
     return ALIASES.get(n, n)
 
 
-def main(tag, workload="cfg3_500k_1920x1080"):
+def main(tag, workload="cfg3_500k_1920x1080", prefix="pmc_", label=None):
+    """prefix / label: the counter passes of another variant of the step (profile_round.sh: "posepmc_" = the pose-only backward)
+    go to profiles/<tag>_<label>_pmc and to traffic.json under "<workload> (<label>)"."""
     src = os.path.join(ROOT, "gpurun_out", tag)
     if tag.startswith("-") or not os.path.isdir(src):
         raise SystemExit(f"usage: summarize_profiles.py <tag>   ({src} does not exist)")
     dst = os.path.join(ROOT, "profiles")
-    stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+    suffix = "" if label is None else "_" + label
+    stats = glob.glob(os.path.join(src, "stats" if label is None else label + "_stats", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
-        shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats_cfg3.csv"))
+        shutil.copy(stats[0], os.path.join(dst, f"{tag}{suffix}_kernel_stats_cfg3.csv"))
     bench = os.path.join(src, "bench.json")
-    if os.path.exists(bench) and os.path.getsize(bench):
+    if label is None and os.path.exists(bench) and os.path.getsize(bench):
         shutil.copy(bench, os.path.join(dst, f"{tag}_bench_cfg3.json"))
-    os.makedirs(os.path.join(dst, f"{tag}_pmc"), exist_ok=True)
+    os.makedirs(os.path.join(dst, f"{tag}{suffix}_pmc"), exist_ok=True)
     per_kernel = defaultdict(lambda: defaultdict(list))
-    for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+    for d in sorted(glob.glob(os.path.join(src, prefix + "*"))):
         if not os.path.isdir(d):
             continue
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
@@ -54,8 +57,8 @@ def main(tag, workload="cfg3_500k_1920x1080"):
         # autograd comparison's launches of the plain one (which reads gradient images): keep the timed kernel's only
         if any("blend_bwd3_kernel<true" in r["Kernel_Name"] for r in rows):
             rows = [r for r in rows if "blend_bwd3_kernel<false" not in r["Kernel_Name"]]
-        name = os.path.basename(d)[4:].lower()
-        with open(os.path.join(dst, f"{tag}_pmc", f"{name}_lvdgs_kernels.csv"), "w", newline="") as f:
+        name = os.path.basename(d)[len(prefix):].lower()
+        with open(os.path.join(dst, f"{tag}{suffix}_pmc", f"{name}_lvdgs_kernels.csv"), "w", newline="") as f:
             w = csv.writer(f)
             w.writerow(["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count",
                         "Counter_Name", "Counter_Value"])
@@ -81,10 +84,13 @@ def main(tag, workload="cfg3_500k_1920x1080"):
                     entry[k][key] = int(sum(c[name]) / len(c[name]))
     if entry:
         entry["_source"] = f"gpurun_out/{tag} (tools/profile_round.sh), summarised by tools/summarize_profiles.py"
-        traffic[workload] = entry
+        traffic[workload if label is None else f"{workload} ({label})"] = entry
         json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
     print("kernels with traffic:", [k for k in entry if not k.startswith("_")])
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r01_x")
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01_x"
+    main(tag)
+    if glob.glob(os.path.join(ROOT, "gpurun_out", tag, "posepmc_*")):
+        main(tag, prefix="posepmc_", label="pose")
