@@ -277,6 +277,9 @@ def test_the_keyframe_stepper_continues_from_the_torch_optimisers_state_and_hand
     assert moved >= 3   # (Adam's sixth step from imported moments differs from a first step by far more than the tolerance)
 
 
+TRACKING_ITERATION_BOUND = 8e-6   # (achieved: 9.9e-7 / 1.65e-6 at worst, the quaternion gradient) relative L2 and largest element error (of the tensor's scale) of every gradient below
+
+
 def test_a_tracking_iteration_at_kitti_size_matches_the_cpu_chain_end_to_end():
     """One TrackingSession.step (lvdgs_forward -> lvdgs_backward_fused_loss -> lvdgs_tracking_tail) at KITTI-07's geometry
     against the chain it stands for, on the CPU: the C oracle's forward -> get_loss_tracking as PyTorch statements (opacity
@@ -296,6 +299,17 @@ def test_a_tracking_iteration_at_kitti_size_matches_the_cpu_chain_end_to_end():
     with torch.no_grad():
         cam.exposure_a.fill_(0.04); cam.exposure_b.fill_(-0.03)
     pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False)
+    # The loss is an L1: where a rendered value sits within rounding of its target, two pipelines that agree to 1e-5 can take
+    # different signs and that pixel's whole contribution flips.  The target is moved off such pixels (by 1e-3 where a residual
+    # is below 2e-4), so that what is compared is the arithmetic, not a coin toss.
+    from lvdgs.gaussian_renderer import render
+    with torch.no_grad():
+        pre = render(cam, model, pipe, torch.zeros(3, device=dev))
+        shown = torch.exp(cam.exposure_a) * pre["render"] + cam.exposure_b
+        r = shown - cam.original_image
+        near = r.abs() < 2e-4
+        cam.original_image = torch.where(near, shown - 1e-3 * torch.where(r >= 0, 1.0, -1.0), cam.original_image).contiguous()
+        assert int(near.sum()) < 5000
     s = TrackingSession(cam, model, bench.CONFIG, pipe, torch.zeros(3, device=dev), gaussian_gradients=True)
     cpu = lambda t: t.detach().cpu().contiguous().clone()
     view, proj, proj_raw, campos = cpu(s.view), cpu(s.proj), cpu(s.proj_raw), cpu(s.campos)   # the camera the step renders from
@@ -330,15 +344,15 @@ def test_a_tracking_iteration_at_kitti_size_matches_the_cpu_chain_end_to_end():
            "rotations": (g_q - q * (q * g_q).sum(1, keepdims=True)) / qn, "shs": b_ora["shs"], "tau": b_ora["tau"]}
     got = {"means3D": cpu(s.d_m3).numpy(), "scales": cpu(s.d_sc).numpy(), "opacities": cpu(s.d_op).numpy(), "rotations": cpu(s.d_rot).numpy(),
            "shs": cpu(s.d_sh).numpy(), "tau": cpu(s.d_tau).numpy()}
-    # (an L1 loss: at pixels within rounding of their target the two pipelines may take different signs -- a handful per frame;
-    # the tensors as wholes to 2e-4, elements to 1 % of the tensor's scale; the fixed-gradient parity cases are the strict ones)
+    # (no residual of the loss within rounding of zero -- above -- so what is left is the rasterizer's float32 latitude; asserted at
+    # five times what the run achieves, profiles/r04_parity_report.txt; round 3, with the coin tosses in: 2e-4 and 1e-2)
     for n in ("means3D", "opacities", "scales", "rotations", "shs", "tau"):
         r = np.asarray(ref[n], np.float32)
         a = got[n].reshape(r.shape)
         st = tp.parity_stats_record("tracking iteration, grad " + n, a, r)
         scale = max(float(np.abs(r).max()), 1e-30)
-        assert st["rel_l2"] <= 2e-4, (n, st)
-        assert float(np.abs(a - r).max()) <= 1e-2 * scale, (n, st)
+        assert st["rel_l2"] <= TRACKING_ITERATION_BOUND, (n, st)
+        assert float(np.abs(a - r).max()) <= TRACKING_ITERATION_BOUND * scale, (n, st)
     for got_e, ref_e, n in ((s.d_a, cpu_view.exposure_a.grad, "exposure_a"), (s.d_b, cpu_view.exposure_b.grad, "exposure_b")):
         a, b = float(got_e), float(ref_e)
         assert abs(a - b) <= 2e-4 * max(abs(b), 1e-6), (n, a, b)
