@@ -355,7 +355,7 @@ struct Bwd3Shared {
     uint32_t slot[BR];
     float acc[4][BR * ACC];              // per wave: Sx Sy Sxx Sxy Syy Su C0 C1 C2 CD of every entry it accumulated
     unsigned long long mask[4];
-    uint32_t wmax[4], wall[4];           // per wave: deepest list position its pixels reached, among pixels with a gradient / among all
+    uint32_t wmax[4], wall[4];           // wall: per wave, the deepest list position its pixels reached (wmax: unused since round 4, kept for the layout)
     float loss_sum[4][4];                // fused loss: [sum][wave]
     MT M[4][NB][64];                     // per wave: (u, w) of [batch slot][pixel]
     uint32_t bj[4][NB];                  // per wave: entry (position in the round) of every batch slot
@@ -429,13 +429,12 @@ __global__ void __launch_bounds__(256, POSE_ONLY ? (DEPTH_GRAD ? 6 : LVDGS_BWD_W
     // brightness masks, a static mask) adds exactly zero to every sum: its wave sits the lists out.
     const uint32_t m_all = m;
     if (__ballot(gC0 != 0.f || gC1 != 0.f || gC2 != 0.f || gD != 0.f || gO != 0.f) == 0ull) m = 0u;
-    if (lane == 0) { sh.wmax[wave] = m; sh.wall[wave] = m_all; }
+    if (lane == 0) sh.wall[wave] = m_all;
     const int wave_last = (int)m;
     __syncthreads();
     if constexpr (FUSED_LOSS) {
         if (tid < 4) p.loss.partial[4 * (size_t)tile + tid] = ((sh.loss_sum[tid][0] + sh.loss_sum[tid][1]) + sh.loss_sum[tid][2]) + sh.loss_sum[tid][3];
     }
-    const int depth_max = (int)max(max(sh.wmax[0], sh.wmax[1]), max(sh.wmax[2], sh.wmax[3]));
     // Only the entries some pixel of the tile composited can receive anything: the list is walked from the deepest of them.
     // The pairs behind it -- on opaque surfaces nine tenths of a list -- are neither staged nor written; their slots keep
     // pair_valid = 0 and preprocess_bwd passes over them.  (The depth is the forward pass's alone, not this call's
@@ -468,7 +467,7 @@ __global__ void __launch_bounds__(256, POSE_ONLY ? (DEPTH_GRAD ? 6 : LVDGS_BWD_W
         }
         __syncthreads();
         uint64_t wrote = 0ull;
-        if (base < depth_max) {
+        if (base < wave_last) {   // (a wave none of whose pixels got this far has nothing to test: on opaque surfaces two thirds of the (wave, round) pairs)
             bool keep = false;
             if (lane < cnt && base + lane < wave_last) {
                 const float4 A = sh.a[lane];
