@@ -199,7 +199,9 @@ def main():
     make_window = (lambda m: build_window(args.workload, 12, dev, m, n_window=8)) if real_window else (lambda m: build_window(args.workload, world, dev, m))
     if not tracking:
         backend, window = make_window(model)
-        if world > 1:   # the two small MAX collectives on a communicator of their own: in flight under the gradient all-reduce
+        if world > 1 and os.environ.get("LVDGS_BENCH_AUX_GROUP", "1") != "0":
+            # the two small MAX collectives on a communicator of their own: in flight under the gradient all-reduce
+            # (LVDGS_BENCH_AUX_GROUP=0: all three collectives on the one communicator, as in round 3)
             backend.shard_aux_group = dist.new_group(backend=backend_name if backend_name != "nccl" else None)
     elif use_session:
         from lvdgs.fast_tracking import TrackingSession

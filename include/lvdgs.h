@@ -29,7 +29,8 @@
  *    buffers alive until backward (PyTorch: ctx.save_for_backward);
  *  - no global mutable state that results depend on: besides the optional profiling counters, lvdgs_forward keeps a
  *    per-thread, per-device block of pinned, device-visible words (the tile-scan kernel writes the pair count lvdgs_forward
- *    returns there, and the frame's longest tile segment, which only selects the sort kernels the next frame launches); the environment is looked at once per
+ *    returns there, and the frame's longest tile segment, which only selects WHICH kernels the next frame launches for its long tile
+ *    lists -- the sort kernels, and the deep-lists build of the forward blend kernel: a hint, never a result); the environment is looked at once per
  *    process for the test hook LVDGS_FORCE_RADIX_GROUPING;
  *  - all float tensors are float32, contiguous, row-major; matrices are 4x4 in the
  *    row-vector layout the reference's Camera produces (world_view_transform =
