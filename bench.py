@@ -203,6 +203,9 @@ def main():
             # the two small MAX collectives on a communicator of their own: in flight under the gradient all-reduce
             # (LVDGS_BENCH_AUX_GROUP=0: all three collectives on the one communicator, as in round 3)
             backend.shard_aux_group = dist.new_group(backend=backend_name if backend_name != "nccl" else None)
+        # LVDGS_BENCH_SHARDED_ADAM=1: the Gaussian Adam as reduce-scatter -> every rank steps its share -> all-gather
+        # (backend_map.ShardedAdam; off by default: modelled, never measured on more than one GPU)
+        backend.shard_optimizer = world > 1 and os.environ.get("LVDGS_BENCH_SHARDED_ADAM", "0") == "1"
     elif use_session:
         from lvdgs.fast_tracking import TrackingSession
         # BASELINE configs[2] names the full pose + map backward: the headline computes every Gaussian gradient.  (The product's

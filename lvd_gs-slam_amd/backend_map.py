@@ -193,8 +193,10 @@ class FlatReducer:
         self.ibuf = self._fit(self.ibuf, int(total), torch.int32, device)
         return self.ibuf[:int(total)]
 
-    def sum_floats(self, tensors: Sequence[Optional[torch.Tensor]], sizes: Sequence[int], device, group=None):
+    def sum_floats(self, tensors: Sequence[Optional[torch.Tensor]], sizes: Sequence[int], device, group=None, scatter=None, scatter_len=0):
         """Pack (None counts as zeros), all-reduce SUM, return views of the reduced pieces in order.
+        ``scatter`` (a ShardedAdam) with ``scatter_len``: the first ``scatter_len`` floats are reduce-SCATTERED instead -- this
+        rank's summed share is left in ``self.share``, the views of that part are NOT reduced -- and the rest all-reduced.
 
         A tensor that already IS its slice of the bucket (a ``.grad`` assigned from the previous call's result and
         accumulated into since) stays where it is; one that merely overlaps the bucket is copied out first."""
@@ -231,7 +233,12 @@ class FlatReducer:
                 else:
                     flat[off:off + n].copy_(t)
         _, world = _world(group)
-        if world > 1:
+        self.share = None
+        if world > 1 and scatter is not None and scatter_len > 0:
+            self.share = scatter.reduce_scatter(flat[:scatter_len])
+            if total > scatter_len:
+                dist.all_reduce(flat[scatter_len:], op=dist.ReduceOp.SUM, group=group)
+        elif world > 1:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         return list(flat.split(list(sizes)))
 
@@ -262,6 +269,144 @@ def _max_bytes(flags: torch.Tensor, group=None, async_op=False):
     if world > 1 and flags.numel():
         work = dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group, async_op=async_op)
     return work if async_op else flags
+
+
+class ShardedAdam:
+    """The map's Adam step with every rank stepping ONE SHARE of the parameters (``map_window(sharded_adam=True)`` /
+    ``backend.shard_optimizer``): the float bucket's parameter-gradient part is reduce-scattered instead of all-reduced -- rank r
+    receives the sum of share r, a contiguous 1 / world of the bucket, cutting through the parameter tensors wherever it falls
+    (Adam is elementwise) -- every rank runs Adam on its share alone, and the stepped shares are all-gathered back into the
+    parameter tensors: the collective volume of the all-reduce (reduce-scatter + all-gather IS an all-reduce), 1 / world of the
+    Adam arithmetic and moment traffic per rank.  Every parameter element is computed by exactly one rank and copied to the
+    others, so the replicas stay bit-identical.  The moments of a rank are current on its share only: ``sync_moments()``
+    all-gathers them before anything that edits or reads them per Gaussian (densification, pruning, the opacity reset, a
+    pruning pass, a switch back to the replicated step) -- every ~150 iterations in the reference's schedule.
+    Priced in DESIGN.md section 4: worth ~35 us of ~1.1 ms at 500 k Gaussians on eight GPUs, ~100 us of ~3 ms at 2 M; OFF by
+    default (no multi-GPU box was available to measure it)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank, self.world = _world(group)
+        self.stale = False          # moments current on the local share only
+        self.bufs = {}
+
+    def _buf(self, name, n, dev):
+        b = self.bufs.get(name)
+        if b is None or b.numel() < n or b.device != dev:
+            b = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+            self.bufs[name] = b
+        return b[:n]
+
+    def plan(self, params):
+        """Flat layout of the parameter tensors (the order of the float bucket) padded to a multiple of the world size."""
+        sizes = [int(p.numel()) for p in params]
+        total = sum(sizes)
+        padded = -(-max(total, 1) // self.world) * self.world
+        share = padded // self.world
+        return sizes, total, padded, share
+
+    def pieces(self, params):
+        """[(tensor index, start in the tensor, start in the share, length)] of this rank's share."""
+        sizes, total, padded, share = self.plan(params)
+        lo, hi = self.rank * share, min((self.rank + 1) * share, total)
+        out, off = [], 0
+        for k, n in enumerate(sizes):
+            a, b = max(lo, off), min(hi, off + n)
+            if b > a:
+                out.append((k, a - off, a - lo, b - a))
+            off += n
+        return out, share
+
+    def reduce_scatter(self, flat_grads):
+        """``flat_grads``: the bucket's parameter-gradient part (padded length).  Returns this rank's summed share."""
+        share = flat_grads.numel() // self.world
+        out = self._buf("grad_share", share, flat_grads.device)
+        dist.reduce_scatter_tensor(out, flat_grads, op=dist.ReduceOp.SUM, group=self.group)
+        return out
+
+    def _gather_into(self, tensors, name):
+        """All-gather every rank's share of ``tensors`` (flat layout of ``plan``) and copy the result into them."""
+        sizes, total, padded, share = self.plan(tensors)
+        dev = tensors[0].device
+        mine = self._buf(name + "_share", share, dev)
+        pieces, _ = self.pieces(tensors)
+        for k, a, c, n in pieces:
+            mine[c:c + n].copy_(tensors[k].detach().reshape(-1)[a:a + n])
+        full = self._buf(name + "_full", padded, dev)
+        dist.all_gather_into_tensor(full, mine, group=self.group)
+        off = 0
+        for t, n in zip(tensors, sizes):
+            if n:
+                t.detach().reshape(-1).copy_(full[off:off + n])
+            off += n
+
+    def step(self, optimizer, params, grad_share, skip=()):
+        """Adam on this rank's share (the optimiser's own state tensors and hyper-parameters; its step counters advance on
+        every rank), then the all-gather of the stepped parameters.  ``skip``: indices of parameter tensors that have no
+        gradient this iteration (just replaced by the bookkeeping): not stepped, counters untouched."""
+        import math
+        by_param = {}
+        for gp in optimizer.param_groups:
+            for q in gp["params"]:
+                by_param[id(q)] = gp
+        items = []
+        for k, p in enumerate(params):
+            gp = by_param[id(p)]
+            st = optimizer.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            if k not in skip:
+                st["step"] = st["step"] + 1
+            items.append((gp, st))
+        pieces, _ = self.pieces(params)
+        pieces = [pc for pc in pieces if pc[0] not in skip]
+        if len(skip) == len(params):
+            return
+        dev = params[0].device
+        use_kernel = dev.type == "cuda" and all(_on_gpu_f32(p.detach(), optimizer.state[p]["exp_avg"], optimizer.state[p]["exp_avg_sq"]) for p in params if p.numel())
+        if use_kernel and pieces:
+            arr = (_lib.AdamTensor * 8)()
+            b1, b2 = items[pieces[0][0]][0]["betas"]
+            eps = float(items[pieces[0][0]][0]["eps"])
+            for n_, (k, a, c, n) in enumerate(pieces):
+                gp, st = items[k]
+                if tuple(gp["betas"]) != (b1, b2) or float(gp["eps"]) != eps or gp.get("weight_decay", 0) or gp.get("amsgrad", False):
+                    use_kernel = False
+                    break
+                t = arr[n_]
+                t.param = C.c_void_p(params[k].data_ptr() + 4 * a)
+                t.grad = C.c_void_p(grad_share.data_ptr() + 4 * c)
+                t.exp_avg = C.c_void_p(st["exp_avg"].data_ptr() + 4 * a)
+                t.exp_avg_sq = C.c_void_p(st["exp_avg_sq"].data_ptr() + 4 * a)
+                t.numel, t.step, t.lr = n, int(st["step"]), float(gp["lr"])
+            if use_kernel:
+                with _lib.on_device(dev):
+                    _lib.check(_lib.lib().lvdgs_adam_step(arr, len(pieces), float(b1), float(b2), eps, _lib.raw_stream(dev)), "lvdgs_adam_step (share)")
+        if not use_kernel:
+            for k, a, c, n in pieces:   # torch.optim.Adam's statements (no weight decay / amsgrad) on the slices
+                gp, st = items[k]
+                b1, b2 = gp["betas"]
+                step = float(st["step"])
+                g = grad_share[c:c + n]
+                pv = params[k].detach().reshape(-1)[a:a + n]
+                m, v = st["exp_avg"].reshape(-1)[a:a + n], st["exp_avg_sq"].reshape(-1)[a:a + n]
+                m.mul_(b1).add_(g, alpha=1 - b1)
+                v.mul_(b2).addcmul_(g, g, value=1 - b2)
+                denom = (v.sqrt() / math.sqrt(1 - b2 ** step)).add_(gp["eps"])
+                pv.addcdiv_(m, denom, value=-gp["lr"] / (1 - b1 ** step))
+        self._gather_into(params, "param")
+        self.stale = True
+
+    def sync_moments(self, optimizer, params):
+        """Bring every rank's moments up to date (no-op when they are)."""
+        if not self.stale:
+            return
+        for key in ("exp_avg", "exp_avg_sq"):
+            tensors = [optimizer.state[p][key] for p in params]
+            self._gather_into(tensors, key)
+        self.stale = False
 
 
 _P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
@@ -525,7 +670,8 @@ def view_loss(backend, viewpoint, pkg):
 
 
 def map_window(backend, current_window, prune=False, iters=1, up_pose=True, group=None, reducer: Optional[FlatReducer] = None,
-               render_fn=render, view_loss_fn=None, stats: Optional[Dict] = None, fused=True, aux_group=None, bands_ok: Optional[bool] = None):
+               render_fn=render, view_loss_fn=None, stats: Optional[Dict] = None, fused=True, aux_group=None, bands_ok: Optional[bool] = None,
+               sharded_adam: Optional[bool] = None):
     """``BackEnd.map(current_window, prune, iters, up_pose)`` (reference utils/slam_backend.py:153-390) with the
     iteration's views sharded over ``group``.  Returns ``gaussian_split`` of the last iteration like the reference.
     ``stats`` (optional dict) receives per-iteration records: loss, views of this rank, collective time.
@@ -542,11 +688,15 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
     ``bands_ok``: may window views be cut into bands of tile rows (several ranks)?  Only a loss that is a sum over pixels gated
     by the target's own validity masks survives that (``_BandView``): ``get_loss_mapping`` is one, so the default is True for the
     default ``view_loss_fn`` -- keyframes with a static mask excepted, as always -- and False for a caller's own, which then
-    says so itself (the CPU tests' float64 statement of the same loss does)."""
+    says so itself (the CPU tests' float64 statement of the same loss does).
+    ``sharded_adam`` (default: ``backend.shard_optimizer``, else False; several ranks only): the Gaussian Adam as reduce-scatter ->
+    every rank steps its share -> all-gather (``ShardedAdam``) instead of an all-reduce and the same step on every rank."""
     if len(current_window) == 0:
         return
     if bands_ok is None:
         bands_ok = view_loss_fn is None or view_loss_fn is view_loss
+    if sharded_adam is None:
+        sharded_adam = bool(getattr(backend, "shard_optimizer", False))
     view_loss_fn = view_loss if view_loss_fn is None else view_loss_fn
     rank, world = _world(group)
     reducer = reducer if reducer is not None else getattr(backend, "_lvdgs_reducer", None) or FlatReducer()
@@ -556,6 +706,16 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
         pass
     cfg = backend.config
     G = backend.gaussians
+    sharder = getattr(backend, "_lvdgs_sharder", None)
+    if sharded_adam and world > 1 and (sharder is None or sharder.group is not group):
+        sharder = ShardedAdam(group)
+        try:
+            backend._lvdgs_sharder = sharder
+        except Exception:
+            pass
+    if sharder is not None and not (sharded_adam and world > 1):
+        sharder.sync_moments(G.optimizer, G.parameters())   # back to the replicated step: every rank needs every moment
+        sharder = None
     viewpoint_stack = [backend.viewpoints[kf_idx] for kf_idx in current_window]
     frames_to_optimize = cfg["Training"]["pose_window"]
     window_set = set(current_window)
@@ -592,9 +752,13 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
         # bucket the all-reduce works on (no packing copy); the statistics' float pieces live there too
         plan = first = None
         N0 = G.get_xyz.shape[0]
+        pad = 0   # (sharded Adam: the parameter-gradient part of the bucket is a multiple of the world size)
         if world > 1:
             live = G.parameters()
-            plan = reducer.plan_floats([p.numel() for p in live] + [p.numel() for p in kf_params] + [N0, N0, 2 * N0 * len(split), 1],
+            if sharder is not None:
+                _, total_p, padded_p, _ = sharder.plan(live)
+                pad = padded_p - total_p
+            plan = reducer.plan_floats([p.numel() for p in live] + [pad] + [p.numel() for p in kf_params] + [N0, N0, 2 * N0 * len(split), 1],
                                        live[0].device)
             if vpass is not None:
                 first = {n: plan[k].view_as(p) for k, (n, p) in enumerate(zip(_PARAM_FIELDS, live))}
@@ -658,12 +822,17 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
                 small_group = aux_group if aux_group is not None else (getattr(backend, "shard_aux_group", None) or group)
                 (radii_red,), w_radii = reducer.max_ints([radii_max], dev, small_group, async_op=True)
                 small_works = [w for w in (w_radii, _max_bytes(flags, small_group, async_op=True)) if w is not None]
+            grad_share = None
             if not prune and world > 1:
-                tensors = [p.grad for p in params] + [p.grad for p in kf_params] + [norm_sum, vis_count, split_xy,
+                tensors = [p.grad for p in params] + [None] + [p.grad for p in kf_params] + [norm_sum, vis_count, split_xy,
                            loss_mapping.detach().reshape(1).float() if torch.is_tensor(loss_mapping) else None]
-                sizes = [p.numel() for p in params] + [p.numel() for p in kf_params] + [N, N, 2 * N * len(split), 1]
-                red = reducer.sum_floats(tensors, sizes, dev, group)
-                for p, g in zip(params + kf_params, red):
+                sizes = [p.numel() for p in params] + [pad] + [p.numel() for p in kf_params] + [N, N, 2 * N * len(split), 1]
+                n_par = sum(p.numel() for p in params)
+                red = reducer.sum_floats(tensors, sizes, dev, group, scatter=sharder, scatter_len=(n_par + pad) if sharder is not None else 0)
+                grad_share = reducer.share
+                for p, g in zip(params, red):
+                    p.grad = None if sharder is not None else g.view_as(p)   # (sharded: no rank holds the whole reduced gradient)
+                for p, g in zip(kf_params, red[len(params) + 1:]):
                     p.grad = g.view_as(p)
                 norm_sum, vis_count, split_xy = red[-4], red[-3], red[-2]
                 if stats is not None:
@@ -689,6 +858,8 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
             # they are still there when the next call's backward accumulates.  To keep that sum right across ranks
             # the gradients of this pass stay LOCAL (unreduced): the next pass reduces old + new together.
             if prune:
+                if sharder is not None:
+                    sharder.sync_moments(G.optimizer, G.parameters())   # pruning edits the moments per Gaussian
                 if n_window == cfg["Training"]["window_size"]:
                     prune_mode = cfg["Training"]["prune_mode"]
                     prune_coviz = cfg["Training"]["prune_num"]
@@ -718,6 +889,9 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
 
             update_gaussian = backend.iteration_count % backend.gaussian_update_every == backend.gaussian_update_offset
             gaussian_split = False
+            resetting = (backend.iteration_count % backend.gaussian_reset) == 0 and (not update_gaussian)
+            if sharder is not None and (update_gaussian or resetting):
+                sharder.sync_moments(G.optimizer, G.parameters())   # densification / the reset edit the moments per Gaussian
             if update_gaussian:
                 G.densify_and_prune(backend.opt_params.densify_grad_threshold, backend.gaussian_th, backend.gaussian_extent,
                                     backend.size_threshold)
@@ -730,7 +904,16 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
             if stats is not None and callable(stats.get("before_steps")):
                 stats["before_steps"](backend)   # tests look at the (reduced) gradients here
             if marks: marks.mark("bookkeeping")
-            G.optimizer.step()
+            if sharder is not None and grad_share is not None:
+                # A parameter tensor the bookkeeping has just replaced carries no gradient, and torch's Adam passes over it
+                # (all of them after a densification -- the reference's iteration then steps nothing --, the opacities after the
+                # reset of the non-visible): the same here.
+                now = G.parameters()
+                replaced = {k for k, (a, b) in enumerate(zip(params, now)) if a is not b}
+                if len(now) == len(params) and all(a.numel() == b.numel() for a, b in zip(params, now)):
+                    sharder.step(G.optimizer, now, grad_share, skip=replaced)
+            else:
+                G.optimizer.step()
             G.optimizer.zero_grad(set_to_none=True)
             G.update_learning_rate(backend.iteration_count)
             stepper = None

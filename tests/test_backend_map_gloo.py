@@ -47,7 +47,7 @@ def _half_blind(render_fn):
     return render
 
 
-def _run(group_world, policy="leftover", half_blind=False, real_window=False, aux_group=None):
+def _run(group_world, policy="leftover", half_blind=False, real_window=False, aux_group=None, sharded=False):
     """One run of ITERS iterations + the pruning pass; returns a dict of numpy results.  ``real_window``: the reference's
     window instead of the fixtures' -- 8 keyframes + 2 random older ones of 12 (configs/mono/KITTI/base_config.yaml:37,
     utils/slam_backend.py:275), two iterations, the first of them through the opacity reset of the non-visible."""
@@ -68,18 +68,18 @@ def _run(group_world, policy="leftover", half_blind=False, real_window=False, au
     be = tl._backend(sc, cfg)
     be.initialized = True
     be.shard_aux_group = aux_group
+    be.shard_optimizer = sharded      # (several ranks: the Gaussian Adam as reduce-scatter -> step of a share -> all-gather)
     for i, cam in enumerate(sc["cameras"]):
         be.viewpoints[i] = cam
     window = sc["window"]
     be.current_window = window
     be.keyframe_optimizers = sc["make_keyframe_optimizer"](be.viewpoints, window, cfg)
-    counts = []
-    sc["gaussians"].optimizer.register_step_pre_hook(lambda opt, a, k: counts.append(int(opt.param_groups[0]["params"][0].shape[0])))
+    counts = []   # Gaussians at every optimiser step (taken where map_window is about to step: the sharded step is not optimizer.step())
     if group_world == 1:
         # single process: draw the random keyframes the way the ranks do, so that the runs are comparable
         keyed = bm.random_view_indices
         bm.random_view_indices = lambda n, k, it, world, seed=0: keyed(n, k, it, 2, seed)
-    stats = {}
+    stats = {"before_steps": lambda backend: counts.append(int(backend.gaussians.get_xyz.shape[0]))}
     try:
         bm.map_window(be, window, iters=2 if real_window else ITERS, render_fn=dense_render, view_loss_fn=tl._cpu_view_loss, stats=stats, bands_ok=True)
         n_mid = be.gaussians.get_xyz.shape[0]
@@ -88,7 +88,7 @@ def _run(group_world, policy="leftover", half_blind=False, real_window=False, au
         bm.map_window(be, window, prune=True, render_fn=dense_render, view_loss_fn=tl._cpu_view_loss, bands_ok=True)
         # one more iteration after the pruning pass: its (unreduced) gradients must have been dropped with the
         # replaced parameters, or carried consistently
-        bm.map_window(be, window, iters=1, render_fn=dense_render, view_loss_fn=tl._cpu_view_loss, bands_ok=True)
+        bm.map_window(be, window, iters=1, render_fn=dense_render, view_loss_fn=tl._cpu_view_loss, bands_ok=True, stats=stats)
     except _Done:
         pass
     finally:
@@ -130,7 +130,7 @@ def _digest(res):
     return h.hexdigest()
 
 
-def _worker(rank, world, port, q, policy, half_blind, real_window=False):
+def _worker(rank, world, port, q, policy, half_blind, real_window=False, sharded=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     if world >= 8:
@@ -140,7 +140,7 @@ def _worker(rank, world, port, q, policy, half_blind, real_window=False):
         torch.manual_seed(100 + rank)   # the ranks' global generators differ on purpose: nothing may depend on them
         # the small MAX collectives on a communicator of their own (map_window's aux_group), in the runs with >= 4 ranks
         aux = dist.new_group() if world >= 4 else None
-        res = _run(world, policy, half_blind, real_window, aux)
+        res = _run(world, policy, half_blind, real_window, aux, sharded)
         q.put((rank, _digest(res), res))
     finally:
         dist.destroy_process_group()
@@ -156,12 +156,14 @@ def _single_process(half_blind):
     return _SINGLE[half_blind]
 
 
-@pytest.mark.parametrize("world,policy,half_blind", [(2, "leftover", False), (4, "leftover", False), (3, "all", True)])   # (two ranks, every view in bands: the GPU twin of this test)
-def test_ranks_stay_bit_identical_and_match_the_single_process_run(world, policy, half_blind):
+# (two ranks, every view in bands: the GPU twin of this test.  sharded: the Gaussian Adam as reduce-scatter -> every rank steps its
+# share -> all-gather, through a densification, the opacity reset of the non-visible and the pruning pass)
+@pytest.mark.parametrize("world,policy,half_blind,sharded", [(4, "leftover", False, False), (3, "all", True, False), (2, "leftover", False, True), (3, "all", True, True)])
+def test_ranks_stay_bit_identical_and_match_the_single_process_run(world, policy, half_blind, sharded):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + 7 * world + (3 if policy == "all" else 0) + (1 if half_blind else 0)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, policy, half_blind)) for r in range(world)]
+    port = 29500 + (os.getpid() % 2000) + 7 * world + (3 if policy == "all" else 0) + (1 if half_blind else 0) + (40 if sharded else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, policy, half_blind, False, sharded)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted([q.get(timeout=900) for _ in range(world)], key=lambda r: r[0])
