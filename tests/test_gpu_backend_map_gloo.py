@@ -29,7 +29,7 @@ def _paths():
     import lvdgs  # noqa: F401
 
 
-def _run(group_world, policy="leftover"):
+def _run(group_world, policy="leftover", sharded=False):
     _paths()
     import test_loop_golden as tl
     from loop_scene import build_scene, loop_config
@@ -39,22 +39,22 @@ def _run(group_world, policy="leftover"):
     sc = build_scene("cuda")
     be = tl._backend(sc, cfg)
     be.initialized = True
+    be.shard_optimizer = sharded   # (the Gaussian Adam as reduce-scatter -> lvdgs_adam_step on this rank's share -> all-gather)
     for i, cam in enumerate(sc["cameras"]):
         be.viewpoints[i] = cam
     window = sc["window"]
     be.current_window = window
     be.keyframe_optimizers = sc["make_keyframe_optimizer"](be.viewpoints, window, cfg)
     counts = []
-    sc["gaussians"].optimizer.register_step_pre_hook(lambda opt, a, k: counts.append(int(opt.param_groups[0]["params"][0].shape[0])))
     if group_world == 1:
         keyed = bm.random_view_indices
         bm.random_view_indices = lambda n, k, it, world, seed=0: keyed(n, k, it, 2, seed)
-    stats = {}
+    stats = {"before_steps": lambda backend: counts.append(int(backend.gaussians.get_xyz.shape[0]))}
     try:
         bm.map_window(be, window, iters=ITERS, stats=stats)
         n_mid = be.gaussians.get_xyz.shape[0]
         bm.map_window(be, window, prune=True)
-        bm.map_window(be, window, iters=1)
+        bm.map_window(be, window, iters=1, stats=stats)
     finally:
         if group_world == 1:
             bm.random_view_indices = keyed
@@ -73,7 +73,7 @@ def _run(group_world, policy="leftover"):
         out[f"exp{i}"] = np.array([float(cam.exposure_a.detach()), float(cam.exposure_b.detach())])
     for kf in window:
         out[f"occ{kf}"] = cpu(be.occ_aware_visibility[kf])
-    out["views_per_iteration"] = np.array([len(r["views"]) for r in stats["iterations"]])
+    out["views_per_iteration"] = np.array([len(r["views"]) for r in stats["iterations"][:ITERS]])
     out["used_view_pass"] = np.array(int(getattr(be, "_lvdgs_view_pass", None) is not None))
     return out
 
@@ -87,14 +87,14 @@ def _digest(res):
     return h.hexdigest()
 
 
-def _worker(rank, world, port, q, policy):
+def _worker(rank, world, port, q, policy, sharded=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.manual_seed(100 + rank)
-        res = _run(world, policy)
+        res = _run(world, policy, sharded)
         q.put((rank, _digest(res), res))
     finally:
         dist.destroy_process_group()
@@ -103,15 +103,16 @@ def _worker(rank, world, port, q, policy):
 _SINGLE = {}
 
 
-@pytest.mark.parametrize("world,policy", [(2, "leftover"), (2, "all")])
-def test_ranks_on_one_gpu_stay_bit_identical_and_match_the_single_process_run(world, policy):
+@pytest.mark.parametrize("world,policy,sharded", [(2, "leftover", False), (2, "all", True)])
+def test_ranks_on_one_gpu_stay_bit_identical_and_match_the_single_process_run(world, policy, sharded):
     """world 2: whole views (six views, three each), and EVERY view cut into two bands of tile rows, one per rank (the band
-    path of the rasterizer, lvdgs_args.tile_row_*, the split views' statistics, the byte-wise flag OR).  (Three ranks with a
-    band each were run by the builder too; a third interpreter start costs the suite half a minute.)"""
+    path of the rasterizer, lvdgs_args.tile_row_*, the split views' statistics, the byte-wise flag OR) -- the latter with the
+    Gaussian Adam sharded (backend_map.ShardedAdam: reduce-scatter, lvdgs_adam_step on this rank's sub-ranges, all-gather).
+    (Three ranks with a band each were run by the builder too; a third interpreter start costs the suite half a minute.)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 31500 + (os.getpid() % 2000) + 11 * world
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, policy)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port + (5 if sharded else 0), q, policy, sharded)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted([q.get(timeout=900) for _ in range(world)], key=lambda r: r[0])
