@@ -47,21 +47,27 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int N, int gx, const ui
 // not serialise thousands of atomics on one lane.
 
 // (Two-call API: clears what the later kernels of the frame accumulate into, n_touched and the tile-sort queue.)
-template <int GROUP_THREADS, int PER>
+template <int GROUP_THREADS, int OWNERS, int PER>
 __global__ void __launch_bounds__(GROUP_THREADS) count_pairs_kernel(int N, int gx, int T, const uint4 *__restrict__ rect,
                                                                    uint32_t *__restrict__ hist, int32_t *__restrict__ n_touched,
                                                                    uint32_t *__restrict__ queue_counts) {
-    constexpr int GROUP_CHUNK = GROUP_THREADS * PER;
+    constexpr int GROUP_CHUNK = OWNERS * PER;
+    constexpr bool HELPERS = GROUP_THREADS > OWNERS;
+    static_assert(!HELPERS || PER == 1, "helper waves: one Gaussian per owner thread");
     extern __shared__ uint32_t s_tile[];
+    __shared__ BigRectQueue s_big;
     for (int t = threadIdx.x; t < T; t += GROUP_THREADS) s_tile[t] = 0u;
     if (blockIdx.x == 0 && threadIdx.x < 64) queue_counts[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) s_big.count = 0u;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < PER; k++) {
-        const int i = blockIdx.x * GROUP_CHUNK + k * GROUP_THREADS + (int)threadIdx.x;
-        if (i < N) n_touched[i] = 0;
-        const uint4 r = i < N ? rect[i] : make_uint4(0u, 0u, 0u, 0u);
-        for_each_pair_of_rect(r, i, gx, 0u, [&](int tile, uint32_t, uint32_t) { atomicAdd(&s_tile[tile], 1u); });
+        const int i = blockIdx.x * GROUP_CHUNK + k * OWNERS + (int)threadIdx.x;
+        const bool mine = (int)threadIdx.x < OWNERS && i < N;
+        if (mine) n_touched[i] = 0;
+        const uint4 r = mine ? rect[i] : make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (HELPERS) for_each_pair_of_rect_wg(r, i, gx, 0u, s_big, [&](int tile, uint32_t, uint32_t) { atomicAdd(&s_tile[tile], 1u); });
+        else for_each_pair_of_rect(r, i, gx, 0u, [&](int tile, uint32_t, uint32_t) { atomicAdd(&s_tile[tile], 1u); });
     }
     __syncthreads();
     uint32_t *row = hist + (size_t)blockIdx.x * T;
@@ -263,7 +269,7 @@ __global__ void __launch_bounds__(1024) group_tilescan_kernel(int T, const uint3
 #ifndef LVDGS_SCATTER_XCD
 #define LVDGS_SCATTER_XCD 1   // A/B builds: 0 = workgroup b takes chunk b
 #endif
-template <int GROUP_THREADS, int PER, bool SLOT_SCAN>
+template <int GROUP_THREADS, int OWNERS, int PER, bool SLOT_SCAN>
 __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int gx, int T, const uint4 *__restrict__ rect,
                                                                      const uint32_t *__restrict__ hist,
                                                                      const uint2 *__restrict__ ranges, uint32_t capacity,
@@ -271,10 +277,15 @@ __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int
                                                                      unsigned long long *__restrict__ keys64,
                                                                      const uint32_t *__restrict__ tt, const uint32_t *__restrict__ chunk_sums,
                                                                      uint32_t *__restrict__ slot_base, uint8_t *__restrict__ pair_valid) {
-    constexpr int GROUP_CHUNK = GROUP_THREADS * PER;
+    constexpr int GROUP_CHUNK = OWNERS * PER;
+    constexpr bool HELPERS = GROUP_THREADS > OWNERS;   // waves without a Gaussian of their own: they help with the large rectangles
+    static_assert(!HELPERS || PER == 1, "helper waves: one Gaussian per owner thread");
     extern __shared__ uint32_t s_tile[];
     __shared__ uint32_t s_scan[33];
     __shared__ uint32_t s_slots[2];
+    __shared__ BigRectQueue s_big;
+    const bool owner = (int)threadIdx.x < OWNERS;
+    if (threadIdx.x == 0) s_big.count = 0u;
     const int chunk = LVDGS_SCATTER_XCD ? xcd_contiguous_chunk((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     const uint32_t *row = hist + (size_t)chunk * T;
     // this thread's Gaussians: requested before anything else (their first use is behind several workgroup barriers, which
@@ -283,9 +294,9 @@ __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int
     uint32_t my_depth[PER];
 #pragma unroll
     for (int k = 0; k < PER; k++) {
-        const int i = chunk * GROUP_CHUNK + k * GROUP_THREADS + (int)threadIdx.x;
-        my_rect[k] = i < N ? rect[i] : make_uint4(0u, 0u, 0u, 0u);
-        my_depth[k] = i < N ? depth_bits[i] : 0u;
+        const int i = chunk * GROUP_CHUNK + k * OWNERS + (int)threadIdx.x;
+        my_rect[k] = (owner && i < N) ? rect[i] : make_uint4(0u, 0u, 0u, 0u);
+        my_depth[k] = (owner && i < N) ? depth_bits[i] : 0u;
     }
     for (int t = threadIdx.x; t < T; t += GROUP_THREADS) s_tile[t] = ranges[t].x + row[t];  // (empty tiles are never visited)
     uint32_t slots_lo = 0, slots_hi = 0;   // the chunk's Gaussians' gradient slots: [lo, hi)
@@ -295,7 +306,7 @@ __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int
         const int base = chunk * GROUP_CHUNK + (int)threadIdx.x * PER;
         uint32_t v[PER], mine = 0;
 #pragma unroll
-        for (int k = 0; k < PER; k++) { v[k] = base + k < N ? tt[base + k] : 0u; mine += v[k]; }
+        for (int k = 0; k < PER; k++) { v[k] = (owner && base + k < N) ? tt[base + k] : 0u; mine += v[k]; }
         uint32_t prefix;
         scan_workgroup<GROUP_THREADS>(before, s_scan, &prefix);  // only the total is of interest
         __syncthreads();                     // s_scan is used again
@@ -303,7 +314,7 @@ __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int
         uint32_t run = scan_workgroup<GROUP_THREADS>(mine, s_scan, &total) + prefix;
 #pragma unroll
         for (int k = 0; k < PER; k++) {
-            if (base + k < N) slot_base[base + k] = run;
+            if (owner && base + k < N) slot_base[base + k] = run;
             run += v[k];
         }
         slots_lo = prefix; slots_hi = prefix + total;
@@ -327,14 +338,20 @@ __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < PER; k++) {
-        const int i = chunk * GROUP_CHUNK + k * GROUP_THREADS + (int)threadIdx.x;
+        const int i = chunk * GROUP_CHUNK + k * OWNERS + (int)threadIdx.x;
         const uint4 r = my_rect[k];
-        for_each_pair_of_rect(r, i, gx, my_depth[k], [&](int tile, uint32_t id, uint32_t depth) {
+        auto place = [&](int tile, uint32_t id, uint32_t depth) {
             const uint32_t pos = atomicAdd(&s_tile[tile], 1u);
             // the tile sort's key, so that it need not gather depths; beyond the caller's capacity: dropped (the caller
-            // is told and re-runs).  (id, depth: this thread's own Gaussian, or the one its wave walks together.)
+            // is told and re-runs).  (id, depth: this thread's own Gaussian, or the one its wave / workgroup walks together.)
+#ifdef LVDGS_DIAG_SCATTER_NO_STORE   // diagnostic build: what the walk and the LDS atomics cost without the key stores (results are garbage)
+            if (pos == 0xffffffffu) keys64[0] = ((unsigned long long)depth << 32) | (unsigned long long)id;
+#else
             if (pos < capacity) keys64[pos] = ((unsigned long long)depth << 32) | (unsigned long long)id;
-        });
+#endif
+        };
+        if constexpr (HELPERS) for_each_pair_of_rect_wg(r, i, gx, my_depth[k], s_big, place);
+        else for_each_pair_of_rect(r, i, gx, my_depth[k], place);
     }
 }
 
@@ -370,10 +387,10 @@ int launch_group_count(const lvdgs_args &a, const GeomView &g, const ImageView &
     const size_t lds = (size_t)T * sizeof(uint32_t);
     static unsigned char done[GROUP_SHAPES][16];
     ProfScope ps("group_count", s);
-    if (int e = group_dispatch(group_shape_for(N), [&](auto threads_, auto per_, int d) {
-            constexpr int THREADS = decltype(threads_)::value, PER = decltype(per_)::value;
-            if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&count_pairs_kernel<THREADS, PER>), GROUP_MAX_TILES * 4, done[d])) return e;
-            hipLaunchKernelGGL((count_pairs_kernel<THREADS, PER>), dim3(nchunks), dim3(THREADS), lds, s, N, gx, T, (const uint4 *)g.rect, w.group_hist,
+    if (int e = group_dispatch(group_shape_for(N), [&](auto threads_, auto owners_, auto per_, int d) {
+            constexpr int THREADS = decltype(threads_)::value, OWNERS = decltype(owners_)::value, PER = decltype(per_)::value;
+            if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&count_pairs_kernel<THREADS, OWNERS, PER>), GROUP_MAX_TILES * 4, done[d])) return e;
+            hipLaunchKernelGGL((count_pairs_kernel<THREADS, OWNERS, PER>), dim3(nchunks), dim3(THREADS), lds, s, N, gx, T, (const uint4 *)g.rect, w.group_hist,
                                a.n_touched, im.long_count);
             return (int)LVDGS_OK;
         })) return e;
@@ -420,9 +437,9 @@ int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView
                            (const uint32_t *)w.chunk_sums, g.slot_base, pair_valid);
         return (int)LVDGS_OK;
     };
-    if (int e = group_dispatch(group_shape_for(N), [&](auto threads_, auto per_, int d) {
-            constexpr int THREADS = decltype(threads_)::value, PER = decltype(per_)::value;
-            return slot_scan ? launch(&scatter_pairs_kernel<THREADS, PER, true>, 2 * d, THREADS) : launch(&scatter_pairs_kernel<THREADS, PER, false>, 2 * d + 1, THREADS);
+    if (int e = group_dispatch(group_shape_for(N), [&](auto threads_, auto owners_, auto per_, int d) {
+            constexpr int THREADS = decltype(threads_)::value, OWNERS = decltype(owners_)::value, PER = decltype(per_)::value;
+            return slot_scan ? launch(&scatter_pairs_kernel<THREADS, OWNERS, PER, true>, 2 * d, THREADS) : launch(&scatter_pairs_kernel<THREADS, OWNERS, PER, false>, 2 * d + 1, THREADS);
         })) return e;
     LVDGS_LAUNCH_CHECK("group_scatter", a.debug, s);
     return LVDGS_OK;

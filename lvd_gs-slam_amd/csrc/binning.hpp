@@ -16,6 +16,10 @@ namespace lvdgs {
 // projection's reach tests, the counting and the scatter are all work per Gaussian on a chip 60 % idle.  The chunk is chosen so
 // that a map of up to 2^19 Gaussians makes 256-512 workgroups (the scan of the count matrix holds up to 512 rows in registers).
 constexpr int GROUP_THREADS_MAX = 1024;
+#ifndef LVDGS_GROUP_HELPER_THREADS
+#define LVDGS_GROUP_HELPER_THREADS 1024   // A/B builds: 256 = no helper waves
+#endif
+constexpr int GROUP_HELPER_THREADS = LVDGS_GROUP_HELPER_THREADS;   // threads launched per workgroup of the 256-Gaussian shape
 template <int V> struct template_int { static constexpr int value = V; };
 struct GroupShape { int threads, per; };   // Gaussians per workgroup = threads x per
 __host__ __device__ constexpr GroupShape group_shape_default(int N) {
@@ -23,15 +27,17 @@ __host__ __device__ constexpr GroupShape group_shape_default(int N) {
          : N <= (1 << 20) ? GroupShape{1024, 2} : GroupShape{1024, 4};
 }
 GroupShape group_shape_for(int N);   // binning.hip: the default, or a -DLVDGS_GROUP_CHUNK=256/512/1024/2048/4096 build (A/B measurements)
-// the instantiations of the grouping kernels: f(THREADS, PER as integral constants, index of the instantiation)
+// the instantiations of the grouping kernels: f(THREADS launched, OWNERS = threads that hold a Gaussian, PER as integral constants,
+// index of the instantiation).  The smallest shape launches 1024 threads for its 256 Gaussians: the twelve waves without a
+// Gaussian of their own are HELPERS in the walks over rectangles of more than 64 tiles (for_each_pair_of_rect_wg).
 template <typename F>
 inline int group_dispatch(GroupShape g, F &&f) {
     template_int<1> one; template_int<2> two; template_int<4> four;
-    if (g.threads == 256) return f(template_int<256>{}, one, 0);
-    if (g.threads == 512) return f(template_int<512>{}, one, 1);
-    if (g.per == 1) return f(template_int<1024>{}, one, 2);
-    if (g.per == 2) return f(template_int<1024>{}, two, 3);
-    return f(template_int<1024>{}, four, 4);
+    if (g.threads == 256) return f(template_int<GROUP_HELPER_THREADS>{}, template_int<256>{}, one, 0);
+    if (g.threads == 512) return f(template_int<512>{}, template_int<512>{}, one, 1);
+    if (g.per == 1) return f(template_int<1024>{}, template_int<1024>{}, one, 2);
+    if (g.per == 2) return f(template_int<1024>{}, template_int<1024>{}, two, 3);
+    return f(template_int<1024>{}, template_int<1024>{}, four, 4);
 }
 constexpr int GROUP_SHAPES = 5;
 constexpr int GROUP_MAX_TILES = 16384;  // 64 KiB of LDS counters
@@ -69,6 +75,49 @@ __device__ __forceinline__ void for_each_pair_of_rect(const uint4 r, int i, int 
             const int ty = div_by(t, bw, inv_w), tx = t - ty * bw;
             const int block = div_by(ty, g.bh, inv_gh) * 8 + div_by(tx, g.bw, inv_gw);   // = g.block_of(tx, ty)
             if ((bm >> block) & 1ull) visit((by0 + ty) * gx + bx0 + tx, bi, bp);
+        }
+    }
+}
+
+// The same for a workgroup with HELPER waves (more threads than Gaussians: maps of up to 2^17 Gaussians, whose 256-Gaussian chunks
+// are four waves each -- 100 k Gaussians are 1563 waves for 1024 SIMDs, and when they are large, a wave's walk over its
+// rectangles of hundreds of tiles, one Gaussian after the other with a returning LDS atomic per round, is part of what the kernel's
+// time is: scatter 98.6 -> 91.1 us, projection + counting 62.0 -> 57.4 us on the opaque-surface workload with the helpers, same box).  Rectangles of up to 64 tiles are walked by their owner as
+// above; the larger ones are queued in LDS and taken by ALL the workgroup's waves in turn.  Reached by every thread of the
+// workgroup (one barrier); the queue holds one item per owner and is used ONCE per kernel (one Gaussian per owner thread): the
+// caller zeroes q.count in front of a barrier of its own.
+struct BigRectQueue {
+    uint32_t count;
+    struct Item { uint32_t rx, ry, mlo, mhi, id, payload; } items[256];
+};
+template <typename F>
+__device__ __forceinline__ void for_each_pair_of_rect_wg(const uint4 r, int i, int gx, uint32_t payload, BigRectQueue &q, F visit) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = blockDim.x >> 6;
+    const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
+    const int w = x1 - x0, area = w * (y1 - y0);
+    if (area > GROUP_BIG_RECT) {
+        const uint32_t at = atomicAdd(&q.count, 1u);
+        q.items[at] = BigRectQueue::Item{r.x, r.y, r.z, r.w, (uint32_t)i, payload};
+    }
+    if (area > 0 && area <= GROUP_BIG_RECT) {
+        uint64_t m = (uint64_t)r.z | ((uint64_t)r.w << 32);
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++, m >>= 1)
+                if (m & 1ull) visit(y * gx + x, (uint32_t)i, payload);
+    }
+    __syncthreads();
+    const int n = (int)q.count;
+    for (int it = wave; it < n; it += waves) {
+        const BigRectQueue::Item b = q.items[it];
+        const int bx0 = (int)(b.rx & 0xffffu), by0 = (int)(b.ry & 0xffffu), bw = (int)(b.rx >> 16) - bx0, bh = (int)(b.ry >> 16) - by0;
+        const int barea = bw * bh;
+        const uint64_t bm = (uint64_t)b.mlo | ((uint64_t)b.mhi << 32);
+        const RectBlocks g(bw, bh);
+        const float inv_w = __builtin_amdgcn_rcpf((float)bw), inv_gw = __builtin_amdgcn_rcpf((float)g.bw), inv_gh = __builtin_amdgcn_rcpf((float)g.bh);
+        for (int t = lane; t < barea; t += 64) {
+            const int ty = div_by(t, bw, inv_w), tx = t - ty * bw;
+            const int block = div_by(ty, g.bh, inv_gh) * 8 + div_by(tx, g.bw, inv_gw);
+            if ((bm >> block) & 1ull) visit((by0 + ty) * gx + bx0 + tx, b.id, b.payload);
         }
     }
 }

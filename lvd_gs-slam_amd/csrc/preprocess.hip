@@ -218,32 +218,38 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(FwdParams p) {
 // row of the [chunk][tile] count matrix and the chunk's pair total -- the grouping's first kernel and its re-read of
 // every rectangle are gone from the single-call forward (lvdgs_forward).  Also clears what the later kernels of the
 // frame accumulate into (n_touched, the tile-sort queue counters).
-template <int GROUP_THREADS, int PER>
+template <int GROUP_THREADS, int OWNERS, int PER>
 __global__ void __launch_bounds__(GROUP_THREADS, 8) preprocess_count_kernel(FwdParams p, int T, uint32_t *__restrict__ hist,
                                                                         uint32_t *__restrict__ chunk_sums, int32_t *__restrict__ n_touched,
                                                                         uint32_t *__restrict__ queue_counts) {
+    constexpr bool HELPERS = GROUP_THREADS > OWNERS;   // waves without a Gaussian of their own: they help with the large rectangles (binning.hpp)
+    static_assert(!HELPERS || PER == 1, "helper waves: one Gaussian per owner thread");
     extern __shared__ uint32_t s_tile[];
     __shared__ uint32_t s_sum[GROUP_THREADS / 64];
+    __shared__ BigRectQueue s_big;
+    const bool owner = (int)threadIdx.x < OWNERS;
     // the first Gaussian's values are on their way while the counters are cleared
-    const int i_first = blockIdx.x * (GROUP_THREADS * PER) + (int)threadIdx.x;
+    const int i_first = blockIdx.x * (OWNERS * PER) + (int)threadIdx.x;
     RawGaussian raw{};
-    if (i_first < p.N) raw = load_raw(p, i_first);
+    if (owner && i_first < p.N) raw = load_raw(p, i_first);
     for (int t = threadIdx.x; t < T; t += GROUP_THREADS) s_tile[t] = 0u;
     if (blockIdx.x == 0 && threadIdx.x < 64) queue_counts[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) s_big.count = 0u;
     __syncthreads();
     uint32_t mine = 0;
 #pragma unroll 1
     for (int k = 0; k < PER; k++) {
-        const int i = blockIdx.x * (GROUP_THREADS * PER) + k * GROUP_THREADS + (int)threadIdx.x;
+        const int i = blockIdx.x * (OWNERS * PER) + k * OWNERS + (int)threadIdx.x;
         uint32_t tiles = 0;
         uint4 rect = make_uint4(0u, 0u, 0u, 0u);
-        if (i < p.N) {
+        if (owner && i < p.N) {
             if (k > 0) raw = load_raw(p, i);
             preprocess_one(p, i, raw, tiles, rect);
             n_touched[i] = 0;
         }
         mine += tiles;
-        for_each_pair_of_rect(rect, i, p.cam.gx, 0u, [&](int tile, uint32_t, uint32_t) { atomicAdd(&s_tile[tile], 1u); });
+        if constexpr (HELPERS) for_each_pair_of_rect_wg(rect, i, p.cam.gx, 0u, s_big, [&](int tile, uint32_t, uint32_t) { atomicAdd(&s_tile[tile], 1u); });
+        else for_each_pair_of_rect(rect, i, p.cam.gx, 0u, [&](int tile, uint32_t, uint32_t) { atomicAdd(&s_tile[tile], 1u); });
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mine += (uint32_t)__shfl_xor((int)mine, off, 64);
@@ -1049,10 +1055,10 @@ int launch_preprocess_count(const lvdgs_args &a, const GeomView &g, const ImageV
     const size_t lds = (size_t)T * sizeof(uint32_t);
     static unsigned char done[GROUP_SHAPES][16];
     ProfScope ps("preprocess_fwd", s);
-    if (int e = group_dispatch(group_shape_for(N), [&](auto threads_, auto per_, int d) {
-            constexpr int THREADS = decltype(threads_)::value, PER = decltype(per_)::value;
-            if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&preprocess_count_kernel<THREADS, PER>), GROUP_MAX_TILES * 4, done[d])) return e;
-            hipLaunchKernelGGL((preprocess_count_kernel<THREADS, PER>), dim3(nchunks), dim3(THREADS), lds, s, p, T, w.group_hist, w.chunk_sums, a.n_touched,
+    if (int e = group_dispatch(group_shape_for(N), [&](auto threads_, auto owners_, auto per_, int d) {
+            constexpr int THREADS = decltype(threads_)::value, OWNERS = decltype(owners_)::value, PER = decltype(per_)::value;
+            if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&preprocess_count_kernel<THREADS, OWNERS, PER>), GROUP_MAX_TILES * 4, done[d])) return e;
+            hipLaunchKernelGGL((preprocess_count_kernel<THREADS, OWNERS, PER>), dim3(nchunks), dim3(THREADS), lds, s, p, T, w.group_hist, w.chunk_sums, a.n_touched,
                                im.long_count);
             return (int)LVDGS_OK;
         })) return e;
