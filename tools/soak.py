@@ -22,7 +22,9 @@ dev = torch.device("cuda", 0)
 pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False)
 
 model, cam, _, (N, W, H) = bench.build_scene("kitti07_geom", 0, dev)
-s = TrackingSession(cam, model, bench.CONFIG, pipe, torch.zeros(3, device=dev))
+# converged_threshold < 0: the sticky "converged" flag is never raised, so EVERY iteration's pose step is applied (round 3's soak
+# converged after a few dozen iterations and soaked render + backward with a no-op optimiser step behind them)
+s = TrackingSession(cam, model, bench.CONFIG, pipe, torch.zeros(3, device=dev), converged_threshold=-1.0)
 for _ in range(50):
     s.step()
 torch.cuda.synchronize()
@@ -39,8 +41,10 @@ prev = (0, 0.0)
 for k, t, loss, ok in marks:
     print(f"tracking: iterations {prev[0]:6d}..{k:6d}: {1e3 * (t - prev[1]) / (k - prev[0]):.4f} ms each, loss {loss:.6f}, pose gradient finite: {ok}")
     prev = (k, t)
-print(f"tracking: device memory in use {mem0 / 2**20:.1f} MiB -> {mem1 / 2**20:.1f} MiB")
-assert mem1 == mem0 and all(ok for *_, ok in marks)
+applied = s.finish()
+print(f"tracking: device memory in use {mem0 / 2**20:.1f} MiB -> {mem1 / 2**20:.1f} MiB; pose steps applied {applied} of {T + 50} enqueued "
+      f"(pose-only backward: {s.pose_only}); |T| {float(s.T.norm()):.4f}")
+assert mem1 == mem0 and all(ok for *_, ok in marks) and applied == T + 50 and bool(torch.isfinite(s.R).all())
 
 model, _, _, _ = bench.build_scene("kitti07_geom", 0, dev)
 be, window = bench.build_window("kitti07_geom", 12, dev, model, n_window=8)
