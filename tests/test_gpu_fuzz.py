@@ -29,7 +29,7 @@ def _case(rng):
     return c
 
 
-@pytest.mark.parametrize("case_seed", list(range(int(os.environ.get("LVDGS_FUZZ_CASES", "40")))))  # more: set the variable
+@pytest.mark.parametrize("case_seed", list(range(int(os.environ.get("LVDGS_FUZZ_CASES", "80")))))  # more: set the variable
 def test_random_scene_matches_oracle(case_seed):
     _check_case(_case(np.random.default_rng(1000 + case_seed)))
 
