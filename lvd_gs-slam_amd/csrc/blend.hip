@@ -336,6 +336,15 @@ __device__ __forceinline__ float fma_rotated(float g, float w, float acc) {  // 
 #ifndef LVDGS_BWD_NB
 #define LVDGS_BWD_NB 8   // survivors per batch of the backward pass: 8 or 4 (A/B builds)
 #endif
+#ifdef LVDGS_DIAG_PHASES
+// diagnostic build: where the workgroup at the head of the order (the longest list) spends its time, in shader clock ticks of wave 0:
+// [0] prologue, [1] staging up to its barrier, [2] test + survivor batches, [3] wait for the other waves, [4] flush, [5] rounds, [6] survivors of wave 0, [7] launches
+__device__ unsigned long long g_phase_diag[8];
+// ... and of EVERY workgroup of the last launch: start, end (s_memrealtime: 100 MHz, one clock for the chip), survivors of its four waves,
+// list length, HW_ID, XCC_ID
+__device__ unsigned long long g_wg_diag[8192][4];
+__device__ unsigned g_wg_surv[8192];
+#endif
 #ifdef LVDGS_DIAG_FILL
 // diagnostic build (tools/fill_diag.py): survivors, splat batches, full batches, (wave, round) pairs with survivors, summed over launches
 __device__ unsigned long long g_fill_diag[4];
@@ -387,6 +396,12 @@ __global__ void __launch_bounds__(256, POSE_ONLY ? (DEPTH_GRAD ? 6 : LVDGS_BWD_W
     const float rx0 = (float)qx0, ry0 = (float)qy0, rx1 = (float)(qx0 + 7), ry1 = (float)(qy0 + 7);
     const size_t pix = (size_t)py * p.W + px, P = (size_t)p.W * p.H;
 
+#ifdef LVDGS_DIAG_PHASES
+    const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0 && blockIdx.x < 8192) g_wg_surv[blockIdx.x] = 0u;
+    unsigned long long ph_t = __builtin_amdgcn_s_memtime(), ph[7] = {0, 0, 0, 0, 0, 0, 0};
+    auto ph_mark = [&](int k) { const unsigned long long n = __builtin_amdgcn_s_memtime(); ph[k] += n - ph_t; ph_t = n; };
+#endif
     const uint2 range = p.ranges[tile];
     const float T_final = inside ? p.final_T[pix] : 0.f;
     const uint32_t my_last = inside ? p.n_contrib[pix] : 0u;
@@ -452,6 +467,9 @@ __global__ void __launch_bounds__(256, POSE_ONLY ? (DEPTH_GRAD ? 6 : LVDGS_BWD_W
 #ifdef LVDGS_DIAG_FILL
     unsigned diag_surv = 0, diag_batches = 0, diag_full = 0, diag_rounds = 0;
 #endif
+#ifdef LVDGS_DIAG_PHASES
+    ph_mark(0);
+#endif
     for (int r = rounds - 1; r >= 0; r--) {
         const int base = r * BR;
         const int cnt = min(BR, todo - base);
@@ -466,6 +484,9 @@ __global__ void __launch_bounds__(256, POSE_ONLY ? (DEPTH_GRAD ? 6 : LVDGS_BWD_W
             sh.slot[tid] = pair_slot(p, id, tx, ty);
         }
         __syncthreads();
+#ifdef LVDGS_DIAG_PHASES
+        ph_mark(1); ph[5]++;
+#endif
         uint64_t wrote = 0ull;
         if (base < wave_last) {   // (a wave none of whose pixels got this far has nothing to test: on opaque surfaces two thirds of the (wave, round) pairs)
             bool keep = false;
@@ -476,6 +497,9 @@ __global__ void __launch_bounds__(256, POSE_ONLY ? (DEPTH_GRAD ? 6 : LVDGS_BWD_W
             uint64_t live = __ballot(keep);
             const uint32_t rel_last = my_last > (uint32_t)base ? my_last - (uint32_t)base : 0u;  // entries below this position composited
             wrote = live;
+#ifdef LVDGS_DIAG_PHASES
+            ph[6] += (unsigned long long)__popcll(live);
+#endif
 #ifdef LVDGS_DIAG_FILL
             diag_surv += (unsigned)__popcll(live); diag_rounds += live ? 1u : 0u;
 #endif
@@ -604,7 +628,13 @@ __global__ void __launch_bounds__(256, POSE_ONLY ? (DEPTH_GRAD ? 6 : LVDGS_BWD_W
             }
         }
         if (lane == 0) sh.mask[wave] = wrote;
+#ifdef LVDGS_DIAG_PHASES
+        ph_mark(2);
+#endif
         __syncthreads();
+#ifdef LVDGS_DIAG_PHASES
+        ph_mark(3);
+#endif
         if (tid < cnt) {
             float acc[ACC];
 #pragma unroll
@@ -634,7 +664,25 @@ __global__ void __launch_bounds__(256, POSE_ONLY ? (DEPTH_GRAD ? 6 : LVDGS_BWD_W
             }
         }
         __syncthreads();
+#ifdef LVDGS_DIAG_PHASES
+        ph_mark(4);
+#endif
     }
+#ifdef LVDGS_DIAG_PHASES
+    if (blockIdx.x == 0 && tid == 0) {
+        for (int k = 0; k < 7; k++) atomicAdd(&g_phase_diag[k], ph[k]);
+        atomicAdd(&g_phase_diag[7], 1ull);
+    }
+    if (blockIdx.x < 8192) {
+        if (lane == 0) atomicAdd(&g_wg_surv[blockIdx.x], (unsigned)ph[6]);
+        if (tid == 0) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)), xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));
+            g_wg_diag[blockIdx.x][0] = wg_t0; g_wg_diag[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime();
+            g_wg_diag[blockIdx.x][2] = ((unsigned long long)(range.y - range.x) << 32) | (unsigned)tile;
+            g_wg_diag[blockIdx.x][3] = ((unsigned long long)xcc << 32) | hw;
+        }
+    }
+#endif
 #ifdef LVDGS_DIAG_FILL
     if (lane == 0) {
         atomicAdd(&g_fill_diag[0], (unsigned long long)diag_surv); atomicAdd(&g_fill_diag[1], (unsigned long long)diag_batches);
@@ -707,6 +755,23 @@ int launch_blend_bwd_fused_loss(const lvdgs_args &a, const GeomView &g, const Bi
 
 }  // namespace lvdgs
 
+#ifdef LVDGS_DIAG_PHASES
+extern "C" int lvdgs_diag_phases(unsigned long long *out8, int reset) {
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(lvdgs::g_phase_diag), 8 * sizeof(unsigned long long)) != hipSuccess) return LVDGS_E_HIP;
+    if (reset) {
+        const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(lvdgs::g_phase_diag), z, sizeof(z)) != hipSuccess) return LVDGS_E_HIP;
+    }
+    return LVDGS_OK;
+}
+#endif
+#ifdef LVDGS_DIAG_PHASES
+extern "C" int lvdgs_diag_workgroups(unsigned long long *out_8192x4, unsigned *surv_8192) {
+    if (hipMemcpyFromSymbol(out_8192x4, HIP_SYMBOL(lvdgs::g_wg_diag), 8192 * 4 * sizeof(unsigned long long)) != hipSuccess) return LVDGS_E_HIP;
+    if (hipMemcpyFromSymbol(surv_8192, HIP_SYMBOL(lvdgs::g_wg_surv), 8192 * sizeof(unsigned)) != hipSuccess) return LVDGS_E_HIP;
+    return LVDGS_OK;
+}
+#endif
 #ifdef LVDGS_DIAG_FILL
 extern "C" int lvdgs_diag_fill(unsigned long long *out4, int reset) {
     if (out4 && hipMemcpyFromSymbol(out4, HIP_SYMBOL(lvdgs::g_fill_diag), 4 * sizeof(unsigned long long)) != hipSuccess) return LVDGS_E_HIP;
