@@ -25,6 +25,9 @@
 // first two-pass backward) left the library in round 3: profiles/experiments/r02_superseded_blend_kernels.hip.txt.
 // What bounds the kernels and what was tried: DESIGN.md section 2, profiles/experiments/README.md.
 #include <type_traits>
+#ifdef LVDGS_DIAG_GRID
+#include <cstdlib>
+#endif
 
 #include "common.hpp"
 #include "device_utils.hpp"
@@ -711,6 +714,9 @@ BlendParams make_params(const lvdgs_args &a, const GeomView &g, const BinView &b
 int launch_blend_fwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, bool deep_lists, hipStream_t s) {
     BlendParams p = make_params(a, g, b, im);
     if (p.num_tiles == 0) return LVDGS_OK;
+#ifdef LVDGS_DIAG_GRID   // diagnostic build: only the first $LVDGS_DIAG_GRID workgroups (small grids: the heaviest tiles) -- timings, not results
+    if (const char *e = getenv("LVDGS_DIAG_GRID")) p.num_tiles = min(p.num_tiles, atoi(e));
+#endif
     ProfScope ps("blend_fwd", s);
     if (deep_lists) hipLaunchKernelGGL(blend_fwd2_deep_kernel, dim3(p.num_tiles), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(blend_fwd2_kernel, dim3(p.num_tiles), dim3(256), 0, s, p);
@@ -726,6 +732,9 @@ int launch_blend_bwd(const lvdgs_args &a, const GeomView &g, const BinView &b, c
     BlendParams p = make_params(a, g, b, im);
     p.pair_grads = w.pair_grads; p.pair_valid = b.pair_valid;
     if (p.num_tiles == 0) return LVDGS_OK;
+#ifdef LVDGS_DIAG_GRID
+    if (const char *e = getenv("LVDGS_DIAG_GRID")) p.num_tiles = min(p.num_tiles, atoi(e));
+#endif
     ProfScope ps("blend_bwd", s);
     const bool depth = LVDGS_BWD_DEPTH_ALWAYS || p.dL_ddepth, pose_only = (a.flags & LVDGS_FLAG_POSE_ONLY) != 0;
     if (pose_only && depth) hipLaunchKernelGGL((blend_bwd3_kernel<false, true, true>), dim3(p.num_tiles), dim3(256), 0, s, p);
@@ -743,6 +752,9 @@ int launch_blend_bwd_fused_loss(const lvdgs_args &a, const GeomView &g, const Bi
     p.loss = loss;
     p.loss_propagate_opacity = propagate_opacity;
     if (p.num_tiles == 0) return LVDGS_OK;
+#ifdef LVDGS_DIAG_GRID
+    if (const char *e = getenv("LVDGS_DIAG_GRID")) p.num_tiles = min(p.num_tiles, atoi(e));
+#endif
     ProfScope ps("blend_bwd", s);
     const bool depth = LVDGS_BWD_DEPTH_ALWAYS || (loss.depth && loss.gt_depth && loss.w_d != 0.f), pose_only = (a.flags & LVDGS_FLAG_POSE_ONLY) != 0;
     if (pose_only && depth) hipLaunchKernelGGL((blend_bwd3_kernel<true, true, true>), dim3(p.num_tiles), dim3(256), 0, s, p);
