@@ -13,9 +13,13 @@
 //      at barriers;
 //   longer: queued -- by the tile-range scan on the counting path, by the wave kernel itself on the radix path -- and
 //      sorted by the LAST workgroups of the same launch (256 threads, LDS up to 2048 entries, in place on global memory
-//      beyond), or, when the previous frame on this device had such segments, by kernels launched behind the tile sort:
-//      one wave per segment with 32 keys per lane (<= 2048 entries), a 1024-thread workgroup on 128 KiB of LDS (<= 16384),
-//      global memory beyond.  (Round 2 launched the 1024-thread kernel on every frame: ~6 us for an empty queue.)
+//      beyond), or, when the previous frame on this device had such segments: up to 2048 entries by workgroups at the HEAD of
+//      the same launch, the four waves of one sorting a segment together in registers (8 keys per lane, the three
+//      stages that cross waves through LDS); beyond by a kernel launched behind the tile sort, a 1024-thread workgroup on
+//      128 KiB of LDS (<= 16384), global memory beyond.  (Round 2 launched the 1024-thread kernel on every frame: ~6 us for
+//      an empty queue.  Until round 4 segments of 1025-2048 entries had a kernel of their own behind the tile sort, one wave
+//      each with 32 keys per lane: 184 registers, two waves per SIMD, and 1100 keys padded to 2048 by ONE wave -- 52 us on top
+//      of the wave kernel's 57 on the opaque-surface frame, whose lists are 900-1130 entries.)
 #include "common.hpp"
 #include "device_utils.hpp"
 
@@ -98,22 +102,43 @@ __device__ __forceinline__ u64 lane_xor64(u64 v, int lane) {
     return ((u64)lane_xor32<MASK>((uint32_t)(v >> 32), lane) << 32) | (u64)lane_xor32<MASK>((uint32_t)v, lane);
 }
 
-// Classic bitonic network over 64 * E keys held E per lane (element e = lane * E + r), ascending.  Keys are
+// Classic bitonic network over LANES * E keys held E per lane (element e = g * E + r), ascending.  Keys are
 // distinct (the id is part of the key), so "take the other key" is one comparison xor a per-stage lane mask.
-template <int E, int K, int J>
-__device__ __forceinline__ void wave_bitonic_stage(u64 (&key)[E], int lane) {
-    if constexpr (J >= E) {
+// LANES = 64: one wave (g = lane).  LANES = 256: the four waves of a workgroup sort one segment together (g = thread index);
+// the three stages whose partner sits in another wave -- same lane, same register -- go through xbuf (16 KB of LDS, eight
+// registers at a time) between two workgroup barriers: every wave of the workgroup must be in the same sort.
+template <int E, int LANES, int K, int J>
+__device__ __forceinline__ void wave_bitonic_stage(u64 (&key)[E], int g, u64 *xbuf) {
+    const int lane = g & 63;
+    if constexpr (J >= 64 * E) {
+        static_assert(LANES > 64, "partner in another wave");
+        const bool ascending = K >= LANES * E || (g & (K / E)) == 0;
+        const bool keep_min = ((g & (J / E)) == 0) == ascending;
+        const int w = g >> 6, pw = w ^ (J / (64 * E));
+#pragma unroll
+        for (int h = 0; h < E; h += 8) {
+            __syncthreads();   // (the previous exchange has been read)
+#pragma unroll
+            for (int r = 0; r < 8 && h + r < E; r++) xbuf[(w * 8 + r) * 64 + lane] = key[h + r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 8 && h + r < E; r++) {
+                const u64 other = xbuf[(pw * 8 + r) * 64 + lane];
+                key[h + r] = ((other < key[h + r]) == keep_min) ? other : key[h + r];
+            }
+        }
+    } else if constexpr (J >= E) {
         // partner element e ^ J lives in lane ^ (J / E), same register; the direction of the K-block and which side
         // of the pair this lane is on are the same for all its registers
-        const bool ascending = K >= 64 * E || (lane & (K / E)) == 0;
-        const bool keep_min = ((lane & (J / E)) == 0) == ascending;
+        const bool ascending = K >= LANES * E || (g & (K / E)) == 0;
+        const bool keep_min = ((g & (J / E)) == 0) == ascending;
         u64 other[E];  // all the lane exchanges first: they are independent, the selects then follow without stalls
 #pragma unroll
         for (int r = 0; r < E; r++) other[r] = lane_xor64<J / E>(key[r], lane);
 #pragma unroll
         for (int r = 0; r < E; r++) key[r] = ((other[r] < key[r]) == keep_min) ? other[r] : key[r];
     } else {
-        const bool lane_ascending = K >= 64 * E || (lane & (K / E)) == 0;  // used when K >= E
+        const bool lane_ascending = K >= LANES * E || (g & (K / E)) == 0;  // used when K >= E
 #pragma unroll
         for (int r = 0; r < E; r++) {
             if ((r & J) == 0) {
@@ -125,32 +150,28 @@ __device__ __forceinline__ void wave_bitonic_stage(u64 (&key)[E], int lane) {
             }
         }
     }
-    if constexpr (J > 1) wave_bitonic_stage<E, K, J / 2>(key, lane);
+    if constexpr (J > 1) wave_bitonic_stage<E, LANES, K, J / 2>(key, g, xbuf);
 }
 
-template <int E, int K>
-__device__ __forceinline__ void wave_bitonic_merge(u64 (&key)[E], int lane) {
-    wave_bitonic_stage<E, K, K / 2>(key, lane);
-    if constexpr (K < 64 * E) wave_bitonic_merge<E, 2 * K>(key, lane);
+template <int E, int LANES, int K>
+__device__ __forceinline__ void wave_bitonic_merge(u64 (&key)[E], int g, u64 *xbuf) {
+    wave_bitonic_stage<E, LANES, K, K / 2>(key, g, xbuf);
+    if constexpr (K < LANES * E) wave_bitonic_merge<E, LANES, 2 * K>(key, g, xbuf);
 }
 
-template <int E>
-__device__ __forceinline__ void wave_bitonic_sort(u64 (&key)[E], int lane) {
-    wave_bitonic_merge<E, 2>(key, lane);
-}
-
-template <int E>
-__device__ __forceinline__ void wave_sort_segment(const KeySource &src, uint32_t first, uint32_t *__restrict__ seg, int n, int lane) {
+// g: the lane (LANES = 64) or the thread index in a workgroup of 256 whose four waves all make this call (LANES = 256)
+template <int E, int LANES = 64>
+__device__ __forceinline__ void wave_sort_segment(const KeySource &src, uint32_t first, uint32_t *__restrict__ seg, int n, int g, u64 *xbuf = nullptr) {
     u64 key[E];
 #pragma unroll
     for (int r = 0; r < E; r++) {
-        const int i = r * 64 + lane;  // any assignment of elements to slots will do before sorting
+        const int i = r * LANES + g;  // any assignment of elements to slots will do before sorting
         key[r] = i < n ? src.load(first + i) : ~0ull;
     }
-    wave_bitonic_sort<E>(key, lane);
+    wave_bitonic_merge<E, LANES, 2>(key, g, xbuf);
 #pragma unroll
     for (int r = 0; r < E; r++) {
-        const int e = lane * E + r;
+        const int e = g * E + r;
         if (e < n) seg[e] = (uint32_t)key[r];
     }
 }
@@ -160,7 +181,8 @@ constexpr int CLASS_L = 2048;  // longest segment a workgroup of the same launch
 constexpr int CLASS_B = 16384; // longest segment the separate 1024-thread kernel sorts in (dynamic) LDS
 constexpr int SORT_WAVES = 4;  // tiles per workgroup (16 were measured: the same at 8160 tiles, twice the time at 1848 -- too few workgroups)
 constexpr int LONG_WGS = 256;  // workgroups at the end of the grid that take the queue of over-long segments
-constexpr int CLASS_M = 2048;  // longest segment one wave of the mid kernel sorts in registers (32 keys per lane)
+constexpr int CLASS_G = 2048;  // longest segment a workgroup's four waves sort together in registers (8 keys per lane; 16 per lane for 4096 entries would take the whole kernel from 69 to 97 registers)
+static_assert(CLASS_L * sizeof(u64) >= 4 * 8 * 64 * sizeof(u64), "the four waves' exchange buffer is the in-launch LDS sort's array");
 
 // `count` queued segments, one workgroup per segment in turn: in LDS up to `lds_cap` entries, in place on
 // global memory beyond (64-bit key scratch).  Only segments of more than `take_from` and at most `take_upto` entries
@@ -197,9 +219,9 @@ __device__ __forceinline__ void sort_queued_segments(u64 *s_keys, int lds_cap, i
 //  * counting path (QUEUED): the tile-range scan has queued them already (binning.hip) and the LAST LONG_WGS workgroups
 //    of this very launch take them -- no launch of their own on every frame's critical path for a queue that is nearly
 //    always empty -- in LDS up to CLASS_L entries, in place on global memory beyond.  When the previous frame on this
-//    device had such segments the host launches better-suited kernels behind this one (a wave per segment with 32 keys
-//    per lane up to CLASS_M entries, a 1024-thread workgroup on 128 KiB of LDS beyond) and tells the workgroups here which
-//    lengths are still theirs (take_from, take_upto).  A hint: results never depend on it;
+//    device had such segments the host puts group_wgs workgroups at the HEAD of this launch (a segment of up to CLASS_G
+//    entries each, sorted by the four waves together) and a 1024-thread kernel on 128 KiB of LDS behind it, and tells the
+//    last workgroups which lengths are still theirs (take_from, take_upto).  A hint: results never depend on it;
 //  * radix path: queued here with one atomic each, sorted by the launch that follows.
 // tile_order (small grids, or null): the tiles by descending list length -- the waves of a workgroup then sort
 // segments of similar length, and the long ones start first.  Only tiles [t_lo, t_hi) are looked at (the band being
@@ -211,15 +233,27 @@ template <bool QUEUED>
 __global__ void __launch_bounds__(64 * SORT_WAVES, LVDGS_SORT_OCC) tile_depth_sort_wave_kernel(const uint2 *__restrict__ ranges, int t_lo, int t_hi, KeySource src,
                                                                     uint32_t *__restrict__ point_list, uint32_t *queue_count,
                                                                     uint32_t *__restrict__ queue, const uint32_t *__restrict__ tile_order,
-                                                                    u64 *keys, int sort_wgs, int take_from, int take_upto) {
+                                                                    u64 *keys, int group_wgs, int sort_wgs, int take_from, int take_upto) {
     __shared__ u64 s_long[QUEUED ? CLASS_L : 1];
-    if (QUEUED && (int)blockIdx.x >= sort_wgs) {
+    if (QUEUED && (int)blockIdx.x < group_wgs) {
+        // the FIRST group_wgs workgroups (the host launches them when the previous frame queued segments): a queued segment of
+        // up to CLASS_G entries per workgroup in turn, its four waves sorting it together
+        const int count = (int)*queue_count;
+        for (int q = blockIdx.x; q < count; q += group_wgs) {
+            const uint2 r = ranges[queue[q]];
+            const int n = (int)(r.y - r.x);
+            if (n > CLASS_W && n <= CLASS_G) wave_sort_segment<CLASS_G / 256, 256>(src, r.x, point_list + r.x, n, (int)threadIdx.x, s_long);
+        }
+        return;
+    }
+    const int block = (int)blockIdx.x - (QUEUED ? group_wgs : 0);
+    if (QUEUED && block >= sort_wgs) {
         sort_queued_segments(s_long, CLASS_L, take_from, take_upto, ranges, src, point_list, (int)*queue_count, queue, keys,
-                             (int)blockIdx.x - sort_wgs, LONG_WGS);
+                             block - sort_wgs, LONG_WGS);
         return;
     }
     const int lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * SORT_WAVES + (threadIdx.x >> 6);
+    const int slot = block * SORT_WAVES + (threadIdx.x >> 6);
     if (slot >= t_hi - t_lo) return;
     const int tile = tile_order ? (int)tile_order[slot] : t_lo + slot;
     const uint2 r = ranges[tile];
@@ -232,21 +266,6 @@ __global__ void __launch_bounds__(64 * SORT_WAVES, LVDGS_SORT_OCC) tile_depth_so
     else if (n <= 512) wave_sort_segment<8>(src, r.x, point_list + r.x, n, lane);
     else if (n <= CLASS_W) wave_sort_segment<16>(src, r.x, point_list + r.x, n, lane);
     else if (!QUEUED && lane == 0) queue[atomicAdd(queue_count, 1u)] = (uint32_t)tile;
-}
-
-// Queued segments of CLASS_W + 1 .. CLASS_M entries, one WAVE each with 32 keys per lane in registers -- the lists of a map
-// made of large Gaussians (500-2000 entries per tile) are mostly of this class, and a workgroup's LDS network takes five
-// times as long for them.  A kernel of its own because 32 keys per lane need twice the registers of the common case;
-// launched only when the previous frame on this device had such segments (the queue's length then sizes the grid).
-__global__ void __launch_bounds__(256) tile_depth_sort_mid_kernel(const uint2 *__restrict__ ranges, KeySource src, uint32_t *__restrict__ point_list,
-                                                                  const uint32_t *queue_count, const uint32_t *__restrict__ queue) {
-    const int lane = threadIdx.x & 63;
-    const int count = (int)*queue_count, waves = gridDim.x * 4;
-    for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < count; q += waves) {
-        const uint2 r = ranges[queue[q]];
-        const int n = (int)(r.y - r.x);
-        if (n > CLASS_W && n <= CLASS_M) wave_sort_segment<32>(src, r.x, point_list + r.x, n, lane);
-    }
 }
 
 // queued segments: in 128 KiB of LDS up to CLASS_B entries, in place on global memory beyond; segments of up to
@@ -294,29 +313,25 @@ int launch_tile_depth_sort(const ImageView &im, int num_tiles, int t_lo, int t_h
     const int sort_wgs = cdiv(t_hi - t_lo, SORT_WAVES);
     // longest_expected: the longest segment the previous frame on this device queued (0: none; negative: unknown, assume the
     // worst).  Segments that turn up against the expectation are still sorted -- by the launch's own last workgroups.
-    const bool mid = keys_ready && longest_expected > CLASS_W, big = !keys_ready || longest_expected > CLASS_M || longest_expected < 0;
+    // grouped: workgroups at the head of the launch for the queue the previous frame leads to expect (one segment each, a quarter
+    // more than it had; whatever the queue turns out to hold is sorted all the same, by them in turn or by the launch's last workgroups)
+    const bool grouped = keys_ready && longest_expected > CLASS_W, big = !keys_ready || longest_expected > CLASS_G || longest_expected < 0;
+    const int group_wgs = grouped ? min(8192, max(64, (int)((int64_t)queue_expected * 5 / 4))) : 0;
     {
         ProfScope ps("tile_sort", s);
-        if (keys_ready)   // counting path: the queue is there already, the last workgroups of the launch take it
-            hipLaunchKernelGGL(tile_depth_sort_wave_kernel<true>, dim3(sort_wgs + LONG_WGS), dim3(64 * SORT_WAVES), 0, s, (const uint2 *)im.ranges, t_lo, t_hi, src,
+        if (keys_ready)   // counting path: the queue is there already
+            hipLaunchKernelGGL(tile_depth_sort_wave_kernel<true>, dim3(group_wgs + sort_wgs + LONG_WGS), dim3(64 * SORT_WAVES), 0, s, (const uint2 *)im.ranges, t_lo, t_hi, src,
                                point_list, im.long_count, im.long_tiles, tile_order_in_use(num_tiles) ? im.long_tiles + num_tiles : nullptr,
-                               (u64 *)keys64, sort_wgs, mid ? CLASS_M : CLASS_W, big ? CLASS_M : 0x7fffffff);
+                               (u64 *)keys64, group_wgs, sort_wgs, grouped ? CLASS_G : CLASS_W, big ? CLASS_G : 0x7fffffff);
         else
             hipLaunchKernelGGL(tile_depth_sort_wave_kernel<false>, dim3(sort_wgs), dim3(64 * SORT_WAVES), 0, s, (const uint2 *)im.ranges, t_lo, t_hi, src,
-                               point_list, im.long_count, im.long_tiles, (const uint32_t *)nullptr, (u64 *)keys64, sort_wgs, 0, 0);
+                               point_list, im.long_count, im.long_tiles, (const uint32_t *)nullptr, (u64 *)keys64, 0, sort_wgs, 0, 0);
         LVDGS_LAUNCH_CHECK("tile_sort", dbg, s);
-    }
-    if (mid) {
-        ProfScope ps("tile_sort_mid", s);
-        const int wgs = min(4096, max(64, cdiv((int64_t)queue_expected * 5 / 4, 4)));
-        hipLaunchKernelGGL(tile_depth_sort_mid_kernel, dim3(wgs), dim3(256), 0, s, (const uint2 *)im.ranges, src, point_list,
-                           (const uint32_t *)im.long_count, (const uint32_t *)im.long_tiles);
-        LVDGS_LAUNCH_CHECK("tile_sort_mid", dbg, s);
     }
     if (big) {
         ProfScope ps("tile_sort_long", s);
         hipLaunchKernelGGL(tile_depth_sort_long_kernel, dim3(256), dim3(1024), CLASS_B * 8, s, (const uint2 *)im.ranges, src, point_list,
-                           (const uint32_t *)im.long_count, (const uint32_t *)im.long_tiles, (unsigned long long *)keys64, keys_ready ? CLASS_M : 0);
+                           (const uint32_t *)im.long_count, (const uint32_t *)im.long_tiles, (unsigned long long *)keys64, keys_ready ? CLASS_G : 0);
         LVDGS_LAUNCH_CHECK("tile_sort_long", dbg, s);
     }
     return LVDGS_OK;
