@@ -185,6 +185,7 @@ def main():
         else:
             dist.init_process_group(backend_name, rank=rank, world_size=world)
 
+    notes = []   # what did not go as planned in the parts around the timed region (printed in the line: config.notes)
     torch.manual_seed(0)   # (the single-GPU mapping window draws its two random views from the global generator)
     model, cam, g_cpu, (N, W, H) = build_scene(args.workload, rank, dev)
     pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False)
@@ -202,7 +203,12 @@ def main():
         if world > 1 and os.environ.get("LVDGS_BENCH_AUX_GROUP", "1") != "0":
             # the two small MAX collectives on a communicator of their own: in flight under the gradient all-reduce
             # (LVDGS_BENCH_AUX_GROUP=0: all three collectives on the one communicator, as in round 3)
-            backend.shard_aux_group = dist.new_group(backend=backend_name if backend_name != "nccl" else None)
+            # (a job whose second communicator cannot be made runs its three collectives on the first: every rank takes the same branch,
+            # new_group is collective and fails on all of them or on none)
+            try:
+                backend.shard_aux_group = dist.new_group(backend=backend_name if backend_name != "nccl" else None)
+            except Exception as e:   # noqa: BLE001
+                notes.append(f"no second communicator ({type(e).__name__}: {e}): MAX collectives on the first")
         # LVDGS_BENCH_SHARDED_ADAM=1: the Gaussian Adam as reduce-scatter -> every rank steps its share -> all-gather
         # (backend_map.ShardedAdam; off by default: modelled, never measured on more than one GPU)
         backend.shard_optimizer = world > 1 and os.environ.get("LVDGS_BENCH_SHARDED_ADAM", "0") == "1"
@@ -369,40 +375,45 @@ def main():
         del po
         side = run_side(dev, pipe)
 
+    # The two measurements below come AFTER the timed region and are extras: an exception in them (an unsupported collective call
+    # raises on every rank alike) is recorded in config.notes and does not cost the line its headline.
     same_step_single = None
-    if world > 1 and not tracking:
-        # The same step on ONE GPU, measured inside this job (every rank alone in a group of its own: no collective),
-        # so that the N-GPU number can be read against the right single-GPU number: bench.py's N = 1 default is the
-        # tracking iteration of BASELINE configs[2], a different (lighter) step than the mapping iteration timed here.
-        solo_groups = [dist.new_group(ranks=[r]) for r in range(world)]
-        solo_model = GaussianModel.from_activated(g_cpu["means3D"], g_cpu["scales"], g_cpu["rotations"], g_cpu["opacities"], shs=g_cpu["shs"],
-                                                  sh_degree=0, device=dev)
-        solo_backend, solo_window = make_window(solo_model) if real_window else build_window(args.workload, 1, dev, solo_model)
-        for _ in range(3):
-            backend_map.map_window(solo_backend, solo_window, iters=1, group=solo_groups[rank])
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            backend_map.map_window(solo_backend, solo_window, iters=1, group=solo_groups[rank])
-        torch.cuda.synchronize()
-        solo = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
-        dist.all_reduce(solo, op=dist.ReduceOp.MAX)
-        same_step_single = round(args.steps / float(solo.item()), 3)
-        del solo_backend
-
     comm_us = phases = None
-    if not tracking:
-        # the iteration by phase (events on the stream at the phase boundaries, one wait at the end of each iteration)
-        st = {}
-        for _ in range(5):
-            backend_map.map_window(backend, window, iters=1, stats=st)
-        per = [r["phases"].seconds() for r in st["iterations"]]
-        names = list(per[0])
-        t = torch.tensor([sum(p[n] for p in per) / len(per) for n in names], device=dev, dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        phases = {n: round(float(v) * 1e6, 1) for n, v in zip(names, t.tolist())}
-        comm_us = phases.get("collectives")
+    try:
+        if world > 1 and not tracking:
+            # The same step on ONE GPU, measured inside this job (every rank alone in a group of its own: no collective),
+            # so that the N-GPU number can be read against the right single-GPU number: bench.py's N = 1 default is the
+            # tracking iteration of BASELINE configs[2], a different (lighter) step than the mapping iteration timed here.
+            solo_groups = [dist.new_group(ranks=[r]) for r in range(world)]
+            solo_model = GaussianModel.from_activated(g_cpu["means3D"], g_cpu["scales"], g_cpu["rotations"], g_cpu["opacities"], shs=g_cpu["shs"],
+                                                      sh_degree=0, device=dev)
+            solo_backend, solo_window = make_window(solo_model) if real_window else build_window(args.workload, 1, dev, solo_model)
+            for _ in range(3):
+                backend_map.map_window(solo_backend, solo_window, iters=1, group=solo_groups[rank])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                backend_map.map_window(solo_backend, solo_window, iters=1, group=solo_groups[rank])
+            torch.cuda.synchronize()
+            solo = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            dist.all_reduce(solo, op=dist.ReduceOp.MAX)
+            same_step_single = round(args.steps / float(solo.item()), 3)
+            del solo_backend
+
+        if not tracking:
+            # the iteration by phase (events on the stream at the phase boundaries, one wait at the end of each iteration)
+            st = {}
+            for _ in range(5):
+                backend_map.map_window(backend, window, iters=1, stats=st)
+            per = [r["phases"].seconds() for r in st["iterations"]]
+            names = list(per[0])
+            t = torch.tensor([sum(p[n] for p in per) / len(per) for n in names], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            phases = {n: round(float(v) * 1e6, 1) for n, v in zip(names, t.tolist())}
+            comm_us = phases.get("collectives")
+    except Exception as e:   # noqa: BLE001
+        notes.append(f"extras after the timed region failed ({type(e).__name__}: {e})")
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -443,7 +454,7 @@ def main():
                        "views_per_step": views_per_step, "comm_us_per_step": comm_us, "phases_us_per_step": phases,
                        "autograd_api_iters_per_s": autograd_rate, "pose_only_iters_per_s": pose_only_rate,
                        "mapping_window_views_per_s": None if not side else side.get("mapping_window_" + args.workload, {}).get("views_per_s"),
-                       "side": side, "same_step_on_one_gpu_iters_per_s": same_step_single,
+                       "side": side, "notes": notes or None, "same_step_on_one_gpu_iters_per_s": same_step_single,
                        "same_step_on_one_gpu_value": None if same_step_single is None else round(same_step_single * views_per_step / (1 if real_window else world), 3)},
             **({"collective_backend": backend_name + " (functional check only, not a benchmark result)"} if world > 1 and backend_name != "nccl" else {}),
             **({"timing_note": "warm-up + timed region last under ~40 ms: after start-up idle this GPU needs ~17 ms of load to reach its clocks, "
