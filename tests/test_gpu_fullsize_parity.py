@@ -99,6 +99,28 @@ def test_opaque_surfaces_of_large_gaussians_match_oracle(name):
         np.testing.assert_array_equal(f_all[k], f_hip[k], err_msg=k)
 
 
+def test_long_lists_sort_the_same_on_every_frame_whichever_workgroups_take_them():
+    """The tile sort's size classes are chosen by a HINT (the longest list the previous frame on this device queued, read back with
+    its pair count): a first frame's lists of more than 1024 entries are sorted by the launch's last workgroups, the following
+    frames' by workgroups at its head, four waves to a list (tilesort.hip).  Same order every time: the oracle's, entry for entry
+    (exact-list mode), through a frame of SHORT lists in between (which must not disturb the hint's bookkeeping either)."""
+    orc, hr, syn = tp._mods()
+    g, cam, N, W, H = _workload("surface_12k_640x480", 2)
+    bg = torch.tensor([0.1, 0.3, 0.2])
+    f_ora, _ = hr.run_oracle(orc, g, cam, W, H, bg)
+    lists = f_ora["ranges"][:, 1].astype(np.int64) - f_ora["ranges"][:, 0]
+    assert (lists > 1024).sum() > 20 and lists.max() <= 2048
+    small, small_cam = tp._scene(syn, 3000, 320, 240, seed=5)
+    for frame in range(4):
+        f_all, _ = hr.run_hip(g, cam, W, H, bg, tile_cull=False)
+        np.testing.assert_array_equal(f_all["point_list"], f_ora["ids_sorted"], err_msg=f"frame {frame}")
+        np.testing.assert_array_equal(f_all["ranges"], f_ora["ranges"])
+        if frame == 1:
+            f_s, _ = hr.run_hip(small, small_cam, 320, 240, bg, tile_cull=False)
+            f_so, _ = hr.run_oracle(orc, small, small_cam, 320, 240, bg)
+            np.testing.assert_array_equal(f_s["point_list"], f_so["ids_sorted"])
+
+
 # ---------------------------------------------------------------------------------------------------------------
 def _kitti_camera(pose_seed=2):
     """A Camera-like namespace at KITTI-07's geometry with the attributes render() reads, matrices on the GPU."""
