@@ -226,6 +226,9 @@ __device__ __forceinline__ void sort_queued_segments(u64 *s_keys, int lds_cap, i
 // tile_order (small grids, or null): the tiles by descending list length -- the waves of a workgroup then sort
 // segments of similar length, and the long ones start first.  Only tiles [t_lo, t_hi) are looked at (the band being
 // rendered).
+#ifndef LVDGS_SORT_SOLO
+#define LVDGS_SORT_SOLO 1   // A/B builds: 0 = segments of 513-1024 entries by one wave whatever the grid
+#endif
 template <bool QUEUED>
 #ifndef LVDGS_SORT_OCC
 #define LVDGS_SORT_OCC 1
@@ -233,7 +236,7 @@ template <bool QUEUED>
 __global__ void __launch_bounds__(64 * SORT_WAVES, LVDGS_SORT_OCC) tile_depth_sort_wave_kernel(const uint2 *__restrict__ ranges, int t_lo, int t_hi, KeySource src,
                                                                     uint32_t *__restrict__ point_list, uint32_t *queue_count,
                                                                     uint32_t *__restrict__ queue, const uint32_t *__restrict__ tile_order,
-                                                                    u64 *keys, int group_wgs, int sort_wgs, int take_from, int take_upto) {
+                                                                    u64 *keys, int group_wgs, int solo_wgs, int sort_wgs, int take_from, int take_upto) {
     __shared__ u64 s_long[QUEUED ? CLASS_L : 1];
     if (QUEUED && (int)blockIdx.x < group_wgs) {
         // the FIRST group_wgs workgroups (the host launches them when the previous frame queued segments): a queued segment of
@@ -246,7 +249,17 @@ __global__ void __launch_bounds__(64 * SORT_WAVES, LVDGS_SORT_OCC) tile_depth_so
         }
         return;
     }
-    const int block = (int)blockIdx.x - (QUEUED ? group_wgs : 0);
+    if (QUEUED && (int)blockIdx.x < group_wgs + solo_wgs) {
+        // small grids (solo_wgs = the band's tiles, else 0): a workgroup per tile for the segments of 513-1024 entries, its four
+        // waves sorting together with 4 keys per lane -- a KITTI frame's 800 such tiles are otherwise one wave's 3 800-instruction
+        // chain each on a chip with more SIMDs than the frame has tiles; the workgroups of the other tiles leave at once
+        const int slot = (int)blockIdx.x - group_wgs;
+        const uint2 r = ranges[tile_order ? (int)tile_order[slot] : t_lo + slot];
+        const int n = (int)(r.y - r.x);
+        if (n > 512 && n <= CLASS_W) wave_sort_segment<CLASS_W / 256, 256>(src, r.x, point_list + r.x, n, (int)threadIdx.x, s_long);
+        return;
+    }
+    const int block = (int)blockIdx.x - (QUEUED ? group_wgs + solo_wgs : 0);
     if (QUEUED && block >= sort_wgs) {
         sort_queued_segments(s_long, CLASS_L, take_from, take_upto, ranges, src, point_list, (int)*queue_count, queue, keys,
                              block - sort_wgs, LONG_WGS);
@@ -264,7 +277,7 @@ __global__ void __launch_bounds__(64 * SORT_WAVES, LVDGS_SORT_OCC) tile_depth_so
     }
     if (n <= 256) wave_sort_segment<4>(src, r.x, point_list + r.x, n, lane);
     else if (n <= 512) wave_sort_segment<8>(src, r.x, point_list + r.x, n, lane);
-    else if (n <= CLASS_W) wave_sort_segment<16>(src, r.x, point_list + r.x, n, lane);
+    else if (n <= CLASS_W) { if (!QUEUED || solo_wgs == 0) wave_sort_segment<16>(src, r.x, point_list + r.x, n, lane); }
     else if (!QUEUED && lane == 0) queue[atomicAdd(queue_count, 1u)] = (uint32_t)tile;
 }
 
@@ -317,15 +330,16 @@ int launch_tile_depth_sort(const ImageView &im, int num_tiles, int t_lo, int t_h
     // more than it had; whatever the queue turns out to hold is sorted all the same, by them in turn or by the launch's last workgroups)
     const bool grouped = keys_ready && longest_expected > CLASS_W, big = !keys_ready || longest_expected > CLASS_G || longest_expected < 0;
     const int group_wgs = grouped ? min(8192, max(64, (int)((int64_t)queue_expected * 5 / 4))) : 0;
+    const int solo_wgs = (LVDGS_SORT_SOLO && keys_ready && tile_order_in_use(num_tiles)) ? t_hi - t_lo : 0;
     {
         ProfScope ps("tile_sort", s);
         if (keys_ready)   // counting path: the queue is there already
-            hipLaunchKernelGGL(tile_depth_sort_wave_kernel<true>, dim3(group_wgs + sort_wgs + LONG_WGS), dim3(64 * SORT_WAVES), 0, s, (const uint2 *)im.ranges, t_lo, t_hi, src,
+            hipLaunchKernelGGL(tile_depth_sort_wave_kernel<true>, dim3(group_wgs + solo_wgs + sort_wgs + LONG_WGS), dim3(64 * SORT_WAVES), 0, s, (const uint2 *)im.ranges, t_lo, t_hi, src,
                                point_list, im.long_count, im.long_tiles, tile_order_in_use(num_tiles) ? im.long_tiles + num_tiles : nullptr,
-                               (u64 *)keys64, group_wgs, sort_wgs, grouped ? CLASS_G : CLASS_W, big ? CLASS_G : 0x7fffffff);
+                               (u64 *)keys64, group_wgs, solo_wgs, sort_wgs, grouped ? CLASS_G : CLASS_W, big ? CLASS_G : 0x7fffffff);
         else
             hipLaunchKernelGGL(tile_depth_sort_wave_kernel<false>, dim3(sort_wgs), dim3(64 * SORT_WAVES), 0, s, (const uint2 *)im.ranges, t_lo, t_hi, src,
-                               point_list, im.long_count, im.long_tiles, (const uint32_t *)nullptr, (u64 *)keys64, 0, sort_wgs, 0, 0);
+                               point_list, im.long_count, im.long_tiles, (const uint32_t *)nullptr, (u64 *)keys64, 0, 0, sort_wgs, 0, 0);
         LVDGS_LAUNCH_CHECK("tile_sort", dbg, s);
     }
     if (big) {
