@@ -227,7 +227,7 @@ __device__ __forceinline__ void sort_queued_segments(u64 *s_keys, int lds_cap, i
 // segments of similar length, and the long ones start first.  Only tiles [t_lo, t_hi) are looked at (the band being
 // rendered).
 #ifndef LVDGS_SORT_SOLO
-#define LVDGS_SORT_SOLO 1   // A/B builds: 0 = segments of 513-1024 entries by one wave whatever the grid
+#define LVDGS_SORT_SOLO 2   // A/B builds: 0 = one wave per segment up to 1024 entries whatever the grid; 1 = a workgroup per segment of 513-1024 entries on small grids; 2 = of 257-1024
 #endif
 template <bool QUEUED>
 #ifndef LVDGS_SORT_OCC
@@ -250,13 +250,16 @@ __global__ void __launch_bounds__(64 * SORT_WAVES, LVDGS_SORT_OCC) tile_depth_so
         return;
     }
     if (QUEUED && (int)blockIdx.x < group_wgs + solo_wgs) {
-        // small grids (solo_wgs = the band's tiles, else 0): a workgroup per tile for the segments of 513-1024 entries, its four
-        // waves sorting together with 4 keys per lane -- a KITTI frame's 800 such tiles are otherwise one wave's 3 800-instruction
-        // chain each on a chip with more SIMDs than the frame has tiles; the workgroups of the other tiles leave at once
+        // small grids (solo_wgs = the band's tiles, else 0): a workgroup per tile for the segments of 257-1024 entries, its four
+        // waves sorting together with 2 or 4 keys per lane -- a KITTI frame's 800 tiles of 513-1024 entries are otherwise one wave's
+        // 3 800-instruction chain each on a chip with more SIMDs than the frame has tiles (tile sort 18.6 -> 14.0 us; with the
+        // 257-512 class too: 12.6; 640x480 / 100 k Gaussians, whose lists are 130-310 entries: 10.8 -> 8.5); the workgroups of the
+        // other tiles leave at once
         const int slot = (int)blockIdx.x - group_wgs;
         const uint2 r = ranges[tile_order ? (int)tile_order[slot] : t_lo + slot];
         const int n = (int)(r.y - r.x);
         if (n > 512 && n <= CLASS_W) wave_sort_segment<CLASS_W / 256, 256>(src, r.x, point_list + r.x, n, (int)threadIdx.x, s_long);
+        else if (LVDGS_SORT_SOLO > 1 && n > 256 && n <= 512) wave_sort_segment<2, 256>(src, r.x, point_list + r.x, n, (int)threadIdx.x, s_long);
         return;
     }
     const int block = (int)blockIdx.x - (QUEUED ? group_wgs + solo_wgs : 0);
@@ -276,7 +279,7 @@ __global__ void __launch_bounds__(64 * SORT_WAVES, LVDGS_SORT_OCC) tile_depth_so
         return;
     }
     if (n <= 256) wave_sort_segment<4>(src, r.x, point_list + r.x, n, lane);
-    else if (n <= 512) wave_sort_segment<8>(src, r.x, point_list + r.x, n, lane);
+    else if (n <= 512) { if (!QUEUED || solo_wgs == 0 || LVDGS_SORT_SOLO < 2) wave_sort_segment<8>(src, r.x, point_list + r.x, n, lane); }
     else if (n <= CLASS_W) { if (!QUEUED || solo_wgs == 0) wave_sort_segment<16>(src, r.x, point_list + r.x, n, lane); }
     else if (!QUEUED && lane == 0) queue[atomicAdd(queue_count, 1u)] = (uint32_t)tile;
 }
