@@ -142,6 +142,12 @@ enum {
     LVDGS_FLAG_LIST_ALL_TILES = 1, /* list every tile of a Gaussian's 3-sigma rectangle -- the reference's pair list, bit
                                       for bit (num_rendered, point_list, ranges, n_contrib) -- instead of only the tiles
                                       on which it can reach alpha >= 1/255 (outputs are the same either way) */
+    LVDGS_FLAG_NO_BLEND = 8,       /* R, B: the call leaves its blend pass out -- lvdgs_forward / lvdgs_forward_render stop behind the
+                                      per-tile depth sort (out_color / out_depth / out_opacity / n_touched and the image
+                                      state's final_T / n_contrib are not written), lvdgs_backward_fused_loss starts behind the
+                                      backward blend pass -- because the caller runs that pass for several views of one size in
+                                      ONE launch: lvdgs_blend_forward_batch / lvdgs_blend_backward_fused_loss_batch (the views
+                                      of a mapping window; the results are the single calls', bit for bit) */
     LVDGS_FLAG_POSE_ONLY = 4,      /* B: only the camera-pose gradient (dL_dtau, or its partial sums for lvdgs_tracking_tail) and --
                                       lvdgs_backward_fused_loss -- the loss value and exposure gradients are produced.  The
                                       reference's tracking optimiser holds the pose and the exposure alone
@@ -329,6 +335,17 @@ int lvdgs_pose_step_batch(const lvdgs_pose_step_args *steps, int32_t count, void
  * loss->loss and loss->d_exposure_a / _b.  An empty map or a view that lists no pair (num_gaussians or num_rendered == 0) is
  * fine: the loss of the background image is evaluated, every Gaussian / pose gradient is zero. */
 int lvdgs_backward_fused_loss(const lvdgs_args *a, const lvdgs_loss_args *loss, int32_t propagate_opacity_grad, void *stream);
+
+/* The blend passes of `count` views in one launch each (no counterpart upstream, which renders a mapping window's keyframes one
+ * after the other: utils/slam_backend.py:175-266).  A frame of KITTI's size (1848 tiles) leaves a 256-CU chip's wave slots half
+ * empty and ends in a tail of its heaviest tiles; the ten views of a mapping window together fill it (per view: forward blend
+ * 54 -> 34 us, backward 105 -> 77).  views[k]: the argument block of a view that has been through lvdgs_forward /
+ * lvdgs_forward_render (resp. is about to go through lvdgs_backward_fused_loss) with LVDGS_FLAG_NO_BLEND -- the same
+ * block, every buffer its own; all views the same image size and band of tile rows, losses[k] as for
+ * lvdgs_backward_fused_loss.  Each view's outputs are what its single call without the flag writes, bit for bit. */
+int lvdgs_blend_forward_batch(const lvdgs_args *const *views, int32_t count, void *stream);
+int lvdgs_blend_backward_fused_loss_batch(const lvdgs_args *const *views, const lvdgs_loss_args *const *losses, int32_t count,
+                                          int32_t propagate_opacity_grad, void *stream);
 
 /* The end of a tracking iteration in ONE launch (instead of three at ~6 us each on the iteration's critical path):
  *   - finishes the loss: sums the partial sums lvdgs_photometric_loss_partials(loss) left per 1024 pixels

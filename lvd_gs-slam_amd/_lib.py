@@ -14,6 +14,7 @@ OK, E_INVALID, E_HIP, E_RANGE, E_CAPACITY = 0, 1, 2, 3, 4
 FLAG_LIST_ALL_TILES = 1
 FLAG_ACCUMULATE_PARAM_GRADS = 2   # lvdgs_args.flags
 FLAG_POSE_ONLY = 4
+FLAG_NO_BLEND = 8   # the call leaves its blend pass to lvdgs_blend_*_batch
 
 _fp = C.c_void_p
 
@@ -117,7 +118,7 @@ EXPORTS = (
     "lvdgs_forward",
     "lvdgs_backward", "lvdgs_mark_visible", "lvdgs_state_layout_query", "lvdgs_knn_scratch_bytes",
     "lvdgs_dist2_knn3", "lvdgs_rope2d", "lvdgs_rope2d_strided", "lvdgs_loss_scratch_bytes", "lvdgs_photometric_loss_forward",
-    "lvdgs_photometric_loss_backward", "lvdgs_photometric_loss_value_and_grad", "lvdgs_photometric_loss_partials", "lvdgs_tracking_tail", "lvdgs_backward_fused_loss", "lvdgs_masked_depth_scratch_bytes", "lvdgs_masked_depth_l1_forward",
+    "lvdgs_photometric_loss_backward", "lvdgs_photometric_loss_value_and_grad", "lvdgs_photometric_loss_partials", "lvdgs_tracking_tail", "lvdgs_backward_fused_loss", "lvdgs_blend_forward_batch", "lvdgs_blend_backward_fused_loss_batch", "lvdgs_masked_depth_scratch_bytes", "lvdgs_masked_depth_l1_forward",
     "lvdgs_masked_depth_l1_backward", "lvdgs_pose_step", "lvdgs_host_device_pointer", "lvdgs_pose_step_batch", "lvdgs_adam_step", "lvdgs_isotropic_scratch_bytes", "lvdgs_isotropic_reg", "lvdgs_view_stats", "lvdgs_map_stats_apply", "lvdgs_map_view_tail", "lvdgs_ssim_scratch_bytes", "lvdgs_ssim_l1", "lvdgs_last_error", "lvdgs_version", "lvdgs_profile_enable",
     "lvdgs_profile_reset", "lvdgs_profile_read",
 )
@@ -155,6 +156,8 @@ def lib():
         L.lvdgs_forward_render.argtypes = [C.POINTER(Args), C.c_void_p]
         L.lvdgs_forward.argtypes = [C.POINTER(Args), C.POINTER(C.c_int64), C.c_void_p]
         L.lvdgs_backward.argtypes = [C.POINTER(Args), C.c_void_p]
+        L.lvdgs_blend_forward_batch.argtypes = [C.POINTER(C.POINTER(Args)), C.c_int32, C.c_void_p]
+        L.lvdgs_blend_backward_fused_loss_batch.argtypes = [C.POINTER(C.POINTER(Args)), C.POINTER(C.POINTER(LossArgs)), C.c_int32, C.c_int32, C.c_void_p]
         L.lvdgs_mark_visible.argtypes = [C.c_int32, _fp, _fp, _fp, _fp, C.c_void_p]
         L.lvdgs_host_device_pointer.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.lvdgs_state_layout_query.argtypes = [C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(StateLayout)]

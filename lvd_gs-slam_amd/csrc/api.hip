@@ -419,6 +419,7 @@ int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipSt
                                            probe ? probe->queued : 0, a->debug, s)) return e;
     }
     // (tile lists beyond what one wave sorts on recent frames: the blend kernel built for deep lists)
+    if (a->flags & LVDGS_FLAG_NO_BLEND) return LVDGS_OK;   // the caller blends several views in one launch: lvdgs_blend_forward_batch
     return launch_blend_fwd(*a, g, b, im, probe && probe->longest > 0, s);
 }
 
@@ -525,7 +526,9 @@ int lvdgs_forward(const lvdgs_args *a, int64_t *num_rendered, void *stream) {
     return LVDGS_OK;
 }
 
-static int backward_impl(const lvdgs_args *a, const LossParams *fused, int propagate_opacity, hipStream_t s) {
+// views_out (lvdgs_blend_backward_fused_loss_batch): the call checks its arguments, lays its buffers out and stops there
+struct BackwardViews { GeomView g; BinView b; ImageView im; BwdScratch w; };
+static int backward_impl(const lvdgs_args *a, const LossParams *fused, int propagate_opacity, hipStream_t s, BackwardViews *views_out = nullptr) {
     if (int e = check_common(a)) return e;
     if (int e = check_gaussians(a)) return e;
     const int N = a->num_gaussians, W = a->image_width, H = a->image_height;
@@ -558,8 +561,10 @@ static int backward_impl(const lvdgs_args *a, const LossParams *fused, int propa
     }
     // With the loss inside, the blend pass runs even over empty lists (a view that sees nothing, an empty map): it is what
     // evaluates the loss of the background image -- value and exposure gradients -- and no pair record is written.
+    if (views_out) { *views_out = BackwardViews{g, b, im, w}; return LVDGS_OK; }
     if (fused) {
-        if (int e = launch_blend_bwd_fused_loss(*a, g, b, im, w, *fused, propagate_opacity, s)) return e;
+        if (!(a->flags & LVDGS_FLAG_NO_BLEND))
+            if (int e = launch_blend_bwd_fused_loss(*a, g, b, im, w, *fused, propagate_opacity, s)) return e;
     } else if (D > 0) {
         if (int e = launch_blend_bwd(*a, g, b, im, w, s)) return e;
     }
@@ -575,6 +580,53 @@ int lvdgs_backward_fused_loss(const lvdgs_args *a, const lvdgs_loss_args *loss, 
     if (int e = loss_fused_params(loss, &lp)) return e;
     if (loss->width != a->image_width || loss->height != a->image_height) { set_error("fused loss: image size differs from the rasterizer's"); return LVDGS_E_INVALID; }
     return backward_impl(a, &lp, propagate_opacity_grad != 0, (hipStream_t)stream);
+}
+
+int lvdgs_blend_forward_batch(const lvdgs_args *const *views, int32_t count, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (count < 0 || (count > 0 && !views)) { set_error("blend batch: bad view list"); return LVDGS_E_INVALID; }
+    if (count == 0) return LVDGS_OK;
+    std::vector<GeomView> g(count); std::vector<BinView> b(count); std::vector<ImageView> im(count);
+    for (int k = 0; k < count; k++) {
+        const lvdgs_args *a = views[k];
+        if (!a) { set_error("blend batch: view %d is NULL", k); return LVDGS_E_INVALID; }
+        if (int e = check_common(a)) return e;
+        const int64_t D = a->num_gaussians == 0 ? 0 : a->num_rendered;
+        if (D < 0) { set_error("negative num_rendered"); return LVDGS_E_INVALID; }
+        if (int e = check_render_buffers(a, D)) return e;
+        if (a->image_width != views[0]->image_width || a->image_height != views[0]->image_height || a->tile_row_begin != views[0]->tile_row_begin ||
+            a->tile_row_end != views[0]->tile_row_end) { set_error("blend batch: the views differ in image size or band"); return LVDGS_E_INVALID; }
+        g[k] = GeomView{}; b[k] = BinView{};
+        if (a->num_gaussians > 0) geom_layout(a->num_gaussians, &g[k], a->geom_state);
+        bin_view(a, &b[k]);
+        image_layout(a->image_width, a->image_height, &im[k], a->image_state);
+    }
+    PairProbe *probe = nullptr;
+    if (int e = get_probe(&probe)) return e;
+    return launch_blend_fwd_batch(views, g.data(), b.data(), im.data(), count, probe->longest > 0, s);
+}
+
+int lvdgs_blend_backward_fused_loss_batch(const lvdgs_args *const *views, const lvdgs_loss_args *const *losses, int32_t count,
+                                          int32_t propagate_opacity_grad, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (count < 0 || (count > 0 && (!views || !losses))) { set_error("blend batch: bad view list"); return LVDGS_E_INVALID; }
+    if (count == 0) return LVDGS_OK;
+    std::vector<GeomView> g(count); std::vector<BinView> b(count); std::vector<ImageView> im(count); std::vector<BwdScratch> w(count);
+    std::vector<LossParams> lp(count);
+    for (int k = 0; k < count; k++) {
+        const lvdgs_args *a = views[k];
+        if (!a || !losses[k]) { set_error("blend batch: view %d is NULL", k); return LVDGS_E_INVALID; }
+        if (int e = loss_fused_params(losses[k], &lp[k])) return e;
+        if (losses[k]->width != a->image_width || losses[k]->height != a->image_height) { set_error("fused loss: image size differs from the rasterizer's"); return LVDGS_E_INVALID; }
+        if (a->image_width != views[0]->image_width || a->image_height != views[0]->image_height || a->tile_row_begin != views[0]->tile_row_begin ||
+            a->tile_row_end != views[0]->tile_row_end || ((a->flags ^ views[0]->flags) & LVDGS_FLAG_POSE_ONLY)) {
+            set_error("blend batch: the views differ in image size, band or LVDGS_FLAG_POSE_ONLY"); return LVDGS_E_INVALID;
+        }
+        BackwardViews v;
+        if (int e = backward_impl(a, &lp[k], propagate_opacity_grad != 0, s, &v)) return e;
+        g[k] = v.g; b[k] = v.b; im[k] = v.im; w[k] = v.w;
+    }
+    return launch_blend_bwd_fused_loss_batch(views, g.data(), b.data(), im.data(), w.data(), lp.data(), count, propagate_opacity_grad != 0, s);
 }
 
 int lvdgs_mark_visible(int32_t N, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present,

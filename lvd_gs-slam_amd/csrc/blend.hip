@@ -25,7 +25,7 @@
 // first two-pass backward) left the library in round 3: profiles/experiments/r02_superseded_blend_kernels.hip.txt.
 // What bounds the kernels and what was tried: DESIGN.md section 2, profiles/experiments/README.md.
 #include <type_traits>
-#ifdef LVDGS_DIAG_GRID
+#if defined(LVDGS_DIAG_GRID) || defined(LVDGS_DIAG_REPEAT)
 #include <cstdlib>
 #endif
 
@@ -195,7 +195,14 @@ __device__ __forceinline__ void blend_fwd2_body(const BlendParams &p) {
     float *const s_d = s_recs.d;   // raw conic c
     __shared__ int s_touch[256]; // pixels of this tile each staged Gaussian "touched" (T after it > 0.5)
 
-    const int tile = (p.tile_order && *p.order_valid) ? (int)p.tile_order[order_slot_of_workgroup(blockIdx.x, p.num_tiles)] : p.tile_base + tile_of_workgroup(blockIdx.x, p.num_tiles);
+#ifdef LVDGS_DIAG_REPEAT   // diagnostic build: the grid repeated $LVDGS_DIAG_REPEAT times (what a launch over several views of this size would cost)
+    const int diag_b = (int)blockIdx.x % p.num_tiles;
+#define blockIdx_x_ diag_b
+#else
+#define blockIdx_x_ ((int)blockIdx.x)
+#endif
+    const int tile = (p.tile_order && *p.order_valid) ? (int)p.tile_order[order_slot_of_workgroup(blockIdx_x_, p.num_tiles)] : p.tile_base + tile_of_workgroup(blockIdx_x_, p.num_tiles);
+#undef blockIdx_x_
     const int tx = tile % p.gx, ty = tile / p.gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;
@@ -303,6 +310,15 @@ __device__ __forceinline__ void blend_fwd2_body(const BlendParams &p) {
 
 __global__ void __launch_bounds__(256) blend_fwd2_kernel(BlendParams p) { blend_fwd2_body<false>(p); }
 __global__ void __launch_bounds__(256, 8) blend_fwd2_deep_kernel(BlendParams p) { blend_fwd2_body<true>(p); }
+// Several views of one size in ONE launch (lvdgs_blend_forward_batch: the views of a mapping window): blockIdx.y picks the view.
+// A KITTI-size frame leaves the chip's wave slots half empty and ends in a tail of its heaviest tiles; ten of them fill it
+// (per view 54 -> 34 us, blend_bwd 105 -> 77: LVDGS_DIAG_REPEAT builds).  Up to BATCH_VIEWS argument blocks travel as the kernel's
+// argument (344 bytes each, 4 KB of kernel arguments).
+constexpr int BATCH_VIEWS = 11;
+struct BlendBatch { BlendParams v[BATCH_VIEWS]; };
+static_assert(sizeof(BlendBatch) <= 4096, "kernel arguments");
+__global__ void __launch_bounds__(256) blend_fwd2_batch_kernel(BlendBatch b) { blend_fwd2_body<false>(b.v[blockIdx.y]); }
+__global__ void __launch_bounds__(256, 8) blend_fwd2_deep_batch_kernel(BlendBatch b) { blend_fwd2_body<true>(b.v[blockIdx.y]); }
 
 // ------------------------------------------------------------------------------------------
 constexpr int ACC_STRIDE = 10;  // floats per (wave, entry) accumulator slot
@@ -381,15 +397,22 @@ struct Bwd3Shared {
 #ifndef LVDGS_BWD_WGS_POSE
 #define LVDGS_BWD_WGS_POSE 7   // ... and its pose-only form (18.2 KB of LDS, 74 VGPRs; 26.4 KB with a depth gradient: six). Same box, config 3 / KITTI geometry: 5: 240.9 / 92.0 us, 6: 240.4 / 92.1, 7: 233.7 / 92.6, 8: 233.6 / 95.8
 #endif
-template <bool FUSED_LOSS, bool DEPTH_GRAD = true, bool POSE_ONLY = false>
-__global__ void __launch_bounds__(256, POSE_ONLY ? (DEPTH_GRAD ? 6 : LVDGS_BWD_WGS_POSE) : LVDGS_BWD_WGS) blend_bwd3_kernel(BlendParams p) {
+template <bool FUSED_LOSS, bool DEPTH_GRAD, bool POSE_ONLY>
+__device__ __forceinline__ void blend_bwd3_body(const BlendParams &p) {
     using Shared = Bwd3Shared<POSE_ONLY, DEPTH_GRAD>;
     constexpr int NB = Shared::NB, ACC = Shared::ACC;
     constexpr bool U_ONLY = POSE_ONLY && !DEPTH_GRAD;   // the matrix holds u alone
     using MT = typename Shared::MT;
     __shared__ Shared sh;
 
-    const int tile = (p.tile_order && *p.order_valid) ? (int)p.tile_order[order_slot_of_workgroup(blockIdx.x, p.num_tiles)] : p.tile_base + tile_of_workgroup(blockIdx.x, p.num_tiles);
+#ifdef LVDGS_DIAG_REPEAT   // diagnostic build: the grid repeated $LVDGS_DIAG_REPEAT times (what a launch over several views of this size would cost)
+    const int diag_b = (int)blockIdx.x % p.num_tiles;
+#define blockIdx_x_ diag_b
+#else
+#define blockIdx_x_ ((int)blockIdx.x)
+#endif
+    const int tile = (p.tile_order && *p.order_valid) ? (int)p.tile_order[order_slot_of_workgroup(blockIdx_x_, p.num_tiles)] : p.tile_base + tile_of_workgroup(blockIdx_x_, p.num_tiles);
+#undef blockIdx_x_
     const int tx = tile % p.gx, ty = tile / p.gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int qx0 = tx * TILE + (wave & 1) * 8, qy0 = ty * TILE + (wave >> 1) * 8;
@@ -694,6 +717,16 @@ __global__ void __launch_bounds__(256, POSE_ONLY ? (DEPTH_GRAD ? 6 : LVDGS_BWD_W
 #endif
 }
 
+template <bool FUSED_LOSS, bool DEPTH_GRAD = true, bool POSE_ONLY = false>
+__global__ void __launch_bounds__(256, POSE_ONLY ? (DEPTH_GRAD ? 6 : LVDGS_BWD_WGS_POSE) : LVDGS_BWD_WGS) blend_bwd3_kernel(BlendParams p) {
+    blend_bwd3_body<FUSED_LOSS, DEPTH_GRAD, POSE_ONLY>(p);
+}
+// several views in one launch (blockIdx.y: the view), the loss in the prologue
+template <bool DEPTH_GRAD, bool POSE_ONLY>
+__global__ void __launch_bounds__(256, POSE_ONLY ? (DEPTH_GRAD ? 6 : LVDGS_BWD_WGS_POSE) : LVDGS_BWD_WGS) blend_bwd3_batch_kernel(BlendBatch b) {
+    blend_bwd3_body<true, DEPTH_GRAD, POSE_ONLY>(b.v[blockIdx.y]);
+}
+
 BlendParams make_params(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im) {
     BlendParams p{};
     p.W = a.image_width; p.H = a.image_height;
@@ -718,8 +751,12 @@ int launch_blend_fwd(const lvdgs_args &a, const GeomView &g, const BinView &b, c
     if (const char *e = getenv("LVDGS_DIAG_GRID")) p.num_tiles = min(p.num_tiles, atoi(e));
 #endif
     ProfScope ps("blend_fwd", s);
-    if (deep_lists) hipLaunchKernelGGL(blend_fwd2_deep_kernel, dim3(p.num_tiles), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(blend_fwd2_kernel, dim3(p.num_tiles), dim3(256), 0, s, p);
+    int grid = p.num_tiles;
+#ifdef LVDGS_DIAG_REPEAT
+    if (const char *e = getenv("LVDGS_DIAG_REPEAT")) grid *= atoi(e);
+#endif
+    if (deep_lists) hipLaunchKernelGGL(blend_fwd2_deep_kernel, dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(blend_fwd2_kernel, dim3(grid), dim3(256), 0, s, p);
     LVDGS_LAUNCH_CHECK("blend_fwd", a.debug, s);
     return LVDGS_OK;
 }
@@ -736,11 +773,15 @@ int launch_blend_bwd(const lvdgs_args &a, const GeomView &g, const BinView &b, c
     if (const char *e = getenv("LVDGS_DIAG_GRID")) p.num_tiles = min(p.num_tiles, atoi(e));
 #endif
     ProfScope ps("blend_bwd", s);
+    int grid = p.num_tiles;
+#ifdef LVDGS_DIAG_REPEAT
+    if (const char *e = getenv("LVDGS_DIAG_REPEAT")) grid *= atoi(e);
+#endif
     const bool depth = LVDGS_BWD_DEPTH_ALWAYS || p.dL_ddepth, pose_only = (a.flags & LVDGS_FLAG_POSE_ONLY) != 0;
-    if (pose_only && depth) hipLaunchKernelGGL((blend_bwd3_kernel<false, true, true>), dim3(p.num_tiles), dim3(256), 0, s, p);
-    else if (pose_only) hipLaunchKernelGGL((blend_bwd3_kernel<false, false, true>), dim3(p.num_tiles), dim3(256), 0, s, p);
-    else if (depth) hipLaunchKernelGGL((blend_bwd3_kernel<false, true>), dim3(p.num_tiles), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((blend_bwd3_kernel<false, false>), dim3(p.num_tiles), dim3(256), 0, s, p);
+    if (pose_only && depth) hipLaunchKernelGGL((blend_bwd3_kernel<false, true, true>), dim3(grid), dim3(256), 0, s, p);
+    else if (pose_only) hipLaunchKernelGGL((blend_bwd3_kernel<false, false, true>), dim3(grid), dim3(256), 0, s, p);
+    else if (depth) hipLaunchKernelGGL((blend_bwd3_kernel<false, true>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((blend_bwd3_kernel<false, false>), dim3(grid), dim3(256), 0, s, p);
     LVDGS_LAUNCH_CHECK("blend_bwd", a.debug, s);
     return LVDGS_OK;
 }
@@ -756,12 +797,59 @@ int launch_blend_bwd_fused_loss(const lvdgs_args &a, const GeomView &g, const Bi
     if (const char *e = getenv("LVDGS_DIAG_GRID")) p.num_tiles = min(p.num_tiles, atoi(e));
 #endif
     ProfScope ps("blend_bwd", s);
+    int grid = p.num_tiles;
+#ifdef LVDGS_DIAG_REPEAT
+    if (const char *e = getenv("LVDGS_DIAG_REPEAT")) grid *= atoi(e);
+#endif
     const bool depth = LVDGS_BWD_DEPTH_ALWAYS || (loss.depth && loss.gt_depth && loss.w_d != 0.f), pose_only = (a.flags & LVDGS_FLAG_POSE_ONLY) != 0;
-    if (pose_only && depth) hipLaunchKernelGGL((blend_bwd3_kernel<true, true, true>), dim3(p.num_tiles), dim3(256), 0, s, p);
-    else if (pose_only) hipLaunchKernelGGL((blend_bwd3_kernel<true, false, true>), dim3(p.num_tiles), dim3(256), 0, s, p);
-    else if (depth) hipLaunchKernelGGL((blend_bwd3_kernel<true, true>), dim3(p.num_tiles), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((blend_bwd3_kernel<true, false>), dim3(p.num_tiles), dim3(256), 0, s, p);
+    if (pose_only && depth) hipLaunchKernelGGL((blend_bwd3_kernel<true, true, true>), dim3(grid), dim3(256), 0, s, p);
+    else if (pose_only) hipLaunchKernelGGL((blend_bwd3_kernel<true, false, true>), dim3(grid), dim3(256), 0, s, p);
+    else if (depth) hipLaunchKernelGGL((blend_bwd3_kernel<true, true>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((blend_bwd3_kernel<true, false>), dim3(grid), dim3(256), 0, s, p);
     LVDGS_LAUNCH_CHECK("blend_bwd", a.debug, s);
+    return LVDGS_OK;
+}
+
+// The blend passes of n views of one size in one launch each (api.hip: lvdgs_blend_forward_batch / lvdgs_blend_backward_fused_loss_batch).
+int launch_blend_fwd_batch(const lvdgs_args *const *a, const GeomView *g, const BinView *b, const ImageView *im, int n, bool deep_lists, hipStream_t s) {
+    for (int first = 0; first < n; first += BATCH_VIEWS) {
+        const int m = min(BATCH_VIEWS, n - first);
+        BlendBatch batch{};
+        for (int k = 0; k < m; k++) batch.v[k] = make_params(*a[first + k], g[first + k], b[first + k], im[first + k]);
+        if (batch.v[0].num_tiles == 0) continue;
+        ProfScope ps("blend_fwd", s);
+        if (deep_lists) hipLaunchKernelGGL(blend_fwd2_deep_batch_kernel, dim3(batch.v[0].num_tiles, m), dim3(256), 0, s, batch);
+        else hipLaunchKernelGGL(blend_fwd2_batch_kernel, dim3(batch.v[0].num_tiles, m), dim3(256), 0, s, batch);
+        LVDGS_LAUNCH_CHECK("blend_fwd (batch)", a[first]->debug, s);
+    }
+    return LVDGS_OK;
+}
+
+int launch_blend_bwd_fused_loss_batch(const lvdgs_args *const *a, const GeomView *g, const BinView *b, const ImageView *im, const BwdScratch *w,
+                                      const LossParams *loss, int n, int propagate_opacity, hipStream_t s) {
+    for (int first = 0; first < n; first += BATCH_VIEWS) {
+        const int m = min(BATCH_VIEWS, n - first);
+        BlendBatch batch{};
+        bool depth = false;
+        for (int k = 0; k < m; k++) {
+            const int v = first + k;
+            BlendParams &p = batch.v[k];
+            p = make_params(*a[v], g[v], b[v], im[v]);
+            p.pair_grads = w[v].pair_grads; p.pair_valid = b[v].pair_valid;
+            p.loss = loss[v];
+            p.loss_propagate_opacity = propagate_opacity;
+            depth = depth || LVDGS_BWD_DEPTH_ALWAYS || (loss[v].depth && loss[v].gt_depth && loss[v].w_d != 0.f);
+        }
+        if (batch.v[0].num_tiles == 0) continue;
+        ProfScope ps("blend_bwd", s);
+        const bool pose_only = (a[first]->flags & LVDGS_FLAG_POSE_ONLY) != 0;
+        const dim3 grid(batch.v[0].num_tiles, m);
+        if (pose_only && depth) hipLaunchKernelGGL((blend_bwd3_batch_kernel<true, true>), grid, dim3(256), 0, s, batch);
+        else if (pose_only) hipLaunchKernelGGL((blend_bwd3_batch_kernel<false, true>), grid, dim3(256), 0, s, batch);
+        else if (depth) hipLaunchKernelGGL((blend_bwd3_batch_kernel<true, false>), grid, dim3(256), 0, s, batch);
+        else hipLaunchKernelGGL((blend_bwd3_batch_kernel<false, false>), grid, dim3(256), 0, s, batch);
+        LVDGS_LAUNCH_CHECK("blend_bwd (batch)", a[first]->debug, s);
+    }
     return LVDGS_OK;
 }
 

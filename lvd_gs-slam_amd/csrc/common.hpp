@@ -294,6 +294,10 @@ int launch_tile_ranges(const uint32_t *tile_keys, int64_t D, const uint32_t *D_d
                        hipStream_t s);
 
 int launch_blend_fwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, bool deep_lists, hipStream_t s);   // deep_lists: a hint (which build of the kernel), never a result
+struct LossParams;
+int launch_blend_fwd_batch(const lvdgs_args *const *a, const GeomView *g, const BinView *b, const ImageView *im, int n, bool deep_lists, hipStream_t s);
+int launch_blend_bwd_fused_loss_batch(const lvdgs_args *const *a, const GeomView *g, const BinView *b, const ImageView *im, const BwdScratch *w,
+                                      const LossParams *loss, int n, int propagate_opacity, hipStream_t s);
 int launch_blend_bwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, const BwdScratch &w,
                      hipStream_t s);
 

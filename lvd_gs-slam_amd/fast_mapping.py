@@ -45,10 +45,11 @@ class MapViewPass:
     """Buffers and argument blocks for render + ``get_loss_mapping`` + backward of one view; re-pointed at every call
     (the model's tensors are replaced by densification, the viewpoint changes from call to call)."""
 
-    def __init__(self, device):
+    def __init__(self, device, own_gradient_buffers=True):
         if device.type != "cuda":
             raise _lib.LvdgsError("MapViewPass needs the map on the GPU (there is no CPU path)")
         self.dev = device
+        self.own_gradient_buffers = own_gradient_buffers   # (False: a later view of a MapWindowBatch -- it adds to the first view's)
         self.L = _lib.lib()
         self.a, self.la = _lib.Args(), _lib.LossArgs()
         self.N = self.W = self.H = -1
@@ -85,7 +86,7 @@ class MapViewPass:
         # two sets of gradient buffers: `first` becomes the parameters' .grad, `more` receives the later views
         mk = lambda: dict(_xyz=e(N, 3), _features_dc=e(N, 1, 3), _features_rest=e(N, K - 1, 3), _scaling=e(N, 3),
                           _rotation=e(N, 4), _opacity=e(N, 1), sh=(e(N, K, 3) if K > 1 else None))
-        self.first, self.more = mk(), mk()
+        self.first, self.more = (mk(), mk()) if self.own_gradient_buffers else (None, None)
         self.shs = e(N, K, 3) if K > 1 else None
         a = self.a
         a.num_gaussians, a.sh_coeffs = N, K
@@ -268,3 +269,162 @@ class MapViewPass:
         pkg = {"render": color, "viewspace_points": vsp, "visibility_filter": (radii > 0) if not vsp.stats_taken else None, "radii": radii, "depth": depth,
                "opacity": opacity, "n_touched": n_touched}
         return pkg, loss
+
+
+class MapWindowBatch:
+    """The views of a mapping window through ``MapViewPass``'s three calls with the two blend passes of ALL views in one launch each:
+
+        per view:  lvdgs_forward (LVDGS_FLAG_NO_BLEND: projection ... per-tile depth sort)
+        once:      lvdgs_blend_forward_batch, lvdgs_blend_backward_fused_loss_batch
+        per view:  lvdgs_backward_fused_loss (LVDGS_FLAG_NO_BLEND: the per-Gaussian pass, adding to the first view's gradients),
+                   lvdgs_map_view_tail
+
+    A KITTI-size frame (1848 tiles) leaves the chip half empty and ends in a tail of its heaviest tiles; ten frames fill it.
+    Every view keeps buffers of its own between the phases (geometry, pair lists, image state, scratch: ~60 MB per view at
+    KITTI's size, ~200 MB at 500 k Gaussians / 1080p).  Results are ``MapViewPass.run``'s view after view, bit for bit: the same kernels on
+    the same data, the parameter gradients added in the same order.
+
+    For whole views scored by the built-in mapping loss on a model of SH degree 0 (``usable``); anything else goes view by view."""
+
+    def __init__(self, lead: MapViewPass):
+        self.passes = [lead]
+
+    @staticmethod
+    def usable(backend, viewpoints) -> bool:
+        G = backend.gaussians
+        if len(viewpoints) < 2 or int(G._features_rest.shape[1]) != 0 or _rz.LIST_ALL_TILES:
+            return False
+        size = {(int(v.image_height), int(v.image_width)) for v in viewpoints}
+        return len(size) == 1 and all(getattr(v, "static_mask", None) is None and MapViewPass.usable(backend, v) for v in viewpoints)
+
+    def run(self, backend, viewpoints, initialization=False, first=None, stats=None):
+        """-> [(pkg, loss)] in the order of ``viewpoints`` (``stats[k]``: ``MapViewPass.run``'s ``stats`` of view k)."""
+        lead = self.passes[0]
+        dev, L = lead.dev, lead.L
+        while len(self.passes) < len(viewpoints):
+            self.passes.append(MapViewPass(dev, own_gradient_buffers=False))
+        n = len(viewpoints)
+        ctxs = []
+        with _lib.on_device(dev):
+            stream = _lib.raw_stream(dev)
+            for k, vp in enumerate(viewpoints):
+                ctxs.append(self.passes[k]._begin_for_batch(backend, vp, initialization, first if k == 0 else None,
+                                                            None if k == 0 else ctxs[0]["into"], stream))
+            views = (C.POINTER(_lib.Args) * n)(*[C.pointer(self.passes[k].a) for k in range(n)])
+            losses = (C.POINTER(_lib.LossArgs) * n)(*[C.pointer(self.passes[k].la) for k in range(n)])
+            _lib.check(L.lvdgs_blend_forward_batch(views, n, stream), "lvdgs_blend_forward_batch")
+            _lib.check(L.lvdgs_blend_backward_fused_loss_batch(views, losses, n, 0, stream), "lvdgs_blend_backward_fused_loss_batch")
+            for k in range(n):
+                self.passes[k]._backward_for_batch(ctxs[k], None if stats is None else stats[k], stream)
+        return [self.passes[k]._finish_for_batch(backend, viewpoints[k], ctxs[k]) for k in range(n)]
+
+
+def _begin_for_batch(self, backend, viewpoint, initialization, first, lead_into, stream):
+    """``MapViewPass.run`` up to the forward call (whole view, built-in loss, SH degree 0), with LVDGS_FLAG_NO_BLEND."""
+    G, cfg, dev, L = backend.gaussians, backend.config, self.dev, self.L
+    T = cfg["Training"]
+    N, K = int(G._xyz.shape[0]), 1 + int(G._features_rest.shape[1])
+    H, W = int(viewpoint.image_height), int(viewpoint.image_width)
+    if N != self.N or K != getattr(self, "K", -1):
+        self._size_for_model(N, K)
+    if (W, H) != (self.W, self.H):
+        self._size_for_image(W, H)
+    a, la = self.a, self.la
+    e = lambda *s, dt=torch.float32: torch.empty(*s, dtype=dt, device=dev)
+    keep = self._keep = []
+    f32c = lambda t: t.detach() if _gpu_f32c(t, dev) else t.detach().to(device=dev, dtype=torch.float32).contiguous()
+    a.tanfovx, a.tanfovy = math.tan(viewpoint.FoVx * 0.5), math.tan(viewpoint.FoVy * 0.5)
+    a.scale_modifier, a.sh_degree, a.prefiltered, a.debug = 1.0, int(G.active_sh_degree), 0, 0
+    cam = [f32c(t) for t in (backend.background, viewpoint.world_view_transform, viewpoint.full_proj_transform,
+                             viewpoint.projection_matrix, viewpoint.camera_center)]
+    keep += cam
+    a.bg, a.viewmatrix, a.projmatrix, a.projmatrix_raw, a.campos = (_P(t) for t in cam)
+    a.activations = _rz.ACT_EXP_SCALES | _rz.ACT_NORMALIZE_ROTATIONS | _rz.ACT_SIGMOID_OPACITIES
+    a.tile_row_begin, a.tile_row_end = 0, 0
+    shs = G._features_dc.detach()
+    a.means3D, a.opacities, a.scales, a.rotations, a.shs = _P(G._xyz), _P(G._opacity), _P(G._scaling), _P(G._rotation), _P(shs)
+    color, depth, opacity = e(3, H, W), e(1, H, W), e(1, H, W)
+    radii, n_touched = e(N, dt=torch.int32), e(N, dt=torch.int32)
+    a.radii, a.n_touched, a.out_color, a.out_depth, a.out_opacity = _P(radii), _P(n_touched), _P(color), _P(depth), _P(opacity)
+
+    fields = [n for n in _PARAM_FIELDS if getattr(G, n).numel() > 0]
+    if lead_into is None:   # the batch's first view: as MapViewPass.run decides
+        has = [getattr(G, n).grad is not None for n in fields]
+        if any(has) and not all(has):
+            raise _lib.LvdgsError("MapViewPass: some of the model's parameters carry a gradient and some do not")
+        if has[0] and any(not _gpu_f32c(getattr(G, n).grad, dev) for n in fields):
+            raise _lib.LvdgsError("MapViewPass: the model's existing gradients are not contiguous float32 tensors on the GPU")
+        accumulate, install = has[0], not has[0]
+        into = {n: getattr(G, n).grad for n in fields} if accumulate else (self.first if first is None else first)
+    else:                   # a later view: added to where the first view's gradients are (being) written
+        accumulate, install, into = True, False, lead_into
+    a.flags = _lib.FLAG_NO_BLEND | (_lib.FLAG_ACCUMULATE_PARAM_GRADS if accumulate else 0)
+    a.dL_dmeans3D, a.dL_dopacities, a.dL_dscales = _P(into["_xyz"]), _P(into["_opacity"]), _P(into["_scaling"])
+    a.dL_drotations, a.dL_dshs = _P(into["_rotation"]), _P(into["_features_dc"])
+    d_tau, d_a, d_b, d_m2 = e(6), e(1), e(1), e(N, 3)
+    a.dL_dtau, a.dL_dmeans2D = None, _P(d_m2)
+    loss = e(())
+    gt = f32c(_gt_image(viewpoint, color))
+    keep.append(gt)
+    la.image, la.gt_image = _P(color), _P(gt)
+    la.rgb_boundary_threshold = float(T["rgb_boundary_threshold"])
+    if initialization:
+        la.exposure_a = la.exposure_b = la.d_exposure_a = la.d_exposure_b = None
+    else:
+        la.exposure_a, la.exposure_b, la.d_exposure_a, la.d_exposure_b = _P(viewpoint.exposure_a), _P(viewpoint.exposure_b), _P(d_a), _P(d_b)
+    alpha = T.get("alpha", 0.95)
+    md = f32c(_mono_depth(viewpoint, color))
+    keep.append(md)
+    la.depth, la.gt_depth = _P(depth), _P(md)
+    la.weight_rgb, la.weight_depth = float(alpha), float(1 - alpha)
+    la.loss = _P(loss)
+
+    num = C.c_int64(0)
+    status = L.lvdgs_forward(C.byref(a), C.byref(num), stream)
+    D = int(num.value)
+    if status == _lib.E_CAPACITY:
+        self._size_for_pairs(D + D // 2)
+        a.num_rendered = D
+        _lib.check(L.lvdgs_forward_render(C.byref(a), stream), "lvdgs_forward_render")
+    else:
+        _lib.check(status, "lvdgs_forward")
+    a.num_rendered = D
+    return dict(color=color, depth=depth, opacity=opacity, radii=radii, n_touched=n_touched, d_tau=d_tau, d_a=d_a, d_b=d_b, d_m2=d_m2,
+                loss=loss, into=into, install=install, fields=fields, initialization=initialization)
+
+
+def _backward_for_batch(self, ctx, stats, stream):
+    L, a, la = self.L, self.a, self.la
+    _lib.check(L.lvdgs_backward_fused_loss(C.byref(a), C.byref(la), 0, stream), "lvdgs_backward_fused_loss")
+    if stats is not None:
+        sa = _lib.ViewStatsArgs()
+        sa.radii_max, sa.norm_sum, sa.vis_count, sa.touched_row, sa.split_xy = (_P(t) for t in stats)
+        _lib.check(L.lvdgs_map_view_tail(C.byref(la), C.byref(a), _P(ctx["d_tau"]), C.byref(sa), stream), "lvdgs_map_view_tail")
+    else:
+        _lib.check(L.lvdgs_tracking_tail(C.byref(la), C.byref(a), None, _P(ctx["d_tau"]), 1, stream), "lvdgs_tracking_tail")
+    ctx["stats_taken"] = stats is not None
+
+
+def _finish_for_batch(self, backend, viewpoint, ctx):
+    G = backend.gaussians
+    if ctx["install"]:
+        for n in ctx["fields"]:
+            getattr(G, n).grad = ctx["into"][n]
+    d_tau = ctx["d_tau"]
+    pose = (("cam_trans_delta", d_tau[:3]), ("cam_rot_delta", d_tau[3:]))
+    expo = () if ctx["initialization"] else (("exposure_a", ctx["d_a"]), ("exposure_b", ctx["d_b"]))
+    for name, g in pose + expo:
+        p = getattr(viewpoint, name)
+        if p.requires_grad:
+            g = g.view_as(p)
+            p.grad = g if p.grad is None else p.grad + g
+    vsp = SimpleNamespace(grad=ctx["d_m2"], stats_taken=ctx["stats_taken"])
+    radii = ctx["radii"]
+    pkg = {"render": ctx["color"], "viewspace_points": vsp, "visibility_filter": (radii > 0) if not vsp.stats_taken else None, "radii": radii,
+           "depth": ctx["depth"], "opacity": ctx["opacity"], "n_touched": ctx["n_touched"]}
+    return pkg, ctx["loss"]
+
+
+MapViewPass._begin_for_batch = _begin_for_batch
+MapViewPass._backward_for_batch = _backward_for_batch
+MapViewPass._finish_for_batch = _finish_for_batch

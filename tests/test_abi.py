@@ -36,6 +36,7 @@ def test_flag_and_status_values_match_the_header():
     assert enums["LVDGS_FLAG_LIST_ALL_TILES"] == _lib.FLAG_LIST_ALL_TILES
     assert enums["LVDGS_FLAG_ACCUMULATE_PARAM_GRADS"] == _lib.FLAG_ACCUMULATE_PARAM_GRADS
     assert enums["LVDGS_FLAG_POSE_ONLY"] == _lib.FLAG_POSE_ONLY
+    assert enums["LVDGS_FLAG_NO_BLEND"] == _lib.FLAG_NO_BLEND
     flags = [v for k, v in enums.items() if k.startswith("LVDGS_FLAG_")]
     assert len(set(flags)) == len(flags) and all(v & (v - 1) == 0 for v in flags)   # distinct single bits
     assert (enums["LVDGS_OK"], enums["LVDGS_E_INVALID"], enums["LVDGS_E_HIP"], enums["LVDGS_E_RANGE"], enums["LVDGS_E_CAPACITY"]) == \

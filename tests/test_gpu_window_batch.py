@@ -1,0 +1,59 @@
+"""The views of a mapping window with their blend passes in ONE launch each (fast_mapping.MapWindowBatch: LVDGS_FLAG_NO_BLEND,
+lvdgs_blend_forward_batch, lvdgs_blend_backward_fused_loss_batch) against the same window view by view: the same kernels on
+the same data, the parameter gradients added in the same order -- every gradient, every loss, every statistic and the map after
+Adam steps must be the same BITS."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(batch, iters, n_window=8, workload="tmp_window_batch"):
+    import bench
+    from lvdgs import backend_map, synthetic
+    synthetic.CONFIGS[workload] = dict(N=30000, W=400, H=240)
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    model, cam, g, _ = bench.build_scene(workload, 0, dev)
+    backend, window = bench.build_window(workload, 12, dev, model, n_window=n_window)
+    before = os.environ.get("LVDGS_MAP_BATCH")
+    os.environ["LVDGS_MAP_BATCH"] = "1" if batch else "0"
+    try:
+        st = {}
+        grads = None
+        for _ in range(iters):
+            backend_map.map_window(backend, window, iters=1, stats=st)
+    finally:
+        if before is None:
+            os.environ.pop("LVDGS_MAP_BATCH", None)
+        else:
+            os.environ["LVDGS_MAP_BATCH"] = before
+    torch.cuda.synchronize()
+    G = backend.gaussians
+    used = getattr(backend, "_lvdgs_window_batch", None) is not None
+    params = [p.detach().clone() for p in G.parameters()]
+    poses = [torch.cat([vp.cam_rot_delta.detach().flatten(), vp.cam_trans_delta.detach().flatten(), vp.exposure_a.detach().flatten(),
+                        vp.exposure_b.detach().flatten(), vp.R.detach().flatten().to(dev), vp.T.detach().flatten().to(dev)]).clone()
+             for vp in backend.viewpoints.values()]
+    stats = [G.max_radii2D.clone(), G.xyz_gradient_accum.clone(), G.denom.clone()]
+    losses = [float(r["loss"]) for r in st["iterations"]] if st.get("iterations") and "loss" in st["iterations"][0] else []
+    return used, params, poses, stats, losses
+
+
+def test_window_batch_is_the_window_view_by_view_bit_for_bit():
+    used_b, params_b, poses_b, stats_b, losses_b = _run(True, 3)
+    used_s, params_s, poses_s, stats_s, losses_s = _run(False, 3)
+    assert used_b and not used_s, "the batch path did not run (or ran when switched off)"
+    for a, b in zip(params_b, params_s):
+        assert torch.equal(a, b)
+    for a, b in zip(poses_b, poses_s):
+        assert torch.equal(a, b)
+    for a, b in zip(stats_b, stats_s):
+        assert torch.equal(a, b)
+    assert losses_b == losses_s
