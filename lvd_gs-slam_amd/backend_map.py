@@ -765,16 +765,17 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
                 first = {n: plan[k].view_as(p) for k, (n, p) in enumerate(zip(_PARAM_FIELDS, live))}
         with torch.no_grad():
             vs = _ViewStats(N0, n_window, G.get_xyz.device, split, (plan[-4], plan[-3], plan[-2]) if plan is not None else None)
-        # One GPU, every view whole and scored by the built-in loss: the blend passes of ALL views in one launch each
+        # Every piece of this rank a whole view scored by the built-in loss (one GPU: the whole window; two GPUs: five views each;
+        # beyond, a rank holds one view and bands): the blend passes of ALL of them in one launch each
         # (fast_mapping.MapWindowBatch -- a KITTI-size frame alone leaves the chip half empty; LVDGS_MAP_BATCH=0: view by view)
         batched = False
-        if (vpass is not None and world == 1 and first is None and os.environ.get("LVDGS_MAP_BATCH", "1") != "0"
+        if (vpass is not None and os.environ.get("LVDGS_MAP_BATCH", "1") != "0"
                 and all((r0, r1) == (0, _tile_rows(views[v])) for v, r0, r1 in mine)
                 and MapWindowBatch.usable(backend, [views[v] for v, _, _ in mine])):
             batch = getattr(backend, "_lvdgs_window_batch", None)
             if batch is None or batch.passes[0] is not vpass:
                 batch = backend._lvdgs_window_batch = MapWindowBatch(vpass)
-            for (v, r0, _), (pkg, l) in zip(mine, batch.run(backend, [views[v] for v, _, _ in mine],
+            for (v, r0, _), (pkg, l) in zip(mine, batch.run(backend, [views[v] for v, _, _ in mine], first=first,
                                                              stats=[vs.targets(v, r0) for v, r0, _ in mine])):
                 pkgs.append((v, r0, pkg))
                 direct_losses.append(l)
