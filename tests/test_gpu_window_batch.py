@@ -57,3 +57,41 @@ def test_window_batch_is_the_window_view_by_view_bit_for_bit():
     for a, b in zip(stats_b, stats_s):
         assert torch.equal(a, b)
     assert losses_b == losses_s
+
+
+def test_window_batch_grows_its_pair_buffers_like_the_single_view_pass():
+    """A view whose pair count exceeds its buffers' capacity (the first iterations of a back end, a view that sees far more of the
+    map than the others) makes lvdgs_forward return LVDGS_E_CAPACITY; the view's pass grows its own buffers and re-runs the binning
+    (lvdgs_forward_render, still without its blend pass).  Forced here by starting every pass with buffers for 1000 pairs."""
+    import bench
+    from lvdgs import backend_map, fast_mapping, rasterizer, synthetic
+    workload = "tmp_window_batch_cap"
+    synthetic.CONFIGS[workload] = dict(N=20000, W=320, H=240)
+    dev = torch.device("cuda", 0)
+
+    def run(batch):
+        torch.manual_seed(0)
+        model, cam, g, _ = bench.build_scene(workload, 0, dev)
+        backend, window = bench.build_window(workload, 6, dev, model, n_window=4)
+        before = (os.environ.get("LVDGS_MAP_BATCH"), rasterizer._MIN_PAIR_CAPACITY, rasterizer._PAIRS_PER_GAUSSIAN_GUESS)
+        os.environ["LVDGS_MAP_BATCH"] = "1" if batch else "0"
+        rasterizer._MIN_PAIR_CAPACITY, rasterizer._PAIRS_PER_GAUSSIAN_GUESS = 1000, 0
+        try:
+            for _ in range(2):
+                backend_map.map_window(backend, window, iters=1)
+        finally:
+            rasterizer._MIN_PAIR_CAPACITY, rasterizer._PAIRS_PER_GAUSSIAN_GUESS = before[1], before[2]
+            if before[0] is None:
+                os.environ.pop("LVDGS_MAP_BATCH", None)
+            else:
+                os.environ["LVDGS_MAP_BATCH"] = before[0]
+        torch.cuda.synchronize()
+        b = getattr(backend, "_lvdgs_window_batch", None)
+        caps = [p.cap for p in b.passes] if b is not None else [backend._lvdgs_view_pass.cap]
+        return [p.detach().clone() for p in backend.gaussians.parameters()], caps
+
+    params_b, caps_b = run(True)
+    params_s, caps_s = run(False)
+    assert len(caps_b) > 1 and min(caps_b) > 1000 and caps_s[0] > 1000   # every pass had to grow
+    for a, b in zip(params_b, params_s):
+        assert torch.equal(a, b)
