@@ -572,7 +572,10 @@ static int backward_impl(const lvdgs_args *a, const LossParams *fused, int propa
     return launch_preprocess_bwd(*a, g, w, b.pair_valid, s);
 }
 
-int lvdgs_backward(const lvdgs_args *a, void *stream) { return backward_impl(a, nullptr, 0, (hipStream_t)stream); }
+int lvdgs_backward(const lvdgs_args *a, void *stream) {
+    if (a && (a->flags & LVDGS_FLAG_NO_BLEND)) { set_error("LVDGS_FLAG_NO_BLEND: only lvdgs_backward_fused_loss has a batched blend pass to leave its own to"); return LVDGS_E_INVALID; }
+    return backward_impl(a, nullptr, 0, (hipStream_t)stream);
+}
 
 int lvdgs_backward_fused_loss(const lvdgs_args *a, const lvdgs_loss_args *loss, int32_t propagate_opacity_grad, void *stream) {
     if (!a) { set_error("backward: args is NULL"); return LVDGS_E_INVALID; }

@@ -121,6 +121,9 @@ def test_two_call_forward_and_backward_through_ctypes():
     shs = torch.zeros(N, 4, 3, device=dev)
     a.colors_precomp, a.shs, a.sh_coeffs, a.sh_degree = None, _p(shs), 4, 1
     assert L.lvdgs_backward(C.byref(a), stream) == _lib.E_INVALID and b"POSE_ONLY" in L.lvdgs_last_error()
+    # the plain backward has no batched blend pass to leave its own to
+    a.flags = _lib.FLAG_NO_BLEND
+    assert L.lvdgs_backward(C.byref(a), stream) == _lib.E_INVALID and b"NO_BLEND" in L.lvdgs_last_error()
 
 
 def test_errors_are_reported_not_thrown():
