@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 def _run(batch, iters, n_window=8, workload="tmp_window_batch"):
     import bench
     from lvdgs import backend_map, synthetic
-    synthetic.CONFIGS[workload] = dict(N=30000, W=400, H=240)
+    synthetic.CONFIGS.setdefault(workload, dict(N=30000, W=400, H=240))
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     model, cam, g, _ = bench.build_scene(workload, 0, dev)
@@ -46,9 +46,10 @@ def _run(batch, iters, n_window=8, workload="tmp_window_batch"):
     return used, params, poses, stats, losses
 
 
-def test_window_batch_is_the_window_view_by_view_bit_for_bit():
-    used_b, params_b, poses_b, stats_b, losses_b = _run(True, 3)
-    used_s, params_s, poses_s, stats_s, losses_s = _run(False, 3)
+@pytest.mark.parametrize("workload", ["tmp_window_batch", "surface_12k_640x480"])   # (the second: lists of 500-1500 entries -- the deep-lists build of the forward blend pass, the tile sort's queue)
+def test_window_batch_is_the_window_view_by_view_bit_for_bit(workload):
+    used_b, params_b, poses_b, stats_b, losses_b = _run(True, 3, workload=workload)
+    used_s, params_s, poses_s, stats_s, losses_s = _run(False, 3, workload=workload)
     assert used_b and not used_s, "the batch path did not run (or ran when switched off)"
     for a, b in zip(params_b, params_s):
         assert torch.equal(a, b)
