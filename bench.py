@@ -92,11 +92,26 @@ def build_scene(workload, rank, dev):
     return model, cam, g, (N, W, H)
 
 
-def build_window(workload, world, dev, model, n_window=None):
+def dynamic_object_mask(H, W, seed):
+    """A keyframe's ``static_mask`` (bool (H,W), True = static) as LVD-GS's front end makes it from GroundingDINO + SAM detections
+    (utils/slam_frontend.py:1309-1329; the models are out of scope): two to four "vehicles" -- rectangles of 8-25 % of the image's
+    width and 10-35 % of its height in the lower two thirds of the frame -- marked dynamic, seeded per keyframe."""
+    g = torch.Generator().manual_seed(7000 + seed)
+    m = torch.ones(H, W, dtype=torch.bool)
+    for _ in range(2 + int(torch.randint(0, 3, (1,), generator=g))):
+        w = int(W * (0.08 + 0.17 * float(torch.rand(1, generator=g)))); h = int(H * (0.10 + 0.25 * float(torch.rand(1, generator=g))))
+        x0 = int(torch.randint(0, max(W - w, 1), (1,), generator=g)); y0 = H // 3 + int(torch.randint(0, max(H - H // 3 - h, 1), (1,), generator=g))
+        m[y0:y0 + h, x0:x0 + w] = False
+    return m
+
+
+def build_window(workload, world, dev, model, n_window=None, masked=False):
     """A BackEnd-shaped object (the attributes reference utils/slam_backend.py:21-72 sets) holding `world` keyframes
     of the workload's scene, every one from its own seeded pose with its own seeded target image, built identically
     on every rank.  The window is the newest `n_window` of them (default: all); the others are the older keyframes the
-    iteration draws its two random views from."""
+    iteration draws its two random views from.  `masked`: every keyframe carries a ``static_mask`` -- the reference's default
+    (``dynamic_filtering.enabled``: utils/slam_frontend.py:1218,1429-1433), which sends the window's keyframes down the L1 + SSIM +
+    masked-depth branch of the mapping loss (utils/slam_backend.py:196-261)."""
     from lvdgs.camera_utils import Camera
     from lvdgs.graphics_utils import focal2fov, getProjectionMatrix2
     from lvdgs.pose_utils import SE3_exp
@@ -120,6 +135,8 @@ def build_window(workload, world, dev, model, n_window=None):
             pkg = render(cam, model, pipe, torch.zeros(3, device=dev))
             cam.original_image = (pkg["render"] + 0.05 * torch.randn(3, H, W, generator=gen).to(dev)).clamp_(0.02, 1.0).contiguous()
             cam.mono_depth = (pkg["depth"][0] * (1.0 + 0.02 * torch.randn(H, W, generator=gen).to(dev))).clamp_min_(0.05).cpu().numpy()
+        if masked:
+            cam.static_mask = dynamic_object_mask(H, W, k).to(dev)
         viewpoints[k + 1] = cam
     n_window = world if n_window is None else n_window
     window = list(range(world, world - n_window, -1))  # newest first

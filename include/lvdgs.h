@@ -363,7 +363,8 @@ int lvdgs_tracking_tail(const lvdgs_loss_args *loss, const lvdgs_args *bwd, cons
 /* The end of one VIEW of the mapping iteration in one launch: lvdgs_tracking_tail(loss, bwd, NULL, dL_dtau, 1, ...) -- the
  * view's loss value, exposure gradients and pose gradient from the partial sums lvdgs_backward_fused_loss left -- and
  * lvdgs_view_stats on the view's outputs (bwd->radii, bwd->n_touched, bwd->dL_dmeans2D; see lvdgs_view_stats below for the
- * meaning of the fields, any of vis_count / touched_row / split_xy may be NULL). */
+ * meaning of the fields, any of vis_count / touched_row / split_xy may be NULL).  loss == NULL: a view scored by
+ * lvdgs_masked_loss_batch, whose loss value is finished already -- the pose gradient and the statistics only. */
 typedef struct lvdgs_view_stats_args {
     int32_t *radii_max;   /* N   */
     float *norm_sum;      /* N   */
@@ -446,6 +447,47 @@ typedef struct lvdgs_ssim_args {
 } lvdgs_ssim_args;
 size_t lvdgs_ssim_scratch_bytes(int32_t width, int32_t height, int32_t planes);
 int lvdgs_ssim_l1(const lvdgs_ssim_args *a, void *stream);
+
+/* ---- the static-mask mapping loss as ONE object (reference utils/slam_backend.py:196-261; colour refinement :420-454) ----
+ * LVD-GS's front end attaches a static_mask to every tracked frame and keyframe (utils/slam_frontend.py:1218,1309-1329,1429-1433:
+ * dynamic_filtering.enabled defaults to True), so this -- not get_loss_mapping -- is the loss of every window keyframe of
+ * BackEnd.map:
+ *     loss = (1 - lambda) * mean|a - b| + lambda * (1 - mean SSIM(a, b)) + depth_lambda * mean_{p in M} |D_p - Z_p|
+ *     a, b = rendered / target colour with bg[c] written under the dynamic pixels (static_mask byte 0) of both,
+ *     M    = static_mask & (Z > 0) & (D > 0)     (no depth term when gt_depth is NULL, or M is empty)
+ * lvdgs_masked_loss_batch evaluates it for `count` views of one size in TWO launches whatever the count: the fused L1 + SSIM
+ * kernel over every plane of every view (it also takes the depth term's sum and exact pixel count per 32x32 tile), and a
+ * finish (one workgroup per view).  Per view it writes d_image = d loss / d a (the SSIM gradient is not local, so it is an
+ * image) and out[0..4] = loss, mean|a - b|, mean SSIM, depth term, |M|.  The depth term's gradient is NOT written anywhere:
+ * lvdgs_backward_masked_loss / lvdgs_blend_backward_window_batch evaluate depth_lambda * sign(D - Z) / |M| per pixel from
+ * depth / gt_depth / static_mask and out[4] as the backward blend pass reads its pixels.  Same numbers as lvdgs_ssim_l1 +
+ * lvdgs_masked_depth_l1_forward / _backward + lvdgs_backward on their gradient images (d_image, d_depth: the same bits). */
+typedef struct lvdgs_masked_loss_args {
+    int32_t width, height;
+    const float *image;          /* 3*H*W rendered colour                               */
+    const float *gt_image;       /* 3*H*W                                               */
+    const uint8_t *static_mask;  /* H*W bytes (non-0 = static) or NULL (every pixel)    */
+    const float *bg;             /* 3 or NULL (0): colour written under the mask        */
+    const float *depth;          /* H*W rendered depth, or NULL                         */
+    const float *gt_depth;       /* H*W mono depth, or NULL: no depth term              */
+    float lambda_dssim, depth_lambda;
+    void *scratch; size_t scratch_bytes;   /* lvdgs_masked_loss_scratch_bytes(W,H)      */
+    float *d_image;              /* out: 3*H*W                                          */
+    float *out;                  /* out: 8 floats, [0..4] as above                      */
+} lvdgs_masked_loss_args;
+size_t lvdgs_masked_loss_scratch_bytes(int32_t width, int32_t height);
+int lvdgs_masked_loss_batch(const lvdgs_masked_loss_args *const *views, int32_t count, void *stream);
+/* lvdgs_backward for a view scored by lvdgs_masked_loss_batch: the backward blend pass reads loss->d_image and evaluates the
+ * depth term's gradient itself (a->dL_dout_* are ignored, the opacity image gets no gradient), then the per-Gaussian pass.
+ * With LVDGS_FLAG_NO_BLEND it starts behind the blend pass (lvdgs_blend_backward_window_batch has run it). */
+int lvdgs_backward_masked_loss(const lvdgs_args *a, const lvdgs_masked_loss_args *loss, void *stream);
+/* The backward blend passes of a mapping window in one launch, every view with the loss it is scored by: view k takes
+ * masked[k] when that is non-NULL (a keyframe with a static mask, as lvdgs_backward_masked_loss) and losses[k] otherwise (the
+ * two random older views, keyframes without a mask: as lvdgs_blend_backward_fused_loss_batch).  `masked` may be NULL (no view
+ * is masked); `losses` may be NULL when every view is masked.  Each view's records are its single call's, bit for bit. */
+int lvdgs_blend_backward_window_batch(const lvdgs_args *const *views, const lvdgs_loss_args *const *losses,
+                                      const lvdgs_masked_loss_args *const *masked, int32_t count, int32_t propagate_opacity_grad,
+                                      void *stream);
 
 /* ---- diagnostics ---- */
 const char *lvdgs_last_error(void);

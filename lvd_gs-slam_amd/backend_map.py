@@ -42,7 +42,7 @@ from . import _lib
 
 from .fast_mapping import MapViewPass, MapWindowBatch, _PARAM_FIELDS
 from .gaussian_renderer import render
-from .loss_utils import masked_mapping_loss, masked_mapping_loss_and_grads
+from .loss_utils import masked_mapping_loss
 from .pose_utils import update_pose
 from .slam_utils import get_loss_mapping
 
@@ -765,31 +765,38 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
                 first = {n: plan[k].view_as(p) for k, (n, p) in enumerate(zip(_PARAM_FIELDS, live))}
         with torch.no_grad():
             vs = _ViewStats(N0, n_window, G.get_xyz.device, split, (plan[-4], plan[-3], plan[-2]) if plan is not None else None)
-        # Every piece of this rank a whole view scored by the built-in loss (one GPU: the whole window; two GPUs: five views each;
-        # beyond, a rank holds one view and bands): the blend passes of ALL of them in one launch each
+        # A window keyframe with a static mask -- under the reference's default configuration every one of them
+        # (utils/slam_frontend.py:1218,1429-1433) -- is scored by L1 + SSIM on the static pixels and the masked depth term (:196-261):
+        # (lambda_dssim, depth_lambda) for MapViewPass / MapWindowBatch; every other view by get_loss_mapping (None)
+        masked_spec = (float(backend.opt_params.lambda_dssim), float(cfg["Training"].get("depth_lambda", 0.1)))
+        masked_of = [masked_spec if (i < n_window and getattr(v, "static_mask", None) is not None and vpass is not None
+                                     and MapViewPass.masked_loss_usable(v)) else None for i, v in enumerate(views)]
+        # Every piece of this rank a whole view (one GPU: the whole window; two GPUs: five views each; beyond, a rank holds one
+        # view and bands): the blend passes of ALL of them in one launch each, and so the static-mask losses
         # (fast_mapping.MapWindowBatch -- a KITTI-size frame alone leaves the chip half empty; LVDGS_MAP_BATCH=0: view by view)
         batched = False
         if (vpass is not None and os.environ.get("LVDGS_MAP_BATCH", "1") != "0"
                 and all((r0, r1) == (0, _tile_rows(views[v])) for v, r0, r1 in mine)
-                and MapWindowBatch.usable(backend, [views[v] for v, _, _ in mine])):
+                and all(masked_of[v] is not None or getattr(views[v], "static_mask", None) is None or v >= n_window for v, _, _ in mine)
+                and MapWindowBatch.usable(backend, [views[v] for v, _, _ in mine], [masked_of[v] for v, _, _ in mine])):
             batch = getattr(backend, "_lvdgs_window_batch", None)
             if batch is None or batch.passes[0] is not vpass:
                 batch = backend._lvdgs_window_batch = MapWindowBatch(vpass)
             for (v, r0, _), (pkg, l) in zip(mine, batch.run(backend, [views[v] for v, _, _ in mine], first=first,
-                                                             stats=[vs.targets(v, r0) for v, r0, _ in mine])):
+                                                             stats=[vs.targets(v, r0) for v, r0, _ in mine],
+                                                             masked=[masked_of[v] for v, _, _ in mine])):
                 pkgs.append((v, r0, pkg))
                 direct_losses.append(l)
             batched = True
         for v, r0, r1 in (() if batched else mine):
             whole = (r0, r1) == (0, _tile_rows(views[v]))
             masked = v < n_window and getattr(views[v], "static_mask", None) is not None
-            if vpass is not None and MapViewPass.usable(backend, views[v], allow_static_mask=True):
-                # a window keyframe with a static mask: L1 + SSIM on the static pixels and the masked depth term (:196-261)
-                # bring their own gradient images; every other view: get_loss_mapping inside the backward blend pass
-                image_loss = None if not masked else (lambda color, depth, vp=views[v]: masked_mapping_loss_and_grads(
-                    color, depth, vp, backend.background, backend.opt_params.lambda_dssim, cfg["Training"].get("depth_lambda", 0.1)))
-                pkg, l = vpass.run(backend, views[v], first=first, band=None if whole else (r0, r1), image_loss=image_loss,
-                                   stats=None if masked else vs.targets(v, r0))
+            if vpass is not None and MapViewPass.usable(backend, views[v], allow_static_mask=True) and (not masked or masked_of[v] is not None):
+                # a window keyframe with a static mask: the static-mask loss (its colour-gradient image from the fused L1 + SSIM
+                # launch, the depth term's gradient inside the backward blend pass); every other view: get_loss_mapping inside
+                # the backward blend pass
+                pkg, l = vpass.run(backend, views[v], first=first, band=None if whole else (r0, r1), masked_loss=masked_of[v],
+                                   stats=vs.targets(v, r0))
                 pkgs.append((v, r0, pkg))
                 direct_losses.append(l)
                 continue

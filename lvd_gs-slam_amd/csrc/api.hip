@@ -528,7 +528,8 @@ int lvdgs_forward(const lvdgs_args *a, int64_t *num_rendered, void *stream) {
 
 // views_out (lvdgs_blend_backward_fused_loss_batch): the call checks its arguments, lays its buffers out and stops there
 struct BackwardViews { GeomView g; BinView b; ImageView im; BwdScratch w; };
-static int backward_impl(const lvdgs_args *a, const LossParams *fused, int propagate_opacity, hipStream_t s, BackwardViews *views_out = nullptr) {
+static int backward_impl(const lvdgs_args *a, const LossParams *fused, int propagate_opacity, hipStream_t s, BackwardViews *views_out = nullptr,
+                         const MaskedLossView *masked = nullptr) {
     if (int e = check_common(a)) return e;
     if (int e = check_gaussians(a)) return e;
     const int N = a->num_gaussians, W = a->image_width, H = a->image_height;
@@ -539,7 +540,8 @@ static int backward_impl(const lvdgs_args *a, const LossParams *fused, int propa
     image_layout(W, H, &im, a->image_state);
     const bool pose_only = (a->flags & LVDGS_FLAG_POSE_ONLY) != 0;
     if (N > 0) {
-        if ((!fused && !a->dL_dout_color) || !a->projmatrix_raw || !a->radii) { set_error("a required backward pointer is NULL"); return LVDGS_E_INVALID; }
+        if ((!fused && !masked && !a->dL_dout_color) || !a->projmatrix_raw || !a->radii) { set_error("a required backward pointer is NULL"); return LVDGS_E_INVALID; }
+        if (masked && pose_only) { set_error("LVDGS_FLAG_POSE_ONLY: the static-mask mapping loss is a mapping loss, its backward makes every gradient"); return LVDGS_E_INVALID; }
         if (pose_only) {
             // a view-dependent colour moves with the camera centre: its gradient feeds dL/dtau (preprocess.hip), and the
             // pose-only passes do not make it
@@ -565,6 +567,9 @@ static int backward_impl(const lvdgs_args *a, const LossParams *fused, int propa
     if (fused) {
         if (!(a->flags & LVDGS_FLAG_NO_BLEND))
             if (int e = launch_blend_bwd_fused_loss(*a, g, b, im, w, *fused, propagate_opacity, s)) return e;
+    } else if (masked) {
+        if (D > 0 && !(a->flags & LVDGS_FLAG_NO_BLEND))
+            if (int e = launch_blend_bwd_masked_loss(*a, g, b, im, w, *masked, s)) return e;
     } else if (D > 0) {
         if (int e = launch_blend_bwd(*a, g, b, im, w, s)) return e;
     }
@@ -609,27 +614,59 @@ int lvdgs_blend_forward_batch(const lvdgs_args *const *views, int32_t count, voi
     return launch_blend_fwd_batch(views, g.data(), b.data(), im.data(), count, probe->longest > 0, s);
 }
 
-int lvdgs_blend_backward_fused_loss_batch(const lvdgs_args *const *views, const lvdgs_loss_args *const *losses, int32_t count,
-                                          int32_t propagate_opacity_grad, void *stream) {
+// lvdgs_masked_loss_args as the backward reads it
+static int masked_loss_view(const lvdgs_args *a, const lvdgs_masked_loss_args *m, MaskedLossView *out) {
+    if (!m || !m->d_image || !m->out) { set_error("masked loss backward: loss / d_image / out is NULL"); return LVDGS_E_INVALID; }
+    if (m->width != a->image_width || m->height != a->image_height) { set_error("masked loss backward: image size differs from the rasterizer's"); return LVDGS_E_INVALID; }
+    if (m->gt_depth && !m->depth) { set_error("masked loss backward: gt_depth without the rendered depth"); return LVDGS_E_INVALID; }
+    if (a->tile_row_begin != 0 || a->tile_row_end != 0) { set_error("masked loss backward: the loss is not a sum over pixels, a view scored by it cannot be rendered in bands"); return LVDGS_E_INVALID; }
+    *out = MaskedLossView{m->d_image, m->depth, m->gt_depth, m->static_mask, m->depth_lambda, m->out};
+    return LVDGS_OK;
+}
+
+int lvdgs_backward_masked_loss(const lvdgs_args *a, const lvdgs_masked_loss_args *loss, void *stream) {
+    if (!a) { set_error("backward: args is NULL"); return LVDGS_E_INVALID; }
+    MaskedLossView mv;
+    if (int e = masked_loss_view(a, loss, &mv)) return e;
+    return backward_impl(a, nullptr, 0, (hipStream_t)stream, nullptr, &mv);
+}
+
+int lvdgs_blend_backward_window_batch(const lvdgs_args *const *views, const lvdgs_loss_args *const *losses,
+                                      const lvdgs_masked_loss_args *const *masked, int32_t count, int32_t propagate_opacity_grad, void *stream) {
     hipStream_t s = (hipStream_t)stream;
-    if (count < 0 || (count > 0 && (!views || !losses))) { set_error("blend batch: bad view list"); return LVDGS_E_INVALID; }
+    if (count < 0 || (count > 0 && (!views || (!losses && !masked)))) { set_error("blend batch: bad view list"); return LVDGS_E_INVALID; }
     if (count == 0) return LVDGS_OK;
     std::vector<GeomView> g(count); std::vector<BinView> b(count); std::vector<ImageView> im(count); std::vector<BwdScratch> w(count);
     std::vector<LossParams> lp(count);
+    std::vector<MaskedLossView> mv(count); std::vector<const MaskedLossView *> mp(count, nullptr);
     for (int k = 0; k < count; k++) {
         const lvdgs_args *a = views[k];
-        if (!a || !losses[k]) { set_error("blend batch: view %d is NULL", k); return LVDGS_E_INVALID; }
-        if (int e = loss_fused_params(losses[k], &lp[k])) return e;
-        if (losses[k]->width != a->image_width || losses[k]->height != a->image_height) { set_error("fused loss: image size differs from the rasterizer's"); return LVDGS_E_INVALID; }
+        const lvdgs_masked_loss_args *m = masked ? masked[k] : nullptr;
+        if (!a || (!m && !(losses && losses[k]))) { set_error("blend batch: view %d is NULL or has no loss", k); return LVDGS_E_INVALID; }
         if (a->image_width != views[0]->image_width || a->image_height != views[0]->image_height || a->tile_row_begin != views[0]->tile_row_begin ||
             a->tile_row_end != views[0]->tile_row_end || ((a->flags ^ views[0]->flags) & LVDGS_FLAG_POSE_ONLY)) {
             set_error("blend batch: the views differ in image size, band or LVDGS_FLAG_POSE_ONLY"); return LVDGS_E_INVALID;
         }
         BackwardViews v;
-        if (int e = backward_impl(a, &lp[k], propagate_opacity_grad != 0, s, &v)) return e;
+        if (m) {
+            if (int e = masked_loss_view(a, m, &mv[k])) return e;
+            mp[k] = &mv[k];
+            if (int e = backward_impl(a, nullptr, 0, s, &v, &mv[k])) return e;
+        } else {
+            if (int e = loss_fused_params(losses[k], &lp[k])) return e;
+            if (losses[k]->width != a->image_width || losses[k]->height != a->image_height) { set_error("fused loss: image size differs from the rasterizer's"); return LVDGS_E_INVALID; }
+            if (int e = backward_impl(a, &lp[k], propagate_opacity_grad != 0, s, &v)) return e;
+        }
         g[k] = v.g; b[k] = v.b; im[k] = v.im; w[k] = v.w;
     }
-    return launch_blend_bwd_fused_loss_batch(views, g.data(), b.data(), im.data(), w.data(), lp.data(), count, propagate_opacity_grad != 0, s);
+    return launch_blend_bwd_fused_loss_batch(views, g.data(), b.data(), im.data(), w.data(), lp.data(), masked ? mp.data() : nullptr, count,
+                                             propagate_opacity_grad != 0, s);
+}
+
+int lvdgs_blend_backward_fused_loss_batch(const lvdgs_args *const *views, const lvdgs_loss_args *const *losses, int32_t count,
+                                          int32_t propagate_opacity_grad, void *stream) {
+    if (count > 0 && !losses) { set_error("blend batch: bad view list"); return LVDGS_E_INVALID; }
+    return lvdgs_blend_backward_window_batch(views, losses, nullptr, count, propagate_opacity_grad, stream);
 }
 
 int lvdgs_mark_visible(int32_t N, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present,

@@ -20,8 +20,8 @@
 // whole cache lines.  Gradients are therefore bitwise reproducible.
 //
 // Kernels in this file: blend_fwd2_kernel (its survivor step is the hand-scheduled composite_one) and
-// blend_bwd3_kernel<FUSED_LOSS, DEPTH_GRAD> (with the photometric loss evaluated in its prologue for
-// lvdgs_backward_fused_loss).  Their predecessors (the compiler's form of the forward step, the single-pass and the
+// blend_bwd3_kernel<LOSS, DEPTH_GRAD, POSE_ONLY> (LOSS: where the pixels' gradients come from -- gradient images, the photometric
+// loss evaluated in the prologue for lvdgs_backward_fused_loss, or the static-mask mapping loss of lvdgs_backward_masked_loss).  Their predecessors (the compiler's form of the forward step, the single-pass and the
 // first two-pass backward) left the library in round 3: profiles/experiments/r02_superseded_blend_kernels.hip.txt.
 // What bounds the kernels and what was tried: DESIGN.md section 2, profiles/experiments/README.md.
 #include <type_traits>
@@ -61,7 +61,17 @@ struct BlendParams {
     // backward with the photometric loss evaluated in place of reading dL_d* (lvdgs_backward_fused_loss)
     LossParams loss;             // loss.partial: 4 sums per TILE
     int loss_propagate_opacity;  // dL/d(opacity image) feeds the blend (rasterizer.PROPAGATE_OPACITY_GRAD)
+    // LOSS_MASKED (lvdgs_backward_masked_loss: a keyframe with a static mask, reference utils/slam_backend.py:196-261): the colour
+    // gradient is the image lvdgs_masked_loss_batch wrote (dL_dcolor: the SSIM term is not local), the depth term's gradient is
+    // evaluated per pixel from loss.depth (rendered), loss.gt_depth (mono depth), loss.grad_mask (static mask), loss.w_d
+    // (depth_lambda) and loss.grad_out[4] (|M|, finished by that call)
+    int loss_mode;               // LOSS_FUSED or LOSS_MASKED: which of the two this VIEW takes in a launch compiled for LOSS_PER_VIEW
 };
+// where the backward blend pass takes dL/d(colour, depth, opacity) of its pixels from
+constexpr int LOSS_IMAGES = 0;    // gradient images (lvdgs_backward)
+constexpr int LOSS_FUSED = 1;     // the photometric loss evaluated in the prologue (lvdgs_backward_fused_loss)
+constexpr int LOSS_MASKED = 2;    // the static-mask mapping loss (above)
+constexpr int LOSS_PER_VIEW = 3;  // batch launches whose views differ: BlendParams::loss_mode decides
 
 // Where the partial gradient of the pair (Gaussian id, tile (tx, ty)) goes: the Gaussian's slots follow its kept tiles in
 // row-major order of its rectangle (common.hpp: rect_rank), the order the pairs were counted in.
@@ -397,7 +407,7 @@ struct Bwd3Shared {
 #ifndef LVDGS_BWD_WGS_POSE
 #define LVDGS_BWD_WGS_POSE 7   // ... and its pose-only form (18.2 KB of LDS, 74 VGPRs; 26.4 KB with a depth gradient: six). Same box, config 3 / KITTI geometry: 5: 240.9 / 92.0 us, 6: 240.4 / 92.1, 7: 233.7 / 92.6, 8: 233.6 / 95.8
 #endif
-template <bool FUSED_LOSS, bool DEPTH_GRAD, bool POSE_ONLY>
+template <int LOSS, bool DEPTH_GRAD, bool POSE_ONLY>
 __device__ __forceinline__ void blend_bwd3_body(const BlendParams &p) {
     using Shared = Bwd3Shared<POSE_ONLY, DEPTH_GRAD>;
     constexpr int NB = Shared::NB, ACC = Shared::ACC;
@@ -432,7 +442,21 @@ __device__ __forceinline__ void blend_bwd3_body(const BlendParams &p) {
     const float T_final = inside ? p.final_T[pix] : 0.f;
     const uint32_t my_last = inside ? p.n_contrib[pix] : 0u;
     float gC0 = 0.f, gC1 = 0.f, gC2 = 0.f, gD = 0.f, gO = 0.f;
-    if constexpr (FUSED_LOSS) {
+    const bool fused_loss = LOSS == LOSS_FUSED || (LOSS == LOSS_PER_VIEW && p.loss_mode == LOSS_FUSED);   // (uniform over the launch / the view)
+    if (LOSS == LOSS_MASKED || (LOSS == LOSS_PER_VIEW && !fused_loss)) {
+        if (inside) {
+            gC0 = p.dL_dcolor[pix]; gC1 = p.dL_dcolor[P + pix]; gC2 = p.dL_dcolor[2 * P + pix];
+            if (DEPTH_GRAD && p.loss.gt_depth) {
+                // d(depth_lambda * mean over M of |D - Z|) / dD: the statements of masked_depth_kernel<true> (loss.hip)
+                const float Dv = p.loss.depth[pix], Z = p.loss.gt_depth[pix];
+                const bool in = (!p.loss.grad_mask || p.loss.grad_mask[pix]) && Z > 0.f && Dv > 0.f;
+                const float n = p.loss.grad_out[4];
+                const float scale = n > 0.f ? p.loss.w_d / n : 0.f;
+                const float r = Dv - Z;
+                gD = in ? (r > 0.f ? scale : (r < 0.f ? -scale : 0.f)) : 0.f;
+            }
+        }
+    } else if (LOSS == LOSS_FUSED || LOSS == LOSS_PER_VIEW) {
         // the loss's gradient w.r.t. this pixel's colour / depth / opacity, from the rendered images and the targets:
         // what photometric_kernel<2> would have written into three to five gradient images for this pass to read back
         const LossParams &lp = p.loss;
@@ -473,7 +497,7 @@ __device__ __forceinline__ void blend_bwd3_body(const BlendParams &p) {
     if (lane == 0) sh.wall[wave] = m_all;
     const int wave_last = (int)m;
     __syncthreads();
-    if constexpr (FUSED_LOSS) {
+    if (fused_loss) {
         if (tid < 4) p.loss.partial[4 * (size_t)tile + tid] = ((sh.loss_sum[tid][0] + sh.loss_sum[tid][1]) + sh.loss_sum[tid][2]) + sh.loss_sum[tid][3];
     }
     // Only the entries some pixel of the tile composited can receive anything: the list is walked from the deepest of them.
@@ -717,14 +741,14 @@ __device__ __forceinline__ void blend_bwd3_body(const BlendParams &p) {
 #endif
 }
 
-template <bool FUSED_LOSS, bool DEPTH_GRAD = true, bool POSE_ONLY = false>
+template <int LOSS, bool DEPTH_GRAD = true, bool POSE_ONLY = false>
 __global__ void __launch_bounds__(256, POSE_ONLY ? (DEPTH_GRAD ? 6 : LVDGS_BWD_WGS_POSE) : LVDGS_BWD_WGS) blend_bwd3_kernel(BlendParams p) {
-    blend_bwd3_body<FUSED_LOSS, DEPTH_GRAD, POSE_ONLY>(p);
+    blend_bwd3_body<LOSS, DEPTH_GRAD, POSE_ONLY>(p);
 }
 // several views in one launch (blockIdx.y: the view), the loss in the prologue
-template <bool DEPTH_GRAD, bool POSE_ONLY>
+template <int LOSS, bool DEPTH_GRAD, bool POSE_ONLY>
 __global__ void __launch_bounds__(256, POSE_ONLY ? (DEPTH_GRAD ? 6 : LVDGS_BWD_WGS_POSE) : LVDGS_BWD_WGS) blend_bwd3_batch_kernel(BlendBatch b) {
-    blend_bwd3_body<true, DEPTH_GRAD, POSE_ONLY>(b.v[blockIdx.y]);
+    blend_bwd3_body<LOSS, DEPTH_GRAD, POSE_ONLY>(b.v[blockIdx.y]);
 }
 
 BlendParams make_params(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im) {
@@ -778,10 +802,10 @@ int launch_blend_bwd(const lvdgs_args &a, const GeomView &g, const BinView &b, c
     if (const char *e = getenv("LVDGS_DIAG_REPEAT")) grid *= atoi(e);
 #endif
     const bool depth = LVDGS_BWD_DEPTH_ALWAYS || p.dL_ddepth, pose_only = (a.flags & LVDGS_FLAG_POSE_ONLY) != 0;
-    if (pose_only && depth) hipLaunchKernelGGL((blend_bwd3_kernel<false, true, true>), dim3(grid), dim3(256), 0, s, p);
-    else if (pose_only) hipLaunchKernelGGL((blend_bwd3_kernel<false, false, true>), dim3(grid), dim3(256), 0, s, p);
-    else if (depth) hipLaunchKernelGGL((blend_bwd3_kernel<false, true>), dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((blend_bwd3_kernel<false, false>), dim3(grid), dim3(256), 0, s, p);
+    if (pose_only && depth) hipLaunchKernelGGL((blend_bwd3_kernel<LOSS_IMAGES, true, true>), dim3(grid), dim3(256), 0, s, p);
+    else if (pose_only) hipLaunchKernelGGL((blend_bwd3_kernel<LOSS_IMAGES, false, true>), dim3(grid), dim3(256), 0, s, p);
+    else if (depth) hipLaunchKernelGGL((blend_bwd3_kernel<LOSS_IMAGES, true>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((blend_bwd3_kernel<LOSS_IMAGES, false>), dim3(grid), dim3(256), 0, s, p);
     LVDGS_LAUNCH_CHECK("blend_bwd", a.debug, s);
     return LVDGS_OK;
 }
@@ -802,11 +826,33 @@ int launch_blend_bwd_fused_loss(const lvdgs_args &a, const GeomView &g, const Bi
     if (const char *e = getenv("LVDGS_DIAG_REPEAT")) grid *= atoi(e);
 #endif
     const bool depth = LVDGS_BWD_DEPTH_ALWAYS || (loss.depth && loss.gt_depth && loss.w_d != 0.f), pose_only = (a.flags & LVDGS_FLAG_POSE_ONLY) != 0;
-    if (pose_only && depth) hipLaunchKernelGGL((blend_bwd3_kernel<true, true, true>), dim3(grid), dim3(256), 0, s, p);
-    else if (pose_only) hipLaunchKernelGGL((blend_bwd3_kernel<true, false, true>), dim3(grid), dim3(256), 0, s, p);
-    else if (depth) hipLaunchKernelGGL((blend_bwd3_kernel<true, true>), dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((blend_bwd3_kernel<true, false>), dim3(grid), dim3(256), 0, s, p);
+    if (pose_only && depth) hipLaunchKernelGGL((blend_bwd3_kernel<LOSS_FUSED, true, true>), dim3(grid), dim3(256), 0, s, p);
+    else if (pose_only) hipLaunchKernelGGL((blend_bwd3_kernel<LOSS_FUSED, false, true>), dim3(grid), dim3(256), 0, s, p);
+    else if (depth) hipLaunchKernelGGL((blend_bwd3_kernel<LOSS_FUSED, true>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((blend_bwd3_kernel<LOSS_FUSED, false>), dim3(grid), dim3(256), 0, s, p);
     LVDGS_LAUNCH_CHECK("blend_bwd", a.debug, s);
+    return LVDGS_OK;
+}
+
+// The static-mask mapping loss's fields where the kernel looks for them (BlendParams::loss_mode).
+static void set_masked_loss(BlendParams &p, const MaskedLossView &m) {
+    p.loss = LossParams{};
+    p.dL_dcolor = m.d_image; p.dL_ddepth = nullptr; p.dL_dopacity = nullptr;
+    p.loss.depth = m.gt_depth ? m.depth : nullptr; p.loss.gt_depth = m.gt_depth; p.loss.grad_mask = m.static_mask;
+    p.loss.w_d = m.depth_lambda; p.loss.grad_out = m.out;
+    p.loss_mode = LOSS_MASKED; p.loss_propagate_opacity = 0;
+}
+
+int launch_blend_bwd_masked_loss(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, const BwdScratch &w,
+                                 const MaskedLossView &m, hipStream_t s) {
+    BlendParams p = make_params(a, g, b, im);
+    p.pair_grads = w.pair_grads; p.pair_valid = b.pair_valid;
+    set_masked_loss(p, m);
+    if (p.num_tiles == 0) return LVDGS_OK;
+    ProfScope ps("blend_bwd", s);
+    if (LVDGS_BWD_DEPTH_ALWAYS || m.gt_depth) hipLaunchKernelGGL((blend_bwd3_kernel<LOSS_MASKED, true>), dim3(p.num_tiles), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((blend_bwd3_kernel<LOSS_MASKED, false>), dim3(p.num_tiles), dim3(256), 0, s, p);
+    LVDGS_LAUNCH_CHECK("blend_bwd (masked loss)", a.debug, s);
     return LVDGS_OK;
 }
 
@@ -825,29 +871,44 @@ int launch_blend_fwd_batch(const lvdgs_args *const *a, const GeomView *g, const 
     return LVDGS_OK;
 }
 
+// masked[v] (may be null as a whole): the view is scored by the static-mask mapping loss instead of loss[v].
 int launch_blend_bwd_fused_loss_batch(const lvdgs_args *const *a, const GeomView *g, const BinView *b, const ImageView *im, const BwdScratch *w,
-                                      const LossParams *loss, int n, int propagate_opacity, hipStream_t s) {
+                                      const LossParams *loss, const MaskedLossView *const *masked, int n, int propagate_opacity, hipStream_t s) {
     for (int first = 0; first < n; first += BATCH_VIEWS) {
         const int m = min(BATCH_VIEWS, n - first);
         BlendBatch batch{};
         bool depth = false;
+        int n_masked = 0;
         for (int k = 0; k < m; k++) {
             const int v = first + k;
             BlendParams &p = batch.v[k];
             p = make_params(*a[v], g[v], b[v], im[v]);
             p.pair_grads = w[v].pair_grads; p.pair_valid = b[v].pair_valid;
-            p.loss = loss[v];
-            p.loss_propagate_opacity = propagate_opacity;
-            depth = depth || LVDGS_BWD_DEPTH_ALWAYS || (loss[v].depth && loss[v].gt_depth && loss[v].w_d != 0.f);
+            if (masked && masked[v]) {
+                set_masked_loss(p, *masked[v]);
+                depth = depth || LVDGS_BWD_DEPTH_ALWAYS || masked[v]->gt_depth;
+                n_masked++;
+            } else {
+                p.loss = loss[v];
+                p.loss_mode = LOSS_FUSED;
+                p.loss_propagate_opacity = propagate_opacity;
+                depth = depth || LVDGS_BWD_DEPTH_ALWAYS || (loss[v].depth && loss[v].gt_depth && loss[v].w_d != 0.f);
+            }
         }
         if (batch.v[0].num_tiles == 0) continue;
         ProfScope ps("blend_bwd", s);
         const bool pose_only = (a[first]->flags & LVDGS_FLAG_POSE_ONLY) != 0;
         const dim3 grid(batch.v[0].num_tiles, m);
-        if (pose_only && depth) hipLaunchKernelGGL((blend_bwd3_batch_kernel<true, true>), grid, dim3(256), 0, s, batch);
-        else if (pose_only) hipLaunchKernelGGL((blend_bwd3_batch_kernel<false, true>), grid, dim3(256), 0, s, batch);
-        else if (depth) hipLaunchKernelGGL((blend_bwd3_batch_kernel<true, false>), grid, dim3(256), 0, s, batch);
-        else hipLaunchKernelGGL((blend_bwd3_batch_kernel<false, false>), grid, dim3(256), 0, s, batch);
+        if (n_masked == m) {
+            if (depth) hipLaunchKernelGGL((blend_bwd3_batch_kernel<LOSS_MASKED, true, false>), grid, dim3(256), 0, s, batch);
+            else hipLaunchKernelGGL((blend_bwd3_batch_kernel<LOSS_MASKED, false, false>), grid, dim3(256), 0, s, batch);
+        } else if (n_masked) {
+            if (depth) hipLaunchKernelGGL((blend_bwd3_batch_kernel<LOSS_PER_VIEW, true, false>), grid, dim3(256), 0, s, batch);
+            else hipLaunchKernelGGL((blend_bwd3_batch_kernel<LOSS_PER_VIEW, false, false>), grid, dim3(256), 0, s, batch);
+        } else if (pose_only && depth) hipLaunchKernelGGL((blend_bwd3_batch_kernel<LOSS_FUSED, true, true>), grid, dim3(256), 0, s, batch);
+        else if (pose_only) hipLaunchKernelGGL((blend_bwd3_batch_kernel<LOSS_FUSED, false, true>), grid, dim3(256), 0, s, batch);
+        else if (depth) hipLaunchKernelGGL((blend_bwd3_batch_kernel<LOSS_FUSED, true, false>), grid, dim3(256), 0, s, batch);
+        else hipLaunchKernelGGL((blend_bwd3_batch_kernel<LOSS_FUSED, false, false>), grid, dim3(256), 0, s, batch);
         LVDGS_LAUNCH_CHECK("blend_bwd (batch)", a[first]->debug, s);
     }
     return LVDGS_OK;

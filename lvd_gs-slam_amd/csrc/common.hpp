@@ -296,8 +296,18 @@ int launch_tile_ranges(const uint32_t *tile_keys, int64_t D, const uint32_t *D_d
 int launch_blend_fwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, bool deep_lists, hipStream_t s);   // deep_lists: a hint (which build of the kernel), never a result
 struct LossParams;
 int launch_blend_fwd_batch(const lvdgs_args *const *a, const GeomView *g, const BinView *b, const ImageView *im, int n, bool deep_lists, hipStream_t s);
+// The static-mask mapping loss of one view as the backward blend pass reads it (lvdgs_masked_loss_args, checked by api.hip).
+struct MaskedLossView {
+    const float *d_image;        // 3*P: d loss / d colour, written by lvdgs_masked_loss_batch
+    const float *depth, *gt_depth; const uint8_t *static_mask;   // depth term (gt_depth null: none)
+    float depth_lambda;
+    const float *out;            // lvdgs_masked_loss_args::out: [4] = |M|
+};
+int launch_blend_bwd_masked_loss(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, const BwdScratch &w,
+                                 const MaskedLossView &m, hipStream_t s);
+// masked: null, or per view null (the view is scored by loss[v]) / its static-mask loss
 int launch_blend_bwd_fused_loss_batch(const lvdgs_args *const *a, const GeomView *g, const BinView *b, const ImageView *im, const BwdScratch *w,
-                                      const LossParams *loss, int n, int propagate_opacity, hipStream_t s);
+                                      const LossParams *loss, const MaskedLossView *const *masked, int n, int propagate_opacity, hipStream_t s);
 int launch_blend_bwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, const BwdScratch &w,
                      hipStream_t s);
 

@@ -220,7 +220,7 @@ __device__ __forceinline__ void tracking_tail_body(const TailParams &t) {
     }
     __syncthreads();
     if (threadIdx.x >= 64) return;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && t.loss.loss) {   // (no loss block: a view whose loss value is finished elsewhere, lvdgs_map_view_tail(loss = NULL))
         t.loss.loss[0] = t.loss.w_rgb * (s[0][0] / (3.f * (float)t.loss.P)) + t.loss.w_d * (s[1][0] / (float)t.loss.P);
         if (t.loss.d_a) t.loss.d_a[0] = s[2][0];
         if (t.loss.d_b) t.loss.d_b[0] = s[3][0];
@@ -281,8 +281,10 @@ static int make_tail_params(const lvdgs_loss_args *loss, const lvdgs_args *bwd, 
     if (pose)
         if (int e = check_pose_args(pose)) return e;
     t = TailParams{};
-    if (int e = loss_tail_params(loss, partials_per_tile != 0, &t.loss)) return e;
-    if (partials_per_tile) {   // a band of tile rows (lvdgs_args.tile_row_*): the backward left partial sums for its tiles only
+    if (loss) {
+        if (int e = loss_tail_params(loss, partials_per_tile != 0, &t.loss)) return e;
+    } else if (pose) { set_error("tracking tail: a pose step needs the loss block (its exposure gradients)"); return LVDGS_E_INVALID; }
+    if (loss && partials_per_tile) {   // a band of tile rows (lvdgs_args.tile_row_*): the backward left partial sums for its tiles only
         int row0, row1;
         tile_row_band(*bwd, &row0, &row1);
         const int gx = cdiv(bwd->image_width, TILE);

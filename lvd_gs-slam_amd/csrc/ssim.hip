@@ -35,15 +35,25 @@ constexpr int P3 = ST + 1;
 constexpr int SSIM_THREADS = 512;  // 8 waves per workgroup, 2 workgroups per CU (LDS): 4 waves per SIMD
 constexpr float SSIM_C1 = 0.01f * 0.01f, SSIM_C2 = 0.03f * 0.03f;
 
-struct SsimParams {
-    int W, H, planes, channels;
+// One launch serves up to SSIM_BATCH images of one size (lvdgs_masked_loss_batch: the masked keyframes of a mapping window;
+// blockIdx.z = view * planes + plane), each with its own pointers, mask, background and weights.
+constexpr int SSIM_BATCH = 10;
+struct SsimView {
     const float *x, *y;          // planes*H*W
     const uint8_t *keep;         // H*W or null
     const float *bg;             // channels or null
     float w_l1, w_ssim;          // gradient weights, already divided by the element count
-    float *partial;              // nwg * 2
+    float *partial;              // (workgroups of the view) * 2
     float *d_x;                  // planes*H*W or null
+    // depth term of the static-mask mapping loss (reference utils/slam_backend.py:216-261), taken by the workgroups of the
+    // view's plane 0 over their own 32x32 pixels: sum of |D - Z| and the exact count of M = keep & (Z > 0) & (D > 0)
+    const float *depth, *gt_depth;   // H*W each, or null: no depth term
+    float *dpart;                // per tile: sum (float), count (uint32 bits)
+};
+struct SsimParams {
+    int W, H, planes, channels;  // planes: per view
     float win[SW];
+    SsimView v[SSIM_BATCH];
 };
 
 __device__ __forceinline__ float block_sum8(float v, float *s) {
@@ -75,12 +85,29 @@ __global__ void __launch_bounds__(SSIM_THREADS) ssim_l1_kernel(SsimParams p) {
     static_assert(3 * S2 * P3 <= 4 * S1 * P2, "second horizontal pass must fit the first");
 
     const int tid = threadIdx.x;
-    const int plane = blockIdx.z;
+    const int view = (int)blockIdx.z / p.planes, plane = (int)blockIdx.z - view * p.planes;
+    const SsimView &v = p.v[view];
     const int tx0 = blockIdx.x * ST, ty0 = blockIdx.y * ST;
     const size_t plane_off = (size_t)plane * p.W * p.H;
-    const float *__restrict__ X = p.x + plane_off;
-    const float *__restrict__ Y = p.y + plane_off;
-    const float bgc = p.bg ? p.bg[plane % p.channels] : 0.f;
+    const float *__restrict__ X = v.x + plane_off;
+    const float *__restrict__ Y = v.y + plane_off;
+    const float bgc = v.bg ? v.bg[plane % p.channels] : 0.f;
+    // depth term: this workgroup's own pixels, two per thread, requested with the input windows
+    const bool depth_term = plane == 0 && v.gt_depth != nullptr;
+    float dD[2] = {0.f, 0.f}, dZ[2] = {0.f, 0.f};
+    bool dM[2] = {false, false};
+    if (depth_term) {
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i = tid + k * SSIM_THREADS, r = i / ST, c = i - r * ST;
+            const int gy = ty0 + r, gx = tx0 + c;
+            if (gy < p.H && gx < p.W) {
+                const size_t o = (size_t)gy * p.W + gx;
+                dD[k] = v.depth[o]; dZ[k] = v.gt_depth[o];
+                dM[k] = !v.keep || v.keep[o];
+            }
+        }
+    }
     float w[SW];
 #pragma unroll
     for (int k = 0; k < SW; k++) w[k] = p.win[k];
@@ -103,7 +130,7 @@ __global__ void __launch_bounds__(SSIM_THREADS) ssim_l1_kernel(SsimParams p) {
             const size_t o = in ? (size_t)gy * p.W + gx : 0;
             la[it] = in ? X[o] : 0.f;
             lb[it] = in ? Y[o] : 0.f;
-            lk[it] = (in && p.keep) ? p.keep[o] : (uint8_t)1;
+            lk[it] = (in && v.keep) ? v.keep[o] : (uint8_t)1;
         }
 #pragma unroll
         for (int it = 0; it < NLD; it++) {
@@ -219,9 +246,34 @@ __global__ void __launch_bounds__(SSIM_THREADS) ssim_l1_kernel(SsimParams p) {
         const float t1 = block_sum8(l1, s_red);
         const float t2 = block_sum8(msum, s_red);
         if (tid == 0) {
-            const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-            p.partial[2 * wg] = t1;
-            p.partial[2 * wg + 1] = t2;
+            const size_t wg = ((size_t)plane * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            v.partial[2 * wg] = t1;
+            v.partial[2 * wg + 1] = t2;
+        }
+    }
+    if (depth_term) {   // (uniform over the workgroup)
+        float acc = 0.f;
+        uint32_t cnt = 0u;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const bool in = dM[k] && dZ[k] > 0.f && dD[k] > 0.f;
+            acc += in ? fabsf(dD[k] - dZ[k]) : 0.f;
+            cnt += in ? 1u : 0u;
+        }
+        const float t3 = block_sum8(acc, s_red);
+        // an exact integer count (a float sum would round above 2^24 pixels)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, off, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) s_red[tid >> 6] = __uint_as_float(cnt);
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t n = 0u;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; w8++) n += __float_as_uint(s_red[w8]);
+            const size_t tile = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+            v.dpart[2 * tile] = t3;
+            v.dpart[2 * tile + 1] = __uint_as_float(n);
         }
     }
     if (!GRAD) return;
@@ -261,7 +313,7 @@ __global__ void __launch_bounds__(SSIM_THREADS) ssim_l1_kernel(SsimParams p) {
     __syncthreads();
 
     // ---- 4b. vertical pass, 2 outputs per item (32 columns x 16 row pairs = 512 items), and the gradient of this tile ----
-    float *__restrict__ G = p.d_x + plane_off;
+    float *__restrict__ G = v.d_x + plane_off;
     for (int item = tid; item < ST * (ST / 2); item += SSIM_THREADS) {
         const int c = item % ST, r0 = (item / ST) * 2;
         float va[12], vs[12], vz[12];
@@ -286,11 +338,11 @@ __global__ void __launch_bounds__(SSIM_THREADS) ssim_l1_kernel(SsimParams p) {
             if (gy < p.H && gx < p.W) {
                 const size_t off = (size_t)gy * p.W + gx;
                 float g = 0.f;
-                if (!(p.keep && !p.keep[off])) {  // overwritten pixels do not depend on the input
+                if (!(v.keep && !v.keep[off])) {  // overwritten pixels do not depend on the input
                     const float xv = X[off], yv = Y[off];
                     const float diff = xv - yv;
                     const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
-                    g = p.w_ssim * (a + 2.f * xv * s + yv * z) + p.w_l1 * sgn;
+                    g = v.w_ssim * (a + 2.f * xv * s + yv * z) + v.w_l1 * sgn;
                 }
                 G[off] = g;
             }
@@ -317,6 +369,55 @@ __global__ void __launch_bounds__(512) ssim_finish_kernel(const float2 *__restri
     }
 }
 
+// One workgroup per view of lvdgs_masked_loss_batch: the two means in ssim_finish_kernel's order, the depth term's sum and
+// exact count over the view's tiles, and the loss value.
+struct MaskedFinishView { const float2 *partial; const float2 *dpart; float *out; float lambda, depth_lambda; };
+struct MaskedFinishParams { int nwg, ntiles; float inv_count; MaskedFinishView v[SSIM_BATCH]; };
+
+__global__ void __launch_bounds__(512) masked_loss_finish_kernel(MaskedFinishParams p) {
+    __shared__ float s_red[8];
+    __shared__ unsigned long long s_cnt[8];
+    const MaskedFinishView &v = p.v[blockIdx.x];
+    float a = 0.f, b = 0.f;
+    for (int i0 = threadIdx.x; i0 < p.nwg; i0 += 4 * 512) {
+        float2 q[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) q[k] = i0 + k * 512 < p.nwg ? v.partial[i0 + k * 512] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { a += q[k].x; b += q[k].y; }
+    }
+    const float ta = block_sum8(a, s_red);
+    const float tb = block_sum8(b, s_red);
+    float d = 0.f;
+    unsigned long long n = 0ull;
+    if (v.dpart)
+        for (int i = threadIdx.x; i < p.ntiles; i += 512) { const float2 q = v.dpart[i]; d += q.x; n += (unsigned long long)__float_as_uint(q.y); }
+    const float td = block_sum8(d, s_red);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n += (unsigned long long)__shfl_xor((long long)n, off, 64);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long c = 0ull;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; w8++) c += s_cnt[w8];
+        const float l1 = ta * p.inv_count, ss = tb * p.inv_count;
+        const float dterm = c ? td / (float)c : 0.f;   // nothing is added when M is empty (reference :250)
+        v.out[0] = ((1.f - v.lambda) * l1 - v.lambda * ss + v.lambda) + v.depth_lambda * dterm;
+        v.out[1] = l1;
+        v.out[2] = ss;
+        v.out[3] = dterm;
+        v.out[4] = (float)c;
+    }
+}
+
+void fill_window(float (&win)[SW]) {
+    // the window upstream builds in float32: exp(-(k - 5)^2 / (2 * 1.5^2)), normalised
+    float g[SW], sum = 0.f;
+    for (int k = 0; k < SW; k++) { g[k] = expf(-(float)((k - SR) * (k - SR)) / (2.f * 1.5f * 1.5f)); sum += g[k]; }
+    for (int k = 0; k < SW; k++) win[k] = g[k] / sum;
+}
+
 }  // namespace
 }  // namespace lvdgs
 
@@ -338,16 +439,14 @@ int lvdgs_ssim_l1(const lvdgs_ssim_args *a, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     SsimParams p{};
     p.W = a->width; p.H = a->height; p.planes = a->planes; p.channels = a->channels;
-    p.x = a->img1; p.y = a->img2; p.keep = a->keep_mask; p.bg = a->bg;
+    SsimView &v = p.v[0];
+    v.x = a->img1; v.y = a->img2; v.keep = a->keep_mask; v.bg = a->bg;
     const double count = (double)a->width * a->height * a->planes;
-    p.w_l1 = (float)(a->weight_l1 / count);
-    p.w_ssim = (float)(a->weight_ssim / count);
-    p.partial = (float *)a->scratch;
-    p.d_x = a->d_img1;
-    // the window upstream builds in float32: exp(-(k - 5)^2 / (2 * 1.5^2)), normalised
-    float g[SW], sum = 0.f;
-    for (int k = 0; k < SW; k++) { g[k] = expf(-(float)((k - SR) * (k - SR)) / (2.f * 1.5f * 1.5f)); sum += g[k]; }
-    for (int k = 0; k < SW; k++) p.win[k] = g[k] / sum;
+    v.w_l1 = (float)(a->weight_l1 / count);
+    v.w_ssim = (float)(a->weight_ssim / count);
+    v.partial = (float *)a->scratch;
+    v.d_x = a->d_img1;
+    fill_window(p.win);
     const dim3 grid(cdiv(a->width, ST), cdiv(a->height, ST), a->planes);
     const int nwg = (int)(grid.x * grid.y * grid.z);
     {
@@ -358,8 +457,60 @@ int lvdgs_ssim_l1(const lvdgs_ssim_args *a, void *stream) {
     }
     {
         ProfScope ps("ssim_finish", s);
-        hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(512), 0, s, (const float2 *)p.partial, nwg, (float)(1.0 / count), a->out);
+        hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(512), 0, s, (const float2 *)v.partial, nwg, (float)(1.0 / count), a->out);
         LVDGS_LAUNCH_CHECK("ssim_finish", 0, s);
+    }
+    return LVDGS_OK;
+}
+
+// scratch of one view: the L1 / SSIM partial sums of its 3 planes, then (sum, count) per 32x32 tile for the depth term
+size_t lvdgs_masked_loss_scratch_bytes(int32_t width, int32_t height) {
+    const size_t tiles = (size_t)cdiv(width, ST) * cdiv(height, ST);
+    return align256(3 * tiles * 2 * sizeof(float)) + align256(tiles * 2 * sizeof(float)) + 256;
+}
+
+int lvdgs_masked_loss_batch(const lvdgs_masked_loss_args *const *views, int32_t count, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (count < 0 || (count > 0 && !views)) { set_error("masked loss: bad view list"); return LVDGS_E_INVALID; }
+    for (int32_t first = 0; first < count; first += SSIM_BATCH) {
+        const int m = count - first < SSIM_BATCH ? count - first : SSIM_BATCH;
+        SsimParams p{};
+        MaskedFinishParams f{};
+        const lvdgs_masked_loss_args *a0 = views[first];
+        if (!a0 || a0->width <= 0 || a0->height <= 0) { set_error("masked loss: view %d is NULL or has a bad image size", first); return LVDGS_E_INVALID; }
+        p.W = a0->width; p.H = a0->height; p.planes = 3; p.channels = 3;
+        fill_window(p.win);
+        const size_t tiles = (size_t)cdiv(p.W, ST) * cdiv(p.H, ST);
+        const double n = (double)p.W * p.H * 3;
+        for (int k = 0; k < m; k++) {
+            const lvdgs_masked_loss_args *a = views[first + k];
+            if (!a || a->width != p.W || a->height != p.H) { set_error("masked loss: view %d is NULL or differs in image size", first + k); return LVDGS_E_INVALID; }
+            if (!a->image || !a->gt_image || !a->d_image || !a->out || !a->scratch) { set_error("masked loss: image / gt_image / d_image / out / scratch is NULL"); return LVDGS_E_INVALID; }
+            if (a->scratch_bytes < lvdgs_masked_loss_scratch_bytes(p.W, p.H)) { set_error("masked loss: scratch too small"); return LVDGS_E_INVALID; }
+            if (a->gt_depth && !a->depth) { set_error("masked loss: gt_depth without the rendered depth"); return LVDGS_E_INVALID; }
+            SsimView &v = p.v[k];
+            v.x = a->image; v.y = a->gt_image; v.keep = a->static_mask; v.bg = a->static_mask ? a->bg : nullptr;
+            // d loss / d a = (1 - lambda) d mean|a - b| - lambda d mean SSIM
+            v.w_l1 = (float)((1.0 - (double)a->lambda_dssim) / n);
+            v.w_ssim = (float)(-(double)a->lambda_dssim / n);
+            v.partial = (float *)a->scratch;
+            v.d_x = a->d_image;
+            v.depth = a->gt_depth ? a->depth : nullptr; v.gt_depth = a->gt_depth;
+            v.dpart = a->gt_depth ? (float *)((char *)a->scratch + align256(3 * tiles * 2 * sizeof(float))) : nullptr;
+            f.v[k] = MaskedFinishView{(const float2 *)v.partial, (const float2 *)v.dpart, a->out, a->lambda_dssim, a->gt_depth ? a->depth_lambda : 0.f};
+        }
+        f.nwg = (int)(3 * tiles); f.ntiles = (int)tiles; f.inv_count = (float)(1.0 / n);
+        const dim3 grid(cdiv(p.W, ST), cdiv(p.H, ST), 3 * m);
+        {
+            ProfScope ps("masked_loss", s);
+            hipLaunchKernelGGL(ssim_l1_kernel<true>, grid, dim3(SSIM_THREADS), 0, s, p);
+            LVDGS_LAUNCH_CHECK("masked_loss", 0, s);
+        }
+        {
+            ProfScope ps("masked_loss_finish", s);
+            hipLaunchKernelGGL(masked_loss_finish_kernel, dim3(m), dim3(512), 0, s, f);
+            LVDGS_LAUNCH_CHECK("masked_loss_finish", 0, s);
+        }
     }
     return LVDGS_OK;
 }

@@ -18,8 +18,18 @@ back end:
 with the activations fused into the rasterizer (``lvdgs_args.activations``), so ``lvdgs_backward`` writes the gradients
 w.r.t. the model's RAW parameters: they go straight into the ``.grad`` fields autograd would have filled (the first view
 of an iteration writes them, later views are added with one ``_foreach_add_``), the pose / exposure gradients into the
-viewpoint's ``cam_rot_delta.grad`` ... ``exposure_b.grad``.  Views with a static mask (L1 + SSIM, masked depth) and
-models with non-standard activations keep the autograd path (``usable``).
+viewpoint's ``cam_rot_delta.grad`` ... ``exposure_b.grad``.  Models with non-standard activations keep the autograd path
+(``usable``).
+
+A keyframe that carries a ``static_mask`` -- every window keyframe of LVD-GS under its default configuration
+(utils/slam_frontend.py:1218,1309-1329,1429-1433) -- is scored by L1 + SSIM on the static pixels plus the count-normalised masked
+depth term (utils/slam_backend.py:196-261) instead of ``get_loss_mapping``.  Same three-call shape (``masked_loss``):
+
+    lvdgs_forward -> lvdgs_masked_loss_batch (L1 + SSIM value and gradient image, the depth term's sum and count: two launches)
+                  -> lvdgs_backward_masked_loss (the depth term's gradient evaluated per pixel in the blend pass) -> lvdgs_map_view_tail
+
+on the viewpoint's cached mask bytes and mono depth (``slam_utils._static_mask_bytes`` / ``_mono_depth``: no upload per iteration)
+and scratch the pass owns.
 """
 import ctypes as C
 import math
@@ -30,7 +40,7 @@ import torch
 from . import _lib
 from . import rasterizer as _rz
 from .gaussian_renderer import _raw_parameters
-from .slam_utils import _gt_image, _mono_depth
+from .slam_utils import _gt_image, _mono_depth, _static_mask_bytes
 
 _P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
 _PARAM_FIELDS = ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")
@@ -51,13 +61,28 @@ class MapViewPass:
         self.dev = device
         self.own_gradient_buffers = own_gradient_buffers   # (False: a later view of a MapWindowBatch -- it adds to the first view's)
         self.L = _lib.lib()
-        self.a, self.la = _lib.Args(), _lib.LossArgs()
+        self.a, self.la, self.ml = _lib.Args(), _lib.LossArgs(), _lib.MaskedLossArgs()
         self.N = self.W = self.H = -1
         self.cap = 0
         self.one = torch.ones((), dtype=torch.float32, device=device)
         self._keep = []
 
     # ---- eligibility -------------------------------------------------------------------------------------------------
+    @staticmethod
+    def masked_loss_usable(viewpoint, with_depth=True) -> bool:
+        """Can the static-mask loss of ``viewpoint`` take the fused route?  Mask, target image and mono depth of the image's size
+        (the reference crops all three to their common top-left window when they differ, utils/slam_backend.py:240-246: the
+        autograd path does that)."""
+        H, W = int(viewpoint.image_height), int(viewpoint.image_width)
+        m = getattr(viewpoint, "static_mask", None)
+        if m is not None and (not torch.is_tensor(m) or m.numel() != H * W):
+            return False
+        gt = getattr(viewpoint, "original_image", None)
+        if not torch.is_tensor(gt) or tuple(gt.shape) != (3, H, W):
+            return False
+        md = getattr(viewpoint, "mono_depth", None) if with_depth else None
+        return md is None or int(md.size if not torch.is_tensor(md) else md.numel()) == H * W
+
     @staticmethod
     def usable(backend, viewpoint, allow_static_mask=False) -> bool:
         G = backend.gaussians
@@ -106,6 +131,12 @@ class MapViewPass:
         la.scratch, la.scratch_bytes, la.grad_loss = _P(self.loss_scratch), self.loss_scratch.numel(), _P(self.one)
         la.d_image = la.d_depth = la.d_opacity = la.opacity = la.grad_mask = None
         la.weight_by_opacity = la.depth_needs_opaque = 0
+        # the static-mask loss: its partial sums and the colour-gradient image it hands to the backward blend pass
+        ml = self.ml
+        self.masked_scratch = self._bytes(self.L.lvdgs_masked_loss_scratch_bytes(W, H))
+        self.d_image = e(3, H, W)
+        ml.width, ml.height = W, H
+        ml.scratch, ml.scratch_bytes, ml.d_image = _P(self.masked_scratch), self.masked_scratch.numel(), _P(self.d_image)
         if self.N >= 0:
             self._size_for_pairs(self.cap)
 
@@ -120,8 +151,32 @@ class MapViewPass:
         a.binning_state, a.binning_bytes = _P(self.binning), self.binning.numel()
         a.scratch, a.scratch_bytes = _P(self.scratch), self.scratch.numel()
 
+    def _point_masked_loss(self, backend, viewpoint, masked_loss, color, depth, bg, keep):
+        """Fills ``self.ml`` for ``viewpoint`` (``masked_loss = (lambda_dssim, depth_lambda or None)``; None: no depth term -- colour
+        refinement); returns the view's 8-float result block (``[0]`` = the loss)."""
+        dev, ml = self.dev, self.ml
+        lam, dlam = masked_loss
+        gt = _gt_image(viewpoint, color)
+        gt = gt.detach() if _gpu_f32c(gt, dev) else gt.detach().to(device=dev, dtype=torch.float32).contiguous()
+        keep.append(gt)
+        mask = _static_mask_bytes(viewpoint, color) if getattr(viewpoint, "static_mask", None) is not None else None
+        keep.append(mask)
+        ml.image, ml.gt_image, ml.static_mask, ml.bg = _P(color), _P(gt), _P(mask), _P(bg)
+        ml.lambda_dssim = float(lam)
+        md = getattr(viewpoint, "mono_depth", None) if dlam is not None else None
+        if md is not None:
+            z = _mono_depth(viewpoint, color)
+            z = z if _gpu_f32c(z, dev) else z.to(device=dev, dtype=torch.float32).contiguous()
+            keep.append(z)
+            ml.depth, ml.gt_depth, ml.depth_lambda = _P(depth), _P(z), float(dlam)
+        else:
+            ml.depth, ml.gt_depth, ml.depth_lambda = None, None, 0.0
+        out = torch.empty(8, dtype=torch.float32, device=dev)
+        ml.out = _P(out)
+        return out
+
     # ---- one view ----------------------------------------------------------------------------------------------------
-    def run(self, backend, viewpoint, initialization=False, first=None, image_loss=None, band=None, stats=None):
+    def run(self, backend, viewpoint, initialization=False, first=None, image_loss=None, band=None, stats=None, masked_loss=None):
         """Render ``viewpoint``, evaluate ``get_loss_mapping`` and add its gradients to the model's and the viewpoint's
         ``.grad`` fields (``first``: buffers, by parameter field, for a view that finds no gradients yet to write into --
         the sharded loop passes slices of its all-reduce bucket -- instead of the pass's own).  Returns the render package (fresh tensors, ``viewspace_points`` carries ``.grad``) and the
@@ -136,9 +191,13 @@ class MapViewPass:
         pixels of the images, the band's share of the loss and of every gradient; ``radii`` are the whole view's,
         ``n_touched`` counts the band's pixels.  The other pixels of the returned images are not written.
 
+        ``masked_loss = (lambda_dssim, depth_lambda or None)``: the view is scored by the static-mask mapping loss (module
+        docstring; reference utils/slam_backend.py:196-261, and :420-454 -- colour refinement -- with ``depth_lambda`` None) on its
+        ``static_mask`` (every pixel when the viewpoint has none); no exposure gradients, whole views only.
+
         ``stats = (radii_max, norm_sum, vis_count or None, touched_row or None, split_xy or None)``: the view's statistics
         (``lvdgs_view_stats``) are taken in the launch that finishes its loss (``lvdgs_map_view_tail``) instead of one of
-        their own; built-in mapping loss only."""
+        their own; built-in mapping loss and ``masked_loss``."""
         G, cfg, dev, L = backend.gaussians, backend.config, self.dev, self.L
         T = cfg["Training"]
         N, K = int(G._xyz.shape[0]), 1 + int(G._features_rest.shape[1])
@@ -162,8 +221,10 @@ class MapViewPass:
         a.activations = _rz.ACT_EXP_SCALES | _rz.ACT_NORMALIZE_ROTATIONS | _rz.ACT_SIGMOID_OPACITIES
         a.flags = _lib.FLAG_LIST_ALL_TILES if _rz.LIST_ALL_TILES else 0
         a.tile_row_begin, a.tile_row_end = (0, 0) if band is None else (int(band[0]), int(band[1]))
-        if band is not None and (image_loss is not None or not 0 <= band[0] < band[1]):
+        if band is not None and (image_loss is not None or masked_loss is not None or not 0 <= band[0] < band[1]):
             raise _lib.LvdgsError("MapViewPass: a band needs 0 <= row0 < row1 and the built-in mapping loss")
+        if image_loss is not None and masked_loss is not None:
+            raise _lib.LvdgsError("MapViewPass: image_loss and masked_loss exclude each other")
         if K > 1:
             torch.cat((G._features_dc.detach(), G._features_rest.detach()), dim=1, out=self.shs)
             shs = self.shs
@@ -197,7 +258,10 @@ class MapViewPass:
         a.dL_dtau, a.dL_dmeans2D = None, _P(d_m2)   # the pose gradient's partial sums are reduced together with the loss's
 
         loss = e(())
-        if image_loss is None:
+        if masked_loss is not None:
+            mout = self._point_masked_loss(backend, viewpoint, masked_loss, color, depth, cam[0], keep)
+            loss = mout[0]
+        elif image_loss is None:
             # ---- get_loss_mapping (reference utils/slam_utils.py:82-121) ----
             # (monodepth=True at every call site of the mapping loop, so the loss is the rgb-d one whatever Training.monocular says)
             gt = f32c(_gt_image(viewpoint, color))
@@ -227,7 +291,19 @@ class MapViewPass:
             else:
                 _lib.check(status, "lvdgs_forward")
             a.num_rendered = D
-            if image_loss is None:
+            if masked_loss is not None:
+                ml = self.ml
+                views = (C.POINTER(_lib.MaskedLossArgs) * 1)(C.pointer(ml))
+                _lib.check(L.lvdgs_masked_loss_batch(views, 1, stream), "lvdgs_masked_loss_batch")
+                _lib.check(L.lvdgs_backward_masked_loss(C.byref(a), C.byref(ml), stream), "lvdgs_backward_masked_loss")
+                if stats is not None:
+                    sa = _lib.ViewStatsArgs()
+                    sa.radii_max, sa.norm_sum, sa.vis_count, sa.touched_row, sa.split_xy = (_P(t) for t in stats)
+                    _lib.check(L.lvdgs_map_view_tail(None, C.byref(a), _P(d_tau), C.byref(sa), stream), "lvdgs_map_view_tail")
+                else:
+                    _lib.check(L.lvdgs_tracking_tail(None, C.byref(a), None, _P(d_tau), 1, stream), "lvdgs_tracking_tail")
+                initialization = True   # no exposure gradients from this loss
+            elif image_loss is None:
                 _lib.check(L.lvdgs_backward_fused_loss(C.byref(a), C.byref(la), 0, stream), "lvdgs_backward_fused_loss")
                 if stats is not None:
                     sa = _lib.ViewStatsArgs()
@@ -278,22 +354,27 @@ class MapWindowBatch:
     """The views of a mapping window through ``MapViewPass``'s three calls with the two blend passes of ALL views in one launch each:
 
         per view:  lvdgs_forward (LVDGS_FLAG_NO_BLEND: projection ... per-tile depth sort)
-        once:      lvdgs_blend_forward_batch, lvdgs_blend_backward_fused_loss_batch
-        per view:  lvdgs_backward_fused_loss (LVDGS_FLAG_NO_BLEND: the per-Gaussian pass, adding to the first view's gradients),
-                   lvdgs_map_view_tail
+        once:      lvdgs_blend_forward_batch, [lvdgs_masked_loss_batch over the views with a static mask,] lvdgs_blend_backward_window_batch
+        per view:  lvdgs_backward_fused_loss / lvdgs_backward_masked_loss (LVDGS_FLAG_NO_BLEND: the per-Gaussian pass, adding to the
+                   first view's gradients), lvdgs_map_view_tail
+
+    Keyframes with a static mask -- the reference's default: all eight of the window -- and views without one (the two random older
+    views) share the launches: the backward blend kernel takes each view's pixel gradients from the loss that view is scored by.
 
     A KITTI-size frame (1848 tiles) leaves the chip half empty and ends in a tail of its heaviest tiles; ten frames fill it.
     Every view keeps buffers of its own between the phases (geometry, pair lists, image state, scratch: ~60 MB per view at
     KITTI's size, ~200 MB at 500 k Gaussians / 1080p).  Results are ``MapViewPass.run``'s view after view, bit for bit: the same kernels on
     the same data, the parameter gradients added in the same order.
 
-    For whole views scored by the built-in mapping loss on a model of SH degree 0 (``usable``); anything else goes view by view."""
+    For whole views scored by the built-in mapping loss or the static-mask loss on a model of SH degree 0 (``usable``); anything
+    else goes view by view."""
 
     def __init__(self, lead: MapViewPass):
         self.passes = [lead]
 
     @staticmethod
-    def usable(backend, viewpoints) -> bool:
+    def usable(backend, viewpoints, masked=None) -> bool:
+        """``masked[k]``: view k is scored by the static-mask loss (default: none is)."""
         G = backend.gaussians
         if len(viewpoints) < 2 or int(G._features_rest.shape[1]) != 0 or _rz.LIST_ALL_TILES:
             return False
@@ -302,32 +383,43 @@ class MapWindowBatch:
         # iteration of ten views) and a set of buffers per view (~200 MB there) buys nothing
         if len(size) != 1 or any(((h + 15) // 16) * ((w + 15) // 16) > MAX_BATCH_TILES for h, w in size):
             return False
-        return all(getattr(v, "static_mask", None) is None and MapViewPass.usable(backend, v) for v in viewpoints)
+        masked = masked or [None] * len(viewpoints)
+        return all(MapViewPass.usable(backend, v, allow_static_mask=True) and (m is None or MapViewPass.masked_loss_usable(v, m[1] is not None))
+                   for v, m in zip(viewpoints, masked))
 
-    def run(self, backend, viewpoints, initialization=False, first=None, stats=None):
-        """-> [(pkg, loss)] in the order of ``viewpoints`` (``stats[k]``: ``MapViewPass.run``'s ``stats`` of view k)."""
+    def run(self, backend, viewpoints, initialization=False, first=None, stats=None, masked=None):
+        """-> [(pkg, loss)] in the order of ``viewpoints`` (``stats[k]``: ``MapViewPass.run``'s ``stats`` of view k, ``masked[k]``: its
+        ``masked_loss`` -- None for a view scored by ``get_loss_mapping``)."""
         lead = self.passes[0]
         dev, L = lead.dev, lead.L
         while len(self.passes) < len(viewpoints):
             self.passes.append(MapViewPass(dev, own_gradient_buffers=False))
         n = len(viewpoints)
+        masked = masked or [None] * n
         ctxs = []
         with _lib.on_device(dev):
             stream = _lib.raw_stream(dev)
             for k, vp in enumerate(viewpoints):
                 ctxs.append(self.passes[k]._begin_for_batch(backend, vp, initialization, first if k == 0 else None,
-                                                            None if k == 0 else ctxs[0]["into"], stream))
+                                                            None if k == 0 else ctxs[0]["into"], stream, masked[k]))
             views = (C.POINTER(_lib.Args) * n)(*[C.pointer(self.passes[k].a) for k in range(n)])
             losses = (C.POINTER(_lib.LossArgs) * n)(*[C.pointer(self.passes[k].la) for k in range(n)])
             _lib.check(L.lvdgs_blend_forward_batch(views, n, stream), "lvdgs_blend_forward_batch")
-            _lib.check(L.lvdgs_blend_backward_fused_loss_batch(views, losses, n, 0, stream), "lvdgs_blend_backward_fused_loss_batch")
+            which = [k for k in range(n) if masked[k] is not None]
+            if which:
+                mviews = (C.POINTER(_lib.MaskedLossArgs) * len(which))(*[C.pointer(self.passes[k].ml) for k in which])
+                _lib.check(L.lvdgs_masked_loss_batch(mviews, len(which), stream), "lvdgs_masked_loss_batch")
+                per_view = (C.POINTER(_lib.MaskedLossArgs) * n)(*[C.pointer(self.passes[k].ml) if masked[k] is not None else None for k in range(n)])
+                _lib.check(L.lvdgs_blend_backward_window_batch(views, losses, per_view, n, 0, stream), "lvdgs_blend_backward_window_batch")
+            else:
+                _lib.check(L.lvdgs_blend_backward_fused_loss_batch(views, losses, n, 0, stream), "lvdgs_blend_backward_fused_loss_batch")
             for k in range(n):
                 self.passes[k]._backward_for_batch(ctxs[k], None if stats is None else stats[k], stream)
         return [self.passes[k]._finish_for_batch(backend, viewpoints[k], ctxs[k]) for k in range(n)]
 
 
-def _begin_for_batch(self, backend, viewpoint, initialization, first, lead_into, stream):
-    """``MapViewPass.run`` up to the forward call (whole view, built-in loss, SH degree 0), with LVDGS_FLAG_NO_BLEND."""
+def _begin_for_batch(self, backend, viewpoint, initialization, first, lead_into, stream, masked_loss=None):
+    """``MapViewPass.run`` up to the forward call (whole view, built-in or static-mask loss, SH degree 0), with LVDGS_FLAG_NO_BLEND."""
     G, cfg, dev, L = backend.gaussians, backend.config, self.dev, self.L
     T = cfg["Training"]
     N, K = int(G._xyz.shape[0]), 1 + int(G._features_rest.shape[1])
@@ -371,20 +463,24 @@ def _begin_for_batch(self, backend, viewpoint, initialization, first, lead_into,
     d_tau, d_a, d_b, d_m2 = e(6), e(1), e(1), e(N, 3)
     a.dL_dtau, a.dL_dmeans2D = None, _P(d_m2)
     loss = e(())
-    gt = f32c(_gt_image(viewpoint, color))
-    keep.append(gt)
-    la.image, la.gt_image = _P(color), _P(gt)
-    la.rgb_boundary_threshold = float(T["rgb_boundary_threshold"])
-    if initialization:
-        la.exposure_a = la.exposure_b = la.d_exposure_a = la.d_exposure_b = None
+    if masked_loss is not None:
+        loss = self._point_masked_loss(backend, viewpoint, masked_loss, color, depth, cam[0], keep)[0]
+        initialization = True   # no exposure gradients from this loss
     else:
-        la.exposure_a, la.exposure_b, la.d_exposure_a, la.d_exposure_b = _P(viewpoint.exposure_a), _P(viewpoint.exposure_b), _P(d_a), _P(d_b)
-    alpha = T.get("alpha", 0.95)
-    md = f32c(_mono_depth(viewpoint, color))
-    keep.append(md)
-    la.depth, la.gt_depth = _P(depth), _P(md)
-    la.weight_rgb, la.weight_depth = float(alpha), float(1 - alpha)
-    la.loss = _P(loss)
+        gt = f32c(_gt_image(viewpoint, color))
+        keep.append(gt)
+        la.image, la.gt_image = _P(color), _P(gt)
+        la.rgb_boundary_threshold = float(T["rgb_boundary_threshold"])
+        if initialization:
+            la.exposure_a = la.exposure_b = la.d_exposure_a = la.d_exposure_b = None
+        else:
+            la.exposure_a, la.exposure_b, la.d_exposure_a, la.d_exposure_b = _P(viewpoint.exposure_a), _P(viewpoint.exposure_b), _P(d_a), _P(d_b)
+        alpha = T.get("alpha", 0.95)
+        md = f32c(_mono_depth(viewpoint, color))
+        keep.append(md)
+        la.depth, la.gt_depth = _P(depth), _P(md)
+        la.weight_rgb, la.weight_depth = float(alpha), float(1 - alpha)
+        la.loss = _P(loss)
 
     num = C.c_int64(0)
     status = L.lvdgs_forward(C.byref(a), C.byref(num), stream)
@@ -397,18 +493,23 @@ def _begin_for_batch(self, backend, viewpoint, initialization, first, lead_into,
         _lib.check(status, "lvdgs_forward")
     a.num_rendered = D
     return dict(color=color, depth=depth, opacity=opacity, radii=radii, n_touched=n_touched, d_tau=d_tau, d_a=d_a, d_b=d_b, d_m2=d_m2,
-                loss=loss, into=into, install=install, fields=fields, initialization=initialization)
+                loss=loss, into=into, install=install, fields=fields, initialization=initialization, masked=masked_loss is not None)
 
 
 def _backward_for_batch(self, ctx, stats, stream):
     L, a, la = self.L, self.a, self.la
-    _lib.check(L.lvdgs_backward_fused_loss(C.byref(a), C.byref(la), 0, stream), "lvdgs_backward_fused_loss")
+    if ctx["masked"]:
+        _lib.check(L.lvdgs_backward_masked_loss(C.byref(a), C.byref(self.ml), stream), "lvdgs_backward_masked_loss")
+        la = None   # (the loss value is finished: the tail reduces the pose gradient and takes the statistics)
+    else:
+        _lib.check(L.lvdgs_backward_fused_loss(C.byref(a), C.byref(la), 0, stream), "lvdgs_backward_fused_loss")
+    la_ref = None if la is None else C.byref(la)
     if stats is not None:
         sa = _lib.ViewStatsArgs()
         sa.radii_max, sa.norm_sum, sa.vis_count, sa.touched_row, sa.split_xy = (_P(t) for t in stats)
-        _lib.check(L.lvdgs_map_view_tail(C.byref(la), C.byref(a), _P(ctx["d_tau"]), C.byref(sa), stream), "lvdgs_map_view_tail")
+        _lib.check(L.lvdgs_map_view_tail(la_ref, C.byref(a), _P(ctx["d_tau"]), C.byref(sa), stream), "lvdgs_map_view_tail")
     else:
-        _lib.check(L.lvdgs_tracking_tail(C.byref(la), C.byref(a), None, _P(ctx["d_tau"]), 1, stream), "lvdgs_tracking_tail")
+        _lib.check(L.lvdgs_tracking_tail(la_ref, C.byref(a), None, _P(ctx["d_tau"]), 1, stream), "lvdgs_tracking_tail")
     ctx["stats_taken"] = stats is not None
 
 

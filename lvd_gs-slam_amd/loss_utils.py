@@ -184,23 +184,26 @@ def masked_depth_l1(depth, mono_depth, static_mask=None, return_count=False):
 
 
 def masked_mapping_loss_and_grads(image, depth, viewpoint, background, lambda_dssim, depth_lambda=0.1):
-    """``masked_mapping_loss`` without autograd: (loss, d loss / d image (3,H,W), d loss / d depth (1,H,W) or None) from the
-    fused L1 + SSIM launch (value and gradient image together) and the two masked-depth launches -- what a mapping view
-    with a ``static_mask`` hands to the plain ``lvdgs_backward`` (fast_mapping.MapViewPass, ``image_loss``)."""
+    """``masked_mapping_loss`` without autograd, as SEPARATE launches: (loss, d loss / d image (3,H,W), d loss / d depth (1,H,W) or
+    None) from the fused L1 + SSIM launch (value and gradient image together) and the two masked-depth launches, for a caller that
+    hands gradient images to the plain ``lvdgs_backward`` (``fast_mapping.MapViewPass.run(image_loss=...)``).  The mapping loop itself
+    goes through ``lvdgs_masked_loss_batch`` / ``lvdgs_backward_masked_loss`` (``MapViewPass.run(masked_loss=...)``: no depth-gradient
+    image, one launch for all masked views of a window); the tests hold the two against each other."""
+    from .slam_utils import _mono_depth, _static_mask_bytes
     L = _lib.lib()
     dev = image.device
     H, W = int(image.shape[-2]), int(image.shape[-1])
     gt = viewpoint.original_image.to(dev)
-    mask = viewpoint.static_mask.to(dev)
-    keep = _mask_bytes(mask, H, W)
+    keep = _static_mask_bytes(viewpoint, image)   # (cached with the viewpoint: no upload / conversion per iteration)
+    if keep.numel() != H * W:
+        raise ValueError(f"mask has {keep.numel()} elements, image has {H * W} pixels")
     lam = float(lambda_dssim)
     out, d_image = _launch(image.detach(), gt, keep, _c32(background), 1.0 - lam, -lam, True)
     loss = (1.0 - lam) * out[0] - lam * out[1] + lam
     d_depth = None
     if depth is not None and getattr(viewpoint, "mono_depth", None) is not None:
         d = _c32(_squeeze_hw(depth.detach()))
-        md = viewpoint.mono_depth
-        z = _c32(_squeeze_hw(md if torch.is_tensor(md) else torch.from_numpy(md)).to(dev))
+        z = _c32(_squeeze_hw(_mono_depth(viewpoint, image)))
         if d.shape != z.shape or d.shape != (H, W):
             raise ValueError("masked_mapping_loss_and_grads: depth, mono depth and image must have one size")
         a = _lib.MaskedDepthArgs()

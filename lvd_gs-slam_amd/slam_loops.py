@@ -69,11 +69,12 @@ def color_refinement(backend, iteration_total=26000, render_fn=render, loss_fn=N
         from .loss_utils import l1_dssim_loss as loss_fn
     G = backend.gaussians
     # on the GPU with the default renderer and loss: forward, the fused L1 + SSIM kernel (value and gradient image in one
-    # launch) and backward as three library calls without the autograd engine (fast_mapping.MapViewPass)
+    # launch) and backward as library calls without the autograd engine (fast_mapping.MapViewPass, masked_loss without a depth
+    # term), on the keyframe's cached mask bytes
     vpass = None
     if render_fn is render and G.get_xyz.is_cuda:
         from .fast_mapping import MapViewPass
-        from .loss_utils import _launch, _mask_bytes, l1_dssim_loss
+        from .loss_utils import l1_dssim_loss
         if loss_fn is l1_dssim_loss:
             vpass = MapViewPass(G.get_xyz.device)
     for iteration in range(1, iteration_total + 1):
@@ -82,14 +83,9 @@ def color_refinement(backend, iteration_total=26000, render_fn=render, loss_fn=N
         viewpoint_cam = backend.viewpoints[viewpoint_cam_idx]
         static_mask = getattr(viewpoint_cam, "static_mask", None)
         lam = float(backend.opt_params.lambda_dssim)
-        if vpass is not None and G.get_xyz.shape[0] > 0 and type(vpass).usable(backend, viewpoint_cam, allow_static_mask=True):
-            def image_loss(color, depth=None):
-                gt = viewpoint_cam.original_image.to(color.device)
-                keep_mask = _mask_bytes(static_mask, color.shape[1], color.shape[2])
-                bg = backend.background.detach().float().contiguous() if keep_mask is not None else None
-                out, d = _launch(color, gt, keep_mask, bg, 1.0 - lam, -lam, True)   # as loss_utils.l1_dssim_loss
-                return (1.0 - lam) * out[0] - lam * out[1] + lam, d
-            render_pkg, loss = vpass.run(backend, viewpoint_cam, image_loss=image_loss)
+        if (vpass is not None and G.get_xyz.shape[0] > 0 and type(vpass).usable(backend, viewpoint_cam, allow_static_mask=True)
+                and type(vpass).masked_loss_usable(viewpoint_cam, with_depth=False)):
+            render_pkg, loss = vpass.run(backend, viewpoint_cam, masked_loss=(lam, None))
             visibility_filter, radii = render_pkg["visibility_filter"], render_pkg["radii"]
         else:
             render_pkg = render_fn(viewpoint_cam, G, backend.pipeline_params, backend.background)

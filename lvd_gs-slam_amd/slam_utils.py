@@ -67,6 +67,26 @@ def _mono_depth(viewpoint, like):
     return t
 
 
+def _static_mask_bytes(viewpoint, like):
+    """The viewpoint's ``static_mask`` (bool, True = static; (H,W) or with a unit dimension) as H*W bytes on ``like``'s device,
+    16-byte aligned, for the masked-loss kernels.  The reference uploads and converts the mask in every iteration of every
+    window view (utils/slam_backend.py:199); here the device copy stays with the viewpoint for as long as the mask tensor is the
+    same object and has not been written to (``Tensor._version``)."""
+    m = viewpoint.static_mask
+    cache = getattr(viewpoint, "_lvdgs_static_mask", None)
+    if cache is not None and cache[0] is m and cache[1] == m._version and cache[2].device == like.device:
+        return cache[2]
+    t = m.to(like.device).reshape(-1)
+    t = (t.view(torch.uint8) if t.dtype == torch.bool else t.ne(0).view(torch.uint8)).contiguous()
+    if t is m or t.data_ptr() == m.data_ptr() or t.data_ptr() % 16:
+        t = t.clone()   # (never an alias of the caller's tensor: a later in-place edit must not change the cached bytes unnoticed)
+    try:
+        viewpoint._lvdgs_static_mask = (m, m._version, t)
+    except Exception:
+        pass
+    return t
+
+
 def _exposure(image, viewpoint):
     return torch.exp(viewpoint.exposure_a) * image + viewpoint.exposure_b
 

@@ -63,6 +63,7 @@ def test_ctypes_struct_matches_c_layout(tmp_path):
 
 @pytest.mark.parametrize("ctype,cname", [("LossArgs", "lvdgs_loss_args"), ("MaskedDepthArgs", "lvdgs_masked_depth_args"),
                                          ("SsimArgs", "lvdgs_ssim_args"), ("PoseStepArgs", "lvdgs_pose_step_args"),
+                                         ("MaskedLossArgs", "lvdgs_masked_loss_args"),
                                          ("AdamTensor", "lvdgs_adam_tensor"), ("ViewStatsArgs", "lvdgs_view_stats_args")])
 def test_every_other_ctypes_struct_matches_its_c_layout(tmp_path, ctype, cname):
     """Field offsets and sizes of the ctypes mirrors against a C probe compiled from include/lvdgs.h."""
@@ -94,6 +95,16 @@ def test_pose_and_adam_argument_validation_without_gpu():
     assert L.lvdgs_adam_step(arr, 0, 0.9, 0.999, 1e-15, None) == _lib.OK             # nothing to do
     md = _lib.MaskedDepthArgs()
     assert L.lvdgs_masked_depth_l1_forward(C.byref(md), None) == _lib.E_INVALID
+    ml = _lib.MaskedLossArgs()
+    views = (C.POINTER(_lib.MaskedLossArgs) * 1)(C.pointer(ml))
+    assert L.lvdgs_masked_loss_batch(views, 1, None) == _lib.E_INVALID and b"image size" in L.lvdgs_last_error()
+    ml.width, ml.height = 64, 48
+    assert L.lvdgs_masked_loss_batch(views, 1, None) == _lib.E_INVALID and b"NULL" in L.lvdgs_last_error()
+    assert L.lvdgs_masked_loss_batch(views, 0, None) == _lib.OK
+    assert L.lvdgs_masked_loss_scratch_bytes(1226, 370) % 256 == 0 and L.lvdgs_masked_loss_scratch_bytes(1226, 370) >= 4 * 39 * 12 * 8
+    a = _lib.Args()
+    assert L.lvdgs_backward_masked_loss(C.byref(a), C.byref(ml), None) == _lib.E_INVALID
+    assert L.lvdgs_blend_backward_window_batch(None, None, None, 1, 0, None) == _lib.E_INVALID
 
 
 def test_sizes_are_monotone_and_aligned():

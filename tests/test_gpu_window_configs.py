@@ -162,8 +162,8 @@ def test_kitti07_window_of_8_plus_2_random_keyframes():
 
 def test_2m_gaussians_with_dynamic_object_masks():
     """Keyframes that carry a static mask: fused=True renders, scores and differentiates them without autograd (the
-    L1 + SSIM kernel's and the masked-depth kernels' gradient images into the plain lvdgs_backward, fast_mapping.MapViewPass
-    with ``image_loss``); fused=False is render() -> loss_utils.masked_mapping_loss -> backward() through the autograd
+    static-mask loss of lvdgs_masked_loss_batch into lvdgs_backward_masked_loss, fast_mapping.MapViewPass with
+    ``masked_loss``); fused=False is render() -> loss_utils.masked_mapping_loss -> backward() through the autograd
     engine.  Same losses, same map after two iterations."""
     from lvdgs.backend_map import map_window
     from lvdgs.fast_mapping import MapViewPass
@@ -175,7 +175,7 @@ def test_2m_gaussians_with_dynamic_object_masks():
         assert N == 2_000_000
         calls = []
         run = MapViewPass.run
-        MapViewPass.run = lambda self, *a, **k: (calls.append(k.get("image_loss") is not None) or run(self, *a, **k))
+        MapViewPass.run = lambda self, *a, **k: (calls.append(k.get("masked_loss") is not None) or run(self, *a, **k))
         stats = {}
         try:
             map_window(be, window, iters=2, stats=stats, fused=fused)
