@@ -172,6 +172,11 @@ def main():
     ap.add_argument("--window", choices=["real", "weak"], default="real",
                     help="mapping step: 'real' = the reference's window, 8 keyframes + 2 random older ones per iteration, its ten "
                          "views sharded over the GPUs (strong scaling); 'weak' = one keyframe per GPU, no random views")
+    ap.add_argument("--no-masks", action="store_true",
+                    help="mapping step: keyframes WITHOUT a static_mask (every window view scored by get_loss_mapping).  Default: every keyframe "
+                         "carries one, as LVD-GS's front end attaches it (dynamic_filtering.enabled = True, utils/slam_frontend.py:1218,1429-1433): "
+                         "the eight window views take the L1 + SSIM + masked-depth branch (utils/slam_backend.py:196-261), the two random views "
+                         "get_loss_mapping (:275-300)")
     ap.add_argument("--step", choices=["auto", "tracking", "tracking-autograd", "mapping"], default="auto",
                     help="auto: tracking iteration on 1 GPU, mapping-window iteration on N > 1.  tracking: one iteration of "
                          "the product's tracking loop (fast_tracking.TrackingSession: render, tracking loss, backward, pose "
@@ -214,7 +219,9 @@ def main():
     stats = {}
     backend = window = session = None
     real_window = not tracking and args.window == "real"
-    make_window = (lambda m: build_window(args.workload, 12, dev, m, n_window=8)) if real_window else (lambda m: build_window(args.workload, world, dev, m))
+    masked = not args.no_masks
+    make_window = ((lambda m: build_window(args.workload, 12, dev, m, n_window=8, masked=masked)) if real_window else
+                   (lambda m: build_window(args.workload, world, dev, m, masked=masked)))
     if not tracking:
         backend, window = make_window(model)
         if world > 1 and os.environ.get("LVDGS_BENCH_AUX_GROUP", "1") != "0":
@@ -404,7 +411,7 @@ def main():
             solo_groups = [dist.new_group(ranks=[r]) for r in range(world)]
             solo_model = GaussianModel.from_activated(g_cpu["means3D"], g_cpu["scales"], g_cpu["rotations"], g_cpu["opacities"], shs=g_cpu["shs"],
                                                       sh_degree=0, device=dev)
-            solo_backend, solo_window = make_window(solo_model) if real_window else build_window(args.workload, 1, dev, solo_model)
+            solo_backend, solo_window = make_window(solo_model) if real_window else build_window(args.workload, 1, dev, solo_model, masked=masked)
             for _ in range(3):
                 backend_map.map_window(solo_backend, solo_window, iters=1, group=solo_groups[rank])
             torch.cuda.synchronize()
@@ -460,15 +467,15 @@ def main():
                                  "tracking iteration through the autograd API: render() + get_loss_tracking + backward (pose + all Gaussian grads)")
                                 if tracking else
                                 ("mapping iteration (backend_map.map_window) on the reference's window: 8 keyframes + 2 random older ones = 10 views "
-                                 "per iteration, dealt to the GPUs whole and in bands of tile rows -- render + get_loss_mapping + backward of every "
-                                 "piece, RCCL collectives (gradients + statistics SUM, radii MAX, flags MAX), bookkeeping, Adam over all Gaussians, "
+                                 "per iteration, dealt to the GPUs whole and in bands of tile rows -- render + mapping loss (keyframes with a static mask: "
+                                 "L1 + SSIM + masked depth, whole views; the others: get_loss_mapping) + backward of every piece, RCCL collectives (gradients + statistics SUM, radii MAX, flags MAX), bookkeeping, Adam over all Gaussians, "
                                  "keyframe Adam, pose retraction; value = views (render + backward) per second = 10 x iterations/s"
                                  if real_window else
                                  "mapping iteration (backend_map.map_window), WEAK scaling: a window of N keyframes, one whole keyframe per GPU, no "
                                  "random views -- render + get_loss_mapping + backward, the collectives, bookkeeping, Adam over all Gaussians, "
                                  "keyframe Adam, pose retraction; value = keyframes per second")),
                        "parallelism": ((f"10 views in pieces over {world} GPUs" if real_window else f"keyframe-per-gpu x{world}") if world > 1 else "single"),
-                       "views_per_step": views_per_step, "comm_us_per_step": comm_us, "phases_us_per_step": phases,
+                       "views_per_step": views_per_step, "window_keyframes_carry_static_mask": None if tracking else masked, "comm_us_per_step": comm_us, "phases_us_per_step": phases,
                        "autograd_api_iters_per_s": autograd_rate, "pose_only_iters_per_s": pose_only_rate,
                        "mapping_window_views_per_s": None if not side else side.get("mapping_window_" + args.workload, {}).get("views_per_s"),
                        "side": side, "notes": notes or None, "same_step_on_one_gpu_iters_per_s": same_step_single,
@@ -520,22 +527,27 @@ def run_side(dev, pipe):
         out[w] = ent
         del model, cam
         torch.cuda.empty_cache()
-    for w in ("kitti07_geom", "cfg3_500k_1920x1080"):
+    # the 8 + 2 mapping window on one GPU.  `_masked`: every keyframe carries a static_mask -- the reference's default configuration
+    # (utils/slam_frontend.py:1218,1429-1433) -- so the eight window views take the L1 + SSIM + masked-depth branch of the mapping loss
+    # (utils/slam_backend.py:196-261); without: every view get_loss_mapping
+    for w, masked in (("kitti07_geom", False), ("kitti07_geom", True), ("cfg3_500k_1920x1080", False), ("cfg3_500k_1920x1080", True),
+                      ("cfg5_2m_1920x1280", False), ("cfg5_2m_1920x1280", True)):
         t0 = time.perf_counter()
         torch.manual_seed(0)
         model, _, _, (N, W, H) = build_scene(w, 0, dev)
-        backend, window = build_window(w, 12, dev, model, n_window=8)
+        backend, window = build_window(w, 12, dev, model, n_window=8, masked=masked)
         for _ in range(8):
             backend_map.map_window(backend, window, iters=1)
         torch.cuda.synchronize()
-        iters = 40 if w == "kitti07_geom" else 25
+        iters = 40 if w == "kitti07_geom" else (25 if w == "cfg3_500k_1920x1080" else 12)
         t = time.perf_counter()
         for _ in range(iters):
             backend_map.map_window(backend, window, iters=1)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t
-        out["mapping_window_" + w] = {"views_per_s": round(10 * iters / dt, 2), "ms_per_iteration": round(1e3 * dt / iters, 3), "views_per_iteration": 10,
-                                      "gaussians": N, "width": W, "height": H, "seconds_spent": round(time.perf_counter() - t0, 2)}
+        out["mapping_window_" + w + ("_masked" if masked else "")] = {
+            "views_per_s": round(10 * iters / dt, 2), "ms_per_iteration": round(1e3 * dt / iters, 3), "views_per_iteration": 10,
+            "window_keyframes_carry_static_mask": masked, "gaussians": N, "width": W, "height": H, "seconds_spent": round(time.perf_counter() - t0, 2)}
         del backend, model
         torch.cuda.empty_cache()
     return out

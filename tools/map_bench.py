@@ -21,7 +21,9 @@ n_window = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 n_older = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 dev = torch.device("cuda", 0)
 model, _, _, (N, W, H) = bench.build_scene(workload, 0, dev)
-be, window = bench.build_window(workload, n_window + n_older, dev, model, n_window=n_window)   # the newest n_window keyframes; 1..n_older are the older ones
+# MAP_BENCH_MASKED=1: every keyframe carries a static_mask (the reference's default: utils/slam_frontend.py:1218,1429-1433)
+masked = os.environ.get("MAP_BENCH_MASKED", "0") == "1"
+be, window = bench.build_window(workload, n_window + n_older, dev, model, n_window=n_window, masked=masked)   # the newest n_window keyframes; 1..n_older are the older ones
 # MAP_BENCH_FUSED_ONLY=1 (under rocprofv3 --kernel-trace --stats): 28 fused iterations and nothing else, so that the trace's
 # kernel time / 28 is the GPU-busy time of one iteration without this script's own event timing
 for fused in ((True,) if os.environ.get("MAP_BENCH_FUSED_ONLY") else (True, False)):
@@ -39,5 +41,5 @@ for fused in ((True,) if os.environ.get("MAP_BENCH_FUSED_ONLY") else (True, Fals
     _lib.profile_enable(False)
     k = _lib.profile_read()
     lib_ms = sum(ms for _, ms in k.values()) / 5
-    print(f"{workload} N={N} {W}x{H}, window {n_window} + 2 random, fused={fused}: {1e3 * dt:.2f} ms per iteration = {1 / dt:.1f} it/s = "
+    print(f"{workload} N={N} {W}x{H}, window {n_window} + 2 random, keyframes {'WITH' if masked else 'without'} a static mask, fused={fused}: {1e3 * dt:.2f} ms per iteration = {1 / dt:.1f} it/s = "
           f"{(n_window + 2) / dt:.0f} renders+backwards/s; lvdgs kernels {lib_ms:.2f} ms per iteration ({100 * lib_ms / (1e3 * dt):.0f} % of the wall time)")
