@@ -344,6 +344,16 @@ int lvdgs_backward_fused_loss(const lvdgs_args *a, const lvdgs_loss_args *loss, 
  * block, every buffer its own; all views the same image size and band of tile rows, losses[k] as for
  * lvdgs_backward_fused_loss.  Each view's outputs are what its single call without the flag writes, bit for bit. */
 int lvdgs_blend_forward_batch(const lvdgs_args *const *views, int32_t count, void *stream);
+/* lvdgs_forward for `count` views of ONE map (the same Gaussian tensors, the same num_gaussians / activations) and ONE image size,
+ * every stage of all views in one launch: projection + counting, the two scans, the scatter, the per-tile depth sort and (unless
+ * LVDGS_FLAG_NO_BLEND is set in the views' flags) the forward blend -- 6 launches for a mapping window's ten views instead of 50
+ * (upstream renders them one after the other, utils/slam_backend.py:180-184; at KITTI's frame size the five stages before the blend are
+ * latency-bound launches of 6-16 us each, half a millisecond per window).  Every view brings its own argument block with buffers of its
+ * own, sized for its own pair_capacity as for lvdgs_forward; images of at most 16384 tiles.  The host waits once, with everything
+ * enqueued, for all the pair counts: num_rendered[k] = view k's.  Returns LVDGS_OK, or LVDGS_E_CAPACITY when some view's count exceeds
+ * its capacity -- THAT view's outputs are invalid (its geom_state is valid) and the caller re-runs lvdgs_forward_render for it with
+ * buffers of num_rendered[k] pairs; the other views are complete.  Each view's state and outputs are lvdgs_forward's, bit for bit. */
+int lvdgs_forward_batch(const lvdgs_args *const *views, int32_t count, int64_t *num_rendered, void *stream);
 int lvdgs_blend_backward_fused_loss_batch(const lvdgs_args *const *views, const lvdgs_loss_args *const *losses, int32_t count,
                                           int32_t propagate_opacity_grad, void *stream);
 

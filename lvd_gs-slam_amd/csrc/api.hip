@@ -3,6 +3,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -301,13 +302,15 @@ int lvdgs_state_layout_query(int32_t N, int64_t D, int32_t W, int32_t H, lvdgs_s
 namespace {
 struct PairProbe {
     int device = -1;
-    uint32_t *pinned = nullptr;   // [0] pair count, [1] longest queued tile segment of the frame, [2] length of that queue, [3] sequence number of the call that wrote them
+    uint32_t *pinned = nullptr;   // [0] pair count, [1] longest queued tile segment of the frame, [2] length of that queue, [3] sequence number of the call that wrote them;
+                                  // [16 + 4 k ...]: the same four words of view k of lvdgs_forward_batch
     uint32_t *pinned_dev = nullptr;   // the same words as the device addresses them
     uint32_t seq = 0;             // of the last single-call forward on this thread and device
     hipEvent_t ready = nullptr;
     int longest = 0, queued = 0;  // of the previous frame on this device: which kernels for long segments the next frame
     int keep = 0;                 // launches behind its tile sort (a hint, never a result); kept for a few frames
 };
+constexpr int PROBE_WORDS = 16 + 4 * FWD_BATCH_VIEWS + 8;
 thread_local PairProbe g_probe[16];
 
 int get_probe(PairProbe **out) {
@@ -316,8 +319,8 @@ int get_probe(PairProbe **out) {
     PairProbe &p = g_probe[dev & 15];
     if (p.device != dev || !p.pinned) {
         p.device = dev;
-        if (int e = check_hip(hipHostMalloc((void **)&p.pinned, 64, hipHostMallocMapped | hipHostMallocCoherent), "pinned pair count")) return e;
-        for (int k = 0; k < 16; k++) p.pinned[k] = 0u;
+        if (int e = check_hip(hipHostMalloc((void **)&p.pinned, PROBE_WORDS * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent), "pinned pair count")) return e;
+        for (int k = 0; k < PROBE_WORDS; k++) p.pinned[k] = 0u;
         if (int e = check_hip(hipHostGetDevicePointer((void **)&p.pinned_dev, p.pinned, 0), "device address of the pinned pair count")) return e;
         if (int e = check_hip(hipEventCreateWithFlags(&p.ready, hipEventDisableTiming), "pair count event")) return e;
     }
@@ -334,9 +337,18 @@ int enqueue_prepare(const lvdgs_args *a, const GeomView &g, hipStream_t s) {
     return launch_slot_scan(g.tiles_touched, g.slot_base, w.blocksums, g.total, N, a->debug, s);
 }
 
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield");
+#endif
+}
+
 // The tile scan of this call has written the pinned words when their fourth holds the call's sequence number.
-int wait_for_sequence(PairProbe *probe) {
-    volatile uint32_t *flag = probe->pinned + 3;
+// (words: the four words of the call -- or of one view of lvdgs_forward_batch)
+int wait_for_sequence(PairProbe *probe, const uint32_t *words = nullptr) {
+    volatile const uint32_t *flag = (words ? words : probe->pinned) + 3;
     const uint32_t want = probe->seq;
     const auto t0 = std::chrono::steady_clock::now();
     // The count arrives some tens of microseconds after the call got here (the projection and the two scans); the wait is a
@@ -344,7 +356,7 @@ int wait_for_sequence(PairProbe *probe) {
     // reference's front end and back end are two processes that each sit in this wait once per render.
     for (uint64_t spins = 0;; spins++) {
         if (__atomic_load_n(const_cast<uint32_t *>(flag), __ATOMIC_ACQUIRE) == want) return LVDGS_OK;
-        if (spins < 2000) __builtin_ia32_pause();
+        if (spins < 2000) cpu_relax();
         else std::this_thread::yield();
         if ((spins & 0xffffu) == 0xffffu) {
             if (int e = check_hip(hipGetLastError(), "while waiting for the pair count")) return e;
@@ -524,6 +536,75 @@ int lvdgs_forward(const lvdgs_args *a, int64_t *num_rendered, void *stream) {
         return LVDGS_E_CAPACITY;
     }
     return LVDGS_OK;
+}
+
+// The forward passes of `count` views of one map and one image size, every stage ONE launch (include/lvdgs.h).
+int lvdgs_forward_batch(const lvdgs_args *const *views, int32_t count, int64_t *num_rendered, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (count < 0 || (count > 0 && (!views || !num_rendered))) { set_error("forward batch: bad view list"); return LVDGS_E_INVALID; }
+    if (count == 0) return LVDGS_OK;
+    for (int k = 0; k < count; k++) num_rendered[k] = 0;
+    const lvdgs_args *a0 = views[0];
+    if (!a0) { set_error("forward batch: view 0 is NULL"); return LVDGS_E_INVALID; }
+    const int N = a0->num_gaussians, W = a0->image_width, H = a0->image_height;
+    if (int e = check_common(a0)) return e;
+    const int num_tiles = cdiv(W, TILE) * cdiv(H, TILE);
+    if (N <= 0 || !use_counting_path(num_tiles)) { set_error("forward batch: needs a map (N > 0) and an image of at most %d tiles (the views go through lvdgs_forward one by one otherwise)", group_max_tiles()); return LVDGS_E_INVALID; }
+    std::vector<GeomView> g(count); std::vector<BinView> b(count); std::vector<ImageView> im(count); std::vector<RenderScratch> w(count);
+    std::vector<int64_t> caps(count);
+    for (int k = 0; k < count; k++) {
+        const lvdgs_args *a = views[k];
+        if (!a) { set_error("forward batch: view %d is NULL", k); return LVDGS_E_INVALID; }
+        if (int e = check_common(a)) return e;
+        if (int e = check_gaussians(a)) return e;
+        if (a->num_gaussians != N || a->image_width != W || a->image_height != H || a->tile_row_begin != a0->tile_row_begin || a->tile_row_end != a0->tile_row_end ||
+            a->means3D != a0->means3D || ((a->flags ^ a0->flags) & (LVDGS_FLAG_LIST_ALL_TILES | LVDGS_FLAG_NO_BLEND))) {
+            set_error("forward batch: the views differ in map, image size, band or flags"); return LVDGS_E_INVALID;
+        }
+        const int64_t cap = a->pair_capacity;
+        if (cap <= 0 || cap > 0x7FFFFFFFll) { set_error("pair_capacity must be in 1..2^31-1"); return LVDGS_E_INVALID; }
+        if (!a->radii || !a->geom_state || !a->scratch) { set_error("radii / geom_state / scratch is NULL"); return LVDGS_E_INVALID; }
+        if (a->geom_bytes < lvdgs_geom_bytes(N) || a->scratch_bytes < lvdgs_prepare_scratch_bytes(N)) { set_error("geom_state or scratch too small"); return LVDGS_E_INVALID; }
+        if (int e = check_render_buffers(a, cap)) return e;
+        caps[k] = cap;
+        geom_layout(N, &g[k], a->geom_state);
+        image_layout(W, H, &im[k], a->image_state);
+        render_scratch_layout(N, cap, W, H, &w[k], a->scratch);
+        if (bin_view(a, &b[k]) < cap) { set_error("internal: binning_state smaller than the pair capacity"); return LVDGS_E_INVALID; }
+    }
+    PairProbe *probe = nullptr;
+    if (int e = get_probe(&probe)) return e;
+    probe->seq++; if (probe->seq == 0u) probe->seq = 1u;
+    for (int first = 0; first < count; first += FWD_BATCH_VIEWS) {
+        const int m = count - first < FWD_BATCH_VIEWS ? count - first : FWD_BATCH_VIEWS;
+        const lvdgs_args *const *av = views + first;
+        uint32_t *words = probe->pinned + 16, *words_dev = probe->pinned_dev + 16;
+        if (int e = launch_preprocess_count_batch(av, &g[first], &im[first], &w[first], m, s)) return e;
+        if (int e = launch_group_scan_batch(av, &g[first], &im[first], &w[first], &caps[first], m, words_dev, probe->seq, s)) return e;
+        if (int e = launch_group_scatter_batch(av, &g[first], &im[first], &w[first], &b[first], &caps[first], m, s)) return e;
+        if (int e = launch_tile_depth_sort_batch(av, &g[first], &im[first], &w[first], &b[first], m, probe->longest, probe->queued, s)) return e;
+        if (!(a0->flags & LVDGS_FLAG_NO_BLEND))
+            if (int e = launch_blend_fwd_batch(av, &g[first], &b[first], &im[first], m, probe->longest > 0, s)) return e;
+        // everything is enqueued: now the counts (the GPU is busy with the scatter, the sorts and the blend meanwhile)
+        int longest = 0, queued = 0;
+        for (int k = 0; k < m; k++) {
+            if (int e = wait_for_sequence(probe, words + 4 * k)) return e;
+            num_rendered[first + k] = (int64_t)words[4 * k];
+            longest = std::max(longest, (int)words[4 * k + 1]); queued = std::max(queued, (int)words[4 * k + 2]);
+        }
+        if (m < count) { probe->seq++; if (probe->seq == 0u) probe->seq = 1u; }   // (the next group of views re-uses the words)
+        if (longest >= probe->longest || probe->keep == 0) { probe->longest = longest; probe->queued = queued; probe->keep = longest ? 32 : 0; }
+        else probe->keep--;
+    }
+    int status = LVDGS_OK;
+    for (int k = 0; k < count; k++) {
+        if (num_rendered[k] > 0x7FFFFFFFll) { set_error("%lld (Gaussian, tile) pairs exceed the 2^31 limit", (long long)num_rendered[k]); return LVDGS_E_RANGE; }
+        if (num_rendered[k] > caps[k]) {
+            set_error("view %d: %lld pairs exceed pair_capacity %lld: grow binning_state / scratch and call lvdgs_forward_render for it", k, (long long)num_rendered[k], (long long)caps[k]);
+            status = LVDGS_E_CAPACITY;
+        }
+    }
+    return status;
 }
 
 // views_out (lvdgs_blend_backward_fused_loss_batch): the call checks its arguments, lays its buffers out and stops there

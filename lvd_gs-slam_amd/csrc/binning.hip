@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(GROUP_THREADS) count_pairs_kernel(int N, int g
 // R = 0: more than 32 rows per wave (maps beyond 2 M Gaussians): the rows are read twice, eight at a time.
 constexpr int COLSCAN_TILES = 64;
 template <int R>
-__global__ void __launch_bounds__(1024) group_colscan_kernel(int T, int nchunks, uint32_t *__restrict__ hist, uint32_t *__restrict__ totals) {
+__device__ __forceinline__ void group_colscan_body(int T, int nchunks, uint32_t *__restrict__ hist, uint32_t *__restrict__ totals) {
     __shared__ uint32_t s_part[16][COLSCAN_TILES];
     const int tl = threadIdx.x & 63, cg = threadIdx.x >> 6, groups = blockDim.x >> 6;
     const int t = blockIdx.x * COLSCAN_TILES + tl;
@@ -132,17 +132,27 @@ __global__ void __launch_bounds__(1024) group_colscan_kernel(int T, int nchunks,
     }
     if (cg == 0) totals[t] = total;
 }
+template <int R>
+__global__ void __launch_bounds__(1024) group_colscan_kernel(int T, int nchunks, uint32_t *__restrict__ hist, uint32_t *__restrict__ totals) {
+    group_colscan_body<R>(T, nchunks, hist, totals);
+}
+// lvdgs_forward_batch: the count matrices of several views (blockIdx.y: the view)
+struct ColscanBatch { uint32_t *hist[FWD_BATCH_VIEWS], *totals[FWD_BATCH_VIEWS]; };
+template <int R>
+__global__ void __launch_bounds__(1024) group_colscan_batch_kernel(int T, int nchunks, ColscanBatch b) {
+    group_colscan_body<R>(T, nchunks, b.hist[blockIdx.y], b.totals[blockIdx.y]);
+}
 
 // one workgroup: ranges[t] = [sum of totals before t, + totals[t]), clamped to the pair capacity; the pair count;
 // the queue of segments too long for one wave to sort (tilesort.hip) -- filled here, where every length is at hand, so
 // that the sort needs no pass of its own to find them;
 // tile_order (optional, tiles [t_lo, t_hi)): those tiles by descending list length (in steps of 8 entries; ties in
 // arrival order -- it only decides which workgroup of a blend kernel takes which tile, never a result).
-__global__ void __launch_bounds__(1024) group_tilescan_kernel(int T, const uint32_t *__restrict__ totals, uint32_t capacity,
-                                                              uint2 *__restrict__ ranges, uint32_t *__restrict__ total_out,
-                                                              uint32_t long_limit, uint32_t *__restrict__ queue_count, uint32_t *__restrict__ queue,
-                                                              uint32_t *__restrict__ tile_order, int t_lo, int t_hi, uint32_t *__restrict__ order_valid,
-                                                              uint32_t *host_out, uint32_t host_seq) {
+__device__ __forceinline__ void group_tilescan_body(int T, const uint32_t *__restrict__ totals, uint32_t capacity,
+                                                    uint2 *__restrict__ ranges, uint32_t *__restrict__ total_out,
+                                                    uint32_t long_limit, uint32_t *__restrict__ queue_count, uint32_t *__restrict__ queue,
+                                                    uint32_t *__restrict__ tile_order, int t_lo, int t_hi, uint32_t *__restrict__ order_valid,
+                                                    uint32_t *host_out, uint32_t host_seq) {
     __shared__ uint32_t s_scan[1024];
     __shared__ uint32_t s_q, s_longest, s_total;
     constexpr int PER = GROUP_MAX_TILES / 1024;
@@ -262,6 +272,22 @@ __global__ void __launch_bounds__(1024) group_tilescan_kernel(int T, const uint3
     }
     if (threadIdx.x == 0) *order_valid = 1u;   // (cleared with the tile-sort queue at the start of every frame)
 }
+__global__ void __launch_bounds__(1024) group_tilescan_kernel(int T, const uint32_t *__restrict__ totals, uint32_t capacity,
+                                                              uint2 *__restrict__ ranges, uint32_t *__restrict__ total_out,
+                                                              uint32_t long_limit, uint32_t *__restrict__ queue_count, uint32_t *__restrict__ queue,
+                                                              uint32_t *__restrict__ tile_order, int t_lo, int t_hi, uint32_t *__restrict__ order_valid,
+                                                              uint32_t *host_out, uint32_t host_seq) {
+    group_tilescan_body(T, totals, capacity, ranges, total_out, long_limit, queue_count, queue, tile_order, t_lo, t_hi, order_valid, host_out, host_seq);
+}
+// lvdgs_forward_batch: one workgroup per view (blockIdx.x); view k's pair count and hints go to host_out + 4 k
+struct TilescanView { const uint32_t *totals; uint32_t capacity; uint2 *ranges; uint32_t *total_out, *queue_count, *queue, *tile_order, *order_valid; };
+struct TilescanBatch { TilescanView v[FWD_BATCH_VIEWS]; };
+__global__ void __launch_bounds__(1024) group_tilescan_batch_kernel(int T, TilescanBatch b, uint32_t long_limit, int t_lo, int t_hi, uint32_t *host_out,
+                                                                    uint32_t host_seq) {
+    const TilescanView &v = b.v[blockIdx.x];
+    group_tilescan_body(T, v.totals, v.capacity, v.ranges, v.total_out, long_limit, v.queue_count, v.queue, v.tile_order, t_lo, t_hi, v.order_valid,
+                        host_out + 4 * blockIdx.x, host_seq);
+}
 
 // SLOT_SCAN (lvdgs_forward): also makes slot_base[i] = exclusive scan of tiles_touched in id order (the backward's
 // gradient slots) from the pair totals the projection kernel left per chunk: every workgroup adds up the totals in front
@@ -270,13 +296,13 @@ __global__ void __launch_bounds__(1024) group_tilescan_kernel(int T, const uint3
 #define LVDGS_SCATTER_XCD 1   // A/B builds: 0 = workgroup b takes chunk b
 #endif
 template <int GROUP_THREADS, int OWNERS, int PER, bool SLOT_SCAN>
-__global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int gx, int T, const uint4 *__restrict__ rect,
-                                                                     const uint32_t *__restrict__ hist,
-                                                                     const uint2 *__restrict__ ranges, uint32_t capacity,
-                                                                     const uint32_t *__restrict__ depth_bits,
-                                                                     unsigned long long *__restrict__ keys64,
-                                                                     const uint32_t *__restrict__ tt, const uint32_t *__restrict__ chunk_sums,
-                                                                     uint32_t *__restrict__ slot_base, uint8_t *__restrict__ pair_valid) {
+__device__ __forceinline__ void scatter_pairs_body(int chunk, int N, int gx, int T, const uint4 *__restrict__ rect,
+                                                   const uint32_t *__restrict__ hist,
+                                                   const uint2 *__restrict__ ranges, uint32_t capacity,
+                                                   const uint32_t *__restrict__ depth_bits,
+                                                   unsigned long long *__restrict__ keys64,
+                                                   const uint32_t *__restrict__ tt, const uint32_t *__restrict__ chunk_sums,
+                                                   uint32_t *__restrict__ slot_base, uint8_t *__restrict__ pair_valid) {
     constexpr int GROUP_CHUNK = OWNERS * PER;
     constexpr bool HELPERS = GROUP_THREADS > OWNERS;   // waves without a Gaussian of their own: they help with the large rectangles
     static_assert(!HELPERS || PER == 1, "helper waves: one Gaussian per owner thread");
@@ -286,7 +312,6 @@ __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int
     __shared__ BigRectQueue s_big;
     const bool owner = (int)threadIdx.x < OWNERS;
     if (threadIdx.x == 0) s_big.count = 0u;
-    const int chunk = LVDGS_SCATTER_XCD ? xcd_contiguous_chunk((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     const uint32_t *row = hist + (size_t)chunk * T;
     // this thread's Gaussians: requested before anything else (their first use is behind several workgroup barriers, which
     // the compiler does not move loads across: the round trip would otherwise start after the slot scan)
@@ -353,6 +378,33 @@ __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int
         if constexpr (HELPERS) for_each_pair_of_rect_wg(r, i, gx, my_depth[k], s_big, place);
         else for_each_pair_of_rect(r, i, gx, my_depth[k], place);
     }
+}
+template <int GROUP_THREADS, int OWNERS, int PER, bool SLOT_SCAN>
+__global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int gx, int T, const uint4 *__restrict__ rect,
+                                                                     const uint32_t *__restrict__ hist,
+                                                                     const uint2 *__restrict__ ranges, uint32_t capacity,
+                                                                     const uint32_t *__restrict__ depth_bits,
+                                                                     unsigned long long *__restrict__ keys64,
+                                                                     const uint32_t *__restrict__ tt, const uint32_t *__restrict__ chunk_sums,
+                                                                     uint32_t *__restrict__ slot_base, uint8_t *__restrict__ pair_valid) {
+    const int chunk = LVDGS_SCATTER_XCD ? xcd_contiguous_chunk((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    scatter_pairs_body<GROUP_THREADS, OWNERS, PER, SLOT_SCAN>(chunk, N, gx, T, rect, hist, ranges, capacity, depth_bits, keys64, tt, chunk_sums, slot_base, pair_valid);
+}
+// lvdgs_forward_batch (blockIdx.y: the view).  The grid's x extent is the chunk count rounded up to a multiple of 8, so that a
+// workgroup's XCD is its x index mod 8 whatever the view (workgroups are dealt to the XCDs by their linear index) and an XCD takes
+// consecutive chunks as in the single-view launch; the up to 7 workgroups without a chunk leave at once.
+struct ScatterView {
+    const uint4 *rect; const uint32_t *hist; const uint2 *ranges; uint32_t capacity; const uint32_t *depth_bits; unsigned long long *keys64;
+    const uint32_t *tt, *chunk_sums; uint32_t *slot_base; uint8_t *pair_valid;
+};
+struct ScatterBatch { ScatterView v[FWD_BATCH_VIEWS]; };
+template <int GROUP_THREADS, int OWNERS, int PER>
+__global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_batch_kernel(int N, int gx, int T, int nchunks, ScatterBatch b) {
+    const int chunk = LVDGS_SCATTER_XCD ? xcd_contiguous_chunk((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
+    if (chunk >= nchunks) return;
+    const ScatterView &v = b.v[blockIdx.y];
+    scatter_pairs_body<GROUP_THREADS, OWNERS, PER, true>(chunk, N, gx, T, v.rect, v.hist, v.ranges, v.capacity, v.depth_bits, v.keys64, v.tt, v.chunk_sums,
+                                                         v.slot_base, v.pair_valid);
 }
 
 __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t *__restrict__ tile_keys, int64_t D_cap,
@@ -442,6 +494,56 @@ int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView
             return slot_scan ? launch(&scatter_pairs_kernel<THREADS, OWNERS, PER, true>, 2 * d, THREADS) : launch(&scatter_pairs_kernel<THREADS, OWNERS, PER, false>, 2 * d + 1, THREADS);
         })) return e;
     LVDGS_LAUNCH_CHECK("group_scatter", a.debug, s);
+    return LVDGS_OK;
+}
+
+// ---- lvdgs_forward_batch: the same stages for n views of one map and one image size, one launch each ----
+int launch_group_scan_batch(const lvdgs_args *const *a, const GeomView *g, const ImageView *im, const RenderScratch *w, const int64_t *caps, int n,
+                            uint32_t *host_words, uint32_t host_seq, hipStream_t s) {
+    const int N = a[0]->num_gaussians;
+    const int gx = (a[0]->image_width + TILE - 1) / TILE, gy = (a[0]->image_height + TILE - 1) / TILE, T = gx * gy;
+    if (N == 0 || T == 0 || n == 0) return LVDGS_OK;
+    const int nchunks = (int)group_chunks(N);
+    int row0, row1;
+    tile_row_band(*a[0], &row0, &row1);
+    ColscanBatch cb{};
+    TilescanBatch tb{};
+    for (int k = 0; k < n; k++) {
+        cb.hist[k] = w[k].group_hist; cb.totals[k] = w[k].group_totals;
+        tb.v[k] = TilescanView{w[k].group_totals, (uint32_t)caps[k], im[k].ranges, g[k].total, im[k].long_count, im[k].long_tiles,
+                               tile_order_in_use(T) ? im[k].long_tiles + T : nullptr, im[k].long_count + 1};
+    }
+    ProfScope ps("group_scan", s);
+    const dim3 grid(cdiv(T, COLSCAN_TILES), n);
+    if (nchunks <= 8 * 16) hipLaunchKernelGGL(group_colscan_batch_kernel<8>, grid, dim3(1024), 0, s, T, nchunks, cb);
+    else if (nchunks <= 16 * 16) hipLaunchKernelGGL(group_colscan_batch_kernel<16>, grid, dim3(1024), 0, s, T, nchunks, cb);
+    else if (nchunks <= 32 * 16) hipLaunchKernelGGL(group_colscan_batch_kernel<32>, grid, dim3(1024), 0, s, T, nchunks, cb);
+    else hipLaunchKernelGGL(group_colscan_batch_kernel<0>, grid, dim3(1024), 0, s, T, nchunks, cb);
+    hipLaunchKernelGGL(group_tilescan_batch_kernel, dim3(n), dim3(1024), 0, s, T, tb, (uint32_t)tile_sort_wave_limit(), row0 * gx, row1 * gx, host_words, host_seq);
+    LVDGS_LAUNCH_CHECK("group_scan (batch)", a[0]->debug, s);
+    return LVDGS_OK;
+}
+
+int launch_group_scatter_batch(const lvdgs_args *const *a, const GeomView *g, const ImageView *im, const RenderScratch *w, const BinView *b,
+                               const int64_t *caps, int n, hipStream_t s) {
+    const int N = a[0]->num_gaussians;
+    const int gx = (a[0]->image_width + TILE - 1) / TILE, gy = (a[0]->image_height + TILE - 1) / TILE, T = gx * gy;
+    if (N == 0 || T == 0 || n == 0) return LVDGS_OK;
+    const int nchunks = (int)group_chunks(N);
+    const size_t lds = (size_t)T * sizeof(uint32_t);
+    ScatterBatch sb{};
+    for (int k = 0; k < n; k++)
+        sb.v[k] = ScatterView{(const uint4 *)g[k].rect, w[k].group_hist, im[k].ranges, (uint32_t)caps[k], g[k].depth_bits, (unsigned long long *)w[k].keys,
+                              g[k].tiles_touched, w[k].chunk_sums, g[k].slot_base, b[k].pair_valid};
+    static unsigned char done[GROUP_SHAPES][16];
+    ProfScope ps("group_scatter", s);
+    if (int e = group_dispatch(group_shape_for(N), [&](auto threads_, auto owners_, auto per_, int d) {
+            constexpr int THREADS = decltype(threads_)::value, OWNERS = decltype(owners_)::value, PER = decltype(per_)::value;
+            if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&scatter_pairs_batch_kernel<THREADS, OWNERS, PER>), GROUP_MAX_TILES * 4, done[d])) return e;
+            hipLaunchKernelGGL((scatter_pairs_batch_kernel<THREADS, OWNERS, PER>), dim3((nchunks + 7) & ~7, n), dim3(THREADS), lds, s, N, gx, T, nchunks, sb);
+            return (int)LVDGS_OK;
+        })) return e;
+    LVDGS_LAUNCH_CHECK("group_scatter (batch)", a[0]->debug, s);
     return LVDGS_OK;
 }
 

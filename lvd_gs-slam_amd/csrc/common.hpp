@@ -273,6 +273,17 @@ size_t group_chunks(int N);
 // lvdgs_forward: projection + per-chunk tile counts in one kernel (preprocess.hip); the two-call API projects in
 // lvdgs_forward_prepare and counts with launch_group_count.
 int launch_preprocess_count(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, hipStream_t s);
+// lvdgs_forward_batch: the stages of up to FWD_BATCH_VIEWS views of one map and one image size in one launch each (the view is
+// blockIdx.y; every view its own state and scratch buffers).  caps[k]: view k's pair capacity; host_words: 4 pinned words per view
+// as the device addresses them (pair count, longest queued segment, queue length, the call's sequence number).
+constexpr int FWD_BATCH_VIEWS = 10;
+int launch_preprocess_count_batch(const lvdgs_args *const *a, const GeomView *g, const ImageView *im, const RenderScratch *w, int n, hipStream_t s);
+int launch_group_scan_batch(const lvdgs_args *const *a, const GeomView *g, const ImageView *im, const RenderScratch *w, const int64_t *caps, int n,
+                            uint32_t *host_words, uint32_t host_seq, hipStream_t s);
+int launch_group_scatter_batch(const lvdgs_args *const *a, const GeomView *g, const ImageView *im, const RenderScratch *w, const BinView *b,
+                               const int64_t *caps, int n, hipStream_t s);
+int launch_tile_depth_sort_batch(const lvdgs_args *const *a, const GeomView *g, const ImageView *im, const RenderScratch *w, const BinView *b, int n,
+                                 int longest_expected, int queue_expected, hipStream_t s);
 int launch_group_count(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, hipStream_t s);
 // prefixes over the chunks, tile ranges, the pair count (*total_out, may be null), the queue of over-long segments
 int launch_group_scan(const lvdgs_args &a, const ImageView &im, const RenderScratch &w, int64_t capacity, uint32_t *total_out, hipStream_t s,

@@ -219,9 +219,9 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(FwdParams p) {
 // every rectangle are gone from the single-call forward (lvdgs_forward).  Also clears what the later kernels of the
 // frame accumulate into (n_touched, the tile-sort queue counters).
 template <int GROUP_THREADS, int OWNERS, int PER>
-__global__ void __launch_bounds__(GROUP_THREADS, 8) preprocess_count_kernel(FwdParams p, int T, uint32_t *__restrict__ hist,
-                                                                        uint32_t *__restrict__ chunk_sums, int32_t *__restrict__ n_touched,
-                                                                        uint32_t *__restrict__ queue_counts) {
+__device__ __forceinline__ void preprocess_count_body(const FwdParams &p, int T, uint32_t *__restrict__ hist,
+                                                      uint32_t *__restrict__ chunk_sums, int32_t *__restrict__ n_touched,
+                                                      uint32_t *__restrict__ queue_counts) {
     constexpr bool HELPERS = GROUP_THREADS > OWNERS;   // waves without a Gaussian of their own: they help with the large rectangles (binning.hpp)
     static_assert(!HELPERS || PER == 1, "helper waves: one Gaussian per owner thread");
     extern __shared__ uint32_t s_tile[];
@@ -263,6 +263,24 @@ __global__ void __launch_bounds__(GROUP_THREADS, 8) preprocess_count_kernel(FwdP
     }
     uint32_t *row = hist + (size_t)blockIdx.x * T;
     for (int t = threadIdx.x; t < T; t += GROUP_THREADS) row[t] = s_tile[t];
+}
+
+template <int GROUP_THREADS, int OWNERS, int PER>
+__global__ void __launch_bounds__(GROUP_THREADS, 8) preprocess_count_kernel(FwdParams p, int T, uint32_t *__restrict__ hist,
+                                                                        uint32_t *__restrict__ chunk_sums, int32_t *__restrict__ n_touched,
+                                                                        uint32_t *__restrict__ queue_counts) {
+    preprocess_count_body<GROUP_THREADS, OWNERS, PER>(p, T, hist, chunk_sums, n_touched, queue_counts);
+}
+// The views of a mapping window in ONE launch (lvdgs_forward_batch; blockIdx.y: the view -- same map, same image size, a camera,
+// state buffers and count matrix each).  A KITTI-size frame's projection is 391 workgroups of latency-bound work on 256 CUs: ten
+// of them side by side cost little more than one.
+struct PrepCountView { FwdParams p; uint32_t *hist, *chunk_sums; int32_t *n_touched; uint32_t *queue_counts; };
+struct PrepCountBatch { PrepCountView v[FWD_BATCH_VIEWS]; };
+static_assert(sizeof(PrepCountBatch) <= 4000, "kernel arguments");
+template <int GROUP_THREADS, int OWNERS, int PER>
+__global__ void __launch_bounds__(GROUP_THREADS, 8) preprocess_count_batch_kernel(PrepCountBatch b, int T) {
+    const PrepCountView &v = b.v[blockIdx.y];
+    preprocess_count_body<GROUP_THREADS, OWNERS, PER>(v.p, T, v.hist, v.chunk_sums, v.n_touched, v.queue_counts);
 }
 
 __device__ __forceinline__ void preprocess_one(const FwdParams &p, int i, const RawGaussian &raw, uint32_t &tiles_out, uint4 &rect_out) {
@@ -1063,6 +1081,28 @@ int launch_preprocess_count(const lvdgs_args &a, const GeomView &g, const ImageV
             return (int)LVDGS_OK;
         })) return e;
     LVDGS_LAUNCH_CHECK("preprocess_count", a.debug, s);
+    return LVDGS_OK;
+}
+
+// n views of one map and one image size (lvdgs_forward_batch)
+int launch_preprocess_count_batch(const lvdgs_args *const *a, const GeomView *g, const ImageView *im, const RenderScratch *w, int n, hipStream_t s) {
+    const int N = a[0]->num_gaussians;
+    if (N == 0 || n == 0) return LVDGS_OK;
+    if (n > FWD_BATCH_VIEWS) { set_error("internal: more than %d views in one forward batch", FWD_BATCH_VIEWS); return LVDGS_E_INVALID; }
+    PrepCountBatch batch{};
+    for (int k = 0; k < n; k++) batch.v[k] = PrepCountView{make_fwd_params(*a[k], g[k]), w[k].group_hist, w[k].chunk_sums, a[k]->n_touched, im[k].long_count};
+    const int T = batch.v[0].p.cam.gx * batch.v[0].p.cam.gy;
+    const int nchunks = (int)group_chunks(N);
+    const size_t lds = (size_t)T * sizeof(uint32_t);
+    static unsigned char done[GROUP_SHAPES][16];
+    ProfScope ps("preprocess_fwd", s);
+    if (int e = group_dispatch(group_shape_for(N), [&](auto threads_, auto owners_, auto per_, int d) {
+            constexpr int THREADS = decltype(threads_)::value, OWNERS = decltype(owners_)::value, PER = decltype(per_)::value;
+            if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&preprocess_count_batch_kernel<THREADS, OWNERS, PER>), GROUP_MAX_TILES * 4, done[d])) return e;
+            hipLaunchKernelGGL((preprocess_count_batch_kernel<THREADS, OWNERS, PER>), dim3(nchunks, n), dim3(THREADS), lds, s, batch, T);
+            return (int)LVDGS_OK;
+        })) return e;
+    LVDGS_LAUNCH_CHECK("preprocess_count (batch)", a[0]->debug, s);
     return LVDGS_OK;
 }
 

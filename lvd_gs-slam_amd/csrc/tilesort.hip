@@ -229,14 +229,14 @@ __device__ __forceinline__ void sort_queued_segments(u64 *s_keys, int lds_cap, i
 #ifndef LVDGS_SORT_SOLO
 #define LVDGS_SORT_SOLO 2   // A/B builds: 0 = one wave per segment up to 1024 entries whatever the grid; 1 = a workgroup per segment of 513-1024 entries on small grids; 2 = of 257-1024
 #endif
-template <bool QUEUED>
 #ifndef LVDGS_SORT_OCC
 #define LVDGS_SORT_OCC 1
 #endif
-__global__ void __launch_bounds__(64 * SORT_WAVES, LVDGS_SORT_OCC) tile_depth_sort_wave_kernel(const uint2 *__restrict__ ranges, int t_lo, int t_hi, KeySource src,
-                                                                    uint32_t *__restrict__ point_list, uint32_t *queue_count,
-                                                                    uint32_t *__restrict__ queue, const uint32_t *__restrict__ tile_order,
-                                                                    u64 *keys, int group_wgs, int solo_wgs, int sort_wgs, int take_from, int take_upto) {
+template <bool QUEUED>
+__device__ __forceinline__ void tile_depth_sort_wave_body(const uint2 *__restrict__ ranges, int t_lo, int t_hi, const KeySource src,
+                                                          uint32_t *__restrict__ point_list, uint32_t *queue_count,
+                                                          uint32_t *__restrict__ queue, const uint32_t *__restrict__ tile_order,
+                                                          u64 *keys, int group_wgs, int solo_wgs, int sort_wgs, int take_from, int take_upto) {
     __shared__ u64 s_long[QUEUED ? CLASS_L : 1];
     if (QUEUED && (int)blockIdx.x < group_wgs) {
         // the FIRST group_wgs workgroups (the host launches them when the previous frame queued segments): a queued segment of
@@ -282,6 +282,22 @@ __global__ void __launch_bounds__(64 * SORT_WAVES, LVDGS_SORT_OCC) tile_depth_so
     else if (n <= 512) { if (!QUEUED || solo_wgs == 0 || LVDGS_SORT_SOLO < 2) wave_sort_segment<8>(src, r.x, point_list + r.x, n, lane); }
     else if (n <= CLASS_W) { if (!QUEUED || solo_wgs == 0) wave_sort_segment<16>(src, r.x, point_list + r.x, n, lane); }
     else if (!QUEUED && lane == 0) queue[atomicAdd(queue_count, 1u)] = (uint32_t)tile;
+}
+template <bool QUEUED>
+__global__ void __launch_bounds__(64 * SORT_WAVES, LVDGS_SORT_OCC) tile_depth_sort_wave_kernel(const uint2 *__restrict__ ranges, int t_lo, int t_hi, KeySource src,
+                                                                    uint32_t *__restrict__ point_list, uint32_t *queue_count,
+                                                                    uint32_t *__restrict__ queue, const uint32_t *__restrict__ tile_order,
+                                                                    u64 *keys, int group_wgs, int solo_wgs, int sort_wgs, int take_from, int take_upto) {
+    tile_depth_sort_wave_body<QUEUED>(ranges, t_lo, t_hi, src, point_list, queue_count, queue, tile_order, keys, group_wgs, solo_wgs, sort_wgs, take_from, take_upto);
+}
+// lvdgs_forward_batch: the tile sorts of several views in one launch (blockIdx.y: the view; counting path only)
+struct TileSortView { const uint2 *ranges; KeySource src; uint32_t *point_list, *queue_count, *queue; const uint32_t *tile_order; u64 *keys; };
+struct TileSortBatch { TileSortView v[FWD_BATCH_VIEWS]; };
+__global__ void __launch_bounds__(64 * SORT_WAVES, LVDGS_SORT_OCC) tile_depth_sort_wave_batch_kernel(TileSortBatch b, int t_lo, int t_hi, int group_wgs, int solo_wgs,
+                                                                                                 int sort_wgs, int take_from, int take_upto) {
+    const TileSortView &v = b.v[blockIdx.y];
+    tile_depth_sort_wave_body<true>(v.ranges, t_lo, t_hi, v.src, v.point_list, v.queue_count, v.queue, v.tile_order, v.keys, group_wgs, solo_wgs, sort_wgs,
+                                    take_from, take_upto);
 }
 
 // queued segments: in 128 KiB of LDS up to CLASS_B entries, in place on global memory beyond; segments of up to
@@ -351,6 +367,41 @@ int launch_tile_depth_sort(const ImageView &im, int num_tiles, int t_lo, int t_h
                            (const uint32_t *)im.long_count, (const uint32_t *)im.long_tiles, (unsigned long long *)keys64, keys_ready ? CLASS_G : 0);
         LVDGS_LAUNCH_CHECK("tile_sort_long", dbg, s);
     }
+    return LVDGS_OK;
+}
+
+int launch_tile_depth_sort_batch(const lvdgs_args *const *a, const GeomView *g, const ImageView *im, const RenderScratch *w, const BinView *b, int n,
+                                 int longest_expected, int queue_expected, hipStream_t s) {
+    const int gx = cdiv(a[0]->image_width, TILE), num_tiles = gx * cdiv(a[0]->image_height, TILE);
+    int row0, row1;
+    tile_row_band(*a[0], &row0, &row1);
+    const int t_lo = row0 * gx, t_hi = row1 * gx;
+    if (num_tiles == 0 || t_hi <= t_lo || n == 0) return LVDGS_OK;
+    static unsigned char lds_done[16];
+    if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&tile_depth_sort_long_kernel), CLASS_B * 8, lds_done)) return e;
+    // (as launch_tile_depth_sort on the counting path: the expectation is the window's -- the longest queued segment / the longest
+    // queue any recent view on this device had)
+    const int sort_wgs = cdiv(t_hi - t_lo, SORT_WAVES);
+    const bool grouped = longest_expected > CLASS_W, big = longest_expected > CLASS_G || longest_expected < 0;
+    const int group_wgs = grouped ? min(8192, max(64, (int)((int64_t)queue_expected * 5 / 4))) : 0;
+    const int solo_wgs = (LVDGS_SORT_SOLO && tile_order_in_use(num_tiles)) ? t_hi - t_lo : 0;
+    TileSortBatch batch{};
+    for (int k = 0; k < n; k++)
+        batch.v[k] = TileSortView{(const uint2 *)im[k].ranges, KeySource{g[k].rec, b[k].point_list, (const u64 *)w[k].keys}, b[k].point_list, im[k].long_count,
+                                  im[k].long_tiles, tile_order_in_use(num_tiles) ? im[k].long_tiles + num_tiles : nullptr, (u64 *)w[k].keys};
+    {
+        ProfScope ps("tile_sort", s);
+        hipLaunchKernelGGL(tile_depth_sort_wave_batch_kernel, dim3(group_wgs + solo_wgs + sort_wgs + LONG_WGS, n), dim3(64 * SORT_WAVES), 0, s, batch, t_lo, t_hi,
+                           group_wgs, solo_wgs, sort_wgs, grouped ? CLASS_G : CLASS_W, big ? CLASS_G : 0x7fffffff);
+        LVDGS_LAUNCH_CHECK("tile_sort (batch)", a[0]->debug, s);
+    }
+    if (big)   // segments beyond what the launch above takes (rare: a kernel per view, as in the single-view call)
+        for (int k = 0; k < n; k++) {
+            ProfScope ps("tile_sort_long", s);
+            hipLaunchKernelGGL(tile_depth_sort_long_kernel, dim3(256), dim3(1024), CLASS_B * 8, s, (const uint2 *)im[k].ranges, batch.v[k].src, b[k].point_list,
+                               (const uint32_t *)im[k].long_count, (const uint32_t *)im[k].long_tiles, (unsigned long long *)w[k].keys, CLASS_G);
+            LVDGS_LAUNCH_CHECK("tile_sort_long", a[0]->debug, s);
+        }
     return LVDGS_OK;
 }
 

@@ -33,6 +33,7 @@ and scratch the pass owns.
 """
 import ctypes as C
 import math
+import os
 from types import SimpleNamespace
 
 import torch
@@ -353,7 +354,8 @@ MAX_BATCH_TILES = 4096
 class MapWindowBatch:
     """The views of a mapping window through ``MapViewPass``'s three calls with the two blend passes of ALL views in one launch each:
 
-        per view:  lvdgs_forward (LVDGS_FLAG_NO_BLEND: projection ... per-tile depth sort)
+        once:      lvdgs_forward_batch (LVDGS_FLAG_NO_BLEND: projection + counting, the two scans, the scatter and the per-tile depth
+                   sort of ALL views, a launch per stage; LVDGS_MAP_FWD_BATCH=0: lvdgs_forward view by view, as in round 4)
         once:      lvdgs_blend_forward_batch, [lvdgs_masked_loss_batch over the views with a static mask,] lvdgs_blend_backward_window_batch
         per view:  lvdgs_backward_fused_loss / lvdgs_backward_masked_loss (LVDGS_FLAG_NO_BLEND: the per-Gaussian pass, adding to the
                    first view's gradients), lvdgs_map_view_tail
@@ -397,12 +399,20 @@ class MapWindowBatch:
         n = len(viewpoints)
         masked = masked or [None] * n
         ctxs = []
+        fwd_batch = os.environ.get("LVDGS_MAP_FWD_BATCH", "1") != "0"
         with _lib.on_device(dev):
             stream = _lib.raw_stream(dev)
             for k, vp in enumerate(viewpoints):
                 ctxs.append(self.passes[k]._begin_for_batch(backend, vp, initialization, first if k == 0 else None,
-                                                            None if k == 0 else ctxs[0]["into"], stream, masked[k]))
+                                                            None if k == 0 else ctxs[0]["into"], stream, masked[k], forward=not fwd_batch))
             views = (C.POINTER(_lib.Args) * n)(*[C.pointer(self.passes[k].a) for k in range(n)])
+            if fwd_batch:
+                nums = (C.c_int64 * n)()
+                status = L.lvdgs_forward_batch(views, n, nums, stream)
+                if status not in (_lib.OK, _lib.E_CAPACITY):
+                    _lib.check(status, "lvdgs_forward_batch")
+                for k in range(n):
+                    self.passes[k]._after_forward(int(nums[k]), status == _lib.E_CAPACITY and int(nums[k]) > self.passes[k].cap, stream)
             losses = (C.POINTER(_lib.LossArgs) * n)(*[C.pointer(self.passes[k].la) for k in range(n)])
             _lib.check(L.lvdgs_blend_forward_batch(views, n, stream), "lvdgs_blend_forward_batch")
             which = [k for k in range(n) if masked[k] is not None]
@@ -418,7 +428,17 @@ class MapWindowBatch:
         return [self.passes[k]._finish_for_batch(backend, viewpoints[k], ctxs[k]) for k in range(n)]
 
 
-def _begin_for_batch(self, backend, viewpoint, initialization, first, lead_into, stream, masked_loss=None):
+def _after_forward(self, D, overflow, stream):
+    """The view's pair count is known: more pairs than the buffers hold -> grow them and redo the binning (still without the blend)."""
+    a = self.a
+    if overflow:
+        self._size_for_pairs(D + D // 2)
+        a.num_rendered = D
+        _lib.check(self.L.lvdgs_forward_render(C.byref(a), stream), "lvdgs_forward_render")
+    a.num_rendered = D
+
+
+def _begin_for_batch(self, backend, viewpoint, initialization, first, lead_into, stream, masked_loss=None, forward=True):
     """``MapViewPass.run`` up to the forward call (whole view, built-in or static-mask loss, SH degree 0), with LVDGS_FLAG_NO_BLEND."""
     G, cfg, dev, L = backend.gaussians, backend.config, self.dev, self.L
     T = cfg["Training"]
@@ -482,16 +502,12 @@ def _begin_for_batch(self, backend, viewpoint, initialization, first, lead_into,
         la.weight_rgb, la.weight_depth = float(alpha), float(1 - alpha)
         la.loss = _P(loss)
 
-    num = C.c_int64(0)
-    status = L.lvdgs_forward(C.byref(a), C.byref(num), stream)
-    D = int(num.value)
-    if status == _lib.E_CAPACITY:
-        self._size_for_pairs(D + D // 2)
-        a.num_rendered = D
-        _lib.check(L.lvdgs_forward_render(C.byref(a), stream), "lvdgs_forward_render")
-    else:
-        _lib.check(status, "lvdgs_forward")
-    a.num_rendered = D
+    if forward:   # (else: lvdgs_forward_batch runs the forward passes of all views of the window together)
+        num = C.c_int64(0)
+        status = L.lvdgs_forward(C.byref(a), C.byref(num), stream)
+        if status != _lib.E_CAPACITY:
+            _lib.check(status, "lvdgs_forward")
+        self._after_forward(int(num.value), status == _lib.E_CAPACITY, stream)
     return dict(color=color, depth=depth, opacity=opacity, radii=radii, n_touched=n_touched, d_tau=d_tau, d_a=d_a, d_b=d_b, d_m2=d_m2,
                 loss=loss, into=into, install=install, fields=fields, initialization=initialization, masked=masked_loss is not None)
 
@@ -534,5 +550,6 @@ def _finish_for_batch(self, backend, viewpoint, ctx):
 
 
 MapViewPass._begin_for_batch = _begin_for_batch
+MapViewPass._after_forward = _after_forward
 MapViewPass._backward_for_batch = _backward_for_batch
 MapViewPass._finish_for_batch = _finish_for_batch

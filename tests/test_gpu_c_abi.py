@@ -135,3 +135,104 @@ def test_errors_are_reported_not_thrown():
     assert L.lvdgs_forward(C.byref(a), C.byref(D), None) == _lib.E_INVALID
     assert len(L.lvdgs_last_error()) > 0
     assert L.lvdgs_backward(C.byref(a), None) == _lib.E_INVALID
+
+
+def test_forward_batch_equals_forward_view_by_view_state_and_images():
+    """lvdgs_forward_batch (every stage of several views of one map in one launch) against lvdgs_forward per view: pair counts, the
+    whole geometry / binning / image state and every output image, bit for bit -- with and without LVDGS_FLAG_NO_BLEND, with a view
+    whose pair capacity is too small (LVDGS_E_CAPACITY for that view alone, the others complete), and the argument checks."""
+    from lvdgs import _lib, synthetic
+    L = _lib.lib()
+    dev = torch.device("cuda")
+    N, W, H, V = 20000, 320, 200, 3
+    g = synthetic.make_gaussians(N, W, H, seed=11)
+    t = {k: v.to(dev).contiguous() for k, v in g.items()}
+    bgd = torch.tensor([0.1, 0.2, 0.3], device=dev)
+    buf = lambda n: torch.zeros(max(int(n), 256), dtype=torch.uint8, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    keep = []
+
+    def view(k, cap):
+        cam = synthetic.make_camera(W, H, pose_seed=20 + k)
+        mats = {n: getattr(cam, n).to(dev).contiguous() for n in ("world_view_transform", "full_proj_transform", "projection_matrix", "camera_center")}
+        a = _lib.Args()
+        a.image_height, a.image_width, a.tanfovx, a.tanfovy = H, W, cam.tanfovx, cam.tanfovy
+        a.scale_modifier, a.sh_degree = 1.0, 0
+        a.bg, a.viewmatrix, a.projmatrix = _p(bgd), _p(mats["world_view_transform"]), _p(mats["full_proj_transform"])
+        a.projmatrix_raw, a.campos = _p(mats["projection_matrix"]), _p(mats["camera_center"])
+        a.num_gaussians, a.sh_coeffs = N, 0
+        a.means3D, a.opacities, a.scales, a.rotations, a.colors_precomp = _p(t["means3D"]), _p(t["opacities"]), _p(t["scales"]), _p(t["rotations"]), _p(t["colors"])
+        st = dict(radii=torch.zeros(N, dtype=torch.int32, device=dev), n_touched=torch.zeros(N, dtype=torch.int32, device=dev),
+                  color=torch.zeros(3, H, W, device=dev), depth=torch.zeros(1, H, W, device=dev), opacity=torch.zeros(1, H, W, device=dev),
+                  geom=buf(L.lvdgs_geom_bytes(N)), image=buf(L.lvdgs_image_bytes(W, H)), binning=buf(L.lvdgs_binning_bytes(cap)),
+                  scratch=buf(max(L.lvdgs_prepare_scratch_bytes(N), L.lvdgs_render_scratch_bytes(N, cap, W, H))))
+        a.radii, a.n_touched, a.out_color, a.out_depth, a.out_opacity = _p(st["radii"]), _p(st["n_touched"]), _p(st["color"]), _p(st["depth"]), _p(st["opacity"])
+        a.geom_state, a.geom_bytes, a.image_state, a.image_bytes = _p(st["geom"]), st["geom"].numel(), _p(st["image"]), st["image"].numel()
+        a.binning_state, a.binning_bytes, a.scratch, a.scratch_bytes = _p(st["binning"]), st["binning"].numel(), _p(st["scratch"]), st["scratch"].numel()
+        a.pair_capacity = cap
+        keep.append((mats, st))
+        return a, st
+
+    cap = 400_000
+    single = [view(k, cap) for k in range(V)]
+    counts = []
+    for a, st in single:
+        n = C.c_int64()
+        _lib.check(L.lvdgs_forward(C.byref(a), C.byref(n), stream), "lvdgs_forward")
+        counts.append(n.value)
+    torch.cuda.synchronize()
+    assert min(counts) > 10_000 and len(set(counts)) == V   # three different views
+    lay = _lib.StateLayout()
+
+    def compare(st, ref, D, images=True):
+        L.lvdgs_state_layout_query(N, cap, W, H, C.byref(lay))
+        assert torch.equal(st["radii"], ref["radii"]) and torch.equal(st["geom"], ref["geom"])
+        assert torch.equal(st["binning"][lay.bin_point_list:lay.bin_point_list + 4 * D], ref["binning"][lay.bin_point_list:lay.bin_point_list + 4 * D])
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        assert torch.equal(st["image"][lay.img_ranges:lay.img_ranges + 8 * T], ref["image"][lay.img_ranges:lay.img_ranges + 8 * T])
+        if images:
+            assert torch.equal(st["image"], ref["image"])
+            for n_ in ("color", "depth", "opacity", "n_touched"):
+                assert torch.equal(st[n_], ref[n_]), n_
+
+    for no_blend in (False, True):
+        batch = [view(k, cap) for k in range(V)]
+        for a, _ in batch:
+            a.flags = _lib.FLAG_NO_BLEND if no_blend else 0
+        arr = (C.POINTER(_lib.Args) * V)(*[C.pointer(a) for a, _ in batch])
+        nums = (C.c_int64 * V)()
+        _lib.check(L.lvdgs_forward_batch(arr, V, nums, stream), "lvdgs_forward_batch")
+        assert list(nums) == counts
+        if no_blend:
+            for k, (a, _) in enumerate(batch):
+                a.num_rendered = nums[k]
+            _lib.check(L.lvdgs_blend_forward_batch(arr, V, stream), "lvdgs_blend_forward_batch")
+        torch.cuda.synchronize()
+        for k in range(V):
+            compare(batch[k][1], single[k][1], counts[k])
+
+    # a view with too small a capacity: E_CAPACITY, its count reported, the other views complete
+    small = counts[1] // 2
+    batch = [view(k, small if k == 1 else cap) for k in range(V)]
+    arr = (C.POINTER(_lib.Args) * V)(*[C.pointer(a) for a, _ in batch])
+    nums = (C.c_int64 * V)()
+    assert L.lvdgs_forward_batch(arr, V, nums, stream) == _lib.E_CAPACITY and b"view 1" in L.lvdgs_last_error()
+    assert list(nums) == counts
+    torch.cuda.synchronize()
+    compare(batch[0][1], single[0][1], counts[0]); compare(batch[2][1], single[2][1], counts[2])
+    a1, st1 = batch[1]
+    st1["binning"], st1["scratch"] = buf(L.lvdgs_binning_bytes(counts[1])), buf(L.lvdgs_render_scratch_bytes(N, counts[1], W, H))
+    a1.binning_state, a1.binning_bytes, a1.scratch, a1.scratch_bytes = _p(st1["binning"]), st1["binning"].numel(), _p(st1["scratch"]), st1["scratch"].numel()
+    a1.num_rendered = counts[1]
+    _lib.check(L.lvdgs_forward_render(C.byref(a1), stream), "lvdgs_forward_render")
+    torch.cuda.synchronize()
+    for n_ in ("color", "depth", "opacity", "n_touched", "radii"):
+        assert torch.equal(st1[n_], single[1][1][n_]), n_
+
+    # argument checks: views of different image sizes, a NULL view, no count array
+    bad, _ = view(0, cap)
+    bad.image_width = W - 16
+    arr2 = (C.POINTER(_lib.Args) * 2)(C.pointer(batch[0][0]), C.pointer(bad))
+    assert L.lvdgs_forward_batch(arr2, 2, nums, stream) == _lib.E_INVALID and b"differ" in L.lvdgs_last_error()
+    assert L.lvdgs_forward_batch(arr, V, None, stream) == _lib.E_INVALID
+    assert L.lvdgs_forward_batch(arr, 0, nums, stream) == _lib.OK
