@@ -289,6 +289,7 @@ class ShardedAdam:
         self.group = group
         self.rank, self.world = _world(group)
         self.stale = False          # moments current on the local share only
+        self.layout = None          # sizes of the parameter tensors the stale moments' shares were cut from (step())
         self.bufs = {}
 
     def _buf(self, name, n, dev):
@@ -399,11 +400,18 @@ class ShardedAdam:
                 pv.addcdiv_(m, denom, value=-gp["lr"] / (1 - b1 ** step))
         self._gather_into(params, "param")
         self.stale = True
+        self.layout = tuple(int(p.numel()) for p in params)
 
     def sync_moments(self, optimizer, params):
-        """Bring every rank's moments up to date (no-op when they are)."""
+        """Bring every rank's moments up to date (no-op when they are).  The shares are cut from the flat layout of the CURRENT
+        parameter tensors: a map whose size changed since the last step (an extension, a pruning) has moved every share
+        boundary, and gathering then would overwrite fresh moments with another rank's stale ones -- which is why ``map_window``
+        never returns with stale moments (it syncs before anything that resizes the map, and before it returns)."""
         if not self.stale:
             return
+        if self.layout is not None and self.layout != tuple(int(p.numel()) for p in params):
+            raise RuntimeError("ShardedAdam.sync_moments: the map's size changed while the Adam moments were sharded "
+                               f"(stepped on {self.layout}, now {tuple(int(p.numel()) for p in params)}): sync before resizing the map")
         for key in ("exp_avg", "exp_avg_sq"):
             tensors = [optimizer.state[p][key] for p in params]
             self._gather_into(tensors, key)
@@ -964,6 +972,11 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
                         continue
                     update_pose(viewpoint)
             if marks: marks.mark("optimizer_steps")
+    # The moments leave this function whole on every rank: between calls the reference extends the map (extend_from_pcd_seq on
+    # every keyframe, utils/slam_backend.py:75-78 -- the share boundaries move) and steps the optimiser outside this loop
+    # (initialize_map, color_refinement): an all-gather of 2 x 14 N floats per call of `iters` iterations.
+    if sharder is not None:
+        sharder.sync_moments(G.optimizer, G.parameters())
     return gaussian_split
 
 

@@ -355,3 +355,87 @@ def test_flat_reducer_repacks_and_handles_aliasing():
     assert torch.equal(out3[0], b[:3]) and torch.equal(out3[1], torch.ones(5))
     ints = red.max_ints([torch.tensor([1, 5, 2], dtype=torch.int32), torch.tensor([7], dtype=torch.int32)], torch.device("cpu"))
     assert ints[0].tolist() == [1, 5, 2] and ints[1].tolist() == [7]
+
+
+# ---- ShardedAdam across a change of the map's size BETWEEN map_window calls (the reference extends the map on every keyframe) ----
+def _run_extended(sharded):
+    """Two iterations, an extension of the map by 37 Gaussians (GaussianModel.extend_from_pcd, what extend_from_pcd_seq ends in),
+    an optimiser step outside map_window (initialize_map / color_refinement do that), two more iterations."""
+    _paths()
+    import test_loop_golden as tl
+    from dense_render import dense_render
+    from loop_scene import build_scene, loop_config
+    from lvdgs import backend_map as bm
+    bm.SPLIT_POLICY = "leftover"
+    cfg = loop_config()
+    cfg["Training"].update(gaussian_update_every=1000, gaussian_update_offset=999, gaussian_reset=1000)   # no densification inside the run
+    sc = build_scene("cpu")
+    be = tl._backend(sc, cfg)
+    be.initialized = True
+    be.shard_optimizer = sharded
+    for i, cam in enumerate(sc["cameras"]):
+        be.viewpoints[i] = cam
+    window = sc["window"]
+    be.current_window = window
+    be.keyframe_optimizers = sc["make_keyframe_optimizer"](be.viewpoints, window, cfg)
+    kw = dict(render_fn=dense_render, view_loss_fn=tl._cpu_view_loss, bands_ok=True)
+    bm.map_window(be, window, iters=2, **kw)
+    G = be.gaussians
+    sharder = getattr(be, "_lvdgs_sharder", None)
+    assert (sharder is not None) == sharded and (sharder is None or not sharder.stale)   # the moments left map_window whole
+    gen = torch.Generator().manual_seed(5)
+    n_new, K = 37, G._features_rest.shape[1] + 1
+    src = torch.randint(0, G.get_xyz.shape[0], (n_new,), generator=gen)
+    xyz = G.get_xyz.detach()[src] + 0.01 * torch.randn(n_new, 3, generator=gen)
+    feats = torch.rand(n_new, 3, K, generator=gen) * 0.2
+    G.extend_from_pcd(xyz, feats, G._scaling.detach()[src].clone(), G._rotation.detach()[src].clone(), G._opacity.detach()[src].clone(), kf_id=window[0])
+    # a step outside the loop on every rank alike (gradients: a fixed function of the parameters)
+    for p in G.parameters():
+        p.grad = 1e-3 * torch.sin(p.detach() * 3.0)
+    G.optimizer.step()
+    G.optimizer.zero_grad(set_to_none=True)
+    bm.map_window(be, window, iters=2, **kw)
+    out = {k: v.detach().numpy().copy() for k, v in G._params_by_name().items()}
+    for gp in G.optimizer.param_groups:
+        st = G.optimizer.state.get(gp["params"][0], {})
+        out["m_" + gp["name"]] = st["exp_avg"].numpy().copy()
+        out["v_" + gp["name"]] = st["exp_avg_sq"].numpy().copy()
+    return out
+
+
+def _worker_extended(rank, world, port, q, sharded):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)
+        q.put((rank, sharded, _run_extended(sharded)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_adam_moments_survive_an_extension_of_the_map_between_calls():
+    """The Adam moments of the sharded step against the replicated step's over two map_window calls with an extension of the map
+    and an outside optimiser step in between: a share boundary moved by the extension must not let a rank step elements on
+    moments another rank last updated (round-4 advisor finding).  Replicas bit-identical, moments equal to rounding."""
+    ctx = mp.get_context("spawn")
+    res = {}
+    for sharded in (False, True):
+        q = ctx.Queue()
+        port = 29500 + (os.getpid() % 2000) + 300 + (11 if sharded else 0)
+        procs = [ctx.Process(target=_worker_extended, args=(r, 2, port, q, sharded)) for r in range(2)]
+        for p in procs:
+            p.start()
+        got = sorted([q.get(timeout=600) for _ in range(2)], key=lambda r: r[0])
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        for k in got[0][2]:
+            np.testing.assert_array_equal(got[0][2][k], got[1][2][k], err_msg=f"replicas differ: {k} (sharded={sharded})")
+        res[sharded] = got[0][2]
+    for k, ref in res[False].items():
+        a, b = np.asarray(res[True][k], np.float64), np.asarray(ref, np.float64)
+        assert a.shape == b.shape, k
+        if a.size:
+            tol = 1e-5 * np.abs(b) + 1e-6 * max(np.abs(b).max(), 1e-30)
+            assert (np.abs(a - b) <= tol).all(), (k, float(np.abs(a - b).max()), float(np.abs(b).max()))
