@@ -399,45 +399,71 @@ def main():
         del po
         side = run_side(dev, pipe)
 
-    # The two measurements below come AFTER the timed region and are extras: an exception in them (an unsupported collective call
-    # raises on every rank alike) is recorded in config.notes and does not cost the line its headline.
+    # The two measurements below come AFTER the timed region and are extras: what goes wrong in them is recorded in config.notes and
+    # does not cost the line its headline.  Every collective of this part is issued by every rank whatever happened to it: the
+    # rank-local work (building a second model and window, the timed loops -- an out-of-memory or a HIP error there hits ONE rank)
+    # sits in try blocks of its own, and a MIN all-reduce of an "ok" flag after each decides for all ranks alike how to go on --
+    # a rank that skipped ahead on an exception of its own would leave the others waiting in their next collective for ever.
     same_step_single = None
     comm_us = phases = None
-    try:
-        if world > 1 and not tracking:
-            # The same step on ONE GPU, measured inside this job (every rank alone in a group of its own: no collective),
-            # so that the N-GPU number can be read against the right single-GPU number: bench.py's N = 1 default is the
-            # tracking iteration of BASELINE configs[2], a different (lighter) step than the mapping iteration timed here.
-            solo_groups = [dist.new_group(ranks=[r]) for r in range(world)]
-            solo_model = GaussianModel.from_activated(g_cpu["means3D"], g_cpu["scales"], g_cpu["rotations"], g_cpu["opacities"], shs=g_cpu["shs"],
-                                                      sh_degree=0, device=dev)
-            solo_backend, solo_window = make_window(solo_model) if real_window else build_window(args.workload, 1, dev, solo_model, masked=masked)
-            for _ in range(3):
-                backend_map.map_window(solo_backend, solo_window, iters=1, group=solo_groups[rank])
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                backend_map.map_window(solo_backend, solo_window, iters=1, group=solo_groups[rank])
-            torch.cuda.synchronize()
-            solo = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
-            dist.all_reduce(solo, op=dist.ReduceOp.MAX)
-            same_step_single = round(args.steps / float(solo.item()), 3)
-            del solo_backend
 
-        if not tracking:
-            # the iteration by phase (events on the stream at the phase boundaries, one wait at the end of each iteration)
-            st = {}
-            for _ in range(5):
-                backend_map.map_window(backend, window, iters=1, stats=st)
-            per = [r["phases"].seconds() for r in st["iterations"]]
-            names = list(per[0])
-            t = torch.tensor([sum(p[n] for p in per) / len(per) for n in names], device=dev, dtype=torch.float64)
-            if world > 1:
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            phases = {n: round(float(v) * 1e6, 1) for n, v in zip(names, t.tolist())}
-            comm_us = phases.get("collectives")
-    except Exception as e:   # noqa: BLE001
-        notes.append(f"extras after the timed region failed ({type(e).__name__}: {e})")
+    def all_ok(ok):
+        if world == 1:
+            return bool(ok)
+        t = torch.tensor([1.0 if ok else 0.0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
+    if world > 1 and not tracking:
+        # The same step on ONE GPU, measured inside this job (every rank alone in a group of its own: no collective),
+        # so that the N-GPU number can be read against the right single-GPU number: bench.py's N = 1 default is the
+        # tracking iteration of BASELINE configs[2], a different (lighter) step than the mapping iteration timed here.
+        solo_groups, ok = None, True
+        try:
+            solo_groups = [dist.new_group(ranks=[r]) for r in range(world)]   # (collective: raises on every rank or on none)
+        except Exception as e:   # noqa: BLE001
+            ok = False
+            notes.append(f"no single-rank groups ({type(e).__name__}: {e}): same_step_on_one_gpu not measured")
+        solo_s = 0.0
+        if ok:
+            try:
+                solo_model = GaussianModel.from_activated(g_cpu["means3D"], g_cpu["scales"], g_cpu["rotations"], g_cpu["opacities"], shs=g_cpu["shs"],
+                                                          sh_degree=0, device=dev)
+                solo_backend, solo_window = make_window(solo_model) if real_window else build_window(args.workload, 1, dev, solo_model, masked=masked)
+                for _ in range(3):
+                    backend_map.map_window(solo_backend, solo_window, iters=1, group=solo_groups[rank])
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    backend_map.map_window(solo_backend, solo_window, iters=1, group=solo_groups[rank])
+                torch.cuda.synchronize()
+                solo_s = time.perf_counter() - t1
+                del solo_backend, solo_model
+            except Exception as e:   # noqa: BLE001
+                ok = False
+                notes.append(f"rank {rank}: the one-GPU run of the same step failed ({type(e).__name__}: {e})")
+        if solo_groups is not None:   # (every rank is here: the two collectives below are unconditional)
+            ok = all_ok(ok)
+            solo = torch.tensor([solo_s], device=dev, dtype=torch.float64)
+            dist.all_reduce(solo, op=dist.ReduceOp.MAX)
+            if ok:
+                same_step_single = round(args.steps / float(solo.item()), 3)
+            elif rank == 0 and not notes:
+                notes.append("the one-GPU run of the same step failed on another rank: not reported")
+
+    if not tracking:
+        # the iteration by phase (events on the stream at the phase boundaries, one wait at the end of each iteration).  map_window's
+        # own collectives are the benchmark's: a rank-local failure inside them is fatal for the job as it was in the timed region.
+        st = {}
+        for _ in range(5):
+            backend_map.map_window(backend, window, iters=1, stats=st)
+        per = [r["phases"].seconds() for r in st["iterations"]]
+        names = list(per[0])
+        t = torch.tensor([sum(p[n] for p in per) / len(per) for n in names], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        phases = {n: round(float(v) * 1e6, 1) for n, v in zip(names, t.tolist())}
+        comm_us = phases.get("collectives")
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -576,13 +576,17 @@ class _ViewStats:
         float bucket, so the collective has nothing to pack."""
         self.N, self.n_window, self.dev = N, n_window, dev
         self.split = list(split)
-        self.radii_max = torch.zeros(N, dtype=torch.int32, device=dev)
-        self.flags = torch.zeros(n_window, N, dtype=torch.uint8, device=dev)   # row i: n_touched > 0 in window view i
+        # one zeroed block (one fill launch per iteration instead of three): radii_max | norm_sum, vis_count, split planes | flags
+        n_float = 0 if float_pieces is not None else (2 + 2 * len(self.split)) * N
+        words = N + n_float
+        block = torch.zeros(4 * words + n_window * N, dtype=torch.uint8, device=dev)
+        self.radii_max = block[:4 * N].view(torch.int32)
+        self.flags = block[4 * words:].view(n_window, N)   # row i: n_touched > 0 in window view i
         if float_pieces is not None:
             self.norm_sum, self.vis_count, self.split_xy = float_pieces
             self.norm_sum.zero_(); self.vis_count.zero_(); self.split_xy.zero_()
         else:
-            both = torch.zeros((2 + 2 * len(self.split)) * N, dtype=torch.float32, device=dev)
+            both = block[4 * N:4 * words].view(torch.float32)
             self.norm_sum, self.vis_count, self.split_xy = both[:N], both[N:2 * N], both[2 * N:]
 
     def targets(self, view, row0):

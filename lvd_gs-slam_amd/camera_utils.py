@@ -65,7 +65,7 @@ class Camera(nn.Module):
                 or k[4] is not P or k[5] != P._version):
             view = getWorld2View2(R, T).transpose(0, 1).contiguous()   # row-vector convention (contiguous: the renderer takes its pointer)
             full = view.unsqueeze(0).bmm(P.unsqueeze(0)).squeeze(0)
-            centre = view.inverse()[3, :3]
+            centre = view.inverse()[3, :3].contiguous()   # (the inverse comes back column-major: the row is a strided view, and every render would copy it)
             self._derived, self._derived_key = (view, full, centre), (R, R._version, T, T._version, P, P._version)
         return self._derived
 

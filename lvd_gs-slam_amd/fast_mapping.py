@@ -349,6 +349,7 @@ class MapViewPass:
 
 
 MAX_BATCH_TILES = 4096
+MEMORY_FRACTION = 0.8   # of the device memory still to be had: what a window batch may ask for (MapWindowBatch.usable)
 
 
 class MapWindowBatch:
@@ -386,8 +387,27 @@ class MapWindowBatch:
         if len(size) != 1 or any(((h + 15) // 16) * ((w + 15) // 16) > MAX_BATCH_TILES for h, w in size):
             return False
         masked = masked or [None] * len(viewpoints)
-        return all(MapViewPass.usable(backend, v, allow_static_mask=True) and (m is None or MapViewPass.masked_loss_usable(v, m[1] is not None))
-                   for v, m in zip(viewpoints, masked))
+        if not all(MapViewPass.usable(backend, v, allow_static_mask=True) and (m is None or MapViewPass.masked_loss_usable(v, m[1] is not None))
+                   for v, m in zip(viewpoints, masked)):
+            return False
+        # every view holds geometry, pair lists, image state and scratch of its own: a large map at a small frame size can ask for
+        # more than the device has left (an allocation failure half-way through the batch has no way back to the view-by-view path)
+        dev = G.get_xyz.device
+        (h, w), = size
+        need = MapWindowBatch.bytes_per_view(int(G._xyz.shape[0]), w, h) * len(viewpoints)
+        free, _ = torch.cuda.mem_get_info(dev)
+        cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)   # (what the caching allocator can hand out again)
+        held = getattr(getattr(backend, "_lvdgs_window_batch", None), "bytes_held", 0)
+        return need - held <= MEMORY_FRACTION * (free + cached)
+
+    @staticmethod
+    def bytes_per_view(N, W, H, cap=None):
+        """Device memory one view of the batch keeps between the phases (state, scratch, images, per-Gaussian outputs)."""
+        L = _lib.lib()
+        cap = max(int(cap or 0), _rz._MIN_PAIR_CAPACITY, _rz._PAIRS_PER_GAUSSIAN_GUESS * N, 1)
+        scratch = max(L.lvdgs_prepare_scratch_bytes(N), L.lvdgs_backward_scratch_bytes(N, cap), L.lvdgs_render_scratch_bytes(N, cap, W, H))
+        return int(L.lvdgs_geom_bytes(N) + L.lvdgs_binning_bytes(cap) + L.lvdgs_image_bytes(W, H) + scratch + L.lvdgs_loss_scratch_bytes(W, H)
+                   + L.lvdgs_masked_loss_scratch_bytes(W, H) + 4 * (3 + 5) * W * H + 4 * (2 + 3) * N)
 
     def run(self, backend, viewpoints, initialization=False, first=None, stats=None, masked=None):
         """-> [(pkg, loss)] in the order of ``viewpoints`` (``stats[k]``: ``MapViewPass.run``'s ``stats`` of view k, ``masked[k]``: its
@@ -396,6 +416,8 @@ class MapWindowBatch:
         dev, L = lead.dev, lead.L
         while len(self.passes) < len(viewpoints):
             self.passes.append(MapViewPass(dev, own_gradient_buffers=False))
+        G = backend.gaussians
+        self.bytes_held = self.bytes_per_view(int(G._xyz.shape[0]), int(viewpoints[0].image_width), int(viewpoints[0].image_height)) * len(self.passes)
         n = len(viewpoints)
         masked = masked or [None] * n
         ctxs = []

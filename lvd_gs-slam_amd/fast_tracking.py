@@ -183,6 +183,7 @@ class TrackingSession:
         self._ring = None if self.host_flags is not None else [(torch.cuda.Event(), torch.zeros(2, dtype=torch.float32).pin_memory()) for _ in range(8)]
         self._asked, self._answered = 0, 0
         self.iterations_enqueued = 0
+        self._streams_used = set()
         self.num_rendered = 0
 
     def _size_for_pairs(self, pairs):
@@ -218,6 +219,7 @@ class TrackingSession:
                 record_loss.copy_(self.loss)
         self.iterations_enqueued += 1
         self._drained = False
+        self._streams_used.add(stream.value)   # (raw handles: close() waits for these streams only)
 
     def close(self):
         """Wait for everything the session has enqueued.  The tail launch of every step stores into ``host_flags`` -- pinned
@@ -225,7 +227,10 @@ class TrackingSession:
         flight (the design lets the host run ahead of the device), a late store would land in whoever got the block next.
         ``finish()`` synchronises already; this is for a session that is dropped without it (also called on deletion)."""
         if getattr(self, "iterations_enqueued", 0) and not getattr(self, "_drained", False):
-            torch.cuda.synchronize(self.dev)
+            # only the streams the session's steps went to -- not the device: this runs at garbage-collection time on whichever
+            # thread drops the session (the back end's mapping thread, a stream capture) and must not stall their streams
+            for raw in list(getattr(self, "_streams_used", ())):
+                (torch.cuda.ExternalStream(raw, device=self.dev) if raw else torch.cuda.default_stream(self.dev)).synchronize()
             self._drained = True
 
     def __del__(self):

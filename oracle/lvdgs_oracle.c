@@ -109,6 +109,8 @@ typedef struct {
     real *final_T;           /* P */
     uint32_t *n_contrib;     /* P */
     uint8_t *fragile;        /* P: a threshold comparison on this pixel was within 1e-5 relative */
+    uint32_t *n_contrib_lo;  /* P: n_contrib had every such comparison that decides the last contributor gone the other way: */
+    uint32_t *n_contrib_hi;  /* P: ... the smallest / the largest value an implementation that rounds differently may report */
     /* backward inputs */
     const real *dL_dcolor;   /* 3*H*W */
     const real *dL_ddepth;   /* H*W or NULL */
@@ -294,6 +296,7 @@ int oracle_forward(oracle_ctx *c) {
     c->tiles_touched = zalloc(N, 4); c->rect = zalloc(4 * (size_t)N, 4);
     c->ranges = zalloc(2 * (size_t)NT, 4); c->final_T = zalloc(P, sizeof(real));
     c->n_contrib = zalloc(P, 4); c->fragile = zalloc(P, 1);
+    c->n_contrib_lo = zalloc(P, 4); c->n_contrib_hi = zalloc(P, 4);
 
     /* ---- per-Gaussian projection ---- */
     int64_t D = 0;
@@ -407,6 +410,13 @@ int oracle_forward(oracle_ctx *c) {
                     int pix = y * W + x;
                     real T = 1, C[3] = {0, 0, 0}, Dp = 0;
                     uint32_t contributor = 0, last = 0; uint8_t frag = 0;
+                    /* The last contributor under every way the near-threshold comparisons can fall.  An entry whose alpha is
+                       within 1e-5 of 1/255 is composited by one implementation and skipped by another: skipped here, it may
+                       be the other's last contributor (last_hi); composited here as the last one, the other may stop at the
+                       one before (last_lo).  A transmittance within 1e-5 of the 1e-4 stop: stopped here, the other composites
+                       this entry and stops at the next that qualifies (every alpha >= 1/255 takes T below the threshold for
+                       good); not stopped here, the other stops before it. */
+                    uint32_t last_lo = 0, last_hi = 0;
                     for (uint32_t k = beg; k < end; k++) {
                         contributor++;
                         uint32_t g = ids[k];
@@ -416,11 +426,13 @@ int oracle_forward(oracle_ctx *c) {
                         if (power > 0) continue;
                         real raw = co[3] * R_EXP(power);
                         real alpha = raw < ALPHA_MAX ? raw : ALPHA_MAX;
-                        frag |= near_rel(alpha, ALPHA_MIN);
-                        if (alpha < ALPHA_MIN) continue;
+                        int near_a = near_rel(alpha, ALPHA_MIN);
+                        frag |= near_a;
+                        if (alpha < ALPHA_MIN) { if (near_a) last_hi = contributor; continue; }
                         real test_T = T * ((real)1 - alpha);
-                        frag |= near_rel(test_T, T_STOP);
-                        if (test_T < T_STOP) break;
+                        int near_t = near_rel(test_T, T_STOP);
+                        frag |= near_t;
+                        if (test_T < T_STOP) { if (near_t) last_hi = contributor; break; }
                         real w = alpha * T;
                         for (int ch = 0; ch < 3; ch++) C[ch] += c->rgb[3 * g + ch] * w;
                         Dp += c->depths[g] * w;
@@ -430,8 +442,10 @@ int oracle_forward(oracle_ctx *c) {
                             c->n_touched[g]++;
                         }
                         T = test_T; last = contributor;
+                        if (!near_a && !near_t) last_lo = contributor;
                     }
                     c->final_T[pix] = T; c->n_contrib[pix] = last; c->fragile[pix] = frag;
+                    c->n_contrib_lo[pix] = last_lo; c->n_contrib_hi[pix] = last_hi > last ? last_hi : last;
                     for (int ch = 0; ch < 3; ch++) c->out_color[(size_t)ch * P + pix] = C[ch] + T * c->bg[ch];
                     c->out_depth[pix] = Dp; c->out_opacity[pix] = (real)1 - T;
                 }
@@ -722,7 +736,7 @@ void oracle_free(oracle_ctx *c) {
                      (void **)&c->n_touched, (void **)&c->means2D, (void **)&c->depths, (void **)&c->conic_opacity,
                      (void **)&c->rgb, (void **)&c->cov3D, (void **)&c->clamped, (void **)&c->tiles_touched,
                      (void **)&c->rect, (void **)&c->keys_sorted, (void **)&c->ids_sorted, (void **)&c->ranges,
-                     (void **)&c->final_T, (void **)&c->n_contrib, (void **)&c->fragile, (void **)&c->dL_dmeans3D,
+                     (void **)&c->final_T, (void **)&c->n_contrib, (void **)&c->fragile, (void **)&c->n_contrib_lo, (void **)&c->n_contrib_hi, (void **)&c->dL_dmeans3D,
                      (void **)&c->dL_dmeans2D, (void **)&c->dL_dscales, (void **)&c->dL_drotations,
                      (void **)&c->dL_dopacity, (void **)&c->dL_dcolors, (void **)&c->dL_dshs, (void **)&c->dL_dcov3D,
                      (void **)&c->dL_dtau};

@@ -34,7 +34,7 @@ def _fields(real):
         ("radii", ip), ("n_touched", ip), ("means2D", rp), ("depths", rp), ("conic_opacity", rp), ("rgb", rp),
         ("cov3D", rp), ("clamped", bp), ("tiles_touched", up), ("rect", ip),
         ("keys_sorted", C.POINTER(C.c_uint64)), ("ids_sorted", up), ("ranges", up), ("final_T", rp),
-        ("n_contrib", up), ("fragile", bp),
+        ("n_contrib", up), ("fragile", bp), ("n_contrib_lo", up), ("n_contrib_hi", up),
         ("dL_dcolor", rp), ("dL_ddepth", rp), ("dL_dopacity_img", rp),
         ("dL_dmeans3D", rp), ("dL_dmeans2D", rp), ("dL_dscales", rp), ("dL_drotations", rp), ("dL_dopacity", rp),
         ("dL_dcolors", rp), ("dL_dshs", rp), ("dL_dcov3D", rp), ("dL_dtau", rp),
@@ -137,6 +137,7 @@ class Oracle:
             keys_sorted=_np(c.keys_sorted, (D,), np.uint64), ids_sorted=_np(c.ids_sorted, (D,), np.uint32),
             ranges=_np(c.ranges, (NT, 2), np.uint32), final_T=_np(c.final_T, (c.H, c.W), r),
             n_contrib=_np(c.n_contrib, (c.H, c.W), np.uint32), fragile=_np(c.fragile, (c.H, c.W), np.uint8),
+            n_contrib_lo=_np(c.n_contrib_lo, (c.H, c.W), np.uint32), n_contrib_hi=_np(c.n_contrib_hi, (c.H, c.W), np.uint32),
         )
         return out
 

@@ -179,15 +179,17 @@ def check_pair_lists(f_hip, f_ora, W, H, max_dropped_checked=200_000):
     return 1.0 - len(hip_key) / max(D, 1)
 
 
-def expected_n_contrib(f_hip, f_ora):
+def expected_n_contrib(f_hip, f_ora, field="n_contrib"):
     """The oracle's per-pixel count of list entries up to the last contributor, restated for the HIP path's (possibly
-    shorter) lists: the number of KEPT entries among the tile's first n_contrib ones.  check_pair_lists() first."""
+    shorter) lists: the number of KEPT entries among the tile's first n_contrib ones.  check_pair_lists() first.
+    ``field``: "n_contrib", or its bounds "n_contrib_lo" / "n_contrib_hi" (the last contributor with every near-threshold
+    comparison of the pixel gone the other way: what a correctly rounding implementation may report on a fragile pixel)."""
     kept = f_hip["kept_in_oracle_list"]
     if kept.all():
-        return f_ora["n_contrib"]
+        return f_ora[field]
     H, W = f_ora["n_contrib"].shape
     gx = (W + 15) // 16
     prefix = np.concatenate([[0], np.cumsum(kept)]).astype(np.int64)
     ys, xs = np.mgrid[0:H, 0:W]
     start = f_ora["ranges"].astype(np.int64)[(ys // 16) * gx + xs // 16, 0]
-    return (prefix[start + f_ora["n_contrib"].astype(np.int64)] - prefix[start]).astype(np.uint32)
+    return (prefix[start + f_ora[field].astype(np.int64)] - prefix[start]).astype(np.uint32)

@@ -72,6 +72,17 @@ def _run(group_world, policy="leftover", half_blind=False, real_window=False, au
     for i, cam in enumerate(sc["cameras"]):
         be.viewpoints[i] = cam
     window = sc["window"]
+    if real_window:
+        # LVD-GS's default configuration (dynamic_filtering.enabled, utils/slam_frontend.py:1218,1429-1433): EVERY keyframe carries a
+        # static mask, so the eight window views take the L1 + SSIM + masked-depth branch (not a sum over pixels: whole views only)
+        # and only the two random older views, scored by get_loss_mapping whatever they carry, can be cut into bands
+        gen = torch.Generator().manual_seed(31)
+        for i, cam in enumerate(sc["cameras"]):
+            H, W = int(cam.image_height), int(cam.image_width)
+            m = torch.ones(H, W, dtype=torch.bool)
+            y0, x0 = int(torch.randint(0, H - 16, (1,), generator=gen)), int(torch.randint(0, W - 20, (1,), generator=gen))
+            m[y0:y0 + 16, x0:x0 + 20] = False
+            cam.static_mask = m
     be.current_window = window
     be.keyframe_optimizers = sc["make_keyframe_optimizer"](be.viewpoints, window, cfg)
     counts = []   # Gaussians at every optimiser step (taken where map_window is about to step: the sharded step is not optimizer.step())
@@ -200,7 +211,8 @@ def test_ranks_stay_bit_identical_and_match_the_single_process_run(world, policy
 
 
 def test_the_reference_window_of_ten_views_on_eight_ranks():
-    """The target shape of the sharded iteration, executed (not only planned): 8 window keyframes + 2 random older ones on
+    """The target shape of the sharded iteration, executed (not only planned): 8 window keyframes, every one with a static mask (the
+    reference's default configuration: the masked branch of the loss, whole views only) + 2 random older ones on
     EIGHT ranks -- every rank one whole keyframe, the two other views in bands of tile rows -- for two iterations, the first
     of them through the opacity reset of the non-visible (the "seen by any view" statistic across ranks).  Replicas end
     bit-identical and equal to the single-process run to float rounding."""

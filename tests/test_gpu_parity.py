@@ -82,6 +82,12 @@ def _check_forward(f_hip, f_ora, W, H):
     _close(np.where(solid, f_hip["final_T"], 0), np.where(solid, f_ora["final_T"], 0), what="final_T")
     # ---- blend-time counters ----
     np.testing.assert_array_equal(f_hip["n_contrib"][solid], hip_runner.expected_n_contrib(f_hip, f_ora)[solid])
+    # ... and on the fragile pixels: between the oracle's own bounds -- its last contributor with every comparison that was within
+    # 1e-5 of its threshold (alpha against 1/255, T against 1e-4) gone the other way (oracle/lvdgs_oracle.c: n_contrib_lo / _hi)
+    if (~solid).any():
+        lo, hi = (hip_runner.expected_n_contrib(f_hip, f_ora, k)[~solid].astype(np.int64) for k in ("n_contrib_lo", "n_contrib_hi"))
+        got = f_hip["n_contrib"][~solid].astype(np.int64)
+        assert ((lo <= got) & (got <= hi)).all(), f"n_contrib outside the oracle's bounds on {int(((got < lo) | (got > hi)).sum())} of {got.size} fragile pixels"
     n_fragile = int((~solid).sum())
     diff = np.abs(f_hip["n_touched"].astype(np.int64) - f_ora["n_touched"].astype(np.int64))
     assert diff.sum() <= 4 * n_fragile + 0, (diff.sum(), n_fragile)
