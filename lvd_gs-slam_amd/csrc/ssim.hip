@@ -78,11 +78,13 @@ template <bool GRAD>
 __global__ void __launch_bounds__(SSIM_THREADS) ssim_l1_kernel(SsimParams p) {
     // sxy: the two input windows; later the three derivative maps (3 * S2 * P2 <= 2 * S1 * P1)
     __shared__ float s_in[2 * S1 * P1];
-    // horizontal pass results: 4 x S1 x P2; later the horizontal pass of the derivative maps (3 x S2 x P3)
-    __shared__ float s_h[4 * S1 * P2];
+    // horizontal pass results, TWO maps at a time ((x, y), then (x^2 + y^2, xy)): 2 x S1 x P2; later the horizontal pass of the
+    // derivative maps (3 x S2 x P3).  With all four maps resident the kernel held 57.8 KB of LDS -- two workgroups per CU, four
+    // waves per SIMD, and it is latency-bound (a dozen barriers, dependent LDS round trips): 39.9 KB lets a third and fourth in.
+    __shared__ float s_h[2 * S1 * P2];
     __shared__ float s_red[8];
     static_assert(3 * S2 * P2 <= 2 * S1 * P1, "derivative maps must fit the input windows");
-    static_assert(3 * S2 * P3 <= 4 * S1 * P2, "second horizontal pass must fit the first");
+    static_assert(3 * S2 * P3 <= 2 * S1 * P2, "second horizontal pass must fit the first");
 
     const int tid = threadIdx.x;
     const int view = (int)blockIdx.z / p.planes, plane = (int)blockIdx.z - view * p.planes;
@@ -116,127 +118,130 @@ __global__ void __launch_bounds__(SSIM_THREADS) ssim_l1_kernel(SsimParams p) {
     float l1 = 0.f;
     float *sx = s_in, *sy = s_in + S1 * P1;
     {
-        // all global loads of the window are issued before the first use: with 2 workgroups per CU there
-        // is nobody else to hide their latency
-        constexpr int NLD = (S1 * S1 + SSIM_THREADS - 1) / SSIM_THREADS;
+        // A wave takes 64 columns of one window row (52 of them exist), the workgroup's eight waves eight rows: seven rounds, row and
+        // column without a division (the round-4 form -- thread i takes window element i + 512 k, row = element / 52 -- spent a
+        // third of the kernel's vector instructions on index arithmetic: SQ_INSTS_VALU 1162 per wave for 561 multiply-adds).
+        // All global loads of the window are issued before the first use.
+        constexpr int NLD = (S1 + 7) / 8;
+        const int lc = tid & 63, lr = tid >> 6;
+        const int gx = tx0 - 2 * SR + lc;
+        const bool col_in = lc < S1 && gx >= 0 && gx < p.W;
+        const int gy0 = ty0 - 2 * SR + lr;
         float la[NLD], lb[NLD];
         uint8_t lk[NLD];
 #pragma unroll
         for (int it = 0; it < NLD; it++) {
-            const int i = tid + it * SSIM_THREADS;
-            const int r = i / S1, c = i - r * S1;
-            const int gy = ty0 - 2 * SR + r, gx = tx0 - 2 * SR + c;
-            const bool in = i < S1 * S1 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            const int r = lr + 8 * it, gy = gy0 + 8 * it;
+            const bool in = col_in && r < S1 && gy >= 0 && gy < p.H;
             const size_t o = in ? (size_t)gy * p.W + gx : 0;
             la[it] = in ? X[o] : 0.f;
             lb[it] = in ? Y[o] : 0.f;
             lk[it] = (in && v.keep) ? v.keep[o] : (uint8_t)1;
         }
+        const bool col_own = lc >= 2 * SR && lc < 2 * SR + ST;
 #pragma unroll
         for (int it = 0; it < NLD; it++) {
-            const int i = tid + it * SSIM_THREADS;
-            if (i < S1 * S1) {
-                const int r = i / S1, c = i - r * S1;
-                const int gy = ty0 - 2 * SR + r, gx = tx0 - 2 * SR + c;
-                const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-                float a = la[it], b = lb[it];
-                if (in && !lk[it]) a = b = bgc;
-                if (in && r >= 2 * SR && r < 2 * SR + ST && c >= 2 * SR && c < 2 * SR + ST) l1 += fabsf(a - b);
-                sx[r * P1 + c] = a;
-                sy[r * P1 + c] = b;
+            const int r = lr + 8 * it;
+            if (lc < S1 && r < S1) {
+                float a = la[it], b = lb[it];   // (outside the image: zeros, mask byte 1)
+                if (!lk[it]) a = b = bgc;
+                if (col_own && r >= 2 * SR && r < 2 * SR + ST) l1 += fabsf(a - b);   // (own pixels outside the image add |0 - 0|)
+                sx[r * P1 + lc] = a;
+                sy[r * P1 + lc] = b;
             }
         }
     }
     __syncthreads();
 
-    // ---- 2a. horizontal pass: rows 0..S1, output columns 0..S2; one item = 5 outputs of one row, so the
-    //      52 x 9 items fill one round of the workgroup (the last column group overlaps its neighbour) ----
-    {
-        constexpr int OUT = 5, NIN = OUT + SW - 1, GROUPS = (S2 + OUT - 1) / OUT;  // 52 rows x 9 column groups = 468 items
-        static_assert(S1 * GROUPS <= SSIM_THREADS, "one round");
-        if (tid < S1 * GROUPS) {
-            const int r = tid % S1, g = tid / S1;
-            const int c0 = min(g * OUT, S2 - OUT);
-            float xv[NIN], yv[NIN], qs[NIN], qz[NIN];
+    // ---- 2. separable 11-tap passes, two maps at a time: (x, y) -> A, B, then (x^2 + y^2, xy) -> S, Z.
+    //      horizontal: rows 0..S1, output columns 0..S2; one item = 5 outputs of one row, so the 52 x 9 items fill one round of the
+    //      workgroup (the last column group overlaps its neighbour); vertical: one item = 4 outputs of one column (42 x 11 items,
+    //      the last row group overlaps), kept in registers for step 3 ----
+    constexpr int VOUT = 4, VNIN = VOUT + SW - 1, VGROUPS = (S2 + VOUT - 1) / VOUT;  // 42 columns x 11 row groups = 462 items
+    static_assert(S2 * VGROUPS <= SSIM_THREADS, "one round");
+    const bool v_item = tid < S2 * VGROUPS;
+    const int vc = tid % S2, v_rfirst = (tid / S2) * VOUT, v_r0 = min(v_rfirst, S2 - VOUT);  // the last group overlaps
+    float vA[VOUT], vB[VOUT], vS[VOUT], vZ[VOUT];
 #pragma unroll
-            for (int i = 0; i < NIN; i++) {
-                xv[i] = sx[r * P1 + c0 + i];
-                yv[i] = sy[r * P1 + c0 + i];
+    for (int pass = 0; pass < 2; pass++) {
+        {
+            constexpr int OUT = 5, NIN = OUT + SW - 1, GROUPS = (S2 + OUT - 1) / OUT;  // 52 rows x 9 column groups = 468 items
+            static_assert(S1 * GROUPS <= SSIM_THREADS, "one round");
+            if (tid < S1 * GROUPS) {
+                const int r = tid % S1, g = tid / S1;
+                const int c0 = min(g * OUT, S2 - OUT);
+                float p0[NIN], p1[NIN];
+#pragma unroll
+                for (int i = 0; i < NIN; i++) {
+                    const float xv = sx[r * P1 + c0 + i], yv = sy[r * P1 + c0 + i];
+                    p0[i] = pass == 0 ? xv : fmaf(xv, xv, yv * yv);
+                    p1[i] = pass == 0 ? yv : xv * yv;
+                }
+#pragma unroll
+                for (int o = 0; o < OUT; o++) {
+                    float a = w[0] * p0[o], b = w[0] * p1[o];
+#pragma unroll
+                    for (int k = 1; k < SW; k++) {
+                        a = fmaf(w[k], p0[o + k], a);
+                        b = fmaf(w[k], p1[o + k], b);
+                    }
+                    const int d = r * P2 + c0 + o;
+                    s_h[d] = a;
+                    s_h[S1 * P2 + d] = b;
+                }
+            }
+        }
+        __syncthreads();
+        if (v_item) {
+            float v0[VNIN], v1[VNIN];
+#pragma unroll
+            for (int i = 0; i < VNIN; i++) {
+                const int d = (v_r0 + i) * P2 + vc;
+                v0[i] = s_h[d];
+                v1[i] = s_h[S1 * P2 + d];
             }
 #pragma unroll
-            for (int i = 0; i < NIN; i++) {
-                qs[i] = fmaf(xv[i], xv[i], yv[i] * yv[i]);
-                qz[i] = xv[i] * yv[i];
-            }
-#pragma unroll
-            for (int o = 0; o < OUT; o++) {
-                float a = w[0] * xv[o], b = w[0] * yv[o], sq = w[0] * qs[o], z = w[0] * qz[o];
+            for (int o = 0; o < VOUT; o++) {
+                float a = w[0] * v0[o], b = w[0] * v1[o];
 #pragma unroll
                 for (int k = 1; k < SW; k++) {
-                    a = fmaf(w[k], xv[o + k], a);
-                    b = fmaf(w[k], yv[o + k], b);
-                    sq = fmaf(w[k], qs[o + k], sq);
-                    z = fmaf(w[k], qz[o + k], z);
+                    a = fmaf(w[k], v0[o + k], a);
+                    b = fmaf(w[k], v1[o + k], b);
                 }
-                const int d = r * P2 + c0 + o;
-                s_h[d] = a;
-                s_h[S1 * P2 + d] = b;
-                s_h[2 * S1 * P2 + d] = sq;
-                s_h[3 * S1 * P2 + d] = z;
+                if (pass == 0) { vA[o] = a; vB[o] = b; } else { vS[o] = a; vZ[o] = b; }
             }
         }
+        __syncthreads();   // (pass 0: s_h is written again; pass 1: the input windows make room for the derivative maps)
     }
-    __syncthreads();
 
-    // ---- 2b + 3. vertical pass, m and its derivatives on the S2 x S2 region ----
+    // ---- 3. m and its derivatives on the S2 x S2 region ----
     float msum = 0.f;
     float *sdA = s_in, *sdS = s_in + S2 * P2, *sdZ = s_in + 2 * S2 * P2;
-    {
-        constexpr int OUT = 4, NIN = OUT + SW - 1, GROUPS = (S2 + OUT - 1) / OUT;  // 42 columns x 11 row groups = 462 items
-        static_assert(S2 * GROUPS <= SSIM_THREADS, "one round");
-        if (tid < S2 * GROUPS) {
-            const int c = tid % S2, rfirst = (tid / S2) * OUT, r0 = min(rfirst, S2 - OUT);  // the last group overlaps
-            float va[NIN], vb[NIN], vs[NIN], vz[NIN];
+    if (v_item) {
+        const int gx = tx0 - SR + vc;
 #pragma unroll
-            for (int i = 0; i < NIN; i++) {
-                const int d = (r0 + i) * P2 + c;
-                va[i] = s_h[d];
-                vb[i] = s_h[S1 * P2 + d];
-                vs[i] = s_h[2 * S1 * P2 + d];
-                vz[i] = s_h[3 * S1 * P2 + d];
-            }
-            const int gx = tx0 - SR + c;
-#pragma unroll
-            for (int o = 0; o < OUT; o++) {
-                float A = w[0] * va[o], B = w[0] * vb[o], S = w[0] * vs[o], Z = w[0] * vz[o];
-#pragma unroll
-                for (int k = 1; k < SW; k++) {
-                    A = fmaf(w[k], va[o + k], A);
-                    B = fmaf(w[k], vb[o + k], B);
-                    S = fmaf(w[k], vs[o + k], S);
-                    Z = fmaf(w[k], vz[o + k], Z);
-                }
-                const int r = r0 + o;
-                const int gy = ty0 - SR + r;
-                const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-                const float AB = A * B, AA_BB = fmaf(A, A, B * B);
-                const float num1 = fmaf(2.f, AB, SSIM_C1), num2 = fmaf(2.f, Z - AB, SSIM_C2);
-                const float den1 = AA_BB + SSIM_C1, den2 = (S - AA_BB) + SSIM_C2;
-                // both denominators are >= C1, C2 > 0: the hardware reciprocal (1 ulp) is well inside the tolerance
-                const float inv1 = __builtin_amdgcn_rcpf(den1), inv2 = __builtin_amdgcn_rcpf(den2);
-                const float inv12 = inv1 * inv2;
-                const float m = (num1 * num2) * inv12;
-                if (inside && r >= rfirst && r >= SR && r < SR + ST && c >= SR && c < SR + ST) msum += m;  // overlapped rows count once
-                if (GRAD) {
-                    // dm/dA = 2B (num2 - num1) / (den1 den2) - 2A m (1/den1 - 1/den2); dm/dS = -m / den2; dm/dZ = 2 num1 / (den1 den2)
-                    const float dA = 2.f * B * (num2 - num1) * inv12 - 2.f * A * m * (inv1 - inv2);
-                    const float dS = -m * inv2;
-                    const float dZ = 2.f * num1 * inv12;
-                    const int d = r * P2 + c;
-                    sdA[d] = inside ? dA : 0.f;
-                    sdS[d] = inside ? dS : 0.f;
-                    sdZ[d] = inside ? dZ : 0.f;
-                }
+        for (int o = 0; o < VOUT; o++) {
+            const float A = vA[o], B = vB[o], S = vS[o], Z = vZ[o];
+            const int r = v_r0 + o;
+            const int gy = ty0 - SR + r;
+            const bool inside = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            const float AB = A * B, AA_BB = fmaf(A, A, B * B);
+            const float num1 = fmaf(2.f, AB, SSIM_C1), num2 = fmaf(2.f, Z - AB, SSIM_C2);
+            const float den1 = AA_BB + SSIM_C1, den2 = (S - AA_BB) + SSIM_C2;
+            // both denominators are >= C1, C2 > 0: the hardware reciprocal (1 ulp) is well inside the tolerance
+            const float inv1 = __builtin_amdgcn_rcpf(den1), inv2 = __builtin_amdgcn_rcpf(den2);
+            const float inv12 = inv1 * inv2;
+            const float m = (num1 * num2) * inv12;
+            if (inside && r >= v_rfirst && r >= SR && r < SR + ST && vc >= SR && vc < SR + ST) msum += m;  // overlapped rows count once
+            if (GRAD) {
+                // dm/dA = 2B (num2 - num1) / (den1 den2) - 2A m (1/den1 - 1/den2); dm/dS = -m / den2; dm/dZ = 2 num1 / (den1 den2)
+                const float dA = 2.f * B * (num2 - num1) * inv12 - 2.f * A * m * (inv1 - inv2);
+                const float dS = -m * inv2;
+                const float dZ = 2.f * num1 * inv12;
+                const int d = r * P2 + vc;
+                sdA[d] = inside ? dA : 0.f;
+                sdS[d] = inside ? dS : 0.f;
+                sdZ[d] = inside ? dZ : 0.f;
             }
         }
     }
@@ -316,6 +321,18 @@ __global__ void __launch_bounds__(SSIM_THREADS) ssim_l1_kernel(SsimParams p) {
     float *__restrict__ G = v.d_x + plane_off;
     for (int item = tid; item < ST * (ST / 2); item += SSIM_THREADS) {
         const int c = item % ST, r0 = (item / ST) * 2;
+        // the pixels' own values (for 2 x (w * dm/dS) + y (w * dm/dZ) and the L1 sign): requested before the passes' LDS reads
+        float own_x[2] = {0.f, 0.f}, own_y[2] = {0.f, 0.f};
+        bool own_keep[2] = {false, false};
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+            const int gy = ty0 + r0 + o, gx = tx0 + c;
+            if (gy < p.H && gx < p.W) {
+                const size_t off = (size_t)gy * p.W + gx;
+                own_keep[o] = !(v.keep && !v.keep[off]);
+                own_x[o] = X[off]; own_y[o] = Y[off];
+            }
+        }
         float va[12], vs[12], vz[12];
 #pragma unroll
         for (int i = 0; i < 12; i++) {
@@ -338,8 +355,8 @@ __global__ void __launch_bounds__(SSIM_THREADS) ssim_l1_kernel(SsimParams p) {
             if (gy < p.H && gx < p.W) {
                 const size_t off = (size_t)gy * p.W + gx;
                 float g = 0.f;
-                if (!(v.keep && !v.keep[off])) {  // overwritten pixels do not depend on the input
-                    const float xv = X[off], yv = Y[off];
+                if (own_keep[o]) {  // overwritten pixels do not depend on the input
+                    const float xv = own_x[o], yv = own_y[o];
                     const float diff = xv - yv;
                     const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
                     g = v.w_ssim * (a + 2.f * xv * s + yv * z) + v.w_l1 * sgn;

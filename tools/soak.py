@@ -47,7 +47,8 @@ print(f"tracking: device memory in use {mem0 / 2**20:.1f} MiB -> {mem1 / 2**20:.
 assert mem1 == mem0 and all(ok for *_, ok in marks) and applied == T + 50 and bool(torch.isfinite(s.R).all())
 
 model, _, _, _ = bench.build_scene("kitti07_geom", 0, dev)
-be, window = bench.build_window("kitti07_geom", 12, dev, model, n_window=8)
+# (every keyframe with a static mask -- the reference's default -- unless SOAK_NO_MASKS=1)
+be, window = bench.build_window("kitti07_geom", 12, dev, model, n_window=8, masked=os.environ.get("SOAK_NO_MASKS", "0") != "1")
 torch.manual_seed(0)
 for _ in range(20):
     backend_map.map_window(be, window, iters=1)
