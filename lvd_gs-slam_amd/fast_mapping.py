@@ -348,7 +348,11 @@ class MapViewPass:
         return pkg, loss
 
 
-MAX_BATCH_TILES = 4096
+# Frames of up to 16384 tiles (the counting path's limit: lvdgs_forward_batch).  Round 4 stopped at 4096 -- a 1080p frame fills the
+# chip by itself and the batched BLEND passes alone bought nothing there (5.79 -> 5.77 ms) -- but with the forward chains and the
+# static-mask losses batched too the window gains at every size (same box, ms per 8 + 2 iteration, unmasked / masked keyframes):
+# 500 k / 1080p 5.79 -> 5.42 / 6.47 -> 5.94, 2 M / 1920x1280 12.55 -> 12.14 / 13.06 -> 12.48.  (LVDGS_MAX_BATCH_TILES: A/B knob.)
+MAX_BATCH_TILES = int(os.environ.get("LVDGS_MAX_BATCH_TILES", "16384"))
 MEMORY_FRACTION = 0.8   # of the device memory still to be had: what a window batch may ask for (MapWindowBatch.usable)
 
 
@@ -365,8 +369,8 @@ class MapWindowBatch:
     views) share the launches: the backward blend kernel takes each view's pixel gradients from the loss that view is scored by.
 
     A KITTI-size frame (1848 tiles) leaves the chip half empty and ends in a tail of its heaviest tiles; ten frames fill it.
-    Every view keeps buffers of its own between the phases (geometry, pair lists, image state, scratch: ~60 MB per view at
-    KITTI's size, ~200 MB at 500 k Gaussians / 1080p).  Results are ``MapViewPass.run``'s view after view, bit for bit: the same kernels on
+    Every view keeps buffers of its own between the phases (geometry, pair lists, image state, scratch: ~120 MB per view at
+    KITTI's size, ~300 MB at 500 k Gaussians / 1080p, ~1 GB at 2 M: checked against the device's free memory, ``usable``).  Results are ``MapViewPass.run``'s view after view, bit for bit: the same kernels on
     the same data, the parameter gradients added in the same order.
 
     For whole views scored by the built-in mapping loss or the static-mask loss on a model of SH degree 0 (``usable``); anything
@@ -382,8 +386,6 @@ class MapWindowBatch:
         if len(viewpoints) < 2 or int(G._features_rest.shape[1]) != 0 or _rz.LIST_ALL_TILES:
             return False
         size = {(int(v.image_height), int(v.image_width)) for v in viewpoints}
-        # frames of up to 4096 tiles: beyond, a frame fills the chip by itself (500 k Gaussians / 1080p: 5.79 -> 5.77 ms per
-        # iteration of ten views) and a set of buffers per view (~200 MB there) buys nothing
         if len(size) != 1 or any(((h + 15) // 16) * ((w + 15) // 16) > MAX_BATCH_TILES for h, w in size):
             return False
         masked = masked or [None] * len(viewpoints)

@@ -46,8 +46,10 @@ def _run(batch, iters, n_window=8, workload="tmp_window_batch"):
     return used, params, poses, stats, losses
 
 
-@pytest.mark.parametrize("workload", ["tmp_window_batch", "surface_12k_640x480"])   # (the second: lists of 500-1500 entries -- the deep-lists build of the forward blend pass, the tile sort's queue)
+@pytest.mark.parametrize("workload", ["tmp_window_batch", "surface_12k_640x480", "tmp_window_batch_5k_tiles"])   # (the second: lists of 500-1500 entries -- the deep-lists blend build, queued tile-sort segments; the third: a frame of more than 4096 tiles -- no tile order, runs of tiles per XCD)
 def test_window_batch_is_the_window_view_by_view_bit_for_bit(workload):
+    from lvdgs import synthetic
+    synthetic.CONFIGS.setdefault("tmp_window_batch_5k_tiles", dict(N=40000, W=1440, H=912))   # 90 x 57 = 5130 tiles
     used_b, params_b, poses_b, stats_b, losses_b = _run(True, 3, workload=workload)
     used_s, params_s, poses_s, stats_s, losses_s = _run(False, 3, workload=workload)
     assert used_b and not used_s, "the batch path did not run (or ran when switched off)"

@@ -166,7 +166,7 @@ def test_2m_gaussians_with_dynamic_object_masks():
     ``masked_loss``); fused=False is render() -> loss_utils.masked_mapping_loss -> backward() through the autograd
     engine.  Same losses, same map after two iterations."""
     from lvdgs.backend_map import map_window
-    from lvdgs.fast_mapping import MapViewPass
+    from lvdgs.fast_mapping import MapViewPass, MapWindowBatch
     window = [2, 1]
     out = {}
     for fused in (True, False):
@@ -174,15 +174,17 @@ def test_2m_gaussians_with_dynamic_object_masks():
         be, N = _backend("cfg5_2m_1920x1280", 2, window, masks=True)
         assert N == 2_000_000
         calls = []
-        run = MapViewPass.run
+        run, brun = MapViewPass.run, MapWindowBatch.run
         MapViewPass.run = lambda self, *a, **k: (calls.append(k.get("masked_loss") is not None) or run(self, *a, **k))
+        MapWindowBatch.run = lambda self, *a, **k: (calls.extend(m is not None for m in k.get("masked")) or brun(self, *a, **k))
         stats = {}
         try:
             map_window(be, window, iters=2, stats=stats, fused=fused)
         finally:
-            MapViewPass.run = run
+            MapViewPass.run, MapWindowBatch.run = run, brun
         torch.cuda.synchronize()
-        assert calls == ([True] * 4 if fused else [])        # two masked keyframes x two iterations, none through autograd
+        # two masked keyframes x two iterations, none through autograd (9600 tiles: the two views go through the window batch)
+        assert calls == ([True] * 4 if fused else []) and (getattr(be, "_lvdgs_window_batch", None) is not None) == fused
         losses = [float(x) for x in stats["losses"]]
         assert all(np.isfinite(losses)) and all(0.0 < v < 10.0 for v in losses)
         # masked keyframes take the L1 + SSIM branch: their exposure parameters get no gradient and never move
