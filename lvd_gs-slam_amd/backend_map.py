@@ -783,24 +783,26 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
         masked_spec = (float(backend.opt_params.lambda_dssim), float(cfg["Training"].get("depth_lambda", 0.1)))
         masked_of = [masked_spec if (i < n_window and getattr(v, "static_mask", None) is not None and vpass is not None
                                      and MapViewPass.masked_loss_usable(v)) else None for i, v in enumerate(views)]
-        # Every piece of this rank a whole view (one GPU: the whole window; two GPUs: five views each; beyond, a rank holds one
-        # view and bands): the blend passes of ALL of them in one launch each, and so the static-mask losses
-        # (fast_mapping.MapWindowBatch -- a KITTI-size frame alone leaves the chip half empty; LVDGS_MAP_BATCH=0: view by view)
-        batched = False
-        if (vpass is not None and os.environ.get("LVDGS_MAP_BATCH", "1") != "0"
-                and all((r0, r1) == (0, _tile_rows(views[v])) for v, r0, r1 in mine)
-                and all(masked_of[v] is not None or getattr(views[v], "static_mask", None) is None or v >= n_window for v, _, _ in mine)
-                and MapWindowBatch.usable(backend, [views[v] for v, _, _ in mine], [masked_of[v] for v, _, _ in mine])):
+        # The WHOLE views of this rank (one GPU: the whole window; two GPUs: five views each; four: two each + bands; eight: one +
+        # a band) with every stage in one launch for all of them: forward chains, blend passes, static-mask losses
+        # (fast_mapping.MapWindowBatch -- a KITTI-size frame alone leaves the chip half empty; LVDGS_MAP_BATCH=0: view by view).
+        # The rank's bands, and whole views the batch cannot take, follow view by view and add to the batch's gradients.
+        together = []
+        if vpass is not None and os.environ.get("LVDGS_MAP_BATCH", "1") != "0":
+            together = [(v, r0, r1) for v, r0, r1 in mine if (r0, r1) == (0, _tile_rows(views[v]))
+                        and (masked_of[v] is not None or getattr(views[v], "static_mask", None) is None or v >= n_window)]
+            if not MapWindowBatch.usable(backend, [views[v] for v, _, _ in together], [masked_of[v] for v, _, _ in together]):
+                together = []
+        if together:
             batch = getattr(backend, "_lvdgs_window_batch", None)
             if batch is None or batch.passes[0] is not vpass:
                 batch = backend._lvdgs_window_batch = MapWindowBatch(vpass)
-            for (v, r0, _), (pkg, l) in zip(mine, batch.run(backend, [views[v] for v, _, _ in mine], first=first,
-                                                             stats=[vs.targets(v, r0) for v, r0, _ in mine],
-                                                             masked=[masked_of[v] for v, _, _ in mine])):
+            for (v, r0, _), (pkg, l) in zip(together, batch.run(backend, [views[v] for v, _, _ in together], first=first,
+                                                                 stats=[vs.targets(v, r0) for v, r0, _ in together],
+                                                                 masked=[masked_of[v] for v, _, _ in together])):
                 pkgs.append((v, r0, pkg))
                 direct_losses.append(l)
-            batched = True
-        for v, r0, r1 in (() if batched else mine):
+        for v, r0, r1 in [pc for pc in mine if pc not in together]:
             whole = (r0, r1) == (0, _tile_rows(views[v]))
             masked = v < n_window and getattr(views[v], "static_mask", None) is not None
             if vpass is not None and MapViewPass.usable(backend, views[v], allow_static_mask=True) and (not masked or masked_of[v] is not None):

@@ -29,14 +29,14 @@ def _paths():
     import lvdgs  # noqa: F401
 
 
-def _run(group_world, policy="leftover", sharded=False):
+def _run(group_world, policy="leftover", sharded=False, window=None):
     _paths()
     import test_loop_golden as tl
     from loop_scene import build_scene, loop_config
     from lvdgs import backend_map as bm
     bm.SPLIT_POLICY = policy
     cfg = loop_config()
-    sc = build_scene("cuda")
+    sc = build_scene("cuda", window=window)
     be = tl._backend(sc, cfg)
     be.initialized = True
     be.shard_optimizer = sharded   # (the Gaussian Adam as reduce-scatter -> lvdgs_adam_step on this rank's share -> all-gather)
@@ -75,6 +75,7 @@ def _run(group_world, policy="leftover", sharded=False):
         out[f"occ{kf}"] = cpu(be.occ_aware_visibility[kf])
     out["views_per_iteration"] = np.array([len(r["views"]) for r in stats["iterations"][:ITERS]])
     out["used_view_pass"] = np.array(int(getattr(be, "_lvdgs_view_pass", None) is not None))
+    out["used_window_batch"] = np.array(int(getattr(be, "_lvdgs_window_batch", None) is not None))
     return out
 
 
@@ -87,14 +88,14 @@ def _digest(res):
     return h.hexdigest()
 
 
-def _worker(rank, world, port, q, policy, sharded=False):
+def _worker(rank, world, port, q, policy, sharded=False, window=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.manual_seed(100 + rank)
-        res = _run(world, policy, sharded)
+        res = _run(world, policy, sharded, window)
         q.put((rank, _digest(res), res))
     finally:
         dist.destroy_process_group()
@@ -103,16 +104,19 @@ def _worker(rank, world, port, q, policy, sharded=False):
 _SINGLE = {}
 
 
-@pytest.mark.parametrize("world,policy,sharded", [(2, "leftover", False), (2, "all", True)])
-def test_ranks_on_one_gpu_stay_bit_identical_and_match_the_single_process_run(world, policy, sharded):
-    """world 2: whole views (six views, three each), and EVERY view cut into two bands of tile rows, one per rank (the band
-    path of the rasterizer, lvdgs_args.tile_row_*, the split views' statistics, the byte-wise flag OR) -- the latter with the
-    Gaussian Adam sharded (backend_map.ShardedAdam: reduce-scatter, lvdgs_adam_step on this rank's sub-ranges, all-gather).
+@pytest.mark.parametrize("world,policy,sharded,window", [(2, "leftover", False, None), (2, "all", True, None), (2, "leftover", False, (6, 5, 4))])
+def test_ranks_on_one_gpu_stay_bit_identical_and_match_the_single_process_run(world, policy, sharded, window):
+    """world 2: whole views (six views, three each: the rank's views through the window batch), and EVERY view cut into two bands of
+    tile rows, one per rank (the band path of the rasterizer, lvdgs_args.tile_row_*, the split views' statistics, the byte-wise flag
+    OR) -- the latter with the Gaussian Adam sharded (backend_map.ShardedAdam: reduce-scatter, lvdgs_adam_step on this rank's
+    sub-ranges, all-gather); and a window of three keyframes (+ 2 random = five views): two whole views per rank through the window
+    batch AND a band of the fifth added to their gradients view by view -- the mix a four-GPU job has.
     (Three ranks with a band each were run by the builder too; a third interpreter start costs the suite half a minute.)"""
+    window = None if window is None else list(window)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 31500 + (os.getpid() % 2000) + 11 * world
-    procs = [ctx.Process(target=_worker, args=(r, world, port + (5 if sharded else 0), q, policy, sharded)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port + (5 if sharded else 0) + (9 if window else 0), q, policy, sharded, window)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted([q.get(timeout=900) for _ in range(world)], key=lambda r: r[0])
@@ -126,18 +130,23 @@ def test_ranks_on_one_gpu_stay_bit_identical_and_match_the_single_process_run(wo
             if k != "views_per_iteration":
                 np.testing.assert_array_equal(r0[k], rk[k], err_msg=k)
         assert d0 == dk
-    if policy == "leftover":
+    if window is not None:
+        assert all(r["views_per_iteration"].tolist() == [3] * ITERS for _, _, r in results)   # two whole views + a band of the fifth
+    elif policy == "leftover":
         assert all(r["views_per_iteration"].tolist() == [3] * ITERS for _, _, r in results)
     else:
         assert all(r["views_per_iteration"].min() >= 5 for _, _, r in results)   # a band of (nearly) every view on every rank
-    if "ref" not in _SINGLE:
+    key = "ref" if window is None else "ref" + str(window)
+    if key not in _SINGLE:
         torch.manual_seed(7)
-        _SINGLE["ref"] = _run(1)
-    ref = _SINGLE["ref"]
+        _SINGLE[key] = _run(1, window=window)
+    ref = _SINGLE[key]
     np.testing.assert_array_equal(ref["counts"], r0["counts"])
     assert int(ref["n_mid"]) == int(r0["n_mid"]) and len(set(ref["counts"].tolist())) > 1   # a densification happened
+    if window is not None:
+        assert int(r0["used_window_batch"]) == 1   # the whole views of a rank that also holds a band went through the batch
     for k in ref:
-        if k in ("views_per_iteration", "counts", "n_mid", "used_view_pass"):
+        if k in ("views_per_iteration", "counts", "n_mid", "used_view_pass", "used_window_batch"):
             continue
         a, b = np.asarray(r0[k], np.float64), np.asarray(ref[k], np.float64)
         assert a.shape == b.shape, k
