@@ -73,15 +73,16 @@ def _static_mask_bytes(viewpoint, like):
     window view (utils/slam_backend.py:199); here the device copy stays with the viewpoint for as long as the mask tensor is the
     same object and has not been written to (``Tensor._version``)."""
     m = viewpoint.static_mask
+    version = m._version if torch.is_tensor(m) else None   # (a numpy mask: keyed on identity alone)
     cache = getattr(viewpoint, "_lvdgs_static_mask", None)
-    if cache is not None and cache[0] is m and cache[1] == m._version and cache[2].device == like.device:
+    if cache is not None and cache[0] is m and cache[1] == version and cache[2].device == like.device:
         return cache[2]
-    t = m.to(like.device).reshape(-1)
+    t = (m if torch.is_tensor(m) else torch.as_tensor(m)).to(like.device).reshape(-1)
     t = (t.view(torch.uint8) if t.dtype == torch.bool else t.ne(0).view(torch.uint8)).contiguous()
-    if t is m or t.data_ptr() == m.data_ptr() or t.data_ptr() % 16:
+    if t is m or (torch.is_tensor(m) and m.is_cuda and t.data_ptr() == m.data_ptr()) or t.data_ptr() % 16:
         t = t.clone()   # (never an alias of the caller's tensor: a later in-place edit must not change the cached bytes unnoticed)
     try:
-        viewpoint._lvdgs_static_mask = (m, m._version, t)
+        viewpoint._lvdgs_static_mask = (m, version, t)
     except Exception:
         pass
     return t

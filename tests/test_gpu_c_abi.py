@@ -211,6 +211,18 @@ def test_forward_batch_equals_forward_view_by_view_state_and_images():
         for k in range(V):
             compare(batch[k][1], single[k][1], counts[k])
 
+    # more views than one launch carries (ten): the call goes through them in groups, every group with its own sequence number
+    many = [view(k % V, cap) for k in range(12)]
+    for k, (a, _) in enumerate(many):   # (views k and k + 3 share a camera: the same counts and lists)
+        a.viewmatrix, a.projmatrix, a.campos = single[k % V][0].viewmatrix, single[k % V][0].projmatrix, single[k % V][0].campos
+    arr12 = (C.POINTER(_lib.Args) * 12)(*[C.pointer(a) for a, _ in many])
+    nums12 = (C.c_int64 * 12)()
+    _lib.check(L.lvdgs_forward_batch(arr12, 12, nums12, stream), "lvdgs_forward_batch (12 views)")
+    torch.cuda.synchronize()
+    assert list(nums12) == [counts[k % V] for k in range(12)]
+    for k in (0, 9, 10, 11):
+        compare(many[k][1], single[k % V][1], counts[k % V])
+
     # a view with too small a capacity: E_CAPACITY, its count reported, the other views complete
     small = counts[1] // 2
     batch = [view(k, small if k == 1 else cap) for k in range(V)]
