@@ -55,8 +55,11 @@ def main(tag, workload="cfg3_500k_1920x1080", prefix="pmc_", label=None):
         rows = [r for r in csv.DictReader(open(files[0])) if "lvdgs" in r["Kernel_Name"]]
         # bench.py's timed step launches the fused-loss instantiation of the backward blend; the run also holds the
         # autograd comparison's launches of the plain one (which reads gradient images): keep the timed kernel's only
-        if any("blend_bwd3_kernel<true" in r["Kernel_Name"] for r in rows):
-            rows = [r for r in rows if "blend_bwd3_kernel<false" not in r["Kernel_Name"]]
+        # (the first template argument: true / false until round 4, the LOSS_* code since -- 1 = fused loss, 0 = gradient images)
+        fused = ("blend_bwd3_kernel<true", "blend_bwd3_kernel<1")
+        plain = ("blend_bwd3_kernel<false", "blend_bwd3_kernel<0")
+        if any(any(f in r["Kernel_Name"] for f in fused) for r in rows):
+            rows = [r for r in rows if not any(f in r["Kernel_Name"] for f in plain)]
         name = os.path.basename(d)[len(prefix):].lower()
         with open(os.path.join(dst, f"{tag}{suffix}_pmc", f"{name}_lvdgs_kernels.csv"), "w", newline="") as f:
             w = csv.writer(f)
