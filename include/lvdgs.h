@@ -336,6 +336,19 @@ int lvdgs_pose_step_batch(const lvdgs_pose_step_args *steps, int32_t count, void
  * fine: the loss of the background image is evaluated, every Gaussian / pose gradient is zero. */
 int lvdgs_backward_fused_loss(const lvdgs_args *a, const lvdgs_loss_args *loss, int32_t propagate_opacity_grad, void *stream);
 
+/* lvdgs_forward followed by lvdgs_backward_fused_loss as ONE call (a view whose loss is the photometric one: the tracking iteration,
+ * utils/slam_frontend.py:1492-1517; a mapping view without a static mask).  Same arguments as the two calls (a->pair_capacity sizes
+ * binning_state; scratch >= max of the three scratch sizes AT the capacity: lvdgs_backward_scratch_bytes(N, pair_capacity)), same results,
+ * bit for bit.  What it buys: on frames of up to 4096 tiles the forward and the backward blend pass of a tile run in one launch -- the
+ * loss's gradient at a pixel depends on that pixel alone, so a tile's backward needs nothing but the tile's own forward -- and a frame
+ * of KITTI's size, on which each blend kernel lasts as long as its few heaviest tiles while the chip runs dry, pays that tail once
+ * (KITTI geometry, pose-only: 0.209 -> 0.19 ms per tracking iteration).  Larger frames: the two calls in turn.  Returns LVDGS_OK and
+ * the pair count, or LVDGS_E_CAPACITY (geom_state valid, everything else invalid): the caller grows binning_state / scratch and calls
+ * lvdgs_forward_render, then lvdgs_backward_fused_loss.  The per-tile partial sums of the loss and the pose-gradient partials are left
+ * for lvdgs_tracking_tail / lvdgs_map_view_tail as by lvdgs_backward_fused_loss (with a->dL_dtau == NULL). */
+int lvdgs_forward_backward_fused_loss(const lvdgs_args *a, const lvdgs_loss_args *loss, int32_t propagate_opacity_grad, int64_t *num_rendered,
+                                      void *stream);
+
 /* The blend passes of `count` views in one launch each (no counterpart upstream, which renders a mapping window's keyframes one
  * after the other: utils/slam_backend.py:175-266).  A frame of KITTI's size (1848 tiles) leaves a 256-CU chip's wave slots half
  * empty and ends in a tail of its heaviest tiles; the ten views of a mapping window together fill it (per view: forward blend

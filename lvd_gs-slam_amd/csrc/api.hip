@@ -230,8 +230,10 @@ size_t bwd_scratch_layout(int N, int64_t D, BwdScratch *v, void *base) {
     if (!v) v = &tmp;
     size_t off = 0;
     char *b = (char *)base;
-    carve(v->pair_grads, (size_t)(D > 0 ? D : 1) * PAIR_FLOATS + 8, b, off);   // (+8: the staging loads of preprocess_bwd are 16 bytes wide)
+    // (the pose-gradient partials first: their place must not depend on the pair count -- lvdgs_forward_backward_fused_loss
+    // enqueues the backward before the host knows it, and lvdgs_tracking_tail looks for them with the count the caller then has)
     carve(v->tau_part, (size_t)(cdiv(N > 0 ? N : 1, 256)) * 6, b, off);
+    carve(v->pair_grads, (size_t)(D > 0 ? D : 1) * PAIR_FLOATS + 8, b, off);   // (+8: the staging loads of preprocess_bwd are 16 bytes wide)
     return off;
 }
 
@@ -538,6 +540,70 @@ int lvdgs_forward(const lvdgs_args *a, int64_t *num_rendered, void *stream) {
     return LVDGS_OK;
 }
 
+// views_out (lvdgs_blend_backward_fused_loss_batch): the call checks its arguments, lays its buffers out and stops there
+struct BackwardViews { GeomView g; BinView b; ImageView im; BwdScratch w; };
+static int backward_impl(const lvdgs_args *a, const LossParams *fused, int propagate_opacity, hipStream_t s, BackwardViews *views_out = nullptr,
+                         const MaskedLossView *masked = nullptr) {
+    if (int e = check_common(a)) return e;
+    if (int e = check_gaussians(a)) return e;
+    const int N = a->num_gaussians, W = a->image_width, H = a->image_height;
+    const int64_t D = N == 0 ? 0 : a->num_rendered;
+    if (D < 0) { set_error("negative num_rendered"); return LVDGS_E_INVALID; }
+    if (!a->image_state || a->image_bytes < lvdgs_image_bytes(W, H)) { set_error("image_state is NULL or too small"); return LVDGS_E_INVALID; }
+    GeomView g{}; BinView b{}; ImageView im; BwdScratch w{};
+    image_layout(W, H, &im, a->image_state);
+    const bool pose_only = (a->flags & LVDGS_FLAG_POSE_ONLY) != 0;
+    if (N > 0) {
+        if ((!fused && !masked && !a->dL_dout_color) || !a->projmatrix_raw || !a->radii) { set_error("a required backward pointer is NULL"); return LVDGS_E_INVALID; }
+        if (masked && pose_only) { set_error("LVDGS_FLAG_POSE_ONLY: the static-mask mapping loss is a mapping loss, its backward makes every gradient"); return LVDGS_E_INVALID; }
+        if (pose_only) {
+            // a view-dependent colour moves with the camera centre: its gradient feeds dL/dtau (preprocess.hip), and the
+            // pose-only passes do not make it
+            if (a->shs && a->sh_degree > 0) { set_error("LVDGS_FLAG_POSE_ONLY needs sh_degree 0 or colors_precomp"); return LVDGS_E_INVALID; }
+            if (a->flags & LVDGS_FLAG_ACCUMULATE_PARAM_GRADS) { set_error("LVDGS_FLAG_POSE_ONLY writes no parameter gradients: nothing to accumulate"); return LVDGS_E_INVALID; }
+        } else {
+            if (!a->dL_dmeans3D || !a->dL_dmeans2D || !a->dL_dopacities) { set_error("a required backward pointer is NULL"); return LVDGS_E_INVALID; }
+            if (a->cov3D_precomp ? !a->dL_dcov3D : (!a->dL_dscales || !a->dL_drotations)) { set_error("covariance gradient output is NULL"); return LVDGS_E_INVALID; }
+            if (a->shs ? !a->dL_dshs : !a->dL_dcolors) { set_error("colour gradient output is NULL"); return LVDGS_E_INVALID; }
+        }
+        if (!a->geom_state || !a->scratch || (D > 0 && !a->binning_state)) { set_error("a state / scratch buffer is NULL"); return LVDGS_E_INVALID; }
+        if (a->geom_bytes < lvdgs_geom_bytes(N) || (D > 0 && a->binning_bytes < lvdgs_binning_bytes(D)) ||
+            a->scratch_bytes < lvdgs_backward_scratch_bytes(N, D)) {
+            set_error("a state / scratch buffer is too small"); return LVDGS_E_INVALID;
+        }
+        geom_layout(N, &g, a->geom_state);
+        bwd_scratch_layout(N, D, &w, a->scratch);
+        if (D > 0) bin_view(a, &b);
+    }
+    // With the loss inside, the blend pass runs even over empty lists (a view that sees nothing, an empty map): it is what
+    // evaluates the loss of the background image -- value and exposure gradients -- and no pair record is written.
+    if (views_out) { *views_out = BackwardViews{g, b, im, w}; return LVDGS_OK; }
+    if (fused) {
+        if (!(a->flags & LVDGS_FLAG_NO_BLEND))
+            if (int e = launch_blend_bwd_fused_loss(*a, g, b, im, w, *fused, propagate_opacity, s)) return e;
+    } else if (masked) {
+        if (D > 0 && !(a->flags & LVDGS_FLAG_NO_BLEND))
+            if (int e = launch_blend_bwd_masked_loss(*a, g, b, im, w, *masked, s)) return e;
+    } else if (D > 0) {
+        if (int e = launch_blend_bwd(*a, g, b, im, w, s)) return e;
+    }
+    if (N == 0) return a->dL_dtau ? check_hip(hipMemsetAsync(a->dL_dtau, 0, 6 * sizeof(float), s), "memset tau") : LVDGS_OK;
+    return launch_preprocess_bwd(*a, g, w, b.pair_valid, s);
+}
+
+int lvdgs_backward(const lvdgs_args *a, void *stream) {
+    if (a && (a->flags & LVDGS_FLAG_NO_BLEND)) { set_error("LVDGS_FLAG_NO_BLEND: only lvdgs_backward_fused_loss has a batched blend pass to leave its own to"); return LVDGS_E_INVALID; }
+    return backward_impl(a, nullptr, 0, (hipStream_t)stream);
+}
+
+int lvdgs_backward_fused_loss(const lvdgs_args *a, const lvdgs_loss_args *loss, int32_t propagate_opacity_grad, void *stream) {
+    if (!a) { set_error("backward: args is NULL"); return LVDGS_E_INVALID; }
+    LossParams lp;
+    if (int e = loss_fused_params(loss, &lp)) return e;
+    if (loss->width != a->image_width || loss->height != a->image_height) { set_error("fused loss: image size differs from the rasterizer's"); return LVDGS_E_INVALID; }
+    return backward_impl(a, &lp, propagate_opacity_grad != 0, (hipStream_t)stream);
+}
+
 // The forward passes of `count` views of one map and one image size, every stage ONE launch (include/lvdgs.h).
 int lvdgs_forward_batch(const lvdgs_args *const *views, int32_t count, int64_t *num_rendered, void *stream) {
     hipStream_t s = (hipStream_t)stream;
@@ -607,68 +673,71 @@ int lvdgs_forward_batch(const lvdgs_args *const *views, int32_t count, int64_t *
     return status;
 }
 
-// views_out (lvdgs_blend_backward_fused_loss_batch): the call checks its arguments, lays its buffers out and stops there
-struct BackwardViews { GeomView g; BinView b; ImageView im; BwdScratch w; };
-static int backward_impl(const lvdgs_args *a, const LossParams *fused, int propagate_opacity, hipStream_t s, BackwardViews *views_out = nullptr,
-                         const MaskedLossView *masked = nullptr) {
+// lvdgs_forward + lvdgs_backward_fused_loss as one call; on small grids the two blend passes are ONE launch (blend.hip:
+// blend_fwd_bwd_kernel).  Frames beyond this many tiles fill the chip in either blend kernel by themselves: the calls in turn.
+#ifndef LVDGS_FUSED_BLEND_MAX_TILES
+#define LVDGS_FUSED_BLEND_MAX_TILES 4096   // A/B builds: 0 = never
+#endif
+int lvdgs_forward_backward_fused_loss(const lvdgs_args *a, const lvdgs_loss_args *loss, int32_t propagate_opacity_grad, int64_t *num_rendered,
+                                      void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (!a || !num_rendered) { set_error("forward + backward: args / num_rendered is NULL"); return LVDGS_E_INVALID; }
     if (int e = check_common(a)) return e;
-    if (int e = check_gaussians(a)) return e;
     const int N = a->num_gaussians, W = a->image_width, H = a->image_height;
-    const int64_t D = N == 0 ? 0 : a->num_rendered;
-    if (D < 0) { set_error("negative num_rendered"); return LVDGS_E_INVALID; }
-    if (!a->image_state || a->image_bytes < lvdgs_image_bytes(W, H)) { set_error("image_state is NULL or too small"); return LVDGS_E_INVALID; }
-    GeomView g{}; BinView b{}; ImageView im; BwdScratch w{};
-    image_layout(W, H, &im, a->image_state);
-    const bool pose_only = (a->flags & LVDGS_FLAG_POSE_ONLY) != 0;
-    if (N > 0) {
-        if ((!fused && !masked && !a->dL_dout_color) || !a->projmatrix_raw || !a->radii) { set_error("a required backward pointer is NULL"); return LVDGS_E_INVALID; }
-        if (masked && pose_only) { set_error("LVDGS_FLAG_POSE_ONLY: the static-mask mapping loss is a mapping loss, its backward makes every gradient"); return LVDGS_E_INVALID; }
-        if (pose_only) {
-            // a view-dependent colour moves with the camera centre: its gradient feeds dL/dtau (preprocess.hip), and the
-            // pose-only passes do not make it
-            if (a->shs && a->sh_degree > 0) { set_error("LVDGS_FLAG_POSE_ONLY needs sh_degree 0 or colors_precomp"); return LVDGS_E_INVALID; }
-            if (a->flags & LVDGS_FLAG_ACCUMULATE_PARAM_GRADS) { set_error("LVDGS_FLAG_POSE_ONLY writes no parameter gradients: nothing to accumulate"); return LVDGS_E_INVALID; }
-        } else {
-            if (!a->dL_dmeans3D || !a->dL_dmeans2D || !a->dL_dopacities) { set_error("a required backward pointer is NULL"); return LVDGS_E_INVALID; }
-            if (a->cov3D_precomp ? !a->dL_dcov3D : (!a->dL_dscales || !a->dL_drotations)) { set_error("covariance gradient output is NULL"); return LVDGS_E_INVALID; }
-            if (a->shs ? !a->dL_dshs : !a->dL_dcolors) { set_error("colour gradient output is NULL"); return LVDGS_E_INVALID; }
-        }
-        if (!a->geom_state || !a->scratch || (D > 0 && !a->binning_state)) { set_error("a state / scratch buffer is NULL"); return LVDGS_E_INVALID; }
-        if (a->geom_bytes < lvdgs_geom_bytes(N) || (D > 0 && a->binning_bytes < lvdgs_binning_bytes(D)) ||
-            a->scratch_bytes < lvdgs_backward_scratch_bytes(N, D)) {
-            set_error("a state / scratch buffer is too small"); return LVDGS_E_INVALID;
-        }
-        geom_layout(N, &g, a->geom_state);
-        bwd_scratch_layout(N, D, &w, a->scratch);
-        if (D > 0) bin_view(a, &b);
+    const int num_tiles = cdiv(W, TILE) * cdiv(H, TILE);
+    const int64_t cap = a->pair_capacity;
+    static const bool off = getenv("LVDGS_NO_FUSED_BLEND") != nullptr;   // (test / A-B hook: the two calls in turn whatever the grid)
+    const bool fuse = !off && N > 0 && use_counting_path(num_tiles) && num_tiles <= LVDGS_FUSED_BLEND_MAX_TILES && !(a->flags & LVDGS_FLAG_NO_BLEND) &&
+                      cap > 0 && cap <= 0x7FFFFFFFll;
+    if (!fuse) {
+        if (int e = lvdgs_forward(a, num_rendered, stream)) return e;
+        lvdgs_args b = *a;
+        b.num_rendered = *num_rendered;
+        return lvdgs_backward_fused_loss(&b, loss, propagate_opacity_grad, stream);
     }
-    // With the loss inside, the blend pass runs even over empty lists (a view that sees nothing, an empty map): it is what
-    // evaluates the loss of the background image -- value and exposure gradients -- and no pair record is written.
-    if (views_out) { *views_out = BackwardViews{g, b, im, w}; return LVDGS_OK; }
-    if (fused) {
-        if (!(a->flags & LVDGS_FLAG_NO_BLEND))
-            if (int e = launch_blend_bwd_fused_loss(*a, g, b, im, w, *fused, propagate_opacity, s)) return e;
-    } else if (masked) {
-        if (D > 0 && !(a->flags & LVDGS_FLAG_NO_BLEND))
-            if (int e = launch_blend_bwd_masked_loss(*a, g, b, im, w, *masked, s)) return e;
-    } else if (D > 0) {
-        if (int e = launch_blend_bwd(*a, g, b, im, w, s)) return e;
-    }
-    if (N == 0) return a->dL_dtau ? check_hip(hipMemsetAsync(a->dL_dtau, 0, 6 * sizeof(float), s), "memset tau") : LVDGS_OK;
-    return launch_preprocess_bwd(*a, g, w, b.pair_valid, s);
-}
-
-int lvdgs_backward(const lvdgs_args *a, void *stream) {
-    if (a && (a->flags & LVDGS_FLAG_NO_BLEND)) { set_error("LVDGS_FLAG_NO_BLEND: only lvdgs_backward_fused_loss has a batched blend pass to leave its own to"); return LVDGS_E_INVALID; }
-    return backward_impl(a, nullptr, 0, (hipStream_t)stream);
-}
-
-int lvdgs_backward_fused_loss(const lvdgs_args *a, const lvdgs_loss_args *loss, int32_t propagate_opacity_grad, void *stream) {
-    if (!a) { set_error("backward: args is NULL"); return LVDGS_E_INVALID; }
+    *num_rendered = 0;
+    if (int e = check_gaussians(a)) return e;
     LossParams lp;
     if (int e = loss_fused_params(loss, &lp)) return e;
-    if (loss->width != a->image_width || loss->height != a->image_height) { set_error("fused loss: image size differs from the rasterizer's"); return LVDGS_E_INVALID; }
-    return backward_impl(a, &lp, propagate_opacity_grad != 0, (hipStream_t)stream);
+    if (loss->width != W || loss->height != H) { set_error("fused loss: image size differs from the rasterizer's"); return LVDGS_E_INVALID; }
+    if (!a->radii || !a->geom_state || !a->scratch) { set_error("radii / geom_state / scratch is NULL"); return LVDGS_E_INVALID; }
+    if (a->geom_bytes < lvdgs_geom_bytes(N) || a->scratch_bytes < lvdgs_prepare_scratch_bytes(N)) { set_error("geom_state or scratch too small"); return LVDGS_E_INVALID; }
+    if (int e = check_render_buffers(a, cap)) return e;
+    // the backward's arguments, checked with the pair CAPACITY standing in for the count (the scratch must hold that many records)
+    lvdgs_args bw = *a;
+    bw.num_rendered = cap;
+    BackwardViews v;
+    if (int e = backward_impl(&bw, &lp, propagate_opacity_grad != 0, s, &v)) return e;
+    PairProbe *probe = nullptr;
+    if (int e = get_probe(&probe)) return e;
+    GeomView g;
+    geom_layout(N, &g, a->geom_state);
+    {
+        ImageView im; RenderScratch w{};
+        image_layout(W, H, &im, a->image_state);
+        render_scratch_layout(N, cap, W, H, &w, a->scratch);
+        if (int e = launch_preprocess_count(*a, g, im, w, s)) return e;
+    }
+    probe->seq++; if (probe->seq == 0u) probe->seq = 1u;
+    lvdgs_args fw = *a;
+    fw.flags |= LVDGS_FLAG_NO_BLEND;   // (grouping and tile sort; the blend follows below, together with the backward's)
+    if (int e = enqueue_render(&fw, cap, true, s, true, probe)) return e;
+    if (int e = launch_blend_fwd_bwd_fused_loss(*a, v.g, v.b, v.im, v.w, lp, propagate_opacity_grad != 0, probe->longest > 0, s)) return e;
+    if (int e = launch_preprocess_bwd(*a, v.g, v.w, v.b.pair_valid, s)) return e;
+    if (int e = wait_for_sequence(probe)) return e;
+    const uint32_t total = probe->pinned[0];
+    {
+        const int longest = (int)probe->pinned[1], queued = (int)probe->pinned[2];
+        if (longest >= probe->longest || probe->keep == 0) { probe->longest = longest; probe->queued = queued; probe->keep = longest ? 32 : 0; }
+        else probe->keep--;
+    }
+    if (total > 0x7FFFFFFFu) { set_error("%u (Gaussian, tile) pairs exceed the 2^31 limit", total); return LVDGS_E_RANGE; }
+    *num_rendered = (int64_t)total;
+    if ((int64_t)total > cap) {
+        set_error("%u pairs exceed pair_capacity %lld: grow binning_state / scratch, then lvdgs_forward_render and lvdgs_backward_fused_loss", total, (long long)cap);
+        return LVDGS_E_CAPACITY;
+    }
+    return LVDGS_OK;
 }
 
 int lvdgs_blend_forward_batch(const lvdgs_args *const *views, int32_t count, void *stream) {

@@ -194,16 +194,21 @@ __device__ __forceinline__ int composite_one(const float4 A, const float2 B, con
 // DEEP_LISTS: a build for frames whose tile lists run to a thousand entries and more, of which the pixels composite the first
 // tenth (opaque surfaces): a quadrant looks after every batch of eight whether any of its pixels is still open.  Same results;
 // which of the two kernels runs is decided by the previous frame's longest list (a hint, api.hip).
+// The forward pass's LDS: one object, so that the three reads of a survivor share one address register; laid out so that they are
+// a 16-, an 8- and a 16-byte read (4 + 2 + 4 LDS cycles per wave; a 12-byte read alone costs 8).  (A type of its own since round 5:
+// the kernel that runs the forward and the backward pass of a tile in one launch overlays it with the backward pass's.)
+struct FwdShared {
+    float4 a[256], b[256], c[256];
+    float d[256];
+    int touch[256];   // pixels of this tile each staged Gaussian "touched" (T after it > 0.5)
+};
 template <bool DEEP_LISTS>
-__device__ __forceinline__ void blend_fwd2_body(const BlendParams &p) {
-    // one shared object, so that the three reads of a survivor share one address register; laid out so that they are
-    // a 16-, an 8- and a 16-byte read (4 + 2 + 4 LDS cycles per wave; a 12-byte read alone costs 8)
-    __shared__ struct { float4 a[256], b[256], c[256]; float d[256]; } s_recs;
+__device__ __forceinline__ void blend_fwd2_body(const BlendParams &p, FwdShared &s_recs) {
     float4 *const s_a = s_recs.a;  // x, y, -a/2*log2e, -b*log2e
     float4 *const s_b = s_recs.b;  // -c/2*log2e, opacity | raw conic a, b (for the quadrant test; survivors read the first half only)
     float4 *const s_c = s_recs.c;  // r, g, b, depth
     float *const s_d = s_recs.d;   // raw conic c
-    __shared__ int s_touch[256]; // pixels of this tile each staged Gaussian "touched" (T after it > 0.5)
+    int *const s_touch = s_recs.touch;
 
 #ifdef LVDGS_DIAG_REPEAT   // diagnostic build: the grid repeated $LVDGS_DIAG_REPEAT times (what a launch over several views of this size would cost)
     const int diag_b = (int)blockIdx.x % p.num_tiles;
@@ -318,8 +323,8 @@ __device__ __forceinline__ void blend_fwd2_body(const BlendParams &p) {
     }
 }
 
-__global__ void __launch_bounds__(256) blend_fwd2_kernel(BlendParams p) { blend_fwd2_body<false>(p); }
-__global__ void __launch_bounds__(256, 8) blend_fwd2_deep_kernel(BlendParams p) { blend_fwd2_body<true>(p); }
+__global__ void __launch_bounds__(256) blend_fwd2_kernel(BlendParams p) { __shared__ FwdShared s; blend_fwd2_body<false>(p, s); }
+__global__ void __launch_bounds__(256, 8) blend_fwd2_deep_kernel(BlendParams p) { __shared__ FwdShared s; blend_fwd2_body<true>(p, s); }
 // Several views of one size in ONE launch (lvdgs_blend_forward_batch: the views of a mapping window): blockIdx.y picks the view.
 // A KITTI-size frame leaves the chip's wave slots half empty and ends in a tail of its heaviest tiles; ten of them fill it
 // (per view 54 -> 34 us, blend_bwd 105 -> 77: LVDGS_DIAG_REPEAT builds).  Up to BATCH_VIEWS argument blocks travel as the kernel's
@@ -327,8 +332,8 @@ __global__ void __launch_bounds__(256, 8) blend_fwd2_deep_kernel(BlendParams p) 
 constexpr int BATCH_VIEWS = 11;
 struct BlendBatch { BlendParams v[BATCH_VIEWS]; };
 static_assert(sizeof(BlendBatch) <= 4096, "kernel arguments");
-__global__ void __launch_bounds__(256) blend_fwd2_batch_kernel(BlendBatch b) { blend_fwd2_body<false>(b.v[blockIdx.y]); }
-__global__ void __launch_bounds__(256, 8) blend_fwd2_deep_batch_kernel(BlendBatch b) { blend_fwd2_body<true>(b.v[blockIdx.y]); }
+__global__ void __launch_bounds__(256) blend_fwd2_batch_kernel(BlendBatch b) { __shared__ FwdShared s; blend_fwd2_body<false>(b.v[blockIdx.y], s); }
+__global__ void __launch_bounds__(256, 8) blend_fwd2_deep_batch_kernel(BlendBatch b) { __shared__ FwdShared s; blend_fwd2_body<true>(b.v[blockIdx.y], s); }
 
 // ------------------------------------------------------------------------------------------
 constexpr int ACC_STRIDE = 10;  // floats per (wave, entry) accumulator slot
@@ -408,12 +413,11 @@ struct Bwd3Shared {
 #define LVDGS_BWD_WGS_POSE 7   // ... and its pose-only form (18.2 KB of LDS, 74 VGPRs; 26.4 KB with a depth gradient: six). Same box, config 3 / KITTI geometry: 5: 240.9 / 92.0 us, 6: 240.4 / 92.1, 7: 233.7 / 92.6, 8: 233.6 / 95.8
 #endif
 template <int LOSS, bool DEPTH_GRAD, bool POSE_ONLY>
-__device__ __forceinline__ void blend_bwd3_body(const BlendParams &p) {
+__device__ __forceinline__ void blend_bwd3_body(const BlendParams &p, Bwd3Shared<POSE_ONLY, DEPTH_GRAD> &sh) {
     using Shared = Bwd3Shared<POSE_ONLY, DEPTH_GRAD>;
     constexpr int NB = Shared::NB, ACC = Shared::ACC;
     constexpr bool U_ONLY = POSE_ONLY && !DEPTH_GRAD;   // the matrix holds u alone
     using MT = typename Shared::MT;
-    __shared__ Shared sh;
 
 #ifdef LVDGS_DIAG_REPEAT   // diagnostic build: the grid repeated $LVDGS_DIAG_REPEAT times (what a launch over several views of this size would cost)
     const int diag_b = (int)blockIdx.x % p.num_tiles;
@@ -743,12 +747,32 @@ __device__ __forceinline__ void blend_bwd3_body(const BlendParams &p) {
 
 template <int LOSS, bool DEPTH_GRAD = true, bool POSE_ONLY = false>
 __global__ void __launch_bounds__(256, POSE_ONLY ? (DEPTH_GRAD ? 6 : LVDGS_BWD_WGS_POSE) : LVDGS_BWD_WGS) blend_bwd3_kernel(BlendParams p) {
-    blend_bwd3_body<LOSS, DEPTH_GRAD, POSE_ONLY>(p);
+    __shared__ Bwd3Shared<POSE_ONLY, DEPTH_GRAD> sh;
+    blend_bwd3_body<LOSS, DEPTH_GRAD, POSE_ONLY>(p, sh);
 }
 // several views in one launch (blockIdx.y: the view), the loss in the prologue
 template <int LOSS, bool DEPTH_GRAD, bool POSE_ONLY>
 __global__ void __launch_bounds__(256, POSE_ONLY ? (DEPTH_GRAD ? 6 : LVDGS_BWD_WGS_POSE) : LVDGS_BWD_WGS) blend_bwd3_batch_kernel(BlendBatch b) {
-    blend_bwd3_body<LOSS, DEPTH_GRAD, POSE_ONLY>(b.v[blockIdx.y]);
+    __shared__ Bwd3Shared<POSE_ONLY, DEPTH_GRAD> sh;
+    blend_bwd3_body<LOSS, DEPTH_GRAD, POSE_ONLY>(b.v[blockIdx.y], sh);
+}
+
+// ------------------------------------------------------------------------------------------
+// The forward AND the backward blend pass of a tile in ONE launch (lvdgs_forward_backward_fused_loss: a view whose loss is the
+// photometric one, evaluated per pixel -- the tracking iteration, a mapping view without a static mask).  Everything the backward
+// pass of a tile reads of the forward pass is that tile's own: its pixels' colour / depth / opacity, final transmittance and last
+// contributor, and the loss's gradient at a pixel depends on that pixel alone.  On a small grid (a KITTI frame: 1848 tiles for
+// 1280-2048 workgroup places) each of the two kernels lasts as long as its heaviest tiles -- 41 and 75 us of the 54 and 105 the
+// whole frame takes -- while most of the chip has run dry: one launch pays that tail once, and the light tiles' workgroups are
+// through both passes while the heavy ones are still in their first.  The two passes are the bodies above, one after the other;
+// their LDS is overlaid; a thread reads back only what it wrote itself (the same thread -> pixel mapping in both passes).
+template <bool DEPTH_GRAD, bool POSE_ONLY, bool DEEP_LISTS>
+__global__ void __launch_bounds__(256, POSE_ONLY ? (DEPTH_GRAD ? 6 : LVDGS_BWD_WGS_POSE) : LVDGS_BWD_WGS) blend_fwd_bwd_kernel(BlendParams p) {
+    __shared__ union U { FwdShared f; Bwd3Shared<POSE_ONLY, DEPTH_GRAD> b; __device__ U() {} } u;
+    blend_fwd2_body<DEEP_LISTS>(p, u.f);
+    __threadfence_block();
+    __syncthreads();   // (every wave is through with the forward pass's LDS)
+    blend_bwd3_body<LOSS_FUSED, DEPTH_GRAD, POSE_ONLY>(p, u.b);
 }
 
 BlendParams make_params(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im) {
@@ -853,6 +877,31 @@ int launch_blend_bwd_masked_loss(const lvdgs_args &a, const GeomView &g, const B
     if (LVDGS_BWD_DEPTH_ALWAYS || m.gt_depth) hipLaunchKernelGGL((blend_bwd3_kernel<LOSS_MASKED, true>), dim3(p.num_tiles), dim3(256), 0, s, p);
     else hipLaunchKernelGGL((blend_bwd3_kernel<LOSS_MASKED, false>), dim3(p.num_tiles), dim3(256), 0, s, p);
     LVDGS_LAUNCH_CHECK("blend_bwd (masked loss)", a.debug, s);
+    return LVDGS_OK;
+}
+
+// One launch for both blend passes of a view (api.hip: lvdgs_forward_backward_fused_loss decides when).
+int launch_blend_fwd_bwd_fused_loss(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, const BwdScratch &w,
+                                    const LossParams &loss, int propagate_opacity, bool deep_lists, hipStream_t s) {
+    BlendParams p = make_params(a, g, b, im);
+    p.pair_grads = w.pair_grads; p.pair_valid = b.pair_valid;
+    p.loss = loss; p.loss_mode = LOSS_FUSED;
+    p.loss_propagate_opacity = propagate_opacity;
+    if (p.num_tiles == 0) return LVDGS_OK;
+    ProfScope ps("blend_fwd_bwd", s);
+    const dim3 grid(p.num_tiles), block(256);
+    const bool depth = LVDGS_BWD_DEPTH_ALWAYS || (loss.depth && loss.gt_depth && loss.w_d != 0.f), pose_only = (a.flags & LVDGS_FLAG_POSE_ONLY) != 0;
+#define LVDGS_FUSED_LAUNCH(D, PO)                                                                                        \
+    do {                                                                                                                \
+        if (deep_lists) hipLaunchKernelGGL((blend_fwd_bwd_kernel<D, PO, true>), grid, block, 0, s, p);                  \
+        else hipLaunchKernelGGL((blend_fwd_bwd_kernel<D, PO, false>), grid, block, 0, s, p);                            \
+    } while (0)
+    if (pose_only && depth) LVDGS_FUSED_LAUNCH(true, true);
+    else if (pose_only) LVDGS_FUSED_LAUNCH(false, true);
+    else if (depth) LVDGS_FUSED_LAUNCH(true, false);
+    else LVDGS_FUSED_LAUNCH(false, false);
+#undef LVDGS_FUSED_LAUNCH
+    LVDGS_LAUNCH_CHECK("blend_fwd_bwd", a.debug, s);
     return LVDGS_OK;
 }
 

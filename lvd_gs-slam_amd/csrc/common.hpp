@@ -307,6 +307,8 @@ int launch_tile_ranges(const uint32_t *tile_keys, int64_t D, const uint32_t *D_d
 int launch_blend_fwd(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, bool deep_lists, hipStream_t s);   // deep_lists: a hint (which build of the kernel), never a result
 struct LossParams;
 int launch_blend_fwd_batch(const lvdgs_args *const *a, const GeomView *g, const BinView *b, const ImageView *im, int n, bool deep_lists, hipStream_t s);
+int launch_blend_fwd_bwd_fused_loss(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, const BwdScratch &w,
+                                    const LossParams &loss, int propagate_opacity, bool deep_lists, hipStream_t s);
 // The static-mask mapping loss of one view as the backward blend pass reads it (lvdgs_masked_loss_args, checked by api.hip).
 struct MaskedLossView {
     const float *d_image;        // 3*P: d loss / d colour, written by lvdgs_masked_loss_batch

@@ -202,18 +202,20 @@ class TrackingSession:
         with _lib.on_device(self.dev):
             stream = _lib.raw_stream(self.dev)
             num = C.c_int64(0)
-            status = L.lvdgs_forward(C.byref(a), C.byref(num), stream)
+            # forward and backward as one call: the backward evaluates the loss's image gradients as it reads its pixels (the
+            # objective is the loss: d/d loss = 1), and on small grids the two blend passes of a tile share a launch
+            # (lvdgs_forward_backward_fused_loss); the loss's final reduction, the pose gradient's and the pose step share the
+            # iteration's last launch
+            status = L.lvdgs_forward_backward_fused_loss(C.byref(a), C.byref(self.la), int(_rz.PROPAGATE_OPACITY_GRAD), C.byref(num), stream)
             D = int(num.value)
-            if status == _lib.E_CAPACITY:   # more pairs than the buffers hold: grow them and redo binning + blend
+            if status == _lib.E_CAPACITY:   # more pairs than the buffers hold: grow them and redo binning + blend, then the backward
                 self._size_for_pairs(D + D // 2)
                 a.num_rendered = D
                 _lib.check(L.lvdgs_forward_render(C.byref(a), stream), "lvdgs_forward_render")
+                _lib.check(L.lvdgs_backward_fused_loss(C.byref(a), C.byref(self.la), int(_rz.PROPAGATE_OPACITY_GRAD), stream), "lvdgs_backward_fused_loss")
             else:
-                _lib.check(status, "lvdgs_forward")
+                _lib.check(status, "lvdgs_forward_backward_fused_loss")
             self.num_rendered = a.num_rendered = D
-            # the backward evaluates the loss's image gradients as it reads its pixels (the objective is the loss: d/d loss
-            # = 1); the loss's final reduction, the pose gradient's and the pose step share the iteration's last launch
-            _lib.check(L.lvdgs_backward_fused_loss(C.byref(a), C.byref(self.la), int(_rz.PROPAGATE_OPACITY_GRAD), stream), "lvdgs_backward_fused_loss")
             _lib.check(L.lvdgs_tracking_tail(C.byref(self.la), C.byref(a), C.byref(self.pa), _P(self.d_tau), 1, stream), "lvdgs_tracking_tail")
             if record_loss is not None:
                 record_loss.copy_(self.loss)

@@ -639,3 +639,53 @@ def test_a_view_that_sees_nothing_tracks_and_maps_like_the_autograd_path():
     torch.testing.assert_close(got_pose[2], cam.exposure_a.grad, rtol=2e-5, atol=1e-9)
     torch.testing.assert_close(got_pose[3], cam.exposure_b.grad, rtol=2e-5, atol=1e-9)
     assert int(pkg["n_touched"].sum()) == 0 and not pkg["visibility_filter"].any()
+
+
+@pytest.mark.parametrize("workload,full", [("kitti07_geom", False), ("kitti07_geom", True), ("surface_12k_640x480", False), ("cfg3_500k_1920x1080", False)])
+def test_forward_and_backward_in_one_call_are_the_two_calls_bit_for_bit(workload, full):
+    """lvdgs_forward_backward_fused_loss -- on frames of up to 4096 tiles the forward and the backward blend pass of a tile in ONE launch
+    (blend_fwd_bwd_kernel) -- against lvdgs_forward followed by lvdgs_backward_fused_loss: images, counters, the image state, every
+    gradient, the loss and the stepped pose over three iterations, bit for bit; pose-only and full backward, a scene of deep lists
+    (the deep-lists build of the forward pass, queued tile-sort segments), and a frame too large to fuse (the calls in turn inside)."""
+    import ctypes as C
+    import bench
+    from types import SimpleNamespace
+    from lvdgs import _lib, rasterizer as _rz
+    from lvdgs.fast_tracking import TrackingSession
+    dev = torch.device("cuda", 0)
+    pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False)
+    out = []
+    for one_call in (True, False):
+        model, cam, _, (N, W, H) = bench.build_scene(workload, 0, dev)
+        s = TrackingSession(cam, model, bench.CONFIG, pipe, torch.zeros(3, device=dev), gaussian_gradients=full)
+        snaps = []
+        for it in range(3):
+            if one_call:
+                s.step()
+            else:   # the two calls, then the tail, as TrackingSession.step did until round 4
+                L, a = s.L, s.a
+                stream = _lib.raw_stream(dev)
+                num = C.c_int64(0)
+                _lib.check(L.lvdgs_forward(C.byref(a), C.byref(num), stream), "lvdgs_forward")
+                s.num_rendered = a.num_rendered = int(num.value)
+                _lib.check(L.lvdgs_backward_fused_loss(C.byref(a), C.byref(s.la), int(_rz.PROPAGATE_OPACITY_GRAD), stream), "lvdgs_backward_fused_loss")
+                _lib.check(L.lvdgs_tracking_tail(C.byref(s.la), C.byref(a), C.byref(s.pa), C.c_void_p(s.d_tau.data_ptr()), 1, stream), "lvdgs_tracking_tail")
+                s.iterations_enqueued += 1
+            torch.cuda.synchronize()
+            lay = _lib.StateLayout()
+            s.L.lvdgs_state_layout_query(N, int(s.num_rendered), W, H, C.byref(lay))
+            T_, P_ = ((W + 15) // 16) * ((H + 15) // 16), W * H
+            img = s.image   # (ranges, final_T, n_contrib: the parts of the image state that are results; the rest is the tile sort's queue and padding)
+            snap = dict(color=s.color.clone(), depth=s.depth.clone(), opacity=s.opacity.clone(), radii=s.radii.clone(), n_touched=s.n_touched.clone(),
+                        ranges=img[lay.img_ranges:lay.img_ranges + 8 * T_].clone(), final_T=img[lay.img_final_T:lay.img_final_T + 4 * P_].clone(),
+                        n_contrib=img[lay.img_n_contrib:lay.img_n_contrib + 4 * P_].clone(), d_tau=s.d_tau.clone(), loss=s.loss.clone(), d_a=s.d_a.clone(), d_b=s.d_b.clone(), R=s.R.clone(), T=s.T.clone(),
+                        D=torch.tensor(int(s.num_rendered)))
+            if full:
+                snap.update(d_m3=s.d_m3.clone(), d_m2=s.d_m2.clone(), d_op=s.d_op.clone(), d_sc=s.d_sc.clone(), d_rot=s.d_rot.clone(), d_sh=s.d_sh.clone())
+            snaps.append(snap)
+        s.finish()
+        out.append(snaps)
+    for it, (a, b) in enumerate(zip(*out)):
+        for k in a:
+            assert torch.equal(a[k], b[k]), (it, k)
+        assert float(a["d_tau"].abs().sum()) > 0 and int(a["D"]) > 1000
