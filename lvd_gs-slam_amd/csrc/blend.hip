@@ -524,11 +524,19 @@ __device__ __forceinline__ void blend_bwd3_body(const BlendParams &p, Bwd3Shared
 #ifdef LVDGS_DIAG_PHASES
     ph_mark(0);
 #endif
+    // The id a staging thread gathers its record with is requested a round AHEAD (round 5): a round's staging is two dependent trips to
+    // memory -- the id, then the record -- in front of a barrier the whole workgroup waits at, and on a small grid the kernel lasts as
+    // long as its longest list's chain of rounds (a KITTI frame's heaviest tile: 14 rounds), with nobody else on the CU to hide them.
+#ifndef LVDGS_BWD_ID_AHEAD
+#define LVDGS_BWD_ID_AHEAD 1   // A/B builds: 0 = the id is loaded in the round that stages it
+#endif
+    uint32_t id_ahead = 0u;
+    if (LVDGS_BWD_ID_AHEAD && rounds > 0 && tid < min(BR, todo - (rounds - 1) * BR)) id_ahead = p.point_list[range.x + (rounds - 1) * BR + tid];
     for (int r = rounds - 1; r >= 0; r--) {
         const int base = r * BR;
         const int cnt = min(BR, todo - base);
         if (tid < cnt) {
-            const uint32_t id = p.point_list[range.x + base + tid];
+            const uint32_t id = LVDGS_BWD_ID_AHEAD ? id_ahead : p.point_list[range.x + base + tid];
             const float4 *r4 = reinterpret_cast<const float4 *>(p.rec + (size_t)id * REC_FLOATS);
             const float4 r0 = r4[0], r1 = r4[1], r2 = r4[2];
             sh.a[tid] = r0;
@@ -538,6 +546,7 @@ __device__ __forceinline__ void blend_bwd3_body(const BlendParams &p, Bwd3Shared
             sh.slot[tid] = pair_slot(p, id, tx, ty);
         }
         __syncthreads();
+        if (LVDGS_BWD_ID_AHEAD && r > 0 && tid < BR) id_ahead = p.point_list[range.x + base - BR + tid];   // (every round but the last listed is full)
 #ifdef LVDGS_DIAG_PHASES
         ph_mark(1); ph[5]++;
 #endif
