@@ -722,8 +722,9 @@ int lvdgs_forward_backward_fused_loss(const lvdgs_args *a, const lvdgs_loss_args
     lvdgs_args fw = *a;
     fw.flags |= LVDGS_FLAG_NO_BLEND;   // (grouping and tile sort; the blend follows below, together with the backward's)
     if (int e = enqueue_render(&fw, cap, true, s, true, probe)) return e;
-    if (int e = launch_blend_fwd_bwd_fused_loss(*a, v.g, v.b, v.im, v.w, lp, propagate_opacity_grad != 0, probe->longest > 0, s)) return e;
-    if (int e = launch_preprocess_bwd(*a, v.g, v.w, v.b.pair_valid, s)) return e;
+    // (both halves of the backward look at the frame's pair count on the device and stand down when it exceeds the capacity)
+    if (int e = launch_blend_fwd_bwd_fused_loss(*a, v.g, v.b, v.im, v.w, lp, propagate_opacity_grad != 0, probe->longest > 0, g.total, (uint32_t)cap, s)) return e;
+    if (int e = launch_preprocess_bwd(*a, v.g, v.w, v.b.pair_valid, s, g.total, (uint32_t)cap)) return e;
     if (int e = wait_for_sequence(probe)) return e;
     const uint32_t total = probe->pinned[0];
     {

@@ -66,6 +66,11 @@ struct BlendParams {
     // evaluated per pixel from loss.depth (rendered), loss.gt_depth (mono depth), loss.grad_mask (static mask), loss.w_d
     // (depth_lambda) and loss.grad_out[4] (|M|, finished by that call)
     int loss_mode;               // LOSS_FUSED or LOSS_MASKED: which of the two this VIEW takes in a launch compiled for LOSS_PER_VIEW
+    // blend_fwd_bwd_kernel (forward and backward in one launch, enqueued before the host knows the pair count): the frame's count as the
+    // tile scan left it and the capacity the record buffer was sized for -- beyond it the backward half is left out (its slots
+    // would lie outside the buffer; the caller re-runs both passes with room)
+    const uint32_t *pair_total;
+    uint32_t pair_capacity;
 };
 // where the backward blend pass takes dL/d(colour, depth, opacity) of its pixels from
 constexpr int LOSS_IMAGES = 0;    // gradient images (lvdgs_backward)
@@ -779,6 +784,7 @@ template <bool DEPTH_GRAD, bool POSE_ONLY, bool DEEP_LISTS>
 __global__ void __launch_bounds__(256, POSE_ONLY ? (DEPTH_GRAD ? 6 : LVDGS_BWD_WGS_POSE) : LVDGS_BWD_WGS) blend_fwd_bwd_kernel(BlendParams p) {
     __shared__ union U { FwdShared f; Bwd3Shared<POSE_ONLY, DEPTH_GRAD> b; __device__ U() {} } u;
     blend_fwd2_body<DEEP_LISTS>(p, u.f);
+    if (p.pair_total && *p.pair_total > p.pair_capacity) return;   // (uniform: the forward's outputs are invalid too, the caller knows)
     __threadfence_block();
     __syncthreads();   // (every wave is through with the forward pass's LDS)
     blend_bwd3_body<LOSS_FUSED, DEPTH_GRAD, POSE_ONLY>(p, u.b);
@@ -891,9 +897,11 @@ int launch_blend_bwd_masked_loss(const lvdgs_args &a, const GeomView &g, const B
 
 // One launch for both blend passes of a view (api.hip: lvdgs_forward_backward_fused_loss decides when).
 int launch_blend_fwd_bwd_fused_loss(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, const BwdScratch &w,
-                                    const LossParams &loss, int propagate_opacity, bool deep_lists, hipStream_t s) {
+                                    const LossParams &loss, int propagate_opacity, bool deep_lists, const uint32_t *pair_total, uint32_t pair_capacity,
+                                    hipStream_t s) {
     BlendParams p = make_params(a, g, b, im);
     p.pair_grads = w.pair_grads; p.pair_valid = b.pair_valid;
+    p.pair_total = pair_total; p.pair_capacity = pair_capacity;
     p.loss = loss; p.loss_mode = LOSS_FUSED;
     p.loss_propagate_opacity = propagate_opacity;
     if (p.num_tiles == 0) return LVDGS_OK;

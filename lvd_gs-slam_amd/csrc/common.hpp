@@ -237,7 +237,9 @@ int tile_sort_bits(int W, int H);  // number of key bits to sort for the tile id
 
 // ---- launchers (one per kernel family; all enqueue on `stream` and return a status) ----
 int launch_preprocess_fwd(const lvdgs_args &a, const GeomView &g, uint32_t *blocksums /* one per 256 Gaussians */, hipStream_t s);
-int launch_preprocess_bwd(const lvdgs_args &a, const GeomView &g, const BwdScratch &b, const uint8_t *pair_valid, hipStream_t s);
+// pair_total / pair_capacity (lvdgs_forward_backward_fused_loss): the pass does nothing when *pair_total exceeds the capacity
+int launch_preprocess_bwd(const lvdgs_args &a, const GeomView &g, const BwdScratch &b, const uint8_t *pair_valid, hipStream_t s,
+                          const uint32_t *pair_total = nullptr, uint32_t pair_capacity = 0);
 int launch_mark_visible(int N, const float *means3D, const float *view, uint8_t *present, hipStream_t s);
 
 // stable LSD radix sort of (key, val) pairs on key bits [0, total_bits); result lands in
@@ -308,7 +310,8 @@ int launch_blend_fwd(const lvdgs_args &a, const GeomView &g, const BinView &b, c
 struct LossParams;
 int launch_blend_fwd_batch(const lvdgs_args *const *a, const GeomView *g, const BinView *b, const ImageView *im, int n, bool deep_lists, hipStream_t s);
 int launch_blend_fwd_bwd_fused_loss(const lvdgs_args &a, const GeomView &g, const BinView &b, const ImageView &im, const BwdScratch &w,
-                                    const LossParams &loss, int propagate_opacity, bool deep_lists, hipStream_t s);
+                                    const LossParams &loss, int propagate_opacity, bool deep_lists, const uint32_t *pair_total, uint32_t pair_capacity,
+                                    hipStream_t s);
 // The static-mask mapping loss of one view as the backward blend pass reads it (lvdgs_masked_loss_args, checked by api.hip).
 struct MaskedLossView {
     const float *d_image;        // 3*P: d loss / d colour, written by lvdgs_masked_loss_batch

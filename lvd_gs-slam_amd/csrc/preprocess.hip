@@ -426,6 +426,11 @@ struct BwdParams {
     float *dmeans3D, *dmeans2D, *dopac, *dscales, *drot, *dcov3D, *dshs, *dcolors;
     float *tau_part;
     int accumulate;   // LVDGS_FLAG_ACCUMULATE_PARAM_GRADS: the parameter gradients are added to what their buffers hold
+    // lvdgs_forward_backward_fused_loss enqueues this pass before the host knows the frame's pair count: when the count (left on the
+    // device by the tile scan) exceeds the capacity the buffers were sized for, the pass does NOTHING -- its slots would lie beyond
+    // the record buffer -- and the caller runs the backward again behind a forward with room.  Null: no such check.
+    const uint32_t *pair_total;
+    uint32_t pair_capacity;
 };
 
 #ifndef LVDGS_WAVE_CHUNK
@@ -619,6 +624,7 @@ template <bool POSE_ONLY>
 __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p) {
     constexpr int PF = POSE_ONLY ? PAIR_FLOATS_POSE : PAIR_FLOATS;   // floats per pair record
     __shared__ float s_tau[4][6];
+    if (p.pair_total && *p.pair_total > p.pair_capacity) return;   // (uniform over the launch)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const Cam &c = p.cam;
     // The camera's matrices, read once into scalar registers (the compiler reads them with vector loads where they are
@@ -1106,7 +1112,8 @@ int launch_preprocess_count_batch(const lvdgs_args *const *a, const GeomView *g,
     return LVDGS_OK;
 }
 
-int launch_preprocess_bwd(const lvdgs_args &a, const GeomView &g, const BwdScratch &b, const uint8_t *pair_valid, hipStream_t s) {
+int launch_preprocess_bwd(const lvdgs_args &a, const GeomView &g, const BwdScratch &b, const uint8_t *pair_valid, hipStream_t s,
+                          const uint32_t *pair_total, uint32_t pair_capacity) {
     const int N = a.num_gaussians;
     const int nblk = cdiv(N, 256);
     if (N > 0) {
@@ -1118,6 +1125,7 @@ int launch_preprocess_bwd(const lvdgs_args &a, const GeomView &g, const BwdScrat
         p.dmeans3D = a.dL_dmeans3D; p.dmeans2D = a.dL_dmeans2D; p.dopac = a.dL_dopacities; p.dscales = a.dL_dscales;
         p.drot = a.dL_drotations; p.dcov3D = a.cov3D_precomp ? a.dL_dcov3D : nullptr; p.dshs = a.dL_dshs;
         p.dcolors = a.dL_dcolors; p.tau_part = b.tau_part; p.accumulate = (a.flags & LVDGS_FLAG_ACCUMULATE_PARAM_GRADS) ? 1 : 0;
+        p.pair_total = pair_total; p.pair_capacity = pair_capacity;
         ProfScope ps("preprocess_bwd", s);
         if (a.flags & LVDGS_FLAG_POSE_ONLY) hipLaunchKernelGGL(preprocess_bwd_pose_kernel, dim3(nblk), dim3(256), 0, s, p);
         else hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(256), 0, s, p);

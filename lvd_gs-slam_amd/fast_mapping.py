@@ -283,14 +283,20 @@ class MapViewPass:
         with _lib.on_device(dev):
             stream = _lib.raw_stream(dev)
             num = C.c_int64(0)
-            status = L.lvdgs_forward(C.byref(a), C.byref(num), stream)
+            # the built-in loss: forward and backward as one call (on small frames and bands the two blend passes of a tile share a
+            # launch, lvdgs_forward_backward_fused_loss); a loss that needs the whole image first: the forward alone
+            together = image_loss is None and masked_loss is None
+            status = (L.lvdgs_forward_backward_fused_loss(C.byref(a), C.byref(la), 0, C.byref(num), stream) if together
+                      else L.lvdgs_forward(C.byref(a), C.byref(num), stream))
             D = int(num.value)
             if status == _lib.E_CAPACITY:   # more pairs than the buffers hold: grow them and redo binning + blend
                 self._size_for_pairs(D + D // 2)
                 a.num_rendered = D
                 _lib.check(L.lvdgs_forward_render(C.byref(a), stream), "lvdgs_forward_render")
+                if together:
+                    _lib.check(L.lvdgs_backward_fused_loss(C.byref(a), C.byref(la), 0, stream), "lvdgs_backward_fused_loss")
             else:
-                _lib.check(status, "lvdgs_forward")
+                _lib.check(status, "lvdgs_forward_backward_fused_loss" if together else "lvdgs_forward")
             a.num_rendered = D
             if masked_loss is not None:
                 ml = self.ml
@@ -305,7 +311,6 @@ class MapViewPass:
                     _lib.check(L.lvdgs_tracking_tail(None, C.byref(a), None, _P(d_tau), 1, stream), "lvdgs_tracking_tail")
                 initialization = True   # no exposure gradients from this loss
             elif image_loss is None:
-                _lib.check(L.lvdgs_backward_fused_loss(C.byref(a), C.byref(la), 0, stream), "lvdgs_backward_fused_loss")
                 if stats is not None:
                     sa = _lib.ViewStatsArgs()
                     sa.radii_max, sa.norm_sum, sa.vis_count, sa.touched_row, sa.split_xy = (_P(t) for t in stats)

@@ -689,3 +689,15 @@ def test_forward_and_backward_in_one_call_are_the_two_calls_bit_for_bit(workload
         for k in a:
             assert torch.equal(a[k], b[k]), (it, k)
         assert float(a["d_tau"].abs().sum()) > 0 and int(a["D"]) > 1000
+    # a session whose buffers are too small for the frame: the call reports LVDGS_E_CAPACITY with BOTH passes already enqueued -- the
+    # backward half must have stood down on the device (its record slots lie beyond the buffer) -- and the step re-runs them with room
+    model, cam, _, (N, W, H) = bench.build_scene(workload, 0, dev)
+    s = TrackingSession(cam, model, bench.CONFIG, pipe, torch.zeros(3, device=dev), gaussian_gradients=full)
+    s._size_for_pairs(1000)
+    s.step()
+    torch.cuda.synchronize()
+    first = out[0][0]
+    assert s.a.pair_capacity > 1000 and int(s.num_rendered) == int(first["D"])
+    for k, t in (("color", s.color), ("d_tau", s.d_tau), ("loss", s.loss), ("R", s.R), ("T", s.T), ("n_touched", s.n_touched)):
+        assert torch.equal(t, first[k]), k
+    s.finish()
