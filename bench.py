@@ -488,7 +488,7 @@ def main():
             "config": {"workload": args.workload, "gaussians": N, "width": W, "height": H, "visible": stats["V"],
                        "pairs": stats["D"], "sh_degree": 0,
                        "step": (("tracking iteration of slam_loops.track_frame on a TrackingSession: render + get_loss_tracking + backward "
-                                 "(pose + all Gaussian grads) + pose optimiser step (Adam, SE(3) retraction, camera matrices) -- three C-ABI calls: lvdgs_forward, lvdgs_backward_fused_loss, lvdgs_tracking_tail"
+                                 "(pose + all Gaussian grads) + pose optimiser step (Adam, SE(3) retraction, camera matrices) -- two C-ABI calls: lvdgs_forward_backward_fused_loss (= lvdgs_forward then lvdgs_backward_fused_loss; one blend launch for both passes on frames of up to 4096 tiles, not at this size), lvdgs_tracking_tail"
                                  if session is not None else
                                  "tracking iteration through the autograd API: render() + get_loss_tracking + backward (pose + all Gaussian grads)")
                                 if tracking else
