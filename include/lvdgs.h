@@ -396,6 +396,12 @@ typedef struct lvdgs_view_stats_args {
     float *split_xy;      /* N*2 or NULL */
 } lvdgs_view_stats_args;
 int lvdgs_map_view_tail(const lvdgs_loss_args *loss, const lvdgs_args *bwd, float *dL_dtau, const lvdgs_view_stats_args *stats, void *stream);
+/* lvdgs_map_view_tail for `count` views in ONE launch (a mapping window whose views were rendered and differentiated together:
+ * lvdgs_forward_batch ... ): losses[k] may be NULL as above (losses itself too: no view has a loss block), stats[k] is required.  The
+ * statistics are taken per Gaussian over the views IN ORDER: radii_max / norm_sum / vis_count receive what `count` single calls in
+ * that order give them, bit for bit. */
+int lvdgs_map_view_tail_batch(const lvdgs_loss_args *const *losses, const lvdgs_args *const *bwds, float *const *dL_dtau,
+                              const lvdgs_view_stats_args *const *stats, int32_t count, void *stream);
 
 /* ---- Adam step of the Gaussian map (reference utils/slam_backend.py:144, :378, :458: gaussians.optimizer.step()) ----
  * All parameter tensors in one launch, one pass over (grad, exp_avg, exp_avg_sq, param); torch.optim.Adam's arithmetic

@@ -452,8 +452,21 @@ class MapWindowBatch:
                 _lib.check(L.lvdgs_blend_backward_window_batch(views, losses, per_view, n, 0, stream), "lvdgs_blend_backward_window_batch")
             else:
                 _lib.check(L.lvdgs_blend_backward_fused_loss_batch(views, losses, n, 0, stream), "lvdgs_blend_backward_fused_loss_batch")
+            # the per-Gaussian passes view after view (they add to one set of gradients, in the window's order) ...
+            one_tail = stats is not None and all(st is not None for st in stats) and os.environ.get("LVDGS_MAP_TAIL_BATCH", "1") != "0"
             for k in range(n):
-                self.passes[k]._backward_for_batch(ctxs[k], None if stats is None else stats[k], stream)
+                self.passes[k]._backward_for_batch(ctxs[k], None if stats is None else stats[k], stream, tail=not one_tail)
+            if one_tail:   # ... and their tails -- loss, pose gradient, the view's statistics -- in ONE launch, the statistics in view order
+                sas = []
+                for k in range(n):
+                    sa = _lib.ViewStatsArgs()
+                    sa.radii_max, sa.norm_sum, sa.vis_count, sa.touched_row, sa.split_xy = (_P(t) for t in stats[k])
+                    sas.append(sa)
+                    ctxs[k]["stats_taken"] = True
+                las = (C.POINTER(_lib.LossArgs) * n)(*[None if ctxs[k]["masked"] else C.pointer(self.passes[k].la) for k in range(n)])
+                taus = (C.c_void_p * n)(*[ctxs[k]["d_tau"].data_ptr() for k in range(n)])
+                sap = (C.POINTER(_lib.ViewStatsArgs) * n)(*[C.pointer(sa) for sa in sas])
+                _lib.check(L.lvdgs_map_view_tail_batch(las, views, taus, sap, n, stream), "lvdgs_map_view_tail_batch")
         return [self.passes[k]._finish_for_batch(backend, viewpoints[k], ctxs[k]) for k in range(n)]
 
 
@@ -541,13 +554,16 @@ def _begin_for_batch(self, backend, viewpoint, initialization, first, lead_into,
                 loss=loss, into=into, install=install, fields=fields, initialization=initialization, masked=masked_loss is not None)
 
 
-def _backward_for_batch(self, ctx, stats, stream):
+def _backward_for_batch(self, ctx, stats, stream, tail=True):
     L, a, la = self.L, self.a, self.la
     if ctx["masked"]:
         _lib.check(L.lvdgs_backward_masked_loss(C.byref(a), C.byref(self.ml), stream), "lvdgs_backward_masked_loss")
         la = None   # (the loss value is finished: the tail reduces the pose gradient and takes the statistics)
     else:
         _lib.check(L.lvdgs_backward_fused_loss(C.byref(a), C.byref(la), 0, stream), "lvdgs_backward_fused_loss")
+    ctx["stats_taken"] = False
+    if not tail:   # (the caller finishes all views in one launch: lvdgs_map_view_tail_batch)
+        return
     la_ref = None if la is None else C.byref(la)
     if stats is not None:
         sa = _lib.ViewStatsArgs()
