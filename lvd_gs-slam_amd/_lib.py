@@ -251,6 +251,26 @@ class on_device:
         return False
 
 
+_gc_settled = False
+
+
+def settle_garbage_collector():
+    """Once per process, at the first use of one of the product's loops (``TrackingSession``, ``backend_map.map_window``): a full
+    collection, then ``gc.freeze()`` -- everything alive now (the interpreter's and PyTorch's modules: about a million objects) moves to
+    the permanent generation and is never walked again.  The loops here run at 0.2-2 ms per iteration and allocate a few hundred small
+    Python objects in each, which makes CPython start a FULL collection every few dozen to few hundred iterations; with the whole heap
+    in it that is one stall of 40-110 ms (measured: ``tools/side_stall_diag.py``) -- 20-60 iterations' worth of time.  The reference's
+    own loops allocate as much but run a hundred times slower per iteration, so the same stall does not show there.
+    ``LVDGS_GC_FREEZE=0`` leaves the collector alone."""
+    global _gc_settled
+    if _gc_settled or os.environ.get("LVDGS_GC_FREEZE", "1") == "0":
+        return
+    _gc_settled = True
+    import gc
+    gc.collect()
+    gc.freeze()
+
+
 def check(status, what):
     if status != OK:
         raise LvdgsError(f"{what} failed ({status}): {lib().lvdgs_last_error().decode()}")

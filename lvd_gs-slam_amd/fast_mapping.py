@@ -434,22 +434,34 @@ class MapWindowBatch:
             for k, vp in enumerate(viewpoints):
                 ctxs.append(self.passes[k]._begin_for_batch(backend, vp, initialization, first if k == 0 else None,
                                                             None if k == 0 else ctxs[0]["into"], stream, masked[k], forward=not fwd_batch))
-            views = (C.POINTER(_lib.Args) * n)(*[C.pointer(self.passes[k].a) for k in range(n)])
+            # (the pointer arrays over the passes' argument blocks are made once per window shape: nothing to allocate per iteration)
+            key = (n, tuple(m is not None for m in masked))
+            ct = getattr(self, "_ct", {}).get(key)
+            if ct is None:
+                which = [k for k in range(n) if masked[k] is not None]
+                ct = dict(views=(C.POINTER(_lib.Args) * n)(*[C.pointer(self.passes[k].a) for k in range(n)]),
+                          losses=(C.POINTER(_lib.LossArgs) * n)(*[C.pointer(self.passes[k].la) for k in range(n)]),
+                          nums=(C.c_int64 * n)(), which=which,
+                          mviews=(C.POINTER(_lib.MaskedLossArgs) * max(len(which), 1))(*[C.pointer(self.passes[k].ml) for k in which]),
+                          per_view=(C.POINTER(_lib.MaskedLossArgs) * n)(*[C.pointer(self.passes[k].ml) if masked[k] is not None else None for k in range(n)]),
+                          tail_losses=(C.POINTER(_lib.LossArgs) * n)(*[None if masked[k] is not None else C.pointer(self.passes[k].la) for k in range(n)]),
+                          taus=(C.c_void_p * n)(), sas=[_lib.ViewStatsArgs() for _ in range(n)])
+                ct["sap"] = (C.POINTER(_lib.ViewStatsArgs) * n)(*[C.pointer(sa) for sa in ct["sas"]])
+                self._ct = {key: ct}
+            views = ct["views"]
             if fwd_batch:
-                nums = (C.c_int64 * n)()
+                nums = ct["nums"]
                 status = L.lvdgs_forward_batch(views, n, nums, stream)
                 if status not in (_lib.OK, _lib.E_CAPACITY):
                     _lib.check(status, "lvdgs_forward_batch")
                 for k in range(n):
                     self.passes[k]._after_forward(int(nums[k]), status == _lib.E_CAPACITY and int(nums[k]) > self.passes[k].cap, stream)
-            losses = (C.POINTER(_lib.LossArgs) * n)(*[C.pointer(self.passes[k].la) for k in range(n)])
+            losses = ct["losses"]
             _lib.check(L.lvdgs_blend_forward_batch(views, n, stream), "lvdgs_blend_forward_batch")
-            which = [k for k in range(n) if masked[k] is not None]
+            which = ct["which"]
             if which:
-                mviews = (C.POINTER(_lib.MaskedLossArgs) * len(which))(*[C.pointer(self.passes[k].ml) for k in which])
-                _lib.check(L.lvdgs_masked_loss_batch(mviews, len(which), stream), "lvdgs_masked_loss_batch")
-                per_view = (C.POINTER(_lib.MaskedLossArgs) * n)(*[C.pointer(self.passes[k].ml) if masked[k] is not None else None for k in range(n)])
-                _lib.check(L.lvdgs_blend_backward_window_batch(views, losses, per_view, n, 0, stream), "lvdgs_blend_backward_window_batch")
+                _lib.check(L.lvdgs_masked_loss_batch(ct["mviews"], len(which), stream), "lvdgs_masked_loss_batch")
+                _lib.check(L.lvdgs_blend_backward_window_batch(views, losses, ct["per_view"], n, 0, stream), "lvdgs_blend_backward_window_batch")
             else:
                 _lib.check(L.lvdgs_blend_backward_fused_loss_batch(views, losses, n, 0, stream), "lvdgs_blend_backward_fused_loss_batch")
             # the per-Gaussian passes view after view (they add to one set of gradients, in the window's order) ...
@@ -457,16 +469,12 @@ class MapWindowBatch:
             for k in range(n):
                 self.passes[k]._backward_for_batch(ctxs[k], None if stats is None else stats[k], stream, tail=not one_tail)
             if one_tail:   # ... and their tails -- loss, pose gradient, the view's statistics -- in ONE launch, the statistics in view order
-                sas = []
                 for k in range(n):
-                    sa = _lib.ViewStatsArgs()
+                    sa = ct["sas"][k]
                     sa.radii_max, sa.norm_sum, sa.vis_count, sa.touched_row, sa.split_xy = (_P(t) for t in stats[k])
-                    sas.append(sa)
+                    ct["taus"][k] = ctxs[k]["d_tau"].data_ptr()
                     ctxs[k]["stats_taken"] = True
-                las = (C.POINTER(_lib.LossArgs) * n)(*[None if ctxs[k]["masked"] else C.pointer(self.passes[k].la) for k in range(n)])
-                taus = (C.c_void_p * n)(*[ctxs[k]["d_tau"].data_ptr() for k in range(n)])
-                sap = (C.POINTER(_lib.ViewStatsArgs) * n)(*[C.pointer(sa) for sa in sas])
-                _lib.check(L.lvdgs_map_view_tail_batch(las, views, taus, sap, n, stream), "lvdgs_map_view_tail_batch")
+                _lib.check(L.lvdgs_map_view_tail_batch(ct["tail_losses"], views, ct["taus"], ct["sap"], n, stream), "lvdgs_map_view_tail_batch")
         return [self.passes[k]._finish_for_batch(backend, viewpoints[k], ctxs[k]) for k in range(n)]
 
 

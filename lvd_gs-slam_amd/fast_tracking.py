@@ -65,6 +65,7 @@ class TrackingSession:
         if getattr(pipeline_params, "compute_cov3D_python", False) or getattr(pipeline_params, "convert_SHs_python", False):
             raise NotImplementedError("TrackingSession: pipeline_params with the *_python switches take the autograd path")
         self.L = _lib.lib()
+        _lib.settle_garbage_collector()   # (once per process: no full-heap garbage collection inside a 0.2 ms loop)
         self.dev, self.vp, self.cfg = dev, viewpoint, config
         T = config["Training"]
         H, W = int(viewpoint.image_height), int(viewpoint.image_width)
