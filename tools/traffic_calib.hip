@@ -7,6 +7,7 @@
 //   read4    4 bytes per lane, streaming (a wave: 256 contiguous bytes)
 //   tile4    a 16 x 16 pixel tile per workgroup out of seven image planes: a wave reads four 64-byte row segments per
 //            plane (blend_bwd's prologue; the tile to the right holds the other half of each 128-byte line)
+//   tile4xcd the same with a tile's right-hand neighbour on the SAME XCD (the blend kernels' workgroup -> tile mapping)
 //   gather44 one 44-byte record per lane at a random place of a table, every record once (blend's staging of a list entry:
 //            no re-use, so the count is what ONE miss on such a record moves)
 //   gather44x4  the same table a quarter the size, every record four times (D / V = 4.2 at config 3)
@@ -37,9 +38,14 @@ __global__ void calib_read4_kernel(const uint32_t *__restrict__ src, size_t n, u
     if (acc == 0x12345678u) sink[0] = acc;
 }
 // one workgroup of 256 per tile, tiles in row-major order (neighbours close in time, as in the blend kernels' runs of tiles)
+template <bool XCD_RUNS>
 __global__ void calib_tile4_kernel(const float *__restrict__ planes, int W, int H, int nplanes, uint32_t *__restrict__ sink) {
     const int gx = (W + 15) / 16;
-    const int tx = blockIdx.x % gx, ty = blockIdx.x / gx;
+    // XCD_RUNS: workgroup b runs on XCD b % 8; XCD x takes the x-th eighth of the tiles in row-major order, so that a tile's right-hand
+    // neighbour (the other half of its 128-byte lines) is the same L2's next workgroup -- the blend kernels' mapping
+    int t = blockIdx.x;
+    if (XCD_RUNS) { const int per = (gridDim.x + 7) / 8; t = (blockIdx.x & 7) * per + (blockIdx.x >> 3); if (t >= (int)gridDim.x) return; }
+    const int tx = t % gx, ty = t / gx;
     const int x = tx * 16 + (threadIdx.x & 15), y = ty * 16 + (threadIdx.x >> 4);
     float acc = 0.f;
     if (x < W && y < H)
@@ -105,7 +111,8 @@ int main(int argc, char **argv) {
     for (int r = 0; r < reps; r++) {
         flush_caches(); calib_read16_kernel<<<2048, 256>>>(stream, stream_bytes / 16, sink);
         flush_caches(); calib_read4_kernel<<<2048, 256>>>((const uint32_t *)stream, stream_bytes / 4, sink);
-        flush_caches(); calib_tile4_kernel<<<gx * gy, 256>>>(planes, W, H, NPL, sink);
+        flush_caches(); calib_tile4_kernel<false><<<gx * gy, 256>>>(planes, W, H, NPL, sink);
+        flush_caches(); calib_tile4_kernel<true><<<(gx * gy + 7) / 8 * 8, 256>>>(planes, W, H, NPL, sink);
         flush_caches(); calib_gather44_kernel<<<2048, 256>>>(table, perm, R, sink);
         flush_caches(); calib_gather44_kernel<<<2048, 256>>>(table, perm4, R, sink);
         flush_caches(); calib_store16_kernel<<<2048, 256>>>(stream, stream_bytes / 16);
@@ -115,9 +122,9 @@ int main(int argc, char **argv) {
     }
     CHECK(hipDeviceSynchronize());
     // bytes moved per launch, in launch order (gather44 twice: the second is the x4 form); perm reads (4 bytes per lane) listed apart
-    printf("{\"launch_order\": [\"read16\", \"read4\", \"tile4\", \"gather44\", \"gather44x4\", \"store16\", \"store40\", \"store1\", \"or1\"],\n");
-    printf(" \"read_bytes\": {\"read16\": %zu, \"read4\": %zu, \"tile4\": %zu, \"gather44\": %zu, \"gather44x4\": %zu, \"store40\": %zu, \"store1\": %zu, \"or1\": %zu},\n",
-           stream_bytes, stream_bytes, (size_t)NPL * W * H * 4, R * 44 + R * 4, R / 4 * 44 + R * 4, R * 4, R * 4, R * 4);
+    printf("{\"launch_order\": [\"read16\", \"read4\", \"tile4\", \"tile4xcd\", \"gather44\", \"gather44x4\", \"store16\", \"store40\", \"store1\", \"or1\"],\n");
+    printf(" \"read_bytes\": {\"read16\": %zu, \"read4\": %zu, \"tile4\": %zu, \"tile4xcd\": %zu, \"gather44\": %zu, \"gather44x4\": %zu, \"store40\": %zu, \"store1\": %zu, \"or1\": %zu},\n",
+           stream_bytes, stream_bytes, (size_t)NPL * W * H * 4, (size_t)NPL * W * H * 4, R * 44 + R * 4, R / 4 * 44 + R * 4, R * 4, R * 4, R * 4);
     printf(" \"gather44x4_requested_bytes\": %zu,\n", R * 44 + R * 4);
     printf(" \"write_bytes\": {\"store16\": %zu, \"store40\": %zu, \"store1\": %zu, \"or1_bits_as_bytes\": %zu, \"or1_as_dwords\": %zu}}\n", stream_bytes, R * 40, R, R / 8, R * 4);
     return 0;

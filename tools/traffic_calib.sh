@@ -17,6 +17,7 @@ for f in glob.glob(out + "/*/**/*counter_collection.csv", recursive=True):
     seen = collections.Counter()
     for r in rows:
         n = r["Kernel_Name"].split("calib_")[1].split("_kernel")[0]
+        if n == "tile4" and "<true>" in r["Kernel_Name"]: n = "tile4xcd"
         if n == "gather44":
             seen[r["Counter_Name"]] += 1
             if seen[r["Counter_Name"]] % 2 == 0: n = "gather44x4"
@@ -27,6 +28,7 @@ for f in glob.glob(out + "/trace/**/*kernel_trace.csv", recursive=True):
     k = 0
     for r in rows:
         n = r["Kernel_Name"].split("calib_")[1].split("_kernel")[0]
+        if n == "tile4" and "<true>" in r["Kernel_Name"]: n = "tile4xcd"
         if n == "gather44":
             k += 1
             if k % 2 == 0: n = "gather44x4"
