@@ -408,7 +408,8 @@ int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipSt
             // (single-call forward: the tile scan writes the pair count and the hints into the caller thread's pinned words itself)
             if (int e = launch_group_scan(*a, im, w, cap, counted ? g.total : nullptr, s, counted && probe ? probe->pinned_dev : nullptr,
                                           counted && probe ? probe->seq : 0u)) return e;
-            if (int e = launch_group_scatter(*a, g, im, w, (unsigned long long *)w.keys, cap, counted, b.pair_valid, s)) return e;
+            if (int e = launch_group_scatter(*a, g, im, w, (unsigned long long *)w.keys, cap, counted, b.pair_valid, s, counted ? g.total : nullptr,
+                                             counted && probe ? probe->pinned_dev : nullptr, counted && probe ? probe->seq : 0u)) return e;
             grouped = true;
         } else {
             if (!w.hist) { set_error("internal: scratch was not laid out for the radix grouping"); return LVDGS_E_INVALID; }

@@ -40,7 +40,8 @@ __global__ void __launch_bounds__(256) emit_pairs_kernel(int N, int gx, const ui
 //             (lvdgs_forward: done by the projection kernel itself, preprocess.hip: preprocess_count_kernel)
 //   colscan:  per tile, exclusive prefix of hist over the chunks, and the tile total
 //   tilescan: exclusive scan of the totals                                           -> ranges[tile], the pair count,
-//             the queue of over-long segments for the tile sort, the tiles by list length (small grids)
+//             the queue of over-long segments for the tile sort, the tiles by list length (small grids);
+//             on small frames the last workgroup of the scatter's launch (LVDGS_SCAN_IN_SCATTER below), a kernel of its own otherwise
 //   scatter:  counter[tile] = ranges[tile].begin + hist[chunk][tile]; every pair takes the next slot of its tile
 //             with one returning LDS atomic and writes its sort key there; also makes slot_base (lvdgs_forward).
 // Rectangles larger than a wave's worth of tiles are walked by the whole wave, so one screen-filling Gaussian does
@@ -148,15 +149,17 @@ __global__ void __launch_bounds__(1024) group_colscan_batch_kernel(int T, int nc
 // that the sort needs no pass of its own to find them;
 // tile_order (optional, tiles [t_lo, t_hi)): those tiles by descending list length (in steps of 8 entries; ties in
 // arrival order -- it only decides which workgroup of a blend kernel takes which tile, never a result).
+template <int THREADS>
 __device__ __forceinline__ void group_tilescan_body(int T, const uint32_t *__restrict__ totals, uint32_t capacity,
                                                     uint2 *__restrict__ ranges, uint32_t *__restrict__ total_out,
                                                     uint32_t long_limit, uint32_t *__restrict__ queue_count, uint32_t *__restrict__ queue,
                                                     uint32_t *__restrict__ tile_order, int t_lo, int t_hi, uint32_t *__restrict__ order_valid,
                                                     uint32_t *host_out, uint32_t host_seq) {
+    static_assert(THREADS == 1024 || THREADS == 512, "the grouping kernels' workgroup sizes (the scan rides in the scatter's launch)");
     __shared__ uint32_t s_scan[1024];
     __shared__ uint32_t s_q, s_longest, s_total;
-    constexpr int PER = GROUP_MAX_TILES / 1024;
-    static_assert(PER == 16, "four 16-byte loads, eight 16-byte stores per thread");
+    constexpr int PER = GROUP_MAX_TILES / THREADS;   // 16 or 32 tiles per thread: 16-byte loads, 16-byte stores
+    constexpr int WAVES = THREADS / 64;
     uint32_t v[PER], sum = 0;
     if (threadIdx.x == 0) { s_q = 0u; s_longest = 0u; }
     {
@@ -176,7 +179,7 @@ __device__ __forceinline__ void group_tilescan_body(int T, const uint32_t *__res
 #pragma unroll
         for (int k = 0; k < PER; k++) sum += v[k];
     }
-    // inclusive scan of the 1024 thread sums: inside every wave by lane shifts, then the 16 wave totals by wave 0
+    // inclusive scan of the thread sums: inside every wave by lane shifts, then the up to 16 wave totals by wave 0
     // (two barriers; the log-step scan over all 1024 threads it replaces needed twenty)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t inc = sum;
@@ -188,7 +191,7 @@ __device__ __forceinline__ void group_tilescan_body(int T, const uint32_t *__res
     if (lane == 63) s_scan[wave] = inc;
     __syncthreads();
     if (wave == 0) {
-        uint32_t w = lane < 16 ? s_scan[lane] : 0u;
+        uint32_t w = lane < WAVES ? s_scan[lane] : 0u;
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) {
             const uint32_t x = (uint32_t)__shfl_up((int)w, off, 64);
@@ -198,7 +201,7 @@ __device__ __forceinline__ void group_tilescan_body(int T, const uint32_t *__res
     }
     __syncthreads();
     inc += wave ? s_scan[16 + wave - 1] : 0u;
-    if (threadIdx.x == 1023) {
+    if (threadIdx.x == THREADS - 1) {
         s_total = inc;
         if (total_out) total_out[0] = inc;   // the frame's pair count (before clamping)
     }
@@ -235,7 +238,10 @@ __device__ __forceinline__ void group_tilescan_body(int T, const uint32_t *__res
     if (!tile_order) return;
     // counting sort of the tiles by bucket 1023 - min(length / 8, 1023): bucket 0 holds the longest lists
     auto bucket = [](uint32_t len) { return 1023u - min(len >> 3, 1023u); };
-    s_scan[threadIdx.x] = 0u;
+    constexpr int BPT = 1024 / THREADS;   // buckets per thread (consecutive ones)
+    __syncthreads();   // (s_scan's wave totals have been read)
+#pragma unroll
+    for (int q = 0; q < BPT; q++) s_scan[BPT * threadIdx.x + q] = 0u;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < PER; k++) {
@@ -243,7 +249,9 @@ __device__ __forceinline__ void group_tilescan_body(int T, const uint32_t *__res
         if (t >= t_lo && t < t_hi) atomicAdd(&s_scan[bucket(v[k])], 1u);
     }
     __syncthreads();
-    const uint32_t mine = s_scan[threadIdx.x];
+    uint32_t cnt[BPT], mine = 0u;
+#pragma unroll
+    for (int q = 0; q < BPT; q++) { cnt[q] = s_scan[BPT * threadIdx.x + q]; mine += cnt[q]; }
     uint32_t incl = mine;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -254,7 +262,7 @@ __device__ __forceinline__ void group_tilescan_body(int T, const uint32_t *__res
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
     if (wave == 0) {
-        uint32_t w = lane < 16 ? s_wave[lane] : 0u;
+        uint32_t w = lane < WAVES ? s_wave[lane] : 0u;
 #pragma unroll
         for (int off = 1; off < 16; off <<= 1) {
             const uint32_t x = (uint32_t)__shfl_up((int)w, off, 64);
@@ -263,7 +271,11 @@ __device__ __forceinline__ void group_tilescan_body(int T, const uint32_t *__res
         if (lane < 16) s_wave[16 + lane] = w;
     }
     __syncthreads();
-    s_scan[threadIdx.x] = incl - mine + (wave ? s_wave[16 + wave - 1] : 0u);   // first position of this bucket
+    {
+        uint32_t first = incl - mine + (wave ? s_wave[16 + wave - 1] : 0u);   // first position of this thread's first bucket
+#pragma unroll
+        for (int q = 0; q < BPT; q++) { s_scan[BPT * threadIdx.x + q] = first; first += cnt[q]; }
+    }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < PER; k++) {
@@ -277,7 +289,7 @@ __global__ void __launch_bounds__(1024) group_tilescan_kernel(int T, const uint3
                                                               uint32_t long_limit, uint32_t *__restrict__ queue_count, uint32_t *__restrict__ queue,
                                                               uint32_t *__restrict__ tile_order, int t_lo, int t_hi, uint32_t *__restrict__ order_valid,
                                                               uint32_t *host_out, uint32_t host_seq) {
-    group_tilescan_body(T, totals, capacity, ranges, total_out, long_limit, queue_count, queue, tile_order, t_lo, t_hi, order_valid, host_out, host_seq);
+    group_tilescan_body<1024>(T, totals, capacity, ranges, total_out, long_limit, queue_count, queue, tile_order, t_lo, t_hi, order_valid, host_out, host_seq);
 }
 // lvdgs_forward_batch: one workgroup per view (blockIdx.x); view k's pair count and hints go to host_out + 4 k
 struct TilescanView { const uint32_t *totals; uint32_t capacity; uint2 *ranges; uint32_t *total_out, *queue_count, *queue, *tile_order, *order_valid; };
@@ -285,8 +297,8 @@ struct TilescanBatch { TilescanView v[FWD_BATCH_VIEWS]; };
 __global__ void __launch_bounds__(1024) group_tilescan_batch_kernel(int T, TilescanBatch b, uint32_t long_limit, int t_lo, int t_hi, uint32_t *host_out,
                                                                     uint32_t host_seq) {
     const TilescanView &v = b.v[blockIdx.x];
-    group_tilescan_body(T, v.totals, v.capacity, v.ranges, v.total_out, long_limit, v.queue_count, v.queue, v.tile_order, t_lo, t_hi, v.order_valid,
-                        host_out + 4 * blockIdx.x, host_seq);
+    group_tilescan_body<1024>(T, v.totals, v.capacity, v.ranges, v.total_out, long_limit, v.queue_count, v.queue, v.tile_order, t_lo, t_hi, v.order_valid,
+                              host_out + 4 * blockIdx.x, host_seq);
 }
 
 // SLOT_SCAN (lvdgs_forward): also makes slot_base[i] = exclusive scan of tiles_touched in id order (the backward's
@@ -295,10 +307,23 @@ __global__ void __launch_bounds__(1024) group_tilescan_batch_kernel(int T, Tiles
 #ifndef LVDGS_SCATTER_XCD
 #define LVDGS_SCATTER_XCD 1   // A/B builds: 0 = workgroup b takes chunk b
 #endif
+// The tile scan rides in the scatter's launch (round 5).  A scatter workgroup needs one number per tile from it -- where the tile's
+// list begins -- and has always read all T of them: it now scans the T tile totals itself (4 T bytes out of L2 instead of the 8 T of
+// ranges[], one workgroup scan), and ONE extra workgroup of the launch does what the tile-scan kernel did (ranges[], the pair count
+// and its copy in the host's pinned words, the tile sort's queue, the tile order) beside the others instead of in front of them: a
+// launch less on the critical path of every frame small enough for it (SCAN_IN_SCATTER_RUN; KITTI geometry: 3.4 of 199 us per tracking
+// iteration -- the scan kernel was 7.4 us, half of which the scatter's workgroups now spend on their own scans).
+#ifndef LVDGS_SCAN_IN_SCATTER
+#define LVDGS_SCAN_IN_SCATTER 1   // A/B builds: 0 = the tile scan as a launch of its own in front of the scatter
+#endif
+struct TileScanArgs {   // group_tilescan_body's arguments (ranges == nullptr: no tile scan in this launch)
+    uint2 *ranges; uint32_t *total_out; uint32_t long_limit; uint32_t *queue_count, *queue, *tile_order; int t_lo, t_hi; uint32_t *order_valid;
+    uint32_t *host_out; uint32_t host_seq;
+};
 template <int GROUP_THREADS, int OWNERS, int PER, bool SLOT_SCAN>
 __device__ __forceinline__ void scatter_pairs_body(int chunk, int N, int gx, int T, const uint4 *__restrict__ rect,
                                                    const uint32_t *__restrict__ hist,
-                                                   const uint2 *__restrict__ ranges, uint32_t capacity,
+                                                   const uint2 *__restrict__ ranges, const uint32_t *__restrict__ totals, uint32_t capacity,
                                                    const uint32_t *__restrict__ depth_bits,
                                                    unsigned long long *__restrict__ keys64,
                                                    const uint32_t *__restrict__ tt, const uint32_t *__restrict__ chunk_sums,
@@ -323,7 +348,23 @@ __device__ __forceinline__ void scatter_pairs_body(int chunk, int N, int gx, int
         my_rect[k] = (owner && i < N) ? rect[i] : make_uint4(0u, 0u, 0u, 0u);
         my_depth[k] = (owner && i < N) ? depth_bits[i] : 0u;
     }
-    for (int t = threadIdx.x; t < T; t += GROUP_THREADS) s_tile[t] = ranges[t].x + row[t];  // (empty tiles are never visited)
+    if (LVDGS_SCAN_IN_SCATTER && totals) {
+        // where every tile's list begins: the exclusive scan of the tile totals, made here (a thread takes a run of consecutive
+        // tiles; positions at or beyond the capacity are dropped below, as the clamped ranges[] made them be)
+        // (frames of up to SCAN_IN_SCATTER_RUN tiles per thread only -- launch_group_scatter: a thread's run of tiles is read straight
+        // from memory, 16 bytes of a line per lane; at eight tiles per thread (1080p) that cost 5 us over 489 workgroups, more than the
+        // launch it saved, and staged through LDS -- two more barriers -- it was a wash at every size: same-box A/B in DESIGN section 2)
+        const int per_t = (T + GROUP_THREADS - 1) / GROUP_THREADS;
+        const int t0 = min(T, (int)threadIdx.x * per_t), t1 = min(T, t0 + per_t);
+        uint32_t sum = 0;
+        for (int t = t0; t < t1; t++) sum += totals[t];
+        uint32_t all;
+        uint32_t run = scan_workgroup<GROUP_THREADS>(sum, s_scan, &all);
+        for (int t = t0; t < t1; t++) { s_tile[t] = run + row[t]; run += totals[t]; }
+        __syncthreads();   // (s_scan is used again below)
+    } else {
+        for (int t = threadIdx.x; t < T; t += GROUP_THREADS) s_tile[t] = ranges[t].x + row[t];  // (empty tiles are never visited)
+    }
     uint32_t slots_lo = 0, slots_hi = 0;   // the chunk's Gaussians' gradient slots: [lo, hi)
     if constexpr (SLOT_SCAN) {
         uint32_t before = 0;
@@ -382,13 +423,23 @@ __device__ __forceinline__ void scatter_pairs_body(int chunk, int N, int gx, int
 template <int GROUP_THREADS, int OWNERS, int PER, bool SLOT_SCAN>
 __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int gx, int T, const uint4 *__restrict__ rect,
                                                                      const uint32_t *__restrict__ hist,
-                                                                     const uint2 *__restrict__ ranges, uint32_t capacity,
+                                                                     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ totals, uint32_t capacity,
                                                                      const uint32_t *__restrict__ depth_bits,
                                                                      unsigned long long *__restrict__ keys64,
                                                                      const uint32_t *__restrict__ tt, const uint32_t *__restrict__ chunk_sums,
-                                                                     uint32_t *__restrict__ slot_base, uint8_t *__restrict__ pair_valid) {
-    const int chunk = LVDGS_SCATTER_XCD ? xcd_contiguous_chunk((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
-    scatter_pairs_body<GROUP_THREADS, OWNERS, PER, SLOT_SCAN>(chunk, N, gx, T, rect, hist, ranges, capacity, depth_bits, keys64, tt, chunk_sums, slot_base, pair_valid);
+                                                                     uint32_t *__restrict__ slot_base, uint8_t *__restrict__ pair_valid, TileScanArgs ts) {
+    // (the launch's LAST workgroup is the tile scan's when ts.ranges is set: a workgroup's XCD is its index mod 8, which the chunks'
+    // XCD-contiguous order counts on)
+    const int nchunks = (int)gridDim.x - (ts.ranges ? 1 : 0);
+    if constexpr (GROUP_THREADS == 1024 || GROUP_THREADS == 512) {
+        if ((int)blockIdx.x == nchunks) {
+            group_tilescan_body<GROUP_THREADS>(T, totals, capacity, ts.ranges, ts.total_out, ts.long_limit, ts.queue_count, ts.queue, ts.tile_order, ts.t_lo, ts.t_hi,
+                                               ts.order_valid, ts.host_out, ts.host_seq);
+            return;
+        }
+    }
+    const int chunk = LVDGS_SCATTER_XCD ? xcd_contiguous_chunk((int)blockIdx.x, nchunks) : (int)blockIdx.x;
+    scatter_pairs_body<GROUP_THREADS, OWNERS, PER, SLOT_SCAN>(chunk, N, gx, T, rect, hist, ranges, totals, capacity, depth_bits, keys64, tt, chunk_sums, slot_base, pair_valid);
 }
 // lvdgs_forward_batch (blockIdx.y: the view).  The grid's x extent is the chunk count rounded up to a multiple of 8, so that a
 // workgroup's XCD is its x index mod 8 whatever the view (workgroups are dealt to the XCDs by their linear index) and an XCD takes
@@ -398,12 +449,14 @@ struct ScatterView {
     const uint32_t *tt, *chunk_sums; uint32_t *slot_base; uint8_t *pair_valid;
 };
 struct ScatterBatch { ScatterView v[FWD_BATCH_VIEWS]; };
+// (The views' tile scans stay a launch of their own here -- one workgroup per view in front of this one: with ten views' scatter
+// workgroups each scanning the tile totals the window was 1.645 / 1.77-1.80 ms against 1.62-1.64 / 1.75-1.76, same box.)
 template <int GROUP_THREADS, int OWNERS, int PER>
 __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_batch_kernel(int N, int gx, int T, int nchunks, ScatterBatch b) {
     const int chunk = LVDGS_SCATTER_XCD ? xcd_contiguous_chunk((int)blockIdx.x, (int)gridDim.x) : (int)blockIdx.x;
     if (chunk >= nchunks) return;
     const ScatterView &v = b.v[blockIdx.y];
-    scatter_pairs_body<GROUP_THREADS, OWNERS, PER, true>(chunk, N, gx, T, v.rect, v.hist, v.ranges, v.capacity, v.depth_bits, v.keys64, v.tt, v.chunk_sums,
+    scatter_pairs_body<GROUP_THREADS, OWNERS, PER, true>(chunk, N, gx, T, v.rect, v.hist, v.ranges, nullptr, v.capacity, v.depth_bits, v.keys64, v.tt, v.chunk_sums,
                                                          v.slot_base, v.pair_valid);
 }
 
@@ -451,6 +504,13 @@ int launch_group_count(const lvdgs_args &a, const GeomView &g, const ImageView &
 }
 
 // colscan + tilescan: tile ranges, the pair count (total_out, may be null), the tile sort's queue, the tile order
+constexpr int SCAN_IN_SCATTER_RUN = 4;   // tiles per scatter thread up to which the tile scan rides in the scatter's launch
+static bool scan_rides_in_scatter(int N, int T) {
+    const GroupShape g = group_shape_for(N);
+    const int threads = g.threads == 256 ? GROUP_HELPER_THREADS : g.threads;   // (every shape launches 512 or 1024 threads)
+    return LVDGS_SCAN_IN_SCATTER != 0 && (threads == 512 || threads == 1024) && cdiv(T, threads) <= SCAN_IN_SCATTER_RUN;
+}
+
 int launch_group_scan(const lvdgs_args &a, const ImageView &im, const RenderScratch &w, int64_t capacity, uint32_t *total_out, hipStream_t s,
                       uint32_t *host_out, uint32_t host_seq) {
     const int N = a.num_gaussians;
@@ -466,15 +526,16 @@ int launch_group_scan(const lvdgs_args &a, const ImageView &im, const RenderScra
     else if (nchunks <= 16 * 16) hipLaunchKernelGGL(group_colscan_kernel<16>, dim3(wg_tiles), dim3(1024), 0, s, T, nchunks, w.group_hist, w.group_totals);
     else if (nchunks <= 32 * 16) hipLaunchKernelGGL(group_colscan_kernel<32>, dim3(wg_tiles), dim3(1024), 0, s, T, nchunks, w.group_hist, w.group_totals);
     else hipLaunchKernelGGL(group_colscan_kernel<0>, dim3(wg_tiles), dim3(1024), 0, s, T, nchunks, w.group_hist, w.group_totals);
-    hipLaunchKernelGGL(group_tilescan_kernel, dim3(1), dim3(1024), 0, s, T, (const uint32_t *)w.group_totals, (uint32_t)capacity, im.ranges,
-                       total_out, (uint32_t)tile_sort_wave_limit(), im.long_count, im.long_tiles,
-                       tile_order_in_use(T) ? im.long_tiles + T : nullptr, row0 * gx, row1 * gx, im.long_count + 1, host_out, host_seq);
+    if (!scan_rides_in_scatter(N, T))   // (else: launch_group_scatter's last workgroup)
+        hipLaunchKernelGGL(group_tilescan_kernel, dim3(1), dim3(1024), 0, s, T, (const uint32_t *)w.group_totals, (uint32_t)capacity, im.ranges,
+                           total_out, (uint32_t)tile_sort_wave_limit(), im.long_count, im.long_tiles,
+                           tile_order_in_use(T) ? im.long_tiles + T : nullptr, row0 * gx, row1 * gx, im.long_count + 1, host_out, host_seq);
     LVDGS_LAUNCH_CHECK("group_scan", a.debug, s);
     return LVDGS_OK;
 }
 
 int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, unsigned long long *keys64,
-                         int64_t capacity, bool slot_scan, uint8_t *pair_valid, hipStream_t s) {
+                         int64_t capacity, bool slot_scan, uint8_t *pair_valid, hipStream_t s, uint32_t *total_out, uint32_t *host_out, uint32_t host_seq) {
     const int N = a.num_gaussians;
     const int gx = (a.image_width + TILE - 1) / TILE, gy = (a.image_height + TILE - 1) / TILE, T = gx * gy;
     if (N == 0 || T == 0) return LVDGS_OK;
@@ -482,11 +543,18 @@ int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView
     const size_t lds = (size_t)T * sizeof(uint32_t);
     static unsigned char done[2 * GROUP_SHAPES][16];
     ProfScope ps("group_scatter", s);
+    TileScanArgs ts{};
+    if (scan_rides_in_scatter(N, T)) {   // the tile scan as this launch's last workgroup (launch_group_scan has made the tile totals)
+        int row0, row1;
+        tile_row_band(a, &row0, &row1);
+        ts = TileScanArgs{im.ranges, total_out, (uint32_t)tile_sort_wave_limit(), im.long_count, im.long_tiles, tile_order_in_use(T) ? im.long_tiles + T : nullptr,
+                          row0 * gx, row1 * gx, im.long_count + 1, host_out, host_seq};
+    }
     auto launch = [&](auto kernel, int d, int threads) {
         if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(kernel), GROUP_MAX_TILES * 4, done[d])) return e;
-        hipLaunchKernelGGL(kernel, dim3(nchunks), dim3(threads), lds, s, N, gx, T, (const uint4 *)g.rect, (const uint32_t *)w.group_hist,
-                           (const uint2 *)im.ranges, (uint32_t)capacity, (const uint32_t *)g.depth_bits, keys64, (const uint32_t *)g.tiles_touched,
-                           (const uint32_t *)w.chunk_sums, g.slot_base, pair_valid);
+        hipLaunchKernelGGL(kernel, dim3(nchunks + (ts.ranges ? 1 : 0)), dim3(threads), lds, s, N, gx, T, (const uint4 *)g.rect, (const uint32_t *)w.group_hist,
+                           (const uint2 *)im.ranges, ts.ranges ? (const uint32_t *)w.group_totals : nullptr, (uint32_t)capacity, (const uint32_t *)g.depth_bits, keys64,
+                           (const uint32_t *)g.tiles_touched, (const uint32_t *)w.chunk_sums, g.slot_base, pair_valid, ts);
         return (int)LVDGS_OK;
     };
     if (int e = group_dispatch(group_shape_for(N), [&](auto threads_, auto owners_, auto per_, int d) {

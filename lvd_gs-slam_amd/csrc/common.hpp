@@ -291,8 +291,10 @@ int launch_group_count(const lvdgs_args &a, const GeomView &g, const ImageView &
 int launch_group_scan(const lvdgs_args &a, const ImageView &im, const RenderScratch &w, int64_t capacity, uint32_t *total_out, hipStream_t s,
                       uint32_t *host_out = nullptr, uint32_t host_seq = 0);   // host_out: pinned words the tile scan writes the pair count + hints + host_seq to
 // slot_scan: also makes slot_base from tiles_touched and w.chunk_sums (launch_preprocess_count's leftovers)
+// total_out / host_out / host_seq: launch_group_scan's, for the tile scan that rides in this launch (binning.hip: LVDGS_SCAN_IN_SCATTER)
 int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView &im, const RenderScratch &w, unsigned long long *keys64,
-                         int64_t capacity, bool slot_scan, uint8_t *pair_valid, hipStream_t s);
+                         int64_t capacity, bool slot_scan, uint8_t *pair_valid, hipStream_t s, uint32_t *total_out = nullptr, uint32_t *host_out = nullptr,
+                         uint32_t host_seq = 0);
 int launch_emit_pairs(const lvdgs_args &a, const GeomView &g, uint32_t *tile_keys, uint32_t *ids, int64_t capacity, hipStream_t s);
 // Sorts the segment of every tile in [t_lo, t_hi) by (view-depth bits, id) and leaves the ids in point_list.  keys64 holds
 // D 64-bit keys: already filled per segment (counting path, keys_ready; the queue of segments longer than
