@@ -518,6 +518,16 @@ int lvdgs_blend_backward_window_batch(const lvdgs_args *const *views, const lvdg
                                       const lvdgs_masked_loss_args *const *masked, int32_t count, int32_t propagate_opacity_grad,
                                       void *stream);
 
+/* The per-Gaussian passes (what lvdgs_backward_fused_loss / lvdgs_backward_masked_loss do with LVDGS_FLAG_NO_BLEND) of `count`
+ * views of one map in ONE launch, behind lvdgs_blend_backward_window_batch.  The views share the map and the gradient buffers
+ * (views[0]'s LVDGS_FLAG_ACCUMULATE_PARAM_GRADS says whether the sums are added to what those hold; the later views carry the
+ * flag); a thread walks its Gaussian through the views in order with the parameter gradients in registers and writes them once,
+ * where the view-after-view calls read and write them per view -- the same additions in the same order, the same bits.
+ * Every view keeps its own dL_dmeans2D and pose-gradient partials (dL_dtau NULL: left in its scratch for lvdgs_map_view_tail*).
+ * For SH colours of one coefficient (sh_degree 0, sh_coeffs 1) with scales + rotations; LVDGS_E_INVALID otherwise.
+ * Replaces: the reference's per-view loss.backward() accumulation into .grad (utils/slam_backend.py:262-306). */
+int lvdgs_gaussian_backward_batch(const lvdgs_args *const *views, int32_t count, void *stream);
+
 /* ---- diagnostics ---- */
 const char *lvdgs_last_error(void);
 const char *lvdgs_version(void);

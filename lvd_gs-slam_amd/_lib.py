@@ -131,7 +131,7 @@ EXPORTS = (
     "lvdgs_dist2_knn3", "lvdgs_rope2d", "lvdgs_rope2d_strided", "lvdgs_loss_scratch_bytes", "lvdgs_photometric_loss_forward",
     "lvdgs_photometric_loss_backward", "lvdgs_photometric_loss_value_and_grad", "lvdgs_photometric_loss_partials", "lvdgs_tracking_tail", "lvdgs_backward_fused_loss", "lvdgs_blend_forward_batch", "lvdgs_blend_backward_fused_loss_batch", "lvdgs_masked_depth_scratch_bytes", "lvdgs_masked_depth_l1_forward",
     "lvdgs_masked_depth_l1_backward", "lvdgs_pose_step", "lvdgs_host_device_pointer", "lvdgs_pose_step_batch", "lvdgs_adam_step", "lvdgs_isotropic_scratch_bytes", "lvdgs_isotropic_reg", "lvdgs_view_stats", "lvdgs_map_stats_apply", "lvdgs_map_view_tail", "lvdgs_ssim_scratch_bytes", "lvdgs_ssim_l1",
-    "lvdgs_masked_loss_scratch_bytes", "lvdgs_masked_loss_batch", "lvdgs_backward_masked_loss", "lvdgs_blend_backward_window_batch", "lvdgs_forward_batch", "lvdgs_forward_backward_fused_loss", "lvdgs_map_view_tail_batch", "lvdgs_last_error", "lvdgs_version", "lvdgs_profile_enable",
+    "lvdgs_masked_loss_scratch_bytes", "lvdgs_masked_loss_batch", "lvdgs_backward_masked_loss", "lvdgs_blend_backward_window_batch", "lvdgs_forward_batch", "lvdgs_forward_backward_fused_loss", "lvdgs_map_view_tail_batch", "lvdgs_gaussian_backward_batch", "lvdgs_last_error", "lvdgs_version", "lvdgs_profile_enable",
     "lvdgs_profile_reset", "lvdgs_profile_read",
 )
 
@@ -211,6 +211,7 @@ def lib():
         L.lvdgs_masked_loss_scratch_bytes.argtypes = [C.c_int32, C.c_int32]
         L.lvdgs_masked_loss_batch.argtypes = [C.POINTER(C.POINTER(MaskedLossArgs)), C.c_int32, C.c_void_p]
         L.lvdgs_backward_masked_loss.argtypes = [C.POINTER(Args), C.POINTER(MaskedLossArgs), C.c_void_p]
+        L.lvdgs_gaussian_backward_batch.argtypes = [C.POINTER(C.POINTER(Args)), C.c_int32, C.c_void_p]
         L.lvdgs_blend_backward_window_batch.argtypes = [C.POINTER(C.POINTER(Args)), C.POINTER(C.POINTER(LossArgs)), C.POINTER(C.POINTER(MaskedLossArgs)),
                                                         C.c_int32, C.c_int32, C.c_void_p]
         L.lvdgs_profile_enable.argtypes = [C.c_int]

@@ -821,6 +821,36 @@ int lvdgs_blend_backward_fused_loss_batch(const lvdgs_args *const *views, const 
     return lvdgs_blend_backward_window_batch(views, losses, nullptr, count, propagate_opacity_grad, stream);
 }
 
+// The per-Gaussian passes of `count` views behind their (batched) backward blend pass, in one launch (include/lvdgs.h).
+int lvdgs_gaussian_backward_batch(const lvdgs_args *const *views, int32_t count, void *stream) {
+    hipStream_t s = (hipStream_t)stream;
+    if (count < 0 || (count > 0 && !views)) { set_error("gaussian backward batch: bad view list"); return LVDGS_E_INVALID; }
+    if (count == 0) return LVDGS_OK;
+    std::vector<GeomView> g(count); std::vector<BinView> b(count); std::vector<BwdScratch> w(count);
+    const lvdgs_args *a0 = views[0];
+    if (!a0) { set_error("gaussian backward batch: view 0 is NULL"); return LVDGS_E_INVALID; }
+    for (int k = 0; k < count; k++) {
+        const lvdgs_args *a = views[k];
+        if (!a) { set_error("gaussian backward batch: view %d is NULL", k); return LVDGS_E_INVALID; }
+        if (a->flags & LVDGS_FLAG_POSE_ONLY) { set_error("gaussian backward batch: LVDGS_FLAG_POSE_ONLY makes no parameter gradients"); return LVDGS_E_INVALID; }
+        if (a->num_gaussians != a0->num_gaussians || a->means3D != a0->means3D || a->opacities != a0->opacities || a->scales != a0->scales ||
+            a->rotations != a0->rotations || a->shs != a0->shs || a->activations != a0->activations || a->dL_dmeans3D != a0->dL_dmeans3D ||
+            a->dL_dopacities != a0->dL_dopacities || a->dL_dscales != a0->dL_dscales || a->dL_drotations != a0->dL_drotations || a->dL_dshs != a0->dL_dshs) {
+            set_error("gaussian backward batch: the views differ in map or gradient buffers"); return LVDGS_E_INVALID;
+        }
+        if (!a->shs || a->colors_precomp || a->cov3D_precomp || a->sh_coeffs != 1 || a->sh_degree != 0) {
+            set_error("gaussian backward batch: needs SH colours of one coefficient (degree 0) and scales + rotations (the views go through lvdgs_backward_fused_loss / _masked_loss one by one otherwise)");
+            return LVDGS_E_INVALID;
+        }
+        if (k > 0 && !(a->flags & LVDGS_FLAG_ACCUMULATE_PARAM_GRADS)) { set_error("gaussian backward batch: view %d does not carry LVDGS_FLAG_ACCUMULATE_PARAM_GRADS (the views' gradients are summed)", k); return LVDGS_E_INVALID; }
+        BackwardViews v;
+        LossParams unused{};   // (the checks of a backward call whose pixel gradients came from a loss: the blend pass has run)
+        if (int e = backward_impl(a, &unused, 0, s, &v)) return e;
+        g[k] = v.g; b[k] = v.b; w[k] = v.w;
+    }
+    return launch_preprocess_bwd_views(views, g.data(), w.data(), b.data(), count, s);
+}
+
 int lvdgs_mark_visible(int32_t N, const float *means3D, const float *viewmatrix, const float *projmatrix, uint8_t *present,
                        void *stream) {
     (void)projmatrix;

@@ -238,6 +238,7 @@ int tile_sort_bits(int W, int H);  // number of key bits to sort for the tile id
 // ---- launchers (one per kernel family; all enqueue on `stream` and return a status) ----
 int launch_preprocess_fwd(const lvdgs_args &a, const GeomView &g, uint32_t *blocksums /* one per 256 Gaussians */, hipStream_t s);
 // pair_total / pair_capacity (lvdgs_forward_backward_fused_loss): the pass does nothing when *pair_total exceeds the capacity
+int launch_preprocess_bwd_views(const lvdgs_args *const *a, const GeomView *g, const BwdScratch *w, const BinView *b, int n, hipStream_t s);
 int launch_preprocess_bwd(const lvdgs_args &a, const GeomView &g, const BwdScratch &b, const uint8_t *pair_valid, hipStream_t s,
                           const uint32_t *pair_total = nullptr, uint32_t pair_capacity = 0);
 int launch_mark_visible(int N, const float *means3D, const float *view, uint8_t *present, hipStream_t s);

@@ -620,8 +620,14 @@ __device__ LVDGS_BIG_PATH_ATTR PairSums sum_region_compacted(const float *__rest
 // POSE_ONLY (LVDGS_FLAG_POSE_ONLY): the pose gradient alone -- six-float pair records (d/d 2-D mean, conic, view depth), no
 // opacity / colour reads, no parameter-gradient stores, no scale / quaternion chain.  The statements that make dL/dtau are the
 // same ones in the same order: the partial sums are bit for bit those of the full form.
-template <bool POSE_ONLY>
-__device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p) {
+// IN_REGS (preprocess_bwd_views_kernel: the per-Gaussian passes of several views of a mapping window in one launch): the parameter
+// gradients are not added to memory view after view -- 56 bytes read and 56 written per visible Gaussian and view -- but kept in the
+// thread's registers over the views (acc) and written once by the caller.  The additions are the ones the view-after-view launches
+// make, in the same order: `assign` (the launch's first view when its gradients are not added to what the buffers hold) assigns.
+struct GradAcc { float opac, m3[3], sc[3], rot[4], sh[3]; bool touched; };
+template <bool POSE_ONLY, bool IN_REGS = false>
+__device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p, GradAcc *acc = nullptr, bool assign = false) {
+    static_assert(!(POSE_ONLY && IN_REGS), "the pose-only pass has no parameter gradients to keep");
     constexpr int PF = POSE_ONLY ? PAIR_FLOATS_POSE : PAIR_FLOATS;   // floats per pair record
     __shared__ float s_tau[4][6];
     if (p.pair_total && *p.pair_total > p.pair_capacity) return;   // (uniform over the launch)
@@ -666,25 +672,38 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p) {
     const bool live = in_map && radius_i > 0 && tiles_i > 0u;
     // gradients w.r.t. the parameters: written, or (a later view of a mapping iteration) added to what is there
     const bool accumulate = p.accumulate != 0;
-    auto put = [accumulate](float *dst, float v) { *dst = accumulate ? *dst + v : v; };
+    // (r: the value's place in the registers of an IN_REGS pass)
+    auto put = [=](float *dst, float v, float *r) {
+        if constexpr (IN_REGS) *r = assign ? v : *r + v;
+        else *dst = accumulate ? *dst + v : v;
+    };
     // a Gaussian's three / four values as ONE 12- / 16-byte access per lane: the wave's stores are whole runs of memory
     // instead of three or four passes of every-third-word stores over the same sectors
     struct f3 { float x, y, z; };
     struct f4 { float x, y, z, w; };
-    auto put3 = [accumulate](float *dst, float a, float b, float c) {
-        f3 *d = reinterpret_cast<f3 *>(dst);
-        if (accumulate) { const f3 o = *d; a += o.x; b += o.y; c += o.z; }
-        *d = f3{a, b, c};
+    auto put3 = [=](float *dst, float a, float b, float c, float *r) {
+        if constexpr (IN_REGS) {
+            r[0] = assign ? a : r[0] + a; r[1] = assign ? b : r[1] + b; r[2] = assign ? c : r[2] + c;
+        } else {
+            f3 *d = reinterpret_cast<f3 *>(dst);
+            if (accumulate) { const f3 o = *d; a += o.x; b += o.y; c += o.z; }
+            *d = f3{a, b, c};
+        }
     };
-    auto put4 = [accumulate](float *dst, float a, float b, float c, float e) {
-        f4 *d = reinterpret_cast<f4 *>(dst);
-        if (accumulate) { const f4 o = *d; a += o.x; b += o.y; c += o.z; e += o.w; }
-        *d = f4{a, b, c, e};
+    auto put4 = [=](float *dst, float a, float b, float c, float e, float *r) {
+        if constexpr (IN_REGS) {
+            r[0] = assign ? a : r[0] + a; r[1] = assign ? b : r[1] + b; r[2] = assign ? c : r[2] + c; r[3] = assign ? e : r[3] + e;
+        } else {
+            f4 *d = reinterpret_cast<f4 *>(dst);
+            if (accumulate) { const f4 o = *d; a += o.x; b += o.y; c += o.z; e += o.w; }
+            *d = f4{a, b, c, e};
+        }
     };
+    if constexpr (IN_REGS) { if (live) acc->touched = true; }
     if (!POSE_ONLY && i < p.N && !live) {
 #pragma unroll
         for (int k = 0; k < 3; k++) p.dmeans2D[3 * (size_t)i + k] = 0.f;
-        if (!accumulate) {   // (adding zero: nothing to do)
+        if (!IN_REGS && !accumulate) {   // (adding zero: nothing to do; IN_REGS: the caller writes what the registers hold)
 #pragma unroll
             for (int k = 0; k < 3; k++) p.dmeans3D[3 * (size_t)i + k] = 0.f;
             p.dopac[i] = 0.f;
@@ -813,8 +832,8 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p) {
             // d/d(logit) = d/d(opacity) * o (1 - o) when the sigmoid is fused (o re-evaluated with the forward's expression: the
             // record holds it too, but reading 4 bytes of a 64-byte record per Gaussian moved 20 MB for 2)
             float o = opac_raw;
-            if (p.act & ACT_SIGMOID_OPACITY) { o = 1.f / (1.f + expf(-o)); put(&p.dopac[i], A[5] * o * (1.f - o)); }
-            else put(&p.dopac[i], A[5]);
+            if (p.act & ACT_SIGMOID_OPACITY) { o = 1.f / (1.f + expf(-o)); put(&p.dopac[i], A[5] * o * (1.f - o), IN_REGS ? &acc->opac : nullptr); }
+            else put(&p.dopac[i], A[5], IN_REGS ? &acc->opac : nullptr);
         }
         const float g_ndc[2] = {A[0] * 0.5f * (float)c.W, A[1] * 0.5f * (float)c.H};
         if constexpr (!POSE_ONLY) *reinterpret_cast<f3 *>(&p.dmeans2D[3 * (size_t)i]) = f3{g_ndc[0], g_ndc[1], 0.f};
@@ -826,7 +845,7 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p) {
         // ---- colour ---- (POSE_ONLY: colours without view dependence only -- api.hip -- which give the pose nothing)
         if constexpr (POSE_ONLY) {
         } else if (p.colors_precomp) {
-            put3(&p.dcolors[3 * (size_t)i], g_rgb[0], g_rgb[1], g_rgb[2]);
+            put3(&p.dcolors[3 * (size_t)i], g_rgb[0], g_rgb[1], g_rgb[2], nullptr);   // (IN_REGS: SH colours of one coefficient only, launch_preprocess_bwd_views)
         } else {
             float d[3] = {pos[0] - c.campos[0], pos[1] - c.campos[1], pos[2] - c.campos[2]};
             const float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
@@ -848,14 +867,14 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p) {
 #pragma unroll
             for (int k = 0; k < 16; k++)
                 if (k < nb) {
-                    put3(&dsh[3 * k], B[k] * g_rgb[0], B[k] * g_rgb[1], B[k] * g_rgb[2]);
+                    put3(&dsh[3 * k], B[k] * g_rgb[0], B[k] * g_rgb[1], B[k] * g_rgb[2], IN_REGS ? acc->sh : nullptr);   // (IN_REGS: k = 0 is the only one)
 #pragma unroll
                     for (int ch = 0; ch < 3; ch++) {
                         const float sg = sh[3 * k + ch] * g_rgb[ch];
                         g_u[0] += G[k][0] * sg; g_u[1] += G[k][1] * sg; g_u[2] += G[k][2] * sg;
                     }
                 }
-            if (!accumulate)
+            if (!IN_REGS && !accumulate)
                 for (int k = nb; k < c.M; k++) { dsh[3 * k] = 0.f; dsh[3 * k + 1] = 0.f; dsh[3 * k + 2] = 0.f; }
             // The view direction d = mean - camera centre moves with the mean and with the camera: C = -R^T T, and under
             // T_w2c <- Exp(tau) T_w2c dC/drho = -R^T, dC/dtheta = 0 at tau = 0, so dL/drho += R g_d (oracle: same statement,
@@ -891,8 +910,8 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p) {
             }
         if (!POSE_ONLY && p.dcov3D) {
             float *o = p.dcov3D + 6 * (size_t)i;
-            put(o + 0, g_S[0][0]); put(o + 1, 2.f * g_S[0][1]); put(o + 2, 2.f * g_S[0][2]);
-            put(o + 3, g_S[1][1]); put(o + 4, 2.f * g_S[1][2]); put(o + 5, g_S[2][2]);
+            put(o + 0, g_S[0][0], nullptr); put(o + 1, 2.f * g_S[0][1], nullptr); put(o + 2, 2.f * g_S[0][2], nullptr);   // (never IN_REGS)
+            put(o + 3, g_S[1][1], nullptr); put(o + 4, 2.f * g_S[1][2], nullptr); put(o + 5, g_S[2][2], nullptr);
         }
         float TS[2][3], g_T[2][3];
 #pragma unroll
@@ -937,7 +956,7 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p) {
         for (int a = 0; a < 3; a++) {
             g_world[a] += Vg[4 * a + 0] * g_pview[0] + Vg[4 * a + 1] * g_pview[1] + Vg[4 * a + 2] * g_pview[2];
         }
-        if constexpr (!POSE_ONLY) put3(&p.dmeans3D[3 * (size_t)i], g_world[0], g_world[1], g_world[2]);
+        if constexpr (!POSE_ONLY) put3(&p.dmeans3D[3 * (size_t)i], g_world[0], g_world[1], g_world[2], IN_REGS ? acc->m3 : nullptr);
 
         // ---- camera pose: T' = Exp(tau) T ----
         const float gv[3] = {g_pview[0] + g_pview_proj[0], g_pview[1] + g_pview_proj[1], g_pview[2] + g_pview_proj[2]};
@@ -971,7 +990,7 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p) {
                 // fused exp: d/d(log s) = d/ds * s
                 g_sc[b] = v * c.scale_mod * ((p.act & ACT_EXP_SCALES) ? sc[b] : 1.f);
             }
-            put3(&p.dscales[3 * (size_t)i], g_sc[0], g_sc[1], g_sc[2]);
+            put3(&p.dscales[3 * (size_t)i], g_sc[0], g_sc[1], g_sc[2], IN_REGS ? acc->sc : nullptr);
             const float r = q[0], x = q[1], y = q[2], z = q[3];
             float dq[4];
             dq[0] = 2.f * (-z * g_R[0][1] + y * g_R[0][2] + z * g_R[1][0] - x * g_R[1][2] - y * g_R[2][0] + x * g_R[2][1]);
@@ -984,7 +1003,7 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) dq[k] = (dq[k] - q[k] * dot) / qnorm;
             }
-            put4(&p.drot[4 * (size_t)i], dq[0], dq[1], dq[2], dq[3]);
+            put4(&p.drot[4 * (size_t)i], dq[0], dq[1], dq[2], dq[3], IN_REGS ? acc->rot : nullptr);
         }
     }
     // ---- workgroup sum of the pose gradient -> one partial per workgroup (no atomics) ----
@@ -1006,6 +1025,50 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(Bwd
 #define LVDGS_PBWD_WGS_POSE 5   // (6: 80 VGPRs with 7 spilled; same box 25.1 against 24.1 us at config 3)
 #endif
 __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS_POSE) preprocess_bwd_pose_kernel(BwdParams p) { preprocess_bwd_body<true>(p); }
+
+// The per-Gaussian passes of up to PBWD_VIEWS views of one map in ONE launch (lvdgs_gaussian_backward_batch: the views of a mapping
+// window behind their batched blend pass).  A thread walks its Gaussian through the views in order with the parameter gradients in
+// registers (GradAcc above) and writes them once: the view-after-view launches read and wrote 56 bytes per visible Gaussian and view.
+// Every view keeps what is its own: its records, its dL/d(2-D mean) array, its pose-gradient partials.
+constexpr int PBWD_VIEWS = 12;
+struct BwdView {
+    Cam cam; const int32_t *radii; const float *rec; const uint32_t *tiles_touched, *slot_base; const float *pair_grads; const uint8_t *pair_valid;
+    float *dmeans2D, *tau_part;
+};
+struct BwdViews { BwdParams common; int n; BwdView v[PBWD_VIEWS]; };
+static_assert(sizeof(BwdViews) <= 4000, "kernel arguments");
+#ifndef LVDGS_PBWD_VIEWS_WGS
+#define LVDGS_PBWD_VIEWS_WGS 4
+#endif
+__global__ void __launch_bounds__(256, LVDGS_PBWD_VIEWS_WGS) preprocess_bwd_views_kernel(BwdViews b) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool add_to_memory = b.common.accumulate != 0;   // (the launch's sums are added to what the buffers hold)
+    GradAcc acc{};
+    if (add_to_memory && i < b.common.N) {
+        acc.opac = b.common.dopac[i];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { acc.m3[k] = b.common.dmeans3D[3 * (size_t)i + k]; acc.sc[k] = b.common.dscales[3 * (size_t)i + k]; acc.sh[k] = b.common.dshs[3 * (size_t)i + k]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) acc.rot[k] = b.common.drot[4 * (size_t)i + k];
+    }
+    for (int k = 0; k < b.n; k++) {
+        BwdParams p = b.common;
+        const BwdView &v = b.v[k];
+        p.cam = v.cam; p.radii = v.radii; p.rec = v.rec; p.tiles_touched = v.tiles_touched; p.slot_base = v.slot_base;
+        p.pair_grads = v.pair_grads; p.pair_valid = v.pair_valid; p.dmeans2D = v.dmeans2D; p.tau_part = v.tau_part;
+        preprocess_bwd_body<false, true>(p, &acc, k == 0 && !add_to_memory);
+        __syncthreads();   // (the next view's pass uses the workgroup's LDS again)
+    }
+    if (i < b.common.N && (acc.touched || !add_to_memory)) {   // (a Gaussian no view of the launch saw: zeros, or what was there)
+        struct f3 { float x, y, z; };
+        struct f4 { float x, y, z, w; };
+        b.common.dopac[i] = acc.opac;
+        *reinterpret_cast<f3 *>(&b.common.dmeans3D[3 * (size_t)i]) = f3{acc.m3[0], acc.m3[1], acc.m3[2]};
+        *reinterpret_cast<f3 *>(&b.common.dscales[3 * (size_t)i]) = f3{acc.sc[0], acc.sc[1], acc.sc[2]};
+        *reinterpret_cast<f3 *>(&b.common.dshs[3 * (size_t)i]) = f3{acc.sh[0], acc.sh[1], acc.sh[2]};
+        *reinterpret_cast<f4 *>(&b.common.drot[4 * (size_t)i]) = f4{acc.rot[0], acc.rot[1], acc.rot[2], acc.rot[3]};
+    }
+}
 
 // fixed-order reduction of the per-workgroup pose partials (strided per-thread sums, then a wave fold and a four-term sum:
 // two barriers fewer than an LDS tree, the order of the additions fixed by the code either way)
@@ -1136,6 +1199,43 @@ int launch_preprocess_bwd(const lvdgs_args &a, const GeomView &g, const BwdScrat
         hipLaunchKernelGGL(tau_reduce_kernel, dim3(1), dim3(256), 0, s, b.tau_part, nblk, a.dL_dtau);
         LVDGS_LAUNCH_CHECK("tau_reduce", a.debug, s);
     }
+    return LVDGS_OK;
+}
+
+// The per-Gaussian passes of n views of one map in one launch (preprocess_bwd_views_kernel); the caller has checked that the views
+// share the map and the gradient buffers, colour by SH of ONE coefficient, scales + rotations (no precomputed covariance).
+int launch_preprocess_bwd_views(const lvdgs_args *const *a, const GeomView *g, const BwdScratch *w, const BinView *b, int n, hipStream_t s) {
+    const lvdgs_args &a0 = *a[0];
+    const int N = a0.num_gaussians;
+    const int nblk = cdiv(N, 256);
+    for (int first = 0; first < n && N > 0; first += PBWD_VIEWS) {
+        const int m = n - first < PBWD_VIEWS ? n - first : PBWD_VIEWS;
+        BwdViews bv{};
+        BwdParams &p = bv.common;
+        p.N = N; p.act = a0.activations;
+        p.means3D = a0.means3D; p.opacities = a0.opacities; p.scales = a0.scales; p.rotations = a0.rotations; p.cov3D_precomp = nullptr;
+        p.shs = a0.shs; p.colors_precomp = nullptr;
+        p.dmeans3D = a0.dL_dmeans3D; p.dopac = a0.dL_dopacities; p.dscales = a0.dL_dscales; p.drot = a0.dL_drotations; p.dcov3D = nullptr; p.dshs = a0.dL_dshs;
+        p.dcolors = nullptr;
+        // (a later group of the same call adds to what the first group wrote)
+        p.accumulate = (first > 0 || (a0.flags & LVDGS_FLAG_ACCUMULATE_PARAM_GRADS)) ? 1 : 0;
+        p.pair_total = nullptr; p.pair_capacity = 0;
+        bv.n = m;
+        for (int k = 0; k < m; k++) {
+            const int v = first + k;
+            bv.v[k] = BwdView{make_cam(*a[v]), a[v]->radii, g[v].rec, g[v].tiles_touched, g[v].slot_base, w[v].pair_grads, b[v].pair_valid, a[v]->dL_dmeans2D, w[v].tau_part};
+        }
+        ProfScope ps("preprocess_bwd", s);
+        hipLaunchKernelGGL(preprocess_bwd_views_kernel, dim3(nblk), dim3(256), 0, s, bv);
+        LVDGS_LAUNCH_CHECK("preprocess_bwd (views)", a0.debug, s);
+    }
+    for (int v = 0; v < n; v++)
+        if (a[v]->dL_dtau) {
+            if (N == 0) { if (int e = check_hip(hipMemsetAsync(a[v]->dL_dtau, 0, 6 * sizeof(float), s), "memset tau")) return e; continue; }
+            ProfScope ps("tau_reduce", s);
+            hipLaunchKernelGGL(tau_reduce_kernel, dim3(1), dim3(256), 0, s, w[v].tau_part, nblk, a[v]->dL_dtau);
+            LVDGS_LAUNCH_CHECK("tau_reduce", a[v]->debug, s);
+        }
     return LVDGS_OK;
 }
 

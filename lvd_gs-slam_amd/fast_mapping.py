@@ -367,8 +367,8 @@ class MapWindowBatch:
         once:      lvdgs_forward_batch (LVDGS_FLAG_NO_BLEND: projection + counting, the two scans, the scatter and the per-tile depth
                    sort of ALL views, a launch per stage; LVDGS_MAP_FWD_BATCH=0: lvdgs_forward view by view, as in round 4)
         once:      lvdgs_blend_forward_batch, [lvdgs_masked_loss_batch over the views with a static mask,] lvdgs_blend_backward_window_batch
-        per view:  lvdgs_backward_fused_loss / lvdgs_backward_masked_loss (LVDGS_FLAG_NO_BLEND: the per-Gaussian pass, adding to the
-                   first view's gradients), lvdgs_map_view_tail
+        once:      lvdgs_gaussian_backward_batch (the per-Gaussian passes of all views, the parameter gradients summed in registers in the
+                   window's order and written once), lvdgs_map_view_tail_batch
 
     Keyframes with a static mask -- the reference's default: all eight of the window -- and views without one (the two random older
     views) share the launches: the backward blend kernel takes each view's pixel gradients from the loss that view is scored by.
@@ -464,10 +464,14 @@ class MapWindowBatch:
                 _lib.check(L.lvdgs_blend_backward_window_batch(views, losses, ct["per_view"], n, 0, stream), "lvdgs_blend_backward_window_batch")
             else:
                 _lib.check(L.lvdgs_blend_backward_fused_loss_batch(views, losses, n, 0, stream), "lvdgs_blend_backward_fused_loss_batch")
-            # the per-Gaussian passes view after view (they add to one set of gradients, in the window's order) ...
+            # the per-Gaussian passes of all views in ONE launch, the parameter gradients summed in registers in the window's order
+            # (lvdgs_gaussian_backward_batch; LVDGS_MAP_PBWD_BATCH=0: view after view, each adding to the buffers, as until round 5) ...
             one_tail = stats is not None and all(st is not None for st in stats) and os.environ.get("LVDGS_MAP_TAIL_BATCH", "1") != "0"
+            one_pass = os.environ.get("LVDGS_MAP_PBWD_BATCH", "1") != "0" and int(G.active_sh_degree) == 0
+            if one_pass:
+                _lib.check(L.lvdgs_gaussian_backward_batch(views, n, stream), "lvdgs_gaussian_backward_batch")
             for k in range(n):
-                self.passes[k]._backward_for_batch(ctxs[k], None if stats is None else stats[k], stream, tail=not one_tail)
+                self.passes[k]._backward_for_batch(ctxs[k], None if stats is None else stats[k], stream, tail=not one_tail, gaussian_pass=not one_pass)
             if one_tail:   # ... and their tails -- loss, pose gradient, the view's statistics -- in ONE launch, the statistics in view order
                 for k in range(n):
                     sa = ct["sas"][k]
@@ -562,12 +566,13 @@ def _begin_for_batch(self, backend, viewpoint, initialization, first, lead_into,
                 loss=loss, into=into, install=install, fields=fields, initialization=initialization, masked=masked_loss is not None)
 
 
-def _backward_for_batch(self, ctx, stats, stream, tail=True):
+def _backward_for_batch(self, ctx, stats, stream, tail=True, gaussian_pass=True):
     L, a, la = self.L, self.a, self.la
     if ctx["masked"]:
-        _lib.check(L.lvdgs_backward_masked_loss(C.byref(a), C.byref(self.ml), stream), "lvdgs_backward_masked_loss")
+        if gaussian_pass:
+            _lib.check(L.lvdgs_backward_masked_loss(C.byref(a), C.byref(self.ml), stream), "lvdgs_backward_masked_loss")
         la = None   # (the loss value is finished: the tail reduces the pose gradient and takes the statistics)
-    else:
+    elif gaussian_pass:
         _lib.check(L.lvdgs_backward_fused_loss(C.byref(a), C.byref(la), 0, stream), "lvdgs_backward_fused_loss")
     ctx["stats_taken"] = False
     if not tail:   # (the caller finishes all views in one launch: lvdgs_map_view_tail_batch)
