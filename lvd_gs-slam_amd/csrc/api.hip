@@ -843,6 +843,9 @@ int lvdgs_gaussian_backward_batch(const lvdgs_args *const *views, int32_t count,
             return LVDGS_E_INVALID;
         }
         if (k > 0 && !(a->flags & LVDGS_FLAG_ACCUMULATE_PARAM_GRADS)) { set_error("gaussian backward batch: view %d does not carry LVDGS_FLAG_ACCUMULATE_PARAM_GRADS (the views' gradients are summed)", k); return LVDGS_E_INVALID; }
+    }
+    for (int k = 0; k < count; k++) {
+        const lvdgs_args *a = views[k];
         BackwardViews v;
         LossParams unused{};   // (the checks of a backward call whose pixel gradients came from a loss: the blend pass has run)
         if (int e = backward_impl(a, &unused, 0, s, &v)) return e;

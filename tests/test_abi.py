@@ -135,6 +135,27 @@ def test_argument_validation_without_gpu():
         _lib.check(_lib.E_INVALID, "probe")
 
 
+def test_gaussian_backward_batch_argument_validation_without_gpu():
+    """lvdgs_gaussian_backward_batch refuses view lists it has no single launch for -- before anything is enqueued."""
+    L = _lib.lib()
+    assert L.lvdgs_gaussian_backward_batch(None, 0, None) == _lib.OK   # nothing to do
+    assert L.lvdgs_gaussian_backward_batch(None, 2, None) == _lib.E_INVALID and b"view list" in L.lvdgs_last_error()
+    a, b = _lib.Args(), _lib.Args()
+    views = (C.POINTER(_lib.Args) * 2)(C.pointer(a), C.pointer(b))
+    a.flags = b.flags = _lib.FLAG_POSE_ONLY
+    assert L.lvdgs_gaussian_backward_batch(views, 2, None) == _lib.E_INVALID and b"POSE_ONLY" in L.lvdgs_last_error()
+    a.flags = b.flags = 0
+    assert L.lvdgs_gaussian_backward_batch(views, 2, None) == _lib.E_INVALID and b"one coefficient" in L.lvdgs_last_error()   # no shs
+    a.shs = b.shs = 256   # (never dereferenced: every call here is rejected before a launch)
+    a.sh_coeffs = b.sh_coeffs = 1
+    b.num_gaussians = 5
+    assert L.lvdgs_gaussian_backward_batch(views, 2, None) == _lib.E_INVALID and b"differ in map" in L.lvdgs_last_error()
+    b.num_gaussians = 0
+    assert L.lvdgs_gaussian_backward_batch(views, 2, None) == _lib.E_INVALID and b"ACCUMULATE_PARAM_GRADS" in L.lvdgs_last_error()
+    views[1] = None
+    assert L.lvdgs_gaussian_backward_batch(views, 2, None) == _lib.E_INVALID and b"view 1 is NULL" in L.lvdgs_last_error()
+
+
 def test_rope2d_strided_argument_validation_without_gpu():
     L = _lib.lib()
     tok, pos = C.c_void_p(256), C.c_void_p(512)  # never dereferenced: every call below is rejected before a launch
