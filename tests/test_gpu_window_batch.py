@@ -14,14 +14,14 @@ sys.path.insert(0, ROOT)
 pytestmark = pytest.mark.gpu
 
 
-def _run(batch, iters, n_window=8, workload="tmp_window_batch"):
+def _run(batch, iters, n_window=8, workload="tmp_window_batch", world=12):
     import bench
     from lvdgs import backend_map, synthetic
     synthetic.CONFIGS.setdefault(workload, dict(N=30000, W=400, H=240))
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     model, cam, g, _ = bench.build_scene(workload, 0, dev)
-    backend, window = bench.build_window(workload, 12, dev, model, n_window=n_window)
+    backend, window = bench.build_window(workload, world, dev, model, n_window=n_window)
     before = os.environ.get("LVDGS_MAP_BATCH")
     os.environ["LVDGS_MAP_BATCH"] = "1" if batch else "0"
     try:
@@ -59,6 +59,18 @@ def test_window_batch_is_the_window_view_by_view_bit_for_bit(workload):
         assert torch.equal(a, b)
     for a, b in zip(stats_b, stats_s):
         assert torch.equal(a, b)
+    assert losses_b == losses_s
+
+
+def test_window_batch_with_more_views_than_one_launch_takes():
+    """13 keyframes + 2 random views: more than any of the batched launches takes at once (forward chain 10, blend 11, per-Gaussian pass
+    and tails 12) -- every stage runs in two groups, the second group's per-Gaussian pass ADDING to what the first wrote."""
+    used_b, params_b, poses_b, stats_b, losses_b = _run(True, 2, n_window=13, world=16)
+    used_s, params_s, poses_s, stats_s, losses_s = _run(False, 2, n_window=13, world=16)
+    assert used_b and not used_s
+    for xs, ys in ((params_b, params_s), (poses_b, poses_s), (stats_b, stats_s)):
+        for a, b in zip(xs, ys):
+            assert torch.equal(a, b)
     assert losses_b == losses_s
 
 

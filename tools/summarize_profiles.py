@@ -70,7 +70,9 @@ def main(tag, workload="cfg3_500k_1920x1080", prefix="pmc_", label=None):
                             r["VGPR_Count"], r["SGPR_Count"], r["Counter_Name"], r["Counter_Value"]])
                 per_kernel[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     note = ("(2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE reports half the bytes of 16-byte-per-lane reads "
-            "(MI355X_MICROARCH.md, HBM section); separate --pmc passes, averaged over launches")
+            "(MI355X_MICROARCH.md, HBM section) -- and of every other pattern of these kernels: it counts requests for 128-byte lines at 64 bytes "
+            "each whatever the width per lane (calibrated on known byte counts, profiles/experiments/r05_traffic_calib); separate --pmc passes, "
+            "averaged over launches")
     tpath = os.path.join(dst, "traffic.json")
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
     entry = {}
