@@ -30,6 +30,8 @@ for w, masked in (("kitti07_geom", False), ("kitti07_geom", True), ("kitti07_geo
     ts = []
     del gc_log[:]
     for k in range(96):
+        if k == 8 and os.environ.get("SIDE_DIAG_FREEZE", "1") != "0":   # (as bench.py's run_side does behind its eight warm-up iterations)
+            gc.collect(); gc.freeze()
         torch.cuda.synchronize(); t = time.perf_counter()
         backend_map.map_window(backend, window, iters=1)
         torch.cuda.synchronize(); ts.append(1e3 * (time.perf_counter() - t))
