@@ -10,7 +10,7 @@ scene of large flat Gaussians):
   the same window view by view, keyframes with or without static masks: map, poses, statistics and losses after two Adam iterations.
 
 The oracle comparison of the kernels themselves is tests/test_gpu_fuzz.py; this file pins that the batched / fused launches compute what
-the single-view launches compute.  LVDGS_FUZZ_PATH_CASES: number of cases (default 8; a sweep of 600 is in profiles/r05_fuzz_paths.txt)."""
+the single-view launches compute.  LVDGS_FUZZ_PATH_CASES: number of cases (default 8; a sweep of 600 is in profiles/r05_fuzz_sweeps.txt)."""
 import ctypes as C
 import os
 import sys

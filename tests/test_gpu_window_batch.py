@@ -74,6 +74,42 @@ def test_window_batch_with_more_views_than_one_launch_takes():
     assert losses_b == losses_s
 
 
+def test_gaussian_backward_batch_adds_to_gradients_that_are_there():
+    """lvdgs_gaussian_backward_batch with LVDGS_FLAG_ACCUMULATE_PARAM_GRADS on its FIRST view (the model's parameters already carry
+    gradients when the window's passes begin: nothing cleared them since the last backward): the launch starts from what the buffers
+    hold and adds the views in order -- the bits of the view-after-view launches (LVDGS_MAP_PBWD_BATCH=0), which add in memory."""
+    import bench
+    from lvdgs import synthetic
+    from lvdgs.fast_mapping import MapViewPass, MapWindowBatch
+    workload = "tmp_window_batch"
+    synthetic.CONFIGS.setdefault(workload, dict(N=30000, W=400, H=240))
+    dev = torch.device("cuda", 0)
+    out = {}
+    for one_pass in ("1", "0"):
+        torch.manual_seed(0)
+        model, cam, g, _ = bench.build_scene(workload, 0, dev)
+        backend, window = bench.build_window(workload, 6, dev, model, n_window=4)
+        G = backend.gaussians
+        gen = torch.Generator(device=dev).manual_seed(5)
+        for p_ in G.parameters():
+            p_.grad = torch.randn(p_.shape, device=dev, generator=gen) * 1e-3 if p_.numel() else None
+        views = [backend.viewpoints[k] for k in window]
+        before = os.environ.get("LVDGS_MAP_PBWD_BATCH")
+        os.environ["LVDGS_MAP_PBWD_BATCH"] = one_pass
+        try:
+            MapWindowBatch(MapViewPass(dev)).run(backend, views)
+        finally:
+            if before is None:
+                os.environ.pop("LVDGS_MAP_PBWD_BATCH", None)
+            else:
+                os.environ["LVDGS_MAP_PBWD_BATCH"] = before
+        torch.cuda.synchronize()
+        out[one_pass] = [p_.grad.clone() for p_ in G.parameters() if p_.grad is not None]
+    assert len(out["1"]) >= 5 and all(float(t.abs().sum()) > 0 for t in out["1"])
+    for a, b in zip(out["1"], out["0"]):
+        assert torch.equal(a, b)
+
+
 def test_window_batch_grows_its_pair_buffers_like_the_single_view_pass():
     """A view whose pair count exceeds its buffers' capacity (the first iterations of a back end, a view that sees far more of the
     map than the others) makes lvdgs_forward return LVDGS_E_CAPACITY; the view's pass grows its own buffers and re-runs the binning
