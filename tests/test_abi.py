@@ -135,6 +135,13 @@ def test_argument_validation_without_gpu():
         _lib.check(_lib.E_INVALID, "probe")
 
 
+def test_every_export_is_in_the_integration_guide():
+    """INTEGRATION.md's binding table names every entry point include/lvdgs.h declares (what each replaces on the reference's side)."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [n for n in _lib.EXPORTS if n not in doc]
+    assert not missing, missing
+
+
 def test_gaussian_backward_batch_argument_validation_without_gpu():
     """lvdgs_gaussian_backward_batch refuses view lists it has no single launch for -- before anything is enqueued."""
     L = _lib.lib()
