@@ -72,6 +72,12 @@ struct BlendParams {
     const uint32_t *pair_total;
     uint32_t pair_capacity;
 };
+#ifndef LVDGS_HEAVY_PRIO
+#define LVDGS_HEAVY_PRIO 0        // A/B builds: 1..3 = s_setprio level of the workgroups at the head of the tile order (blend_fwd_bwd_kernel); measured in round 5: nothing (KITTI pose-only 5090-5130 it/s with level 3 on the first 1/16 or 1/64 of the tiles, level 1 on the first 1/8, or none -- the heaviest tile's chain is its own latency, not lost issue slots)
+#endif
+#ifndef LVDGS_HEAVY_PRIO_SHIFT
+#define LVDGS_HEAVY_PRIO_SHIFT 4  // ... the first num_tiles >> SHIFT of them
+#endif
 // where the backward blend pass takes dL/d(colour, depth, opacity) of its pixels from
 constexpr int LOSS_IMAGES = 0;    // gradient images (lvdgs_backward)
 constexpr int LOSS_FUSED = 1;     // the photometric loss evaluated in the prologue (lvdgs_backward_fused_loss)
@@ -783,6 +789,14 @@ __global__ void __launch_bounds__(256, POSE_ONLY ? (DEPTH_GRAD ? 6 : LVDGS_BWD_W
 template <bool DEPTH_GRAD, bool POSE_ONLY, bool DEEP_LISTS>
 __global__ void __launch_bounds__(256, POSE_ONLY ? (DEPTH_GRAD ? 6 : LVDGS_BWD_WGS_POSE) : LVDGS_BWD_WGS) blend_fwd_bwd_kernel(BlendParams p) {
     __shared__ union U { FwdShared f; Bwd3Shared<POSE_ONLY, DEPTH_GRAD> b; __device__ U() {} } u;
+#if LVDGS_HEAVY_PRIO
+    // The launch lasts as long as its heaviest tile's own chain of rounds (a KITTI frame: 116 us of ~136 when that workgroup has its
+    // CU to itself, more beside four others): the waves of the heaviest tiles -- the head of the tile order -- issue first.
+    if (p.tile_order && *p.order_valid) {
+        const int slot = order_slot_of_workgroup((int)blockIdx.x, p.num_tiles);
+        if (slot < (p.num_tiles >> LVDGS_HEAVY_PRIO_SHIFT)) __builtin_amdgcn_s_setprio(LVDGS_HEAVY_PRIO);
+    }
+#endif
     blend_fwd2_body<DEEP_LISTS>(p, u.f);
     if (p.pair_total && *p.pair_total > p.pair_capacity) return;   // (uniform: the forward's outputs are invalid too, the caller knows)
     __threadfence_block();
