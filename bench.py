@@ -92,17 +92,7 @@ def build_scene(workload, rank, dev):
     return model, cam, g, (N, W, H)
 
 
-def dynamic_object_mask(H, W, seed):
-    """A keyframe's ``static_mask`` (bool (H,W), True = static) as LVD-GS's front end makes it from GroundingDINO + SAM detections
-    (utils/slam_frontend.py:1309-1329; the models are out of scope): two to four "vehicles" -- rectangles of 8-25 % of the image's
-    width and 10-35 % of its height in the lower two thirds of the frame -- marked dynamic, seeded per keyframe."""
-    g = torch.Generator().manual_seed(7000 + seed)
-    m = torch.ones(H, W, dtype=torch.bool)
-    for _ in range(2 + int(torch.randint(0, 3, (1,), generator=g))):
-        w = int(W * (0.08 + 0.17 * float(torch.rand(1, generator=g)))); h = int(H * (0.10 + 0.25 * float(torch.rand(1, generator=g))))
-        x0 = int(torch.randint(0, max(W - w, 1), (1,), generator=g)); y0 = H // 3 + int(torch.randint(0, max(H - H // 3 - h, 1), (1,), generator=g))
-        m[y0:y0 + h, x0:x0 + w] = False
-    return m
+dynamic_object_mask = synthetic.dynamic_object_mask   # (a keyframe's static_mask: seeded "vehicle" rectangles marked dynamic)
 
 
 def build_window(workload, world, dev, model, n_window=None, masked=False):

@@ -252,24 +252,63 @@ class on_device:
         return False
 
 
-_gc_settled = False
+_gc_policy = None      # "scoped" | "process" | "off"; None: not decided yet (LVDGS_GC_FREEZE / set_gc_policy / first loop entry)
+_gc_depth = 0
 
 
-def settle_garbage_collector():
-    """Once per process, at the first use of one of the product's loops (``TrackingSession``, ``backend_map.map_window``): a full
-    collection, then ``gc.freeze()`` -- everything alive now (the interpreter's and PyTorch's modules: about a million objects) moves to
-    the permanent generation and is never walked again.  The loops here run at 0.2-2 ms per iteration and allocate a few hundred small
-    Python objects in each, which makes CPython start a FULL collection every few dozen to few hundred iterations; with the whole heap
-    in it that is one stall of 40-110 ms (measured: ``tools/side_stall_diag.py``) -- 20-60 iterations' worth of time.  The reference's
-    own loops allocate as much but run a hundred times slower per iteration, so the same stall does not show there.
-    ``LVDGS_GC_FREEZE=0`` leaves the collector alone."""
-    global _gc_settled
-    if _gc_settled or os.environ.get("LVDGS_GC_FREEZE", "1") == "0":
-        return
-    _gc_settled = True
-    import gc
-    gc.collect()
-    gc.freeze()
+def set_gc_policy(policy):
+    """How the product's loops keep CPython's full-heap garbage collections out of their iterations.
+
+    The loops run at 0.2-2 ms per iteration and allocate a few hundred small Python objects in each, which makes CPython start a
+    FULL collection every few dozen to few hundred iterations; with the whole heap of an application that has PyTorch imported
+    (about a million objects) in the oldest generation that is one stall of 40-110 ms (measured: ``tools/side_stall_diag.py``) --
+    20-60 iterations' worth of time.
+
+    * ``"scoped"`` (the default): ``gc.freeze()`` when the outermost product loop is entered (``track_frame``, ``map_window``,
+      ``initialize_map``, ``color_refinement``, ``slam_sequence``) -- everything alive moves to the permanent generation, two list
+      splices, no collection -- and ``gc.unfreeze()`` when it returns: inside the loop the collector walks only what the loop itself
+      allocated, and afterwards the host application's collector sees its heap exactly as before (``gc.get_freeze_count() == 0``).
+      An application that calls ``gc.freeze()`` ITSELF should pick one of the other two: the scoped exit would thaw its objects too
+      (a freeze found in place at the first loop entry of the process switches the policy to "off" by itself).
+    * ``"process"`` (``LVDGS_GC_FREEZE=1``, what every round up to 5 did unasked): one ``gc.collect(); gc.freeze()`` at the first loop
+      entry, for the life of the process.  Cyclic garbage among the objects alive at that moment is never reclaimed.
+    * ``"off"`` (``LVDGS_GC_FREEZE=0``): the collector is left alone.
+    """
+    global _gc_policy
+    if policy not in ("scoped", "process", "off"):
+        raise ValueError("gc policy: 'scoped', 'process' or 'off'")
+    _gc_policy = policy
+
+
+class quiet_gc:
+    """Context manager around a product loop: see ``set_gc_policy``.  Re-entrant (only the outermost scope acts)."""
+    __slots__ = ("acted",)
+
+    def __enter__(self):
+        global _gc_policy, _gc_depth
+        import gc
+        self.acted = False
+        if _gc_policy is None:
+            env = os.environ.get("LVDGS_GC_FREEZE", "scoped")
+            _gc_policy = {"0": "off", "1": "process"}.get(env, "scoped")
+            if _gc_policy == "scoped" and gc.get_freeze_count() > 0:   # (walks the permanent generation: asked once per process)
+                _gc_policy = "off"   # the host application manages a freeze of its own: hands off
+            if _gc_policy == "process":
+                gc.collect()
+                gc.freeze()
+        _gc_depth += 1
+        if _gc_policy == "scoped" and _gc_depth == 1:
+            gc.freeze()
+            self.acted = True
+        return self
+
+    def __exit__(self, *exc):
+        global _gc_depth
+        _gc_depth -= 1
+        if self.acted:
+            import gc
+            gc.unfreeze()
+        return False
 
 
 def check(status, what):

@@ -706,7 +706,13 @@ def map_window(backend, current_window, prune=False, iters=1, up_pose=True, grou
     every rank steps its share -> all-gather (``ShardedAdam``) instead of an all-reduce and the same step on every rank."""
     if len(current_window) == 0:
         return
-    _lib.settle_garbage_collector()   # (once per process: no full-heap garbage collection inside a 2 ms loop)
+    with _lib.quiet_gc():   # (no full-heap garbage collection inside a 2 ms loop; the host's collector is as before afterwards)
+        return _map_window(backend, current_window, prune, iters, up_pose, group, reducer, render_fn, view_loss_fn, stats, fused, aux_group,
+                           bands_ok, sharded_adam)
+
+
+def _map_window(backend, current_window, prune, iters, up_pose, group, reducer, render_fn, view_loss_fn, stats, fused, aux_group, bands_ok,
+                sharded_adam):
     if bands_ok is None:
         bands_ok = view_loss_fn is None or view_loss_fn is view_loss
     if sharded_adam is None:

@@ -398,14 +398,28 @@ class MapWindowBatch:
                    for v, m in zip(viewpoints, masked)):
             return False
         # every view holds geometry, pair lists, image state and scratch of its own: a large map at a small frame size can ask for
-        # more than the device has left (an allocation failure half-way through the batch has no way back to the view-by-view path)
+        # more than the device has left (an allocation failure half-way through the batch has no way back to the view-by-view path).
+        # The verdict is kept for as long as what it was taken for stands -- map size, frame size, number of views, which of them are
+        # masked, the pair capacity the passes have grown to: torch.cuda.mem_get_info is a driver call, and this runs in every
+        # iteration of a ~1.6 ms loop
         dev = G.get_xyz.device
         (h, w), = size
-        need = MapWindowBatch.bytes_per_view(int(G._xyz.shape[0]), w, h) * len(viewpoints)
+        batch = getattr(backend, "_lvdgs_window_batch", None)
+        cap = max((int(getattr(p, "cap", 0) or 0) for p in batch.passes), default=0) if batch is not None else 0
+        key = (int(G._xyz.shape[0]), w, h, len(viewpoints), tuple(m is not None for m in masked), cap, dev)
+        kept = getattr(backend, "_lvdgs_batch_fits", None)
+        if kept is not None and kept[0] == key:
+            return kept[1]
+        need = MapWindowBatch.bytes_per_view(int(G._xyz.shape[0]), w, h, cap) * len(viewpoints)
         free, _ = torch.cuda.mem_get_info(dev)
         cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)   # (what the caching allocator can hand out again)
-        held = getattr(getattr(backend, "_lvdgs_window_batch", None), "bytes_held", 0)
-        return need - held <= MEMORY_FRACTION * (free + cached)
+        held = getattr(batch, "bytes_held", 0) if batch is not None else 0
+        fits = need - held <= MEMORY_FRACTION * (free + cached)
+        try:
+            backend._lvdgs_batch_fits = (key, fits)
+        except Exception:
+            pass
+        return fits
 
     @staticmethod
     def bytes_per_view(N, W, H, cap=None):
@@ -424,7 +438,9 @@ class MapWindowBatch:
         while len(self.passes) < len(viewpoints):
             self.passes.append(MapViewPass(dev, own_gradient_buffers=False))
         G = backend.gaussians
-        self.bytes_held = self.bytes_per_view(int(G._xyz.shape[0]), int(viewpoints[0].image_width), int(viewpoints[0].image_height)) * len(self.passes)
+        self.runs = getattr(self, "runs", 0) + 1
+        self.bytes_held = self.bytes_per_view(int(G._xyz.shape[0]), int(viewpoints[0].image_width), int(viewpoints[0].image_height),
+                                              max((int(getattr(p, "cap", 0) or 0) for p in self.passes), default=0)) * len(self.passes)
         n = len(viewpoints)
         masked = masked or [None] * n
         ctxs = []

@@ -65,7 +65,6 @@ class TrackingSession:
         if getattr(pipeline_params, "compute_cov3D_python", False) or getattr(pipeline_params, "convert_SHs_python", False):
             raise NotImplementedError("TrackingSession: pipeline_params with the *_python switches take the autograd path")
         self.L = _lib.lib()
-        _lib.settle_garbage_collector()   # (once per process: no full-heap garbage collection inside a 0.2 ms loop)
         self.dev, self.vp, self.cfg = dev, viewpoint, config
         T = config["Training"]
         H, W = int(viewpoint.image_height), int(viewpoint.image_width)
@@ -287,11 +286,12 @@ def track_frame_fused(viewpoint, gaussians, config, pipeline_params, background,
     n_iter = config["Training"]["tracking_itr_num"] if tracking_itr_num is None else tracking_itr_num
     sess = TrackingSession(viewpoint, gaussians, config, pipeline_params, background)
     losses = torch.zeros(max(n_iter, 1), dtype=torch.float32, device=sess.dev) if on_iteration is not None else None
-    for it in range(n_iter):
-        sess.step(None if losses is None else losses[it])
-        if sess.converged_lagging(poll_lag):
-            break
-    applied = sess.finish()
+    with _lib.quiet_gc():   # (no full-heap garbage collection inside a 0.2 ms loop; the host's collector is as before afterwards)
+        for it in range(n_iter):
+            sess.step(None if losses is None else losses[it])
+            if sess.converged_lagging(poll_lag):
+                break
+        applied = sess.finish()
     if on_iteration is not None:
         for it, v in enumerate(losses[:applied].cpu()):
             on_iteration(it, v, None)

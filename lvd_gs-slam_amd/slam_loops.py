@@ -18,17 +18,28 @@ from .pose_utils import update_pose
 from .slam_utils import get_loss_mapping, get_loss_tracking, get_median_depth
 
 
-def initialize_map(backend, cur_frame_idx, viewpoint, render_fn=render, on_iteration=None):
+def initialize_map(backend, cur_frame_idx, viewpoint, render_fn=render, on_iteration=None, fused="auto"):
     """``init_itr_num`` iterations of render -> get_loss_mapping(initialization=True) -> backward -> bookkeeping ->
-    Adam step on one view (reference utils/slam_backend.py:95-149).  Returns the last render package."""
+    Adam step on one view (reference utils/slam_backend.py:95-149).  Returns the last render package.
+    ``fused=False``: every iteration through the public autograd API (``render()`` -> loss -> ``backward()``)."""
     G = backend.gaussians
     render_pkg = None
     # on the GPU with the default renderer: render + loss + backward as three C-ABI calls without the autograd engine
     # (fast_mapping.MapViewPass, as in backend_map.map_window), the gradients written where autograd would have put them
     vpass = None
-    if render_fn is render and G.get_xyz.is_cuda:
+    if fused is not False and render_fn is render and G.get_xyz.is_cuda:
         from .fast_mapping import MapViewPass
         vpass = MapViewPass(G.get_xyz.device)
+    from . import _lib
+    with _lib.quiet_gc():
+        render_pkg, n_touched = _initialize_map_iterations(backend, viewpoint, render_fn, on_iteration, vpass)
+    backend.occ_aware_visibility[cur_frame_idx] = (n_touched > 0).long()
+    return render_pkg
+
+
+def _initialize_map_iterations(backend, viewpoint, render_fn, on_iteration, vpass):
+    G = backend.gaussians
+    render_pkg = n_touched = None
     for mapping_iteration in range(backend.init_itr_num):
         backend.iteration_count += 1
         if vpass is not None and G.get_xyz.shape[0] > 0 and type(vpass).usable(backend, viewpoint):
@@ -53,11 +64,10 @@ def initialize_map(backend, cur_frame_idx, viewpoint, render_fn=render, on_itera
                 G.reset_opacity()
             G.optimizer.step()
             G.optimizer.zero_grad(set_to_none=True)
-    backend.occ_aware_visibility[cur_frame_idx] = (n_touched > 0).long()
-    return render_pkg
+    return render_pkg, n_touched
 
 
-def color_refinement(backend, iteration_total=26000, render_fn=render, loss_fn=None, on_iteration=None):
+def color_refinement(backend, iteration_total=26000, render_fn=render, loss_fn=None, on_iteration=None, fused="auto"):
     """The post-SLAM colour refinement (reference utils/slam_backend.py:393-468): ``iteration_total`` iterations of one
     random keyframe (``random.randint`` on the keyframe list, as the reference draws it) -> render ->
     ``(1 - l) L1 + l (1 - SSIM)``, on the static pixels only when the keyframe carries a ``static_mask`` -> backward ->
@@ -72,34 +82,36 @@ def color_refinement(backend, iteration_total=26000, render_fn=render, loss_fn=N
     # launch) and backward as library calls without the autograd engine (fast_mapping.MapViewPass, masked_loss without a depth
     # term), on the keyframe's cached mask bytes
     vpass = None
-    if render_fn is render and G.get_xyz.is_cuda:
+    if fused is not False and render_fn is render and G.get_xyz.is_cuda:
         from .fast_mapping import MapViewPass
         from .loss_utils import l1_dssim_loss
         if loss_fn is l1_dssim_loss:
             vpass = MapViewPass(G.get_xyz.device)
-    for iteration in range(1, iteration_total + 1):
-        viewpoint_idx_stack = list(backend.viewpoints.keys())
-        viewpoint_cam_idx = viewpoint_idx_stack.pop(random.randint(0, len(viewpoint_idx_stack) - 1))
-        viewpoint_cam = backend.viewpoints[viewpoint_cam_idx]
-        static_mask = getattr(viewpoint_cam, "static_mask", None)
-        lam = float(backend.opt_params.lambda_dssim)
-        if (vpass is not None and G.get_xyz.shape[0] > 0 and type(vpass).usable(backend, viewpoint_cam, allow_static_mask=True)
-                and type(vpass).masked_loss_usable(viewpoint_cam, with_depth=False)):
-            render_pkg, loss = vpass.run(backend, viewpoint_cam, masked_loss=(lam, None))
-            visibility_filter, radii = render_pkg["visibility_filter"], render_pkg["radii"]
-        else:
-            render_pkg = render_fn(viewpoint_cam, G, backend.pipeline_params, backend.background)
-            image, visibility_filter, radii = render_pkg["render"], render_pkg["visibility_filter"], render_pkg["radii"]
-            gt_image = viewpoint_cam.original_image.to(image.device)
-            loss = loss_fn(image, gt_image, backend.opt_params.lambda_dssim, static_mask, backend.background if static_mask is not None else None)
-            loss.backward()
-        if on_iteration is not None:
-            on_iteration(iteration, viewpoint_cam_idx, loss)
-        with torch.no_grad():
-            G.max_radii2D[visibility_filter] = torch.max(G.max_radii2D[visibility_filter], radii[visibility_filter])
-            G.optimizer.step()
-            G.optimizer.zero_grad(set_to_none=True)
-            G.update_learning_rate(iteration)
+    from . import _lib
+    with _lib.quiet_gc():
+        for iteration in range(1, iteration_total + 1):
+            viewpoint_idx_stack = list(backend.viewpoints.keys())
+            viewpoint_cam_idx = viewpoint_idx_stack.pop(random.randint(0, len(viewpoint_idx_stack) - 1))
+            viewpoint_cam = backend.viewpoints[viewpoint_cam_idx]
+            static_mask = getattr(viewpoint_cam, "static_mask", None)
+            lam = float(backend.opt_params.lambda_dssim)
+            if (vpass is not None and G.get_xyz.shape[0] > 0 and type(vpass).usable(backend, viewpoint_cam, allow_static_mask=True)
+                    and type(vpass).masked_loss_usable(viewpoint_cam, with_depth=False)):
+                render_pkg, loss = vpass.run(backend, viewpoint_cam, masked_loss=(lam, None))
+                visibility_filter, radii = render_pkg["visibility_filter"], render_pkg["radii"]
+            else:
+                render_pkg = render_fn(viewpoint_cam, G, backend.pipeline_params, backend.background)
+                image, visibility_filter, radii = render_pkg["render"], render_pkg["visibility_filter"], render_pkg["radii"]
+                gt_image = viewpoint_cam.original_image.to(image.device)
+                loss = loss_fn(image, gt_image, backend.opt_params.lambda_dssim, static_mask, backend.background if static_mask is not None else None)
+                loss.backward()
+            if on_iteration is not None:
+                on_iteration(iteration, viewpoint_cam_idx, loss)
+            with torch.no_grad():
+                G.max_radii2D[visibility_filter] = torch.max(G.max_radii2D[visibility_filter], radii[visibility_filter])
+                G.optimizer.step()
+                G.optimizer.zero_grad(set_to_none=True)
+                G.update_learning_rate(iteration)
 
 
 def make_pose_optimizer(viewpoint, config):

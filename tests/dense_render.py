@@ -21,7 +21,10 @@ def dense_render(viewpoint, pc, pipe, bg_color, scaling_modifier=1.0, override_c
     if N == 0:
         return None
     H, W = int(viewpoint.image_height), int(viewpoint.image_width)
-    tau = torch.cat([viewpoint.cam_trans_delta, viewpoint.cam_rot_delta]).double()
+    if viewpoint.cam_trans_delta is None:   # a frame the front end has cleaned (Camera.clean): rendered for evaluation only
+        tau = torch.zeros(6, dtype=torch.float64)
+    else:
+        tau = torch.cat([viewpoint.cam_trans_delta, viewpoint.cam_rot_delta]).double()
     view, proj, campos = ref_torch.camera_matrices(f64(viewpoint.R), f64(viewpoint.T), tau, f64(viewpoint.projection_matrix))
     screenspace_points = torch.zeros(N, 3, dtype=xyz.dtype, requires_grad=True)
     out = ref_torch.render_dense(

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""The loops as a system: a synthetic drive through an opaque-surface scene at KITTI-07's geometry, from an EMPTY map --
+initialize_map on frame 0, then per frame track_frame -> keyframe test -> seeding -> masked map_window bursts with densification /
+pruning / opacity resets at the reference's cadence -> pruning pass, the back end's free-running iterations between frames, and at
+the end ATE (Umeyama), PSNR before / after a colour refinement (lvdgs.slam_sequence.SlamSequence; reference utils/slam_frontend.py:1740-1899,
+utils/slam_backend.py:485-609, utils/eval_utils_0806.py:33-306).
+
+    python tools/sequence.py [--frames 60] [--scale 1.0] [--cadence reference|short] [--no-fused] [--idle 10] [--refine 500] [--no-masks]
+
+Prints one JSON object (bench.py's config.side.sequence_kitti07_geom is the same record).  `--cadence reference`: the iteration
+counts and densification schedule of configs/mono/KITTI/base_config.yaml as they are; `short`: every burst a fifth of it (the GPU
+test's schedule).  The first three tracked frames of a reference-cadence run are the map's slowest (the map is one keyframe old)."""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+
+import lvdgs  # noqa: E402,F401
+from lvdgs import synthetic  # noqa: E402
+from lvdgs.gaussian_renderer import render  # noqa: E402
+from lvdgs.slam_sequence import SlamSequence  # noqa: E402
+
+SHORT = dict(init_itr_num=210, init_gaussian_update=20, init_gaussian_reset=100, tracking_itr_num=40, mapping_itr_num=30,
+             mapping_itr_nosingle=10, initial_ba_itr_num=60, gaussian_update_every=30, gaussian_update_offset=10, gaussian_reset=401)
+
+
+def kitti_sequence(dev, frames=60, scale=1.0, cadence="reference", masks=True, n_true=None, seed=0, training=None, window_size=None):
+    """(config, dataset, true map): KITTI-07's frame geometry (x ``scale``), the merged KITTI-07 config with the chosen cadence."""
+    import sequence_scene as ss
+    W, H = int(round(1226 * scale)), int(round(370 * scale))
+    fx = fy = 707.0912 * scale
+    cx, cy = 601.8873 * scale, 183.1104 * scale
+    tr = dict(SHORT) if cadence == "short" else {}
+    if window_size is not None:
+        tr.update(window_size=window_size, pose_window=min(3, window_size - 1))
+    tr.update(training or {})
+    cfg = ss.sequence_config(W, H, **tr)
+    cfg["Dataset"]["Calibration"].update(fx=fx, fy=fy, cx=cx, cy=cy)
+    n_true = int(150_000 * scale * scale) if n_true is None else n_true
+    # surfaces of 4..64-pixel footprints (x scale), reaching 0.9 frame widths past the first frame's edges: the camera's field of view
+    # is wider than the generator's (fx < W) and the camera moves
+    truth = ss.truth_model(W, H, n_true, 4.0 * scale, 64.0 * scale, 0.9, dev, seed=11 + seed)
+    ds = synthetic.make_sequence(truth, render, ss.PIPE, W, H, frames, dev, fx=fx, fy=fy, cx=cx, cy=cy, seed=seed, depth_noise=0.02,
+                                 image_noise=0.01, dynamic_objects=masks, step=0.02, sway=0.15, yaw=0.03, period=40.0)
+    return cfg, ds, truth
+
+
+def run_sequence(dev, frames=60, scale=1.0, cadence="reference", fused="auto", idle=10, refine=500, masks=True, seed=0, training=None,
+                 window_size=None, on_event=None):
+    import sequence_scene as ss
+    torch.manual_seed(seed)
+    random.seed(seed)
+    cfg, ds, truth = kitti_sequence(dev, frames, scale, cadence, masks, seed=seed, training=training, window_size=window_size)
+    del truth
+    m = ss.empty_map(cfg, dev)
+    seq = SlamSequence(cfg, ds, m, ss.PIPE, torch.zeros(3, device=dev), fused=fused, idle_map_iters=idle, on_event=on_event)
+    seq.run()
+    out = seq.summary()
+    out["ate_rmse"] = seq.eval_ate()
+    before = seq.eval_rendering()
+    out["psnr_before_refinement"], out["ssim_before_refinement"] = before.get("psnr"), before.get("ssim")
+    out["psnr_static_before_refinement"] = before.get("psnr_static")
+    if refine:
+        seq.refine(refine)
+        after = seq.eval_rendering()
+        out["psnr"], out["ssim"], out["psnr_static"] = after.get("psnr"), after.get("ssim"), after.get("psnr_static")
+        s = seq.seconds["refinement"]
+        out["refinement_ms_per_iteration"] = round(1e3 * s / refine, 4)
+    out["trajectory_length"] = float(sum(float(torch.linalg.inv(ds.poses[i + 1])[:3, 3].sub(torch.linalg.inv(ds.poses[i])[:3, 3]).norm())
+                                         for i in range(len(ds) - 1)))
+    out["window_log"] = seq.window_log
+    out["batched_window_runs"] = int(getattr(getattr(seq.backend, "_lvdgs_window_batch", None), "runs", 0))
+    out.update(width=ds.width, height=ds.height, cadence=cadence, fused=fused, idle_map_iters=idle, keyframes_carry_static_mask=masks)
+    return out, seq
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=60)
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--cadence", choices=["reference", "short"], default="reference")
+    ap.add_argument("--no-fused", action="store_true")
+    ap.add_argument("--idle", type=int, default=10)
+    ap.add_argument("--refine", type=int, default=500)
+    ap.add_argument("--no-masks", action="store_true")
+    ap.add_argument("--window-size", type=int, default=None)
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    t0 = time.perf_counter()
+    ev = (lambda e, s: print(f"  frame {s.counts['frames']:3d} {e:16s} N = {s._n()}", file=sys.stderr)) if a.verbose else None
+    out, _ = run_sequence(dev, a.frames, a.scale, a.cadence, False if a.no_fused else "auto", a.idle, a.refine, not a.no_masks,
+                          window_size=a.window_size, on_event=ev)
+    out["tool_seconds"] = round(time.perf_counter() - t0, 2)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
