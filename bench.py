@@ -189,10 +189,16 @@ def main():
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     dist = None
+    rccl_log = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend_name == "nccl":
+            # RCCL's own version line, kept out of stdout (rank 0 prints ONE JSON line there) and quoted in the JSON: config.comm.rccl_version_line
+            if "NCCL_DEBUG" not in os.environ:
+                os.environ["NCCL_DEBUG"] = "VERSION"
+                os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/lvdgs_rccl_%p.log")
+            rccl_log = os.environ.get("NCCL_DEBUG_FILE", "").replace("%p", str(os.getpid())).replace("%h", os.uname().nodename) or None
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend_name, rank=rank, world_size=world)
@@ -212,20 +218,53 @@ def main():
     masked = not args.no_masks
     make_window = ((lambda m: build_window(args.workload, 12, dev, m, n_window=8, masked=masked)) if real_window else
                    (lambda m: build_window(args.workload, world, dev, m, masked=masked)))
-    if not tracking:
-        backend, window = make_window(model)
-        if world > 1 and os.environ.get("LVDGS_BENCH_AUX_GROUP", "1") != "0":
+    comm = None
+    if world > 1:
+        # Preflight, before anything is built or timed: one tiny collective of every (operation, dtype, communicator) the iteration
+        # issues, each in a try of its own with the verdict agreed over the ranks, and a fallback for everything but the two the
+        # iteration cannot do without (backend_map.collective_preflight).  The first multi-GPU run must not lose its line to a
+        # uint8 reduction or a second communicator.
+        aux_group = None
+        if not tracking and os.environ.get("LVDGS_BENCH_AUX_GROUP", "1") != "0":
             # the two small MAX collectives on a communicator of their own: in flight under the gradient all-reduce
-            # (LVDGS_BENCH_AUX_GROUP=0: all three collectives on the one communicator, as in round 3)
-            # (a job whose second communicator cannot be made runs its three collectives on the first: every rank takes the same branch,
-            # new_group is collective and fails on all of them or on none)
+            # (LVDGS_BENCH_AUX_GROUP=0: all three collectives on the one communicator, as in round 3).  new_group is collective: it
+            # fails on every rank or on none, so every rank takes the same branch
             try:
-                backend.shard_aux_group = dist.new_group(backend=backend_name if backend_name != "nccl" else None)
+                if "aux" in os.environ.get("LVDGS_PREFLIGHT_FAIL", "").split(","):
+                    raise RuntimeError("failed on purpose (LVDGS_PREFLIGHT_FAIL)")
+                aux_group = dist.new_group(backend=backend_name if backend_name != "nccl" else None)
             except Exception as e:   # noqa: BLE001
                 notes.append(f"no second communicator ({type(e).__name__}: {e}): MAX collectives on the first")
+        want_sharded = os.environ.get("LVDGS_BENCH_SHARDED_ADAM", "0") == "1"
+        comm = backend_map.collective_preflight(dev, None, aux_group, sharded_adam=want_sharded and not tracking)
+        notes.extend(comm["notes"])
+        if comm["fatal"]:
+            if rank == 0:
+                print(json.dumps({"metric": "render+backward iters/sec @500k Gaussians 1080p; 1/2/4/8-GPU scaling", "value": None, "n_gpus": world,
+                                  "error": "collective preflight: " + comm["fatal"], "comm": comm}))
+            dist.destroy_process_group()
+            raise SystemExit(3)
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, (rank, local_dev, os.uname().nodename))
+        comm["ranks_seen"] = ranks_seen
+        try:
+            comm["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version()) if backend_name == "nccl" else None
+        except Exception:   # noqa: BLE001
+            comm["rccl_version"] = None
+        comm["rccl_version_line"] = None
+        if rccl_log and os.path.exists(rccl_log):
+            for ln in open(rccl_log, errors="replace"):
+                if "version" in ln.lower():
+                    comm["rccl_version_line"] = ln.strip()
+                    break
+        comm["backend"] = backend_name
+    if not tracking:
+        backend, window = make_window(model)
+        if comm is not None and comm["use_aux_group"]:
+            backend.shard_aux_group = aux_group
         # LVDGS_BENCH_SHARDED_ADAM=1: the Gaussian Adam as reduce-scatter -> every rank steps its share -> all-gather
         # (backend_map.ShardedAdam; off by default: modelled, never measured on more than one GPU)
-        backend.shard_optimizer = world > 1 and os.environ.get("LVDGS_BENCH_SHARDED_ADAM", "0") == "1"
+        backend.shard_optimizer = bool(comm is not None and comm["use_sharded_adam"])
     elif use_session:
         from lvdgs.fast_tracking import TrackingSession
         # BASELINE configs[2] names the full pose + map backward: the headline computes every Gaussian gradient.  (The product's
@@ -441,6 +480,35 @@ def main():
             elif rank == 0 and not notes:
                 notes.append("the one-GPU run of the same step failed on another rank: not reported")
 
+    other_masks_value = None
+    if world > 1 and not tracking and real_window:
+        # The same window with the keyframes' masks the OTHER way round (default run: without masks -- every view scored by
+        # get_loss_mapping, the step of rounds 2-4 under this metric name; --no-masks run: with them), so that lines of different
+        # rounds can be compared like for like.  Built on every rank alike; its collectives are map_window's own.
+        ok = True
+        try:
+            other_model = GaussianModel.from_activated(g_cpu["means3D"], g_cpu["scales"], g_cpu["rotations"], g_cpu["opacities"], shs=g_cpu["shs"],
+                                                       sh_degree=0, device=dev)
+            torch.manual_seed(0)
+            other_backend, other_window = build_window(args.workload, 12, dev, other_model, n_window=8, masked=not masked)
+            other_backend.shard_aux_group = getattr(backend, "shard_aux_group", None)
+            other_backend.shard_optimizer = backend.shard_optimizer
+        except Exception as e:   # noqa: BLE001
+            ok = False
+            notes.append(f"rank {rank}: the window with the masks the other way round could not be built ({type(e).__name__}: {e})")
+        if all_ok(ok):
+            for _ in range(max(args.warmup, 1)):
+                backend_map.map_window(other_backend, other_window, iters=1)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                backend_map.map_window(other_backend, other_window, iters=1)
+            sync()
+            t = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            other_masks_value = round(10 * args.steps / float(t.item()), 3)
+            del other_backend, other_model
+
     if not tracking:
         # the iteration by phase (events on the stream at the phase boundaries, one wait at the end of each iteration).  map_window's
         # own collectives are the benchmark's: a rank-local failure inside them is fatal for the job as it was in the timed region.
@@ -475,6 +543,11 @@ def main():
                                   "(NOT comparable with the weak-scaling values of BENCH_r01/r02)" if real_window else
                                   "keyframes per second of mapping iterations with one keyframe per GPU (weak scaling)")),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # what an N-GPU `value` is to be read against: the SAME step (the ten-view mapping window) on ONE GPU -- measured inside this
+            # job when N > 1, the side run of the same window when N = 1 -- never the N = 1 `value`, which is the tracking iteration
+            "scaling_anchor_value": (None if same_step_single is None else round(same_step_single * views_per_step / (1 if real_window else world), 3)) if world > 1
+                                    else (None if not side else side.get("mapping_window_" + args.workload + "_masked", {}).get("views_per_s")),
+            "scaling_anchor_definition": "views per second of the ten-view mapping window (keyframes with static masks) on one GPU: the 1-GPU point of the N-GPU curve",
             "config": {"workload": args.workload, "gaussians": N, "width": W, "height": H, "visible": stats["V"],
                        "pairs": stats["D"], "sh_degree": 0,
                        "step": (("tracking iteration of slam_loops.track_frame on a TrackingSession: render + get_loss_tracking + backward "
@@ -494,7 +567,9 @@ def main():
                        "views_per_step": views_per_step, "window_keyframes_carry_static_mask": None if tracking else masked, "comm_us_per_step": comm_us, "phases_us_per_step": phases,
                        "autograd_api_iters_per_s": autograd_rate, "pose_only_iters_per_s": pose_only_rate,
                        "mapping_window_views_per_s": None if not side else side.get("mapping_window_" + args.workload, {}).get("views_per_s"),
-                       "side": side, "notes": notes or None, "same_step_on_one_gpu_iters_per_s": same_step_single,
+                       "side": side, "comm": comm,
+                       ("value_with_static_masks" if not masked else "value_without_static_masks"): other_masks_value,
+                       "notes": notes or None, "same_step_on_one_gpu_iters_per_s": same_step_single,
                        "same_step_on_one_gpu_value": None if same_step_single is None else round(same_step_single * views_per_step / (1 if real_window else world), 3)},
             **({"collective_backend": backend_name + " (functional check only, not a benchmark result)"} if world > 1 and backend_name != "nccl" else {}),
             **({"timing_note": "warm-up + timed region last under ~40 ms: after start-up idle this GPU needs ~17 ms of load to reach its clocks, "

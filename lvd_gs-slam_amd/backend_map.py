@@ -261,15 +261,133 @@ class FlatReducer:
         return (list(flat.split(sizes)), work) if async_op else list(flat.split(sizes))
 
 
+FLAGS_AS_INT32 = False   # set by ``collective_preflight`` when the communicator cannot MAX-reduce uint8
+
+
+class _WidenedFlagsWork:
+    """Work handle of a uint8 MAX all-reduce carried out on an int32 copy: ``wait()`` waits for the collective, then narrows the
+    result back into the caller's bytes."""
+
+    def __init__(self, flags, wide, work):
+        self.flags, self.wide, self.work = flags, wide, work
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        self.flags.copy_(self.wide)
+
+
 def _max_bytes(flags: torch.Tensor, group=None, async_op=False):
     """uint8 all-reduce MAX in place: the byte-wise OR of 0 / 1 flags.  (Packed into int32 words and reduced with MAX --
     round 2 -- a word's high byte decided for all four: flags of other ranks were dropped.)  ``async_op``: returns the
-    collective's work handle (None when there is nothing to reduce) instead of the flags."""
+    collective's work handle (None when there is nothing to reduce) instead of the flags.  ``FLAGS_AS_INT32``: every flag widened
+    to an int32 of its own for the collective (four times the bytes, the same result) -- the fallback for a communicator whose
+    uint8 MAX failed the preflight."""
     _, world = _world(group)
     work = None
     if world > 1 and flags.numel():
-        work = dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group, async_op=async_op)
+        if FLAGS_AS_INT32:
+            wide = flags.to(torch.int32)
+            w = dist.all_reduce(wide, op=dist.ReduceOp.MAX, group=group, async_op=async_op)
+            work = _WidenedFlagsWork(flags, wide, w if async_op else None)
+            if not async_op:
+                work.wait()
+        else:
+            work = dist.all_reduce(flags, op=dist.ReduceOp.MAX, group=group, async_op=async_op)
     return work if async_op else flags
+
+
+def collective_preflight(device, group=None, aux_group=None, sharded_adam=False, fail=None):
+    """One tiny collective of every (operation, dtype, communicator) a sharded mapping iteration issues, BEFORE anything is timed or
+    depends on it: float32 SUM all-reduce (the gradient bucket), int32 MAX all-reduce (radii), uint8 MAX all-reduce (visibility flags) on
+    the main group and on the auxiliary one, ``reduce_scatter_tensor`` / ``all_gather_into_tensor`` (the sharded Adam) on the main group.
+    Each runs in a ``try`` of its own and is checked against the value it must produce; the verdict is MIN-all-reduced over the ranks, so
+    every rank takes the same fallback:
+
+      * uint8 MAX fails                -> ``FLAGS_AS_INT32`` (the flags travel as int32);
+      * anything on ``aux_group`` fails -> ``use_aux_group`` False (the two MAX collectives go to the main group: same results, no overlap);
+      * reduce-scatter / all-gather    -> ``use_sharded_adam`` False (the replicated Adam step);
+      * float32 SUM or int32 MAX on the main group -> ``fatal``: the iteration cannot run, the caller must stop with the reason.
+
+    ``fail``: operations to fail on purpose, comma separated (also ``LVDGS_PREFLIGHT_FAIL``) -- the tests' way to walk the fallbacks:
+    ``f32_sum, i32_max, u8_max, aux_i32_max, aux_u8_max, reduce_scatter, all_gather``.  Returns a dict for the benchmark's JSON line."""
+    global FLAGS_AS_INT32
+    rank, world = _world(group)
+    fail = set(x.strip() for x in (fail if fail is not None else os.environ.get("LVDGS_PREFLIGHT_FAIL", "")).split(",") if x.strip())
+    report = dict(world=world, ops={}, notes=[], use_aux_group=aux_group is not None, use_sharded_adam=bool(sharded_adam), fatal=None,
+                  flags_as_int32=False)
+    if world <= 1:
+        return report
+    ok_buf = torch.ones(1, dtype=torch.float32, device=device)
+
+    def agreed(ok):
+        """MIN over the ranks (on the main group with the one operation everything else depends on anyway)."""
+        ok_buf.fill_(1.0 if ok else 0.0)
+        try:
+            dist.all_reduce(ok_buf, op=dist.ReduceOp.MIN, group=group)
+            return bool(ok_buf.item() > 0.5)
+        except Exception:   # noqa: BLE001
+            return False
+
+    def attempt(name, fn):
+        err = None
+        try:
+            if name in fail:
+                raise RuntimeError("failed on purpose (LVDGS_PREFLIGHT_FAIL)")
+            fn()
+            if device.type == "cuda":
+                torch.cuda.synchronize(device)
+        except Exception as e:   # noqa: BLE001
+            err = f"{type(e).__name__}: {e}"
+        ok = agreed(err is None)
+        report["ops"][name] = "ok" if ok else (err or "failed on another rank")
+        return ok
+
+    def reduce_check(dtype, op, g, want):
+        def fn():
+            t = torch.full((64,), rank + 1, dtype=dtype, device=device)
+            dist.all_reduce(t, op=op, group=g)
+            if not bool((t == want).all()):
+                raise RuntimeError(f"wrong result {t[:2].tolist()} (expected {want})")
+        return fn
+
+    total = world * (world + 1) // 2
+    if not attempt("f32_sum", reduce_check(torch.float32, dist.ReduceOp.SUM, group, total)):
+        report["fatal"] = "float32 SUM all-reduce on the main communicator: " + report["ops"]["f32_sum"]
+    if not attempt("i32_max", reduce_check(torch.int32, dist.ReduceOp.MAX, group, world)):
+        report["fatal"] = report["fatal"] or "int32 MAX all-reduce on the main communicator: " + report["ops"]["i32_max"]
+    u8 = attempt("u8_max", reduce_check(torch.uint8, dist.ReduceOp.MAX, group, world))
+    if aux_group is not None:
+        aux_ok = attempt("aux_i32_max", reduce_check(torch.int32, dist.ReduceOp.MAX, aux_group, world))
+        aux_u8 = attempt("aux_u8_max", reduce_check(torch.uint8, dist.ReduceOp.MAX, aux_group, world))
+        if not aux_ok:
+            report["use_aux_group"] = False
+            report["notes"].append("the auxiliary communicator failed its int32 MAX: the MAX collectives run on the main communicator")
+        u8 = u8 and aux_u8
+    if not u8:
+        FLAGS_AS_INT32 = report["flags_as_int32"] = True
+        report["notes"].append("uint8 MAX all-reduce failed: the visibility flags travel as int32")
+    if sharded_adam:
+        def rs():
+            src = torch.arange(world * 8, dtype=torch.float32, device=device) * (rank + 1)
+            out = torch.empty(8, dtype=torch.float32, device=device)
+            dist.reduce_scatter_tensor(out, src, op=dist.ReduceOp.SUM, group=group)
+            want = torch.arange(rank * 8, rank * 8 + 8, dtype=torch.float32, device=device) * total
+            if not torch.equal(out, want):
+                raise RuntimeError("wrong result")
+
+        def ag():
+            mine = torch.full((8,), float(rank), dtype=torch.float32, device=device)
+            full = torch.empty(world * 8, dtype=torch.float32, device=device)
+            dist.all_gather_into_tensor(full, mine, group=group)
+            if not torch.equal(full, torch.arange(world, dtype=torch.float32, device=device).repeat_interleave(8)):
+                raise RuntimeError("wrong result")
+        ok = attempt("reduce_scatter", rs)
+        ok = attempt("all_gather", ag) and ok
+        if not ok:
+            report["use_sharded_adam"] = False
+            report["notes"].append("reduce_scatter_tensor / all_gather_into_tensor failed: the replicated Adam step")
+    return report
 
 
 class ShardedAdam:

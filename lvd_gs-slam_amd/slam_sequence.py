@@ -133,6 +133,7 @@ class SlamSequence:
         self.gaussian_counts = []      # (event, N) whenever the map's size may have changed
         self.seconds = dict(tracking=0.0, mapping=0.0, init=0.0, seeding=0.0, refinement=0.0, other=0.0)
         self.window_log = []           # the window after every keyframe
+        self.frame_log = []            # per tracked frame: tracking iterations, the keyframe test's inputs and its outcome
         self.batched_sizes = []        # the map's size at every mapping call that went through the batched window (MapWindowBatch)
 
     # ------------------------------------------------------------------ helpers
@@ -270,6 +271,7 @@ class SlamSequence:
                                                         tracking_itr_num=self.tracking_itr_num, render_fn=self.render_fn, fused=self.fused)
         self.median_depth = median_depth
         self.counts["tracking_iterations"] += int(its)
+        self._last_tracking_iterations = int(its)
         return render_pkg
 
     def handle_keyframe(self, cur_frame_idx, viewpoint, depth_map):
@@ -322,12 +324,15 @@ class SlamSequence:
         curr_visibility = (render_pkg["n_touched"] > 0).long()
         create_kf = is_keyframe(self.config, self.cameras, cur_frame_idx, last_keyframe_idx, curr_visibility, self.occ_aware_visibility,
                                 self.median_depth)
+        inter, union, _, _ = covisibility(curr_visibility, self.occ_aware_visibility[last_keyframe_idx])
+        point_ratio = inter / union if union else float("nan")
         if len(self.current_window) < self.window_size:
-            inter, union, _, _ = covisibility(curr_visibility, self.occ_aware_visibility[last_keyframe_idx])
-            point_ratio = inter / union if union else float("nan")
             create_kf = check_time and point_ratio < self.config["Training"]["kf_overlap"]
         if self.single_thread:
             create_kf = check_time and create_kf
+        self.frame_log.append(dict(frame=cur_frame_idx, tracking_iterations=self._last_tracking_iterations, median_depth=float(self.median_depth),
+                                   covisibility=point_ratio, visible=int(curr_visibility.count_nonzero()), keyframe=bool(create_kf),
+                                   gaussians_tracked_against=int(self.frontend_gaussians.get_xyz.shape[0])))
         if create_kf:
             self.current_window, removed = add_to_window(self.config, self.cameras, cur_frame_idx, curr_visibility,
                                                          self.occ_aware_visibility, self.current_window, initialized=self.initialized)

@@ -285,6 +285,53 @@ def test_flags_reduce_as_a_bytewise_or():
     assert got[0] == got[1] == [[1, 1, 1, 1, 0], [0, 0, 1, 0, 1]]
 
 
+def _preflight_worker(rank, world, port, q, fail):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lvdgs import backend_map as bm
+    aux = dist.new_group(backend="gloo")
+    rep = bm.collective_preflight(torch.device("cpu"), None, aux, sharded_adam=True, fail=fail)
+    # whatever the preflight decided, the flags still reduce as a byte-wise OR (through int32 when uint8 "failed")
+    flags = torch.zeros(3, 9, dtype=torch.uint8)
+    flags[rank % 3, rank::world] = 1
+    work = bm._max_bytes(flags, aux if rep["use_aux_group"] else None, async_op=True)
+    work.wait()
+    sync = bm._max_bytes((flags * 0 + (rank == 0)).to(torch.uint8), None)
+    q.put((rank, rep, flags.tolist(), sync.tolist(), bm.FLAGS_AS_INT32))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail", ["", "u8_max", "aux_u8_max,aux_i32_max", "all_gather", "i32_max"])
+def test_collective_preflight_and_its_fallbacks(fail):
+    """backend_map.collective_preflight on two gloo ranks: every operation green without injected failures; with one, the fallback the
+    docstring names, taken by BOTH ranks (the verdicts are MIN-reduced), and the flag reduction still a byte-wise OR."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + (os.getpid() % 300) + 7 * len(fail)
+    procs = [ctx.Process(target=_preflight_worker, args=(r, world, port, q, fail)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    reps = [g[1] for g in got]
+    assert reps[0] == reps[1]                      # same verdicts, same fallbacks on every rank
+    rep = reps[0]
+    failed = set(x for x in fail.split(",") if x)
+    assert set(rep["ops"]) == {"f32_sum", "i32_max", "u8_max", "aux_i32_max", "aux_u8_max", "reduce_scatter", "all_gather"}
+    assert {k for k, v in rep["ops"].items() if v != "ok"} == failed
+    assert rep["flags_as_int32"] == bool(failed & {"u8_max", "aux_u8_max"}) == got[0][4] == got[1][4]
+    assert rep["use_aux_group"] == ("aux_i32_max" not in failed)
+    assert rep["use_sharded_adam"] == (not failed & {"reduce_scatter", "all_gather"})
+    assert (rep["fatal"] is not None) == bool(failed & {"f32_sum", "i32_max"})
+    want = torch.zeros(3, 9, dtype=torch.uint8)
+    for r in range(world):
+        want[r % 3, r::world] = 1
+    for g in got:
+        assert g[2] == want.tolist() and g[3] == torch.ones(3, 9, dtype=torch.uint8).tolist()
+
+
 def test_piece_plan_and_random_choice():
     _paths()
     from lvdgs import backend_map as bm
