@@ -593,7 +593,7 @@ static int backward_impl(const lvdgs_args *a, const LossParams *fused, int propa
 }
 
 int lvdgs_backward(const lvdgs_args *a, void *stream) {
-    if (a && (a->flags & LVDGS_FLAG_NO_BLEND)) { set_error("LVDGS_FLAG_NO_BLEND: only lvdgs_backward_fused_loss has a batched blend pass to leave its own to"); return LVDGS_E_INVALID; }
+    if (a && (a->flags & LVDGS_FLAG_NO_BLEND)) { set_error("LVDGS_FLAG_NO_BLEND: lvdgs_backward runs its own blend pass; the calls that leave it to a batched one (lvdgs_blend_backward_fused_loss_batch / lvdgs_blend_backward_window_batch) are lvdgs_backward_fused_loss, lvdgs_backward_masked_loss and lvdgs_gaussian_backward_batch"); return LVDGS_E_INVALID; }
     return backward_impl(a, nullptr, 0, (hipStream_t)stream);
 }
 
@@ -625,8 +625,10 @@ int lvdgs_forward_batch(const lvdgs_args *const *views, int32_t count, int64_t *
         if (int e = check_common(a)) return e;
         if (int e = check_gaussians(a)) return e;
         if (a->num_gaussians != N || a->image_width != W || a->image_height != H || a->tile_row_begin != a0->tile_row_begin || a->tile_row_end != a0->tile_row_end ||
-            a->means3D != a0->means3D || ((a->flags ^ a0->flags) & (LVDGS_FLAG_LIST_ALL_TILES | LVDGS_FLAG_NO_BLEND))) {
-            set_error("forward batch: the views differ in map, image size, band or flags"); return LVDGS_E_INVALID;
+            a->means3D != a0->means3D || a->opacities != a0->opacities || a->scales != a0->scales || a->rotations != a0->rotations ||
+            a->cov3D_precomp != a0->cov3D_precomp || a->shs != a0->shs || a->colors_precomp != a0->colors_precomp || a->sh_coeffs != a0->sh_coeffs ||
+            a->activations != a0->activations || ((a->flags ^ a0->flags) & (LVDGS_FLAG_LIST_ALL_TILES | LVDGS_FLAG_NO_BLEND))) {
+            set_error("forward batch: the views differ in map (means3D / opacities / scales / rotations / cov3D_precomp / shs / colors_precomp / activations), image size, band or flags"); return LVDGS_E_INVALID;
         }
         const int64_t cap = a->pair_capacity;
         if (cap <= 0 || cap > 0x7FFFFFFFll) { set_error("pair_capacity must be in 1..2^31-1"); return LVDGS_E_INVALID; }

@@ -420,7 +420,10 @@ __device__ __forceinline__ void scatter_pairs_body(int chunk, int N, int gx, int
         else for_each_pair_of_rect(r, i, gx, my_depth[k], place);
     }
 }
-template <int GROUP_THREADS, int OWNERS, int PER, bool SLOT_SCAN>
+// SCAN_RIDES: the launch's last workgroup runs the tile scan (small frames only, SCAN_IN_SCATTER_RUN).  A template parameter, so that the
+// instantiations large frames use -- up to 64 KB of dynamic LDS for the tile counters -- do not carry the scan's static LDS (s_scan[1024] and the
+// wave arrays, ~4.3 KB) and its code.
+template <int GROUP_THREADS, int OWNERS, int PER, bool SLOT_SCAN, bool SCAN_RIDES>
 __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int gx, int T, const uint4 *__restrict__ rect,
                                                                      const uint32_t *__restrict__ hist,
                                                                      const uint2 *__restrict__ ranges, const uint32_t *__restrict__ totals, uint32_t capacity,
@@ -430,8 +433,8 @@ __global__ void __launch_bounds__(GROUP_THREADS) scatter_pairs_kernel(int N, int
                                                                      uint32_t *__restrict__ slot_base, uint8_t *__restrict__ pair_valid, TileScanArgs ts) {
     // (the launch's LAST workgroup is the tile scan's when ts.ranges is set: a workgroup's XCD is its index mod 8, which the chunks'
     // XCD-contiguous order counts on)
-    const int nchunks = (int)gridDim.x - (ts.ranges ? 1 : 0);
-    if constexpr (GROUP_THREADS == 1024 || GROUP_THREADS == 512) {
+    const int nchunks = (int)gridDim.x - (SCAN_RIDES ? 1 : 0);
+    if constexpr (SCAN_RIDES && (GROUP_THREADS == 1024 || GROUP_THREADS == 512)) {
         if ((int)blockIdx.x == nchunks) {
             group_tilescan_body<GROUP_THREADS>(T, totals, capacity, ts.ranges, ts.total_out, ts.long_limit, ts.queue_count, ts.queue, ts.tile_order, ts.t_lo, ts.t_hi,
                                                ts.order_valid, ts.host_out, ts.host_seq);
@@ -541,7 +544,7 @@ int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView
     if (N == 0 || T == 0) return LVDGS_OK;
     const int nchunks = (int)group_chunks(N);
     const size_t lds = (size_t)T * sizeof(uint32_t);
-    static unsigned char done[2 * GROUP_SHAPES][16];
+    static unsigned char done[4 * GROUP_SHAPES][16];
     ProfScope ps("group_scatter", s);
     TileScanArgs ts{};
     if (scan_rides_in_scatter(N, T)) {   // the tile scan as this launch's last workgroup (launch_group_scan has made the tile totals)
@@ -559,7 +562,9 @@ int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView
     };
     if (int e = group_dispatch(group_shape_for(N), [&](auto threads_, auto owners_, auto per_, int d) {
             constexpr int THREADS = decltype(threads_)::value, OWNERS = decltype(owners_)::value, PER = decltype(per_)::value;
-            return slot_scan ? launch(&scatter_pairs_kernel<THREADS, OWNERS, PER, true>, 2 * d, THREADS) : launch(&scatter_pairs_kernel<THREADS, OWNERS, PER, false>, 2 * d + 1, THREADS);
+            if (ts.ranges)   // (scan_rides_in_scatter: every shape launches 512 or 1024 threads there)
+                return slot_scan ? launch(&scatter_pairs_kernel<THREADS, OWNERS, PER, true, true>, 4 * d, THREADS) : launch(&scatter_pairs_kernel<THREADS, OWNERS, PER, false, true>, 4 * d + 1, THREADS);
+            return slot_scan ? launch(&scatter_pairs_kernel<THREADS, OWNERS, PER, true, false>, 4 * d + 2, THREADS) : launch(&scatter_pairs_kernel<THREADS, OWNERS, PER, false, false>, 4 * d + 3, THREADS);
         })) return e;
     LVDGS_LAUNCH_CHECK("group_scatter", a.debug, s);
     return LVDGS_OK;

@@ -146,3 +146,55 @@ def test_window_batch_grows_its_pair_buffers_like_the_single_view_pass():
     assert len(caps_b) > 1 and min(caps_b) > 1000 and caps_s[0] > 1000   # every pass had to grow
     for a, b in zip(params_b, params_s):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_window_batch_across_densification_pruning_and_an_opacity_reset(masked):
+    """The map changes size BETWEEN batched iterations -- densify / prune every 3rd iteration, the opacity reset of the non-visible on
+    the 5th, the window's pruning pass at the end (reference utils/slam_backend.py:318-376 at a short period) -- so every per-view
+    buffer of the batch, the cached mask / mono-depth bytes and the memory verdict meet a new N several times.  Batched and view by
+    view must stay the same bits through all of it."""
+    import bench
+    from lvdgs import backend_map, synthetic
+    workload = "tmp_window_batch"
+    synthetic.CONFIGS.setdefault(workload, dict(N=30000, W=400, H=240))
+    dev = torch.device("cuda", 0)
+
+    def run(batch):
+        torch.manual_seed(0)
+        model, cam, g, _ = bench.build_scene(workload, 0, dev)
+        backend, window = bench.build_window(workload, 12, dev, model, n_window=8, masked=masked)
+        backend.gaussian_update_every, backend.gaussian_update_offset, backend.gaussian_reset = 3, 1, 5
+        backend.opt_params.densify_grad_threshold = 2e-5
+        before = os.environ.get("LVDGS_MAP_BATCH")
+        os.environ["LVDGS_MAP_BATCH"] = "1" if batch else "0"
+        sizes, runs = [], []
+        try:
+            for _ in range(8):
+                backend_map.map_window(backend, window, iters=1)
+                sizes.append(int(backend.gaussians.get_xyz.shape[0]))
+                runs.append(getattr(getattr(backend, "_lvdgs_window_batch", None), "runs", 0))
+            backend_map.map_window(backend, window, prune=True)
+            sizes.append(int(backend.gaussians.get_xyz.shape[0]))
+            backend_map.map_window(backend, window, iters=2)
+            sizes.append(int(backend.gaussians.get_xyz.shape[0]))
+        finally:
+            if before is None:
+                os.environ.pop("LVDGS_MAP_BATCH", None)
+            else:
+                os.environ["LVDGS_MAP_BATCH"] = before
+        torch.cuda.synchronize()
+        G = backend.gaussians
+        state = [p.detach().clone() for p in G.parameters()] + [G.max_radii2D.clone(), G.xyz_gradient_accum.clone(), G.denom.clone()]
+        state += [G.optimizer.state[p][k].clone() for p in G.parameters() if p in G.optimizer.state for k in ("exp_avg", "exp_avg_sq")]
+        occ = [backend.occ_aware_visibility[k].clone() for k in window]
+        return sizes, runs, state, occ, G.unique_kfIDs.clone(), G.n_obs.clone()
+
+    sizes_b, runs_b, state_b, occ_b, kf_b, obs_b = run(True)
+    sizes_s, runs_s, state_s, occ_s, kf_s, obs_s = run(False)
+    assert runs_b == list(range(1, 9)) and runs_s == [0] * 8          # batched in every iteration / never
+    assert len(set(sizes_b[:8])) >= 3 and sizes_b[8] < sizes_b[7]     # densified / pruned several times, then the pruning pass
+    assert sizes_b == sizes_s
+    for a, b in zip(state_b + occ_b, state_s + occ_s):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert torch.equal(kf_b, kf_s) and torch.equal(obs_b, obs_s)
