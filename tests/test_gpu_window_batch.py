@@ -165,6 +165,7 @@ def test_window_batch_across_densification_pruning_and_an_opacity_reset(masked):
         model, cam, g, _ = bench.build_scene(workload, 0, dev)
         backend, window = bench.build_window(workload, 12, dev, model, n_window=8, masked=masked)
         backend.gaussian_update_every, backend.gaussian_update_offset, backend.gaussian_reset = 3, 1, 5
+        model.unique_kfIDs = (torch.arange(model.get_xyz.shape[0]) % 12 + 1).to(torch.int32)   # (seeded by keyframes 1..12: the pruning pass looks at the newest three)
         backend.opt_params.densify_grad_threshold = 2e-5
         before = os.environ.get("LVDGS_MAP_BATCH")
         os.environ["LVDGS_MAP_BATCH"] = "1" if batch else "0"
@@ -193,7 +194,7 @@ def test_window_batch_across_densification_pruning_and_an_opacity_reset(masked):
     sizes_b, runs_b, state_b, occ_b, kf_b, obs_b = run(True)
     sizes_s, runs_s, state_s, occ_s, kf_s, obs_s = run(False)
     assert runs_b == list(range(1, 9)) and runs_s == [0] * 8          # batched in every iteration / never
-    assert len(set(sizes_b[:8])) >= 3 and sizes_b[8] < sizes_b[7]     # densified / pruned several times, then the pruning pass
+    assert len(set(sizes_b[:8])) >= 3 and sizes_b[8] < sizes_b[7], sizes_b     # densified / pruned several times, then the pruning pass
     assert sizes_b == sizes_s
     for a, b in zip(state_b + occ_b, state_s + occ_s):
         assert a.shape == b.shape and torch.equal(a, b)
