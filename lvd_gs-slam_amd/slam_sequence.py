@@ -369,6 +369,16 @@ class SlamSequence:
         from .eval_utils import eval_ate
         return eval_ate(self.cameras, self.kf_indices, monocular=self.monocular)
 
+    def pose_errors(self):
+        """Distance between estimated and ground-truth camera centres, frame by frame, WITHOUT any alignment (frame 0 starts at its
+        ground-truth pose): what ``eval_ate``'s similarity alignment -- with scale for monocular runs -- can hide, e.g. a tracker that
+        follows only a fraction of the motion.  -> {frame: error}."""
+        out = {}
+        for i, cam in self.cameras.items():
+            c = lambda R, T: -(R.detach().double().cpu().T @ T.detach().double().cpu())
+            out[i] = float((c(cam.R, cam.T) - c(cam.R_gt, cam.T_gt)).norm())
+        return out
+
     def eval_rendering(self, metrics_fn=None):
         """``eval_rendering``'s numbers (utils/eval_utils_0806.py:172-306): every NON-keyframe frame rendered from its tracked pose
         against the dataset's image; means of PSNR (and of whatever else ``metrics_fn`` returns: default ``eval_utils.frame_metrics``,

@@ -15,50 +15,24 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def sequence_config(W, H, **training):
-    training = dict(training)
-    cfg = json.load(open(os.path.join(HERE, "golden", "config_07.json")))
-    cfg = copy.deepcopy(cfg)
-    cfg["Training"]["monocular"] = cfg["Dataset"]["sensor_type"] == "monocular"   # (set by the absent slam.py entry point)
-    lr = training.pop("lr", None)
-    cfg["Training"].update(training)
-    if lr:
-        cfg["Training"]["lr"].update(lr)
-    cfg["Dataset"]["Calibration"].update(width=W, height=H)
-    cfg["Results"].update(save_results=False, use_gui=False)
-    return cfg
+import sys as _sys
+_sys.path.insert(0, os.path.join(HERE, "..", "tools"))
+from sequence import PIPE, empty_map, sequence_config, truth_model  # noqa: E402,F401  (tools/sequence.py: shared with bench.py)
 
 
-TOY = dict(W=64, H=48, n_true=420, r_min=2.0, r_max=9.0, margin=0.5, n_frames=14, step=0.03, sway=0.10, yaw=0.02, period=14.0)
-TOY_TRAINING = dict(init_itr_num=14, init_gaussian_update=6, init_gaussian_reset=9, init_gaussian_th=0.005, init_gaussian_extent=30,
-                    tracking_itr_num=10, mapping_itr_num=5, mapping_itr_nosingle=4, initial_ba_itr_num=6, gaussian_update_every=6,
+TOY = dict(W=64, H=48, n_true=420, r_min=2.0, r_max=9.0, margin=0.5, n_frames=18, step=0.025, sway=0.08, yaw=0.02, period=14.0)
+TOY_TRAINING = dict(init_itr_num=48, init_gaussian_update=15, init_gaussian_reset=12, init_gaussian_th=0.005, init_gaussian_extent=30,
+                    tracking_itr_num=16, mapping_itr_num=5, mapping_itr_nosingle=4, initial_ba_itr_num=6, gaussian_update_every=6,
                     gaussian_update_offset=2, gaussian_reset=17, gaussian_th=0.4, size_threshold=30, window_size=3, pose_window=2,
                     kf_interval=2, kf_overlap=0.95, kf_translation=0.03, kf_min_translation=0.02, prune_num=1, depth_lambda=0.1,
-                    lr=dict(cam_trans_delta=0.004))   # (ten tracking iterations per frame instead of a hundred: the step a frame may need stays in reach)
+                    lr=dict(cam_trans_delta=0.005))   # (sixteen tracking iterations per frame instead of a hundred: the step a frame may need stays in reach)
 
 
 def toy_dataset_overrides(cfg):
-    cfg["Dataset"].update(pcd_downsample=24, pcd_downsample_init=10, point_size=0.05, adaptive_pointsize=False)
+    cfg["Dataset"].update(pcd_downsample=24, pcd_downsample_init=10, point_size=0.3, adaptive_pointsize=False)
+    cfg["opt_params"]["opacity_lr"] = 0.2   # (an opacity reset is followed by tens of iterations here, not hundreds: logits must be able to come back)
     cfg["opt_params"]["densify_grad_threshold"] = 0.002   # (64-pixel frames: a pixel is 1 / 32 of NDC, gradients per unit of NDC are small multiples of it)
     return cfg
-
-
-def truth_model(W, H, n_true, r_min, r_max, margin, device, seed=11):
-    from lvdgs import synthetic
-    from lvdgs.gaussian_model import GaussianModel
-    g = synthetic.make_surface_gaussians(n_true, W, H, seed=seed, r_min=r_min, r_max=r_max, margin=margin)
-    return GaussianModel.from_activated(g["means3D"], g["scales"], g["rotations"], g["opacities"], shs=g["shs"], device=device)
-
-
-def empty_map(cfg, device):
-    from lvdgs.gaussian_model import GaussianModel
-    m = GaussianModel(cfg["model_params"]["sh_degree"], config=cfg, device=device)
-    m.init_lr(cfg["opt_params"]["init_lr"])
-    m.training_setup(cfg["opt_params"])
-    return m
-
-
-PIPE = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False)
 
 
 def cpu_hooks():

@@ -11,15 +11,16 @@ Prints one JSON object (bench.py's config.side.sequence_kitti07_geom is the same
 counts and densification schedule of configs/mono/KITTI/base_config.yaml as they are; `short`: every burst a fifth of it (the GPU
 test's schedule).  The first three tracked frames of a reference-cadence run are the map's slowest (the map is one keyframe old)."""
 import argparse
+import copy
 import json
 import os
 import random
 import sys
 import time
+from types import SimpleNamespace
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
 import lvdgs  # noqa: E402,F401
@@ -27,13 +28,45 @@ from lvdgs import synthetic  # noqa: E402
 from lvdgs.gaussian_renderer import render  # noqa: E402
 from lvdgs.slam_sequence import SlamSequence  # noqa: E402
 
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+PIPE = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False)
+
+
+def sequence_config(W, H, **training):
+    """The merged KITTI-07 config (tests/golden/config_07.json: ``load_config("configs/mono/KITTI/07.yaml")`` of the reference, captured by
+    tests/golden/make_golden.py) with ``training`` laid over its Training block and the frame size set."""
+    training = dict(training)
+    cfg = copy.deepcopy(json.load(open(os.path.join(GOLDEN, "config_07.json"))))
+    cfg["Training"]["monocular"] = cfg["Dataset"]["sensor_type"] == "monocular"   # (set by the absent slam.py entry point)
+    lr = training.pop("lr", None)
+    cfg["Training"].update(training)
+    if lr:
+        cfg["Training"]["lr"].update(lr)
+    cfg["Dataset"]["Calibration"].update(width=W, height=H)
+    cfg["Results"].update(save_results=False, use_gui=False)
+    return cfg
+
+
+def truth_model(W, H, n_true, r_min, r_max, margin, device, seed=11):
+    from lvdgs.gaussian_model import GaussianModel
+    g = synthetic.make_surface_gaussians(n_true, W, H, seed=seed, r_min=r_min, r_max=r_max, margin=margin)
+    return GaussianModel.from_activated(g["means3D"], g["scales"], g["rotations"], g["opacities"], shs=g["shs"], device=device)
+
+
+def empty_map(cfg, device):
+    from lvdgs.gaussian_model import GaussianModel
+    m = GaussianModel(cfg["model_params"]["sh_degree"], config=cfg, device=device)
+    m.init_lr(cfg["opt_params"]["init_lr"])
+    m.training_setup(cfg["opt_params"])
+    return m
+
+
 SHORT = dict(init_itr_num=210, init_gaussian_update=20, init_gaussian_reset=100, tracking_itr_num=40, mapping_itr_num=30,
              mapping_itr_nosingle=10, initial_ba_itr_num=60, gaussian_update_every=30, gaussian_update_offset=10, gaussian_reset=401)
 
 
 def kitti_sequence(dev, frames=60, scale=1.0, cadence="reference", masks=True, n_true=None, seed=0, training=None, window_size=None):
     """(config, dataset, true map): KITTI-07's frame geometry (x ``scale``), the merged KITTI-07 config with the chosen cadence."""
-    import sequence_scene as ss
     W, H = int(round(1226 * scale)), int(round(370 * scale))
     fx = fy = 707.0912 * scale
     cx, cy = 601.8873 * scale, 183.1104 * scale
@@ -41,26 +74,27 @@ def kitti_sequence(dev, frames=60, scale=1.0, cadence="reference", masks=True, n
     if window_size is not None:
         tr.update(window_size=window_size, pose_window=min(3, window_size - 1))
     tr.update(training or {})
-    cfg = ss.sequence_config(W, H, **tr)
+    cfg = sequence_config(W, H, **tr)
     cfg["Dataset"]["Calibration"].update(fx=fx, fy=fy, cx=cx, cy=cy)
-    n_true = int(150_000 * scale * scale) if n_true is None else n_true
-    # surfaces of 4..64-pixel footprints (x scale), reaching 0.9 frame widths past the first frame's edges: the camera's field of view
-    # is wider than the generator's (fx < W) and the camera moves
-    truth = ss.truth_model(W, H, n_true, 4.0 * scale, 64.0 * scale, 0.9, dev, seed=11 + seed)
-    ds = synthetic.make_sequence(truth, render, ss.PIPE, W, H, frames, dev, fx=fx, fy=fy, cx=cx, cy=cy, seed=seed, depth_noise=0.02,
+    n_true = int(600_000 * scale * scale) if n_true is None else n_true
+    # opaque surfaces of 1.5..16-pixel footprints (x scale) -- texture at the scale of a few pixels, which is what keeps a SLAM map's
+    # Gaussians small and many (the 4..64-pixel footprints of the surface WORKLOADS render to a blur that a few hundred large Gaussians
+    # reproduce: the map then prunes itself down to them) -- reaching 0.9 frame widths past the first frame's edges: the camera's field
+    # of view is wider than the generator's (fx < W) and the camera moves
+    truth = truth_model(W, H, n_true, 1.5 * scale, 16.0 * scale, 0.9, dev, seed=11 + seed)
+    ds = synthetic.make_sequence(truth, render, PIPE, W, H, frames, dev, fx=fx, fy=fy, cx=cx, cy=cy, seed=seed, depth_noise=0.02,
                                  image_noise=0.01, dynamic_objects=masks, step=0.02, sway=0.15, yaw=0.03, period=40.0)
     return cfg, ds, truth
 
 
 def run_sequence(dev, frames=60, scale=1.0, cadence="reference", fused="auto", idle=10, refine=500, masks=True, seed=0, training=None,
                  window_size=None, on_event=None):
-    import sequence_scene as ss
     torch.manual_seed(seed)
     random.seed(seed)
     cfg, ds, truth = kitti_sequence(dev, frames, scale, cadence, masks, seed=seed, training=training, window_size=window_size)
     del truth
-    m = ss.empty_map(cfg, dev)
-    seq = SlamSequence(cfg, ds, m, ss.PIPE, torch.zeros(3, device=dev), fused=fused, idle_map_iters=idle, on_event=on_event)
+    m = empty_map(cfg, dev)
+    seq = SlamSequence(cfg, ds, m, PIPE, torch.zeros(3, device=dev), fused=fused, idle_map_iters=idle, on_event=on_event)
     seq.run()
     out = seq.summary()
     out["ate_rmse"] = seq.eval_ate()
@@ -73,6 +107,8 @@ def run_sequence(dev, frames=60, scale=1.0, cadence="reference", fused="auto", i
         out["psnr"], out["ssim"], out["psnr_static"] = after.get("psnr"), after.get("ssim"), after.get("psnr_static")
         s = seq.seconds["refinement"]
         out["refinement_ms_per_iteration"] = round(1e3 * s / refine, 4)
+    err = seq.pose_errors()
+    out["pose_error_unaligned_mean"], out["pose_error_unaligned_max"] = sum(err.values()) / len(err), max(err.values())
     out["trajectory_length"] = float(sum(float(torch.linalg.inv(ds.poses[i + 1])[:3, 3].sub(torch.linalg.inv(ds.poses[i])[:3, 3]).norm())
                                          for i in range(len(ds) - 1)))
     out["window_log"] = seq.window_log

@@ -48,6 +48,7 @@ def main():
         seq = SlamSequence(cfg, ds.to(dev), ss.empty_map(cfg, dev), ss.PIPE, torch.zeros(3, device=dev), idle_map_iters=2).run()
     else:
         import sequence as tool
+        ss = tool
         kw = dict(frames=44, scale=0.5, cadence="short", window_size=5, idle=4) if which == "half" else dict(frames=60)
         rec, seq = tool.run_sequence(dev, refine=0, **kw)
         print({k: v for k, v in rec.items() if k != "window_log"})

@@ -22,7 +22,6 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch  # noqa: E402
 
@@ -43,7 +42,7 @@ def launches_per_iteration(fn, iterations):
 
 def time_initialize_map(dev, iters=None, fused="auto"):
     import sequence as tool
-    import sequence_scene as ss
+    ss = tool
     from lvdgs.slam_sequence import SlamSequence
     torch.manual_seed(0); random.seed(0)
     cfg, ds, truth = tool.kitti_sequence(dev, frames=1, masks=False)
