@@ -177,7 +177,7 @@ class MapViewPass:
         return out
 
     # ---- one view ----------------------------------------------------------------------------------------------------
-    def run(self, backend, viewpoint, initialization=False, first=None, image_loss=None, band=None, stats=None, masked_loss=None):
+    def run(self, backend, viewpoint, initialization=False, first=None, image_loss=None, band=None, stats=None, masked_loss=None, want_visibility=True):
         """Render ``viewpoint``, evaluate ``get_loss_mapping`` and add its gradients to the model's and the viewpoint's
         ``.grad`` fields (``first``: buffers, by parameter field, for a view that finds no gradients yet to write into --
         the sharded loop passes slices of its all-reduce bucket -- instead of the pass's own).  Returns the render package (fresh tensors, ``viewspace_points`` carries ``.grad``) and the
@@ -348,7 +348,7 @@ class MapViewPass:
                 p.grad = g if p.grad is None else p.grad + g
         vsp = SimpleNamespace(grad=d_m2, stats_taken=stats is not None and image_loss is None)   # stands in for the leaf autograd would have filled: only .grad is read
         # (visibility_filter: a launch of its own; a caller that had the statistics taken by the tail launch does not read it)
-        pkg = {"render": color, "viewspace_points": vsp, "visibility_filter": (radii > 0) if not vsp.stats_taken else None, "radii": radii, "depth": depth,
+        pkg = {"render": color, "viewspace_points": vsp, "visibility_filter": (radii > 0) if (want_visibility and not vsp.stats_taken) else None, "radii": radii, "depth": depth,
                "opacity": opacity, "n_touched": n_touched}
         return pkg, loss
 

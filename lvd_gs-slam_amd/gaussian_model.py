@@ -385,8 +385,18 @@ class GaussianModel:
 
     # ------------------------------------------------------------------ densification
     def add_densification_stats(self, viewspace_point_tensor, update_filter):
-        self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2], dim=-1, keepdim=True)
-        self.denom[update_filter] += 1
+        """``xyz_gradient_accum[f] += |grad[f, :2]|``; ``denom[f] += 1`` -- as element-wise statements over all Gaussians (x + 0 = x: the same
+        bits) instead of boolean gathers and scatters, each of which makes the host wait for the device to learn how many elements were
+        selected: four such waits per iteration of a 0.3 ms loop (``initialize_map``)."""
+        grad = viewspace_point_tensor.grad
+        if update_filter is None or update_filter.dtype is not torch.bool or update_filter.shape[0] != self.denom.shape[0]:
+            self.xyz_gradient_accum[update_filter] += torch.norm(grad[update_filter, :2], dim=-1, keepdim=True)
+            self.denom[update_filter] += 1
+            return
+        f = update_filter[:, None]
+        norm = torch.norm(grad[:, :2], dim=-1, keepdim=True)
+        self.xyz_gradient_accum += torch.where(f, norm, torch.zeros_like(norm)).to(self.xyz_gradient_accum.dtype)
+        self.denom += f.to(self.denom.dtype)
 
     def densify_and_clone(self, grads, grad_threshold, scene_extent):
         sel = (torch.norm(grads, dim=-1) >= grad_threshold) & (self.get_scaling.max(dim=1).values <= self.percent_dense * scene_extent)

@@ -18,6 +18,19 @@ from .pose_utils import update_pose
 from .slam_utils import get_loss_mapping, get_loss_tracking, get_median_depth
 
 
+def _update_max_radii(G, radii, visibility_filter):
+    """``G.max_radii2D[vis] = torch.max(G.max_radii2D[vis], radii[vis])`` (reference utils/slam_backend.py:124, :460) without the boolean
+    gather and scatter -- each of them a device-to-host synchronisation for the number of selected elements, in loops of 0.3-1 ms per
+    iteration.  A Gaussian outside ``vis`` has radius 0 and ``max_radii2D`` is never negative, so the element-wise maximum over ALL
+    Gaussians writes the same bits."""
+    if radii.shape == G.max_radii2D.shape and not radii.dtype.is_floating_point:
+        torch.maximum(G.max_radii2D, radii, out=G.max_radii2D)
+    else:
+        if visibility_filter is None:
+            visibility_filter = radii > 0
+        G.max_radii2D[visibility_filter] = torch.max(G.max_radii2D[visibility_filter], radii[visibility_filter])
+
+
 def initialize_map(backend, cur_frame_idx, viewpoint, render_fn=render, on_iteration=None, fused="auto"):
     """``init_itr_num`` iterations of render -> get_loss_mapping(initialization=True) -> backward -> bookkeeping ->
     Adam step on one view (reference utils/slam_backend.py:95-149).  Returns the last render package.
@@ -53,7 +66,7 @@ def _initialize_map_iterations(backend, viewpoint, render_fn, on_iteration, vpas
         if on_iteration is not None:
             on_iteration(mapping_iteration, loss_init, render_pkg)
         with torch.no_grad():
-            G.max_radii2D[visibility_filter] = torch.max(G.max_radii2D[visibility_filter], radii[visibility_filter])
+            _update_max_radii(G, radii, visibility_filter)
             G.add_densification_stats(viewspace_point_tensor, visibility_filter)
             if mapping_iteration % backend.init_gaussian_update == 0:
                 # replaces every parameter: the step below then finds no gradients (the reference does the same)
@@ -89,16 +102,21 @@ def color_refinement(backend, iteration_total=26000, render_fn=render, loss_fn=N
             vpass = MapViewPass(G.get_xyz.device)
     from . import _lib
     with _lib.quiet_gc():
+        lam = float(backend.opt_params.lambda_dssim)
+        takes = {}   # keyframe -> can the fused pass take it (checked once per keyframe: its tensors do not change under this loop)
         for iteration in range(1, iteration_total + 1):
+            # (`viewpoint_idx_stack.pop(random.randint(0, len - 1))` of the reference: the same draw, the same keyframe)
             viewpoint_idx_stack = list(backend.viewpoints.keys())
-            viewpoint_cam_idx = viewpoint_idx_stack.pop(random.randint(0, len(viewpoint_idx_stack) - 1))
+            viewpoint_cam_idx = viewpoint_idx_stack[random.randint(0, len(viewpoint_idx_stack) - 1)]
             viewpoint_cam = backend.viewpoints[viewpoint_cam_idx]
             static_mask = getattr(viewpoint_cam, "static_mask", None)
-            lam = float(backend.opt_params.lambda_dssim)
-            if (vpass is not None and G.get_xyz.shape[0] > 0 and type(vpass).usable(backend, viewpoint_cam, allow_static_mask=True)
-                    and type(vpass).masked_loss_usable(viewpoint_cam, with_depth=False)):
-                render_pkg, loss = vpass.run(backend, viewpoint_cam, masked_loss=(lam, None))
-                visibility_filter, radii = render_pkg["visibility_filter"], render_pkg["radii"]
+            ok = takes.get(viewpoint_cam_idx) if vpass is not None else False
+            if ok is None:
+                ok = takes[viewpoint_cam_idx] = bool(G.get_xyz.shape[0] > 0 and type(vpass).usable(backend, viewpoint_cam, allow_static_mask=True)
+                                                     and type(vpass).masked_loss_usable(viewpoint_cam, with_depth=False))
+            if ok:
+                render_pkg, loss = vpass.run(backend, viewpoint_cam, masked_loss=(lam, None), want_visibility=False)
+                visibility_filter, radii = None, render_pkg["radii"]
             else:
                 render_pkg = render_fn(viewpoint_cam, G, backend.pipeline_params, backend.background)
                 image, visibility_filter, radii = render_pkg["render"], render_pkg["visibility_filter"], render_pkg["radii"]
@@ -108,7 +126,7 @@ def color_refinement(backend, iteration_total=26000, render_fn=render, loss_fn=N
             if on_iteration is not None:
                 on_iteration(iteration, viewpoint_cam_idx, loss)
             with torch.no_grad():
-                G.max_radii2D[visibility_filter] = torch.max(G.max_radii2D[visibility_filter], radii[visibility_filter])
+                _update_max_radii(G, radii, visibility_filter)
                 G.optimizer.step()
                 G.optimizer.zero_grad(set_to_none=True)
                 G.update_learning_rate(iteration)

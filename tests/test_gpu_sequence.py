@@ -48,8 +48,15 @@ def test_toy_sequence_on_the_hip_path_matches_the_cpu_harness():
     assert h["seq"].kf_indices[:3] == c["seq"].kf_indices[:3]
     assert abs(h["s"]["keyframes"] - c["s"]["keyframes"]) <= 1
     # the dense renderer has no 3-sigma rectangles, no 1/255 cut and no early termination (tests/test_gpu_loop_golden.py: ~1e-3
-    # relative in one iteration's gradients, counts within 2 % after a densification); over a sequence: map sizes within 15 %
-    assert abs(h["s"]["gaussians_last"] - c["s"]["gaussians_last"]) <= 0.15 * c["s"]["gaussians_last"]
+    # relative in one iteration's gradients, counts within 2 % after a densification).  Over a sequence: the same events in the same
+    # order through the first two keyframes with sizes within 3 %; the largest map within 15 %.  (The size at the very END is whatever
+    # the last densify-and-prune left -- a fifth of the map sits near its opacity threshold -- and differs between two CPU runs on
+    # different machines as much as between CPU and GPU: not compared.)
+    hc, cc = h["seq"].gaussian_counts, c["seq"].gaussian_counts
+    k = [i for i, (e, _) in enumerate(cc) if e == "seed"][2] + 1     # up to and including the third seeding (frame 0's is the first)
+    assert [e for e, _ in hc[:k]] == [e for e, _ in cc[:k]], (hc, cc)
+    assert all(abs(a - b) <= 0.03 * b + 2 for (_, a), (_, b) in zip(hc[:k], cc[:k])), (hc, cc)
+    assert abs(h["s"]["gaussians_max"] - c["s"]["gaussians_max"]) <= 0.15 * c["s"]["gaussians_max"]
     assert h["s"]["size_changes_by_densification"] >= 2 and h["s"]["size_changes_by_pruning"] >= 1
     # trajectory error (camera travel ~0.45): both under the bound of the CPU test, within 0.01 of each other; the un-aligned
     # camera-centre errors (no similarity fit to hide behind) within 0.02 of each other frame by frame
