@@ -148,6 +148,12 @@ enum {
                                       backward blend pass -- because the caller runs that pass for several views of one size in
                                       ONE launch: lvdgs_blend_forward_batch / lvdgs_blend_backward_fused_loss_batch (the views
                                       of a mapping window; the results are the single calls', bit for bit) */
+    LVDGS_FLAG_SUPER_TILES = 16,   /* R: a HINT for frames whose Gaussians are listed on many tiles each (opaque surfaces of large flat Gaussians: 70-80
+                                      tiles per Gaussian): the (Gaussian, tile) pairs are grouped and depth-sorted per 64 x 64-pixel super-tile -- a tenth of
+                                      the keys to scatter and sort there -- and every tile's list is read off its super-tile's sorted list.  point_list,
+                                      ranges and every output are the same bits with and without it; worth setting when num_rendered exceeds ~16 pairs per
+                                      Gaussian (lvdgs.rasterizer decides from the previous frame's count).  Ignored with LVDGS_FLAG_LIST_ALL_TILES, with a
+                                      band of tile rows, on frames of fewer than 64 tiles and by lvdgs_forward_batch. */
     LVDGS_FLAG_POSE_ONLY = 4,      /* B: only the camera-pose gradient (dL_dtau, or its partial sums for lvdgs_tracking_tail) and --
                                       lvdgs_backward_fused_loss -- the loss value and exposure gradients are produced.  The
                                       reference's tracking optimiser holds the pose and the exposure alone

@@ -15,6 +15,7 @@ FLAG_LIST_ALL_TILES = 1
 FLAG_ACCUMULATE_PARAM_GRADS = 2   # lvdgs_args.flags
 FLAG_POSE_ONLY = 4
 FLAG_NO_BLEND = 8   # the call leaves its blend pass to lvdgs_blend_*_batch
+FLAG_SUPER_TILES = 16   # hint: group and depth-sort the pairs per 64 x 64-pixel super-tile (same outputs; rasterizer.super_tiles_flag)
 
 _fp = C.c_void_p
 

@@ -214,10 +214,20 @@ size_t render_scratch_layout(int N, int64_t D, int W, int H, RenderScratch *v, v
     carve(v->keys, d, b, off);
     carve(v->vals, d, b, off);
     v->hist = v->totals = v->group_hist = v->group_totals = v->chunk_sums = nullptr;
+    v->super = SuperView{};
     if (use_counting_path(T)) {
         carve(v->group_hist, group_hist_entries(N, T), b, off);
         carve(v->group_totals, (size_t)(T > 0 ? T : 1) + 4, b, off);   // (+4: the tile-range scan reads them 16 bytes at a time)
         carve(v->chunk_sums, group_chunks(N), b, off);
+        // two-level grouping (LVDGS_FLAG_SUPER_TILES): the super-tile grid's own counting state
+        const size_t Ts = (size_t)super_tiles_of(W, H);
+        carve(v->super.rect, (size_t)(N > 0 ? N : 1), b, off);
+        carve(v->super.hist, group_chunks(N) * (Ts ? Ts : 1), b, off);
+        carve(v->super.totals, (Ts ? Ts : 1) + 4, b, off);
+        carve(v->super.ranges, Ts ? Ts : 1, b, off);
+        carve(v->super.long_count, 64, b, off);
+        carve(v->super.long_tiles, 2 * (Ts ? Ts : 1), b, off);
+        carve(v->super.total, 64, b, off);
     } else {
         carve(v->hist, radix_hist_entries(D), b, off);
         carve(v->totals, (size_t)1 << SORT_MAX_BITS, b, off);
@@ -309,6 +319,7 @@ struct PairProbe {
     uint32_t *pinned_dev = nullptr;   // the same words as the device addresses them
     uint32_t seq = 0;             // of the last single-call forward on this thread and device
     hipEvent_t ready = nullptr;
+    int longest_super = -1, queued_super = 0;   // the same hints for the super-tile lists of the two-level grouping (LVDGS_FLAG_SUPER_TILES)
     int longest = 0, queued = 0;  // of the previous frame on this device: which kernels for long segments the next frame
     int keep = 0;                 // launches behind its tile sort (a hint, never a result); kept for a few frames
 };
@@ -397,7 +408,7 @@ int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipSt
             if (int e = check_hip(hipMemsetAsync(a->n_touched, 0, sizeof(int32_t) * (size_t)N, s), "memset n_touched")) return e;
         if (count_on_device) count = g.total;
     }
-    bool grouped = false;
+    bool grouped = false, super = false;
     if (cap > 0) {
         if (bin_view(a, &b) < cap) { set_error("internal: binning_state smaller than the pair capacity"); return LVDGS_E_INVALID; }
         render_scratch_layout(N, cap, W, H, &w, a->scratch);
@@ -408,8 +419,20 @@ int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipSt
             // (single-call forward: the tile scan writes the pair count and the hints into the caller thread's pinned words itself)
             if (int e = launch_group_scan(*a, im, w, cap, counted ? g.total : nullptr, s, counted && probe ? probe->pinned_dev : nullptr,
                                           counted && probe ? probe->seq : 0u)) return e;
-            if (int e = launch_group_scatter(*a, g, im, w, (unsigned long long *)w.keys, cap, counted, b.pair_valid, s, counted ? g.total : nullptr,
-                                             counted && probe ? probe->pinned_dev : nullptr, counted && probe ? probe->seq : 0u)) return e;
+            super = super_tiles_in_use(*a);
+            if (super) {
+                // two-level grouping: keys scattered and sorted per 64 x 64-pixel super-tile, the tiles' lists read off the sorted super lists
+                // (binning.hip); b.tile_keys -- the radix path's -- takes the sorted super lists
+                if (int e = launch_super_group(*a, g, w.super, w, (unsigned long long *)w.keys, cap, counted, b.pair_valid,
+                                               probe ? probe->pinned_dev + 8 : nullptr, s)) return e;
+                ImageView ims{};
+                ims.ranges = w.super.ranges; ims.long_count = w.super.long_count; ims.long_tiles = w.super.long_tiles;
+                const int Ts = super_tiles_of(W, H);
+                if (int e = launch_tile_depth_sort(ims, Ts, 0, Ts, g.rec, b.tile_keys, w.keys, true, probe ? probe->longest_super : -1,
+                                                   probe ? probe->queued_super : 0, a->debug, s)) return e;
+                if (int e = launch_super_expand(*a, g, w.super, im, b.tile_keys, b.point_list, s)) return e;
+            } else if (int e = launch_group_scatter(*a, g, im, w, (unsigned long long *)w.keys, cap, counted, b.pair_valid, s, counted ? g.total : nullptr,
+                                                    counted && probe ? probe->pinned_dev : nullptr, counted && probe ? probe->seq : 0u)) return e;
             grouped = true;
         } else {
             if (!w.hist) { set_error("internal: scratch was not laid out for the radix grouping"); return LVDGS_E_INVALID; }
@@ -428,7 +451,7 @@ int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipSt
     if (!grouped)
         if (int e = launch_tile_ranges(b.tile_keys, cap, count, im, num_tiles, a->debug, s)) return e;
     // w.keys + w.vals: the (depth, id) keys the counting path scattered, or scratch for over-long segments after the radix path
-    if (cap > 0) {
+    if (cap > 0 && !super) {
         // long segments: expected as the recent frames on this device had them (single-call forward), unknown otherwise
         if (int e = launch_tile_depth_sort(im, num_tiles, row0 * gx, row1 * gx, g.rec, b.point_list, w.keys, grouped, probe ? probe->longest : -1,
                                            probe ? probe->queued : 0, a->debug, s)) return e;
@@ -531,6 +554,11 @@ int lvdgs_forward(const lvdgs_args *a, int64_t *num_rendered, void *stream) {
         const int longest = (int)probe->pinned[1], queued = (int)probe->pinned[2];
         if (longest >= probe->longest || probe->keep == 0) { probe->longest = longest; probe->queued = queued; probe->keep = longest ? 32 : 0; }
         else probe->keep--;
+        if (super_tiles_in_use(*a)) {
+            // (the super scan runs behind the tile scan whose sequence number was waited for: these two words may still be the previous
+            // frame's -- they are hints for the next frame's sort launch either way)
+            probe->longest_super = (int)probe->pinned[8 + 1]; probe->queued_super = (int)probe->pinned[8 + 2];
+        }
     }
     if (total > 0x7FFFFFFFu) { set_error("%u (Gaussian, tile) pairs exceed the 2^31 limit", total); return LVDGS_E_RANGE; }
     *num_rendered = (int64_t)total;
@@ -734,6 +762,11 @@ int lvdgs_forward_backward_fused_loss(const lvdgs_args *a, const lvdgs_loss_args
         const int longest = (int)probe->pinned[1], queued = (int)probe->pinned[2];
         if (longest >= probe->longest || probe->keep == 0) { probe->longest = longest; probe->queued = queued; probe->keep = longest ? 32 : 0; }
         else probe->keep--;
+        if (super_tiles_in_use(*a)) {
+            // (the super scan runs behind the tile scan whose sequence number was waited for: these two words may still be the previous
+            // frame's -- they are hints for the next frame's sort launch either way)
+            probe->longest_super = (int)probe->pinned[8 + 1]; probe->queued_super = (int)probe->pinned[8 + 2];
+        }
     }
     if (total > 0x7FFFFFFFu) { set_error("%u (Gaussian, tile) pairs exceed the 2^31 limit", total); return LVDGS_E_RANGE; }
     *num_rendered = (int64_t)total;

@@ -473,6 +473,120 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t *__rest
     if (k == D - 1 || tile_keys[k + 1] != t) ranges[t].y = (uint32_t)(k + 1);
 }
 
+
+// ---- two-level grouping (LVDGS_FLAG_SUPER_TILES) ------------------------------------------------------------------------------------
+// Opaque surfaces of large flat Gaussians -- the regime SLAM maps live in -- list a Gaussian on 70-80 tiles: 7.2 M (Gaussian, tile)
+// pairs for 100 k Gaussians at 1080p, and the scatter of their 8-byte sort keys (94 us) and the per-tile depth sorts (74 us) are
+// what the forward pass then spends its time on outside the blend.  Depth order is a property of the GAUSSIAN, not of the pair: the
+// pairs are therefore emitted, scattered and depth-sorted per SUPER-TILE of SUPER x SUPER tiles (64 x 64 pixels) -- a tenth of the pairs
+// on that scene (tools/supertile_model.py) -- and every tile's list is then read off its super-tile's sorted list: the entries whose
+// kept-tile mask has the tile's bit set, in the list's order (expand_super_kernel).  The same (depth bits, id) order, the same kept
+// tiles: point_list, ranges and everything downstream are the one-level path's, bit for bit.
+//   count_super:  rect_s[i] = the Gaussian's rectangle in super-tile units + which of them hold a listed tile; hist_s[chunk][super-tile]
+//   colscan / tilescan on (hist_s, Ts): ranges_s, the queue of long super lists (the SAME kernels on a grid of Ts "tiles")
+//   scatter on (rect_s, Ts, hist_s, ranges_s): the keys into the super segments; slot_base and pair_valid as ever
+//   tile sort on ranges_s: sorted ids into super_list
+//   expand: one workgroup per super-tile, one WAVE per tile of it
+// The tile-level count (the projection kernel's), colscan and tilescan run as always: they make ranges[] and the pair count.
+__device__ __forceinline__ uint4 super_rect_of(const uint4 r) {
+    const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
+    const int w = x1 - x0, h = y1 - y0, area = w * h;
+    const uint64_t m = (uint64_t)r.z | ((uint64_t)r.w << 32);
+    if (area <= 0 || m == 0ull) return make_uint4(0u, 0u, 0u, 0u);
+    const int sx0 = x0 / SUPER, sx1 = (x1 - 1) / SUPER + 1, sy0 = y0 / SUPER, sy1 = (y1 - 1) / SUPER + 1;
+    const int ws = sx1 - sx0, area_s = ws * (sy1 - sy0);
+    uint64_t ms = 0ull;
+    if (area_s > RECT_MASK_TILES) {
+        ms = ~0ull;   // (a rectangle of more than 64 super-tiles -- over 1000 tiles: every super-tile of it is listed; the expansion drops what no tile keeps)
+    } else if (area <= RECT_MASK_TILES) {
+        const float inv_w = __builtin_amdgcn_rcpf((float)w);
+        for (uint64_t mm = m; mm; mm &= mm - 1ull) {
+            const int k = __builtin_ctzll(mm), ty = div_by(k, w, inv_w), tx = k - ty * w;
+            ms |= 1ull << (((y0 + ty) / SUPER - sy0) * ws + ((x0 + tx) / SUPER - sx0));
+        }
+    } else {
+        const RectBlocks g(w, h);
+        for (uint64_t mm = m; mm; mm &= mm - 1ull) {
+            const int b = __builtin_ctzll(mm);
+            const int bx0 = x0 + (b & 7) * g.bw, by0 = y0 + (b >> 3) * g.bh, bx1 = bx0 + g.width(b), by1 = by0 + g.height(b);
+            for (int cy = by0 / SUPER; cy <= (by1 - 1) / SUPER; cy++)
+                for (int cx = bx0 / SUPER; cx <= (bx1 - 1) / SUPER; cx++) ms |= 1ull << ((cy - sy0) * ws + (cx - sx0));
+        }
+    }
+    return make_uint4((uint32_t)sx0 | ((uint32_t)sx1 << 16), (uint32_t)sy0 | ((uint32_t)sy1 << 16), (uint32_t)ms, (uint32_t)(ms >> 32));
+}
+
+template <int GROUP_THREADS, int OWNERS, int PER>
+__global__ void __launch_bounds__(GROUP_THREADS) count_super_kernel(int N, int gxs, int Ts, const uint4 *__restrict__ rect, uint4 *__restrict__ rect_s,
+                                                                   uint32_t *__restrict__ hist, uint32_t *__restrict__ queue_counts) {
+    constexpr int GROUP_CHUNK = OWNERS * PER;
+    constexpr bool HELPERS = GROUP_THREADS > OWNERS;
+    extern __shared__ uint32_t s_tile[];
+    __shared__ BigRectQueue s_big;
+    for (int t = threadIdx.x; t < Ts; t += GROUP_THREADS) s_tile[t] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < 64) queue_counts[threadIdx.x] = 0u;   // the super lists' own tile-sort queue and order flag
+    if (threadIdx.x == 0) s_big.count = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int i = blockIdx.x * GROUP_CHUNK + k * OWNERS + (int)threadIdx.x;
+        const bool mine = (int)threadIdx.x < OWNERS && i < N;
+        const uint4 r = mine ? super_rect_of(rect[i]) : make_uint4(0u, 0u, 0u, 0u);
+        if (mine) rect_s[i] = r;
+        if constexpr (HELPERS) for_each_pair_of_rect_wg(r, i, gxs, 0u, s_big, [&](int tile, uint32_t, uint32_t) { atomicAdd(&s_tile[tile], 1u); });
+        else for_each_pair_of_rect(r, i, gxs, 0u, [&](int tile, uint32_t, uint32_t) { atomicAdd(&s_tile[tile], 1u); });
+    }
+    __syncthreads();
+    uint32_t *row = hist + (size_t)blockIdx.x * Ts;
+    for (int t = threadIdx.x; t < Ts; t += GROUP_THREADS) row[t] = s_tile[t];
+}
+
+// One workgroup per super-tile, one wave per tile of it (SUPER * SUPER = 16 waves): the super-tile's sorted list is staged through LDS
+// 1024 entries at a time -- id and the Gaussian's tile rectangle + kept-tile mask, 20 bytes each, the gather done ONCE for the sixteen
+// tiles -- and every wave walks the staged entries 64 at a time, keeps those that list its tile (rect_keeps: the bit the projection
+// kernel set, the very test its tile count was taken with) and appends their ids to its tile's segment in list order.
+__global__ void __launch_bounds__(64 * SUPER * SUPER) expand_super_kernel(int gx, int gy, int gxs, const uint2 *__restrict__ ranges_s,
+                                                                        const uint32_t *__restrict__ super_list, const uint4 *__restrict__ rect,
+                                                                        const uint2 *__restrict__ ranges, uint32_t *__restrict__ point_list) {
+    constexpr int STAGE = 64 * SUPER * SUPER;
+    __shared__ uint4 s_rect[STAGE];
+    __shared__ uint32_t s_id[STAGE];
+    const int st = (int)blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tx = (st % gxs) * SUPER + (wave % SUPER), ty = (st / gxs) * SUPER + (wave / SUPER);
+    const bool valid = tx < gx && ty < gy;
+    const uint2 seg = ranges_s[st];
+    const uint2 mine = valid ? ranges[ty * gx + tx] : make_uint2(0u, 0u);
+    uint32_t out = mine.x;
+    const int n = (int)(seg.y - seg.x);
+    for (int base = 0; base < n; base += STAGE) {
+        const int m = min(STAGE, n - base);
+        if ((int)threadIdx.x < m) {
+            const uint32_t id = super_list[seg.x + base + threadIdx.x];
+            s_id[threadIdx.x] = id;
+            s_rect[threadIdx.x] = rect[id];
+        }
+        __syncthreads();
+        if (mine.y > mine.x) {
+            for (int j = 0; j < m; j += 64) {
+                const int e = j + lane;
+                bool keep = false;
+                if (e < m) {
+                    const uint4 r = s_rect[e];
+                    const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
+                    if (tx >= x0 && tx < x1 && ty >= y0 && ty < y1) keep = rect_keeps(r, (ty - y0) * (x1 - x0) + (tx - x0), (x1 - x0) * (y1 - y0));
+                }
+                const uint64_t kept = __ballot(keep);
+                if (keep) {
+                    const uint32_t pos = out + (uint32_t)__popcll(kept & ((1ull << lane) - 1ull));
+                    if (pos < mine.y) point_list[pos] = s_id[e];   // (positions at or beyond the pair capacity: dropped, as the clamped ranges say)
+                }
+                out += (uint32_t)__popcll(kept);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 #ifndef LVDGS_GROUP_CHUNK
@@ -508,7 +622,8 @@ int launch_group_count(const lvdgs_args &a, const GeomView &g, const ImageView &
 
 // colscan + tilescan: tile ranges, the pair count (total_out, may be null), the tile sort's queue, the tile order
 constexpr int SCAN_IN_SCATTER_RUN = 4;   // tiles per scatter thread up to which the tile scan rides in the scatter's launch
-static bool scan_rides_in_scatter(int N, int T) {
+static bool scan_rides_in_scatter(const lvdgs_args &a, int N, int T) {
+    if (super_tiles_in_use(a)) return false;   // (two-level grouping: the tile-level scatter, whose launch the scan would ride in, does not run)
     const GroupShape g = group_shape_for(N);
     const int threads = g.threads == 256 ? GROUP_HELPER_THREADS : g.threads;   // (every shape launches 512 or 1024 threads)
     return LVDGS_SCAN_IN_SCATTER != 0 && (threads == 512 || threads == 1024) && cdiv(T, threads) <= SCAN_IN_SCATTER_RUN;
@@ -529,7 +644,7 @@ int launch_group_scan(const lvdgs_args &a, const ImageView &im, const RenderScra
     else if (nchunks <= 16 * 16) hipLaunchKernelGGL(group_colscan_kernel<16>, dim3(wg_tiles), dim3(1024), 0, s, T, nchunks, w.group_hist, w.group_totals);
     else if (nchunks <= 32 * 16) hipLaunchKernelGGL(group_colscan_kernel<32>, dim3(wg_tiles), dim3(1024), 0, s, T, nchunks, w.group_hist, w.group_totals);
     else hipLaunchKernelGGL(group_colscan_kernel<0>, dim3(wg_tiles), dim3(1024), 0, s, T, nchunks, w.group_hist, w.group_totals);
-    if (!scan_rides_in_scatter(N, T))   // (else: launch_group_scatter's last workgroup)
+    if (!scan_rides_in_scatter(a, N, T))   // (else: launch_group_scatter's last workgroup)
         hipLaunchKernelGGL(group_tilescan_kernel, dim3(1), dim3(1024), 0, s, T, (const uint32_t *)w.group_totals, (uint32_t)capacity, im.ranges,
                            total_out, (uint32_t)tile_sort_wave_limit(), im.long_count, im.long_tiles,
                            tile_order_in_use(T) ? im.long_tiles + T : nullptr, row0 * gx, row1 * gx, im.long_count + 1, host_out, host_seq);
@@ -547,7 +662,7 @@ int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView
     static unsigned char done[4 * GROUP_SHAPES][16];
     ProfScope ps("group_scatter", s);
     TileScanArgs ts{};
-    if (scan_rides_in_scatter(N, T)) {   // the tile scan as this launch's last workgroup (launch_group_scan has made the tile totals)
+    if (scan_rides_in_scatter(a, N, T)) {   // the tile scan as this launch's last workgroup (launch_group_scan has made the tile totals)
         int row0, row1;
         tile_row_band(a, &row0, &row1);
         ts = TileScanArgs{im.ranges, total_out, (uint32_t)tile_sort_wave_limit(), im.long_count, im.long_tiles, tile_order_in_use(T) ? im.long_tiles + T : nullptr,
@@ -567,6 +682,82 @@ int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView
             return slot_scan ? launch(&scatter_pairs_kernel<THREADS, OWNERS, PER, true, false>, 4 * d + 2, THREADS) : launch(&scatter_pairs_kernel<THREADS, OWNERS, PER, false, false>, 4 * d + 3, THREADS);
         })) return e;
     LVDGS_LAUNCH_CHECK("group_scatter", a.debug, s);
+    return LVDGS_OK;
+}
+
+// ---- two-level grouping: count_super -> scans -> scatter on the super grid (the tile sort and the expansion: api.hip calls them) ----
+bool super_tiles_in_use(const lvdgs_args &a) {
+    if (!(a.flags & LVDGS_FLAG_SUPER_TILES) || (a.flags & LVDGS_FLAG_LIST_ALL_TILES)) return false;
+    if (a.tile_row_begin != 0 || a.tile_row_end != 0) return false;   // (bands: a super-tile would straddle the band's edge)
+    const int gx = (a.image_width + TILE - 1) / TILE, gy = (a.image_height + TILE - 1) / TILE;
+    return a.num_gaussians > 0 && gx * gy <= GROUP_MAX_TILES && gx * gy >= 4 * SUPER * SUPER;
+}
+int super_tiles_of(int W, int H) { return cdiv(cdiv(W, TILE), SUPER) * cdiv(cdiv(H, TILE), SUPER); }
+
+int launch_super_group(const lvdgs_args &a, const GeomView &g, const SuperView &sv, const RenderScratch &w, unsigned long long *keys64, int64_t capacity,
+                       bool slot_scan, uint8_t *pair_valid, uint32_t *host_hints, hipStream_t s) {
+    const int N = a.num_gaussians;
+    const int gx = (a.image_width + TILE - 1) / TILE, gy = (a.image_height + TILE - 1) / TILE;
+    const int gxs = cdiv(gx, SUPER), Ts = gxs * cdiv(gy, SUPER);
+    if (N == 0 || Ts == 0) return LVDGS_OK;
+    const int nchunks = (int)group_chunks(N);
+    const size_t lds = (size_t)Ts * sizeof(uint32_t);
+    {
+        static unsigned char done[GROUP_SHAPES][16];
+        ProfScope ps("super_count", s);
+        if (int e = group_dispatch(group_shape_for(N), [&](auto threads_, auto owners_, auto per_, int d) {
+                constexpr int THREADS = decltype(threads_)::value, OWNERS = decltype(owners_)::value, PER = decltype(per_)::value;
+                if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&count_super_kernel<THREADS, OWNERS, PER>), GROUP_MAX_TILES * 4, done[d])) return e;
+                hipLaunchKernelGGL((count_super_kernel<THREADS, OWNERS, PER>), dim3(nchunks), dim3(THREADS), lds, s, N, gxs, Ts, (const uint4 *)g.rect, sv.rect, sv.hist,
+                                   sv.long_count);
+                return (int)LVDGS_OK;
+            })) return e;
+        LVDGS_LAUNCH_CHECK("super_count", a.debug, s);
+    }
+    {
+        ProfScope ps("super_scan", s);
+        const int wg_tiles = cdiv(Ts, COLSCAN_TILES);
+        if (nchunks <= 8 * 16) hipLaunchKernelGGL(group_colscan_kernel<8>, dim3(wg_tiles), dim3(1024), 0, s, Ts, nchunks, sv.hist, sv.totals);
+        else if (nchunks <= 16 * 16) hipLaunchKernelGGL(group_colscan_kernel<16>, dim3(wg_tiles), dim3(1024), 0, s, Ts, nchunks, sv.hist, sv.totals);
+        else if (nchunks <= 32 * 16) hipLaunchKernelGGL(group_colscan_kernel<32>, dim3(wg_tiles), dim3(1024), 0, s, Ts, nchunks, sv.hist, sv.totals);
+        else hipLaunchKernelGGL(group_colscan_kernel<0>, dim3(wg_tiles), dim3(1024), 0, s, Ts, nchunks, sv.hist, sv.totals);
+        // (host_hints: two pinned words for the longest queued super list and the queue's length -- hints for the NEXT frame's sort
+        // launch, read whenever; no sequence number is waited for)
+        hipLaunchKernelGGL(group_tilescan_kernel, dim3(1), dim3(1024), 0, s, Ts, (const uint32_t *)sv.totals, (uint32_t)capacity, sv.ranges, sv.total,
+                           (uint32_t)tile_sort_wave_limit(), sv.long_count, sv.long_tiles, tile_order_in_use(Ts) ? sv.long_tiles + Ts : nullptr, 0, Ts,
+                           sv.long_count + 1, host_hints, 0u);
+        LVDGS_LAUNCH_CHECK("super_scan", a.debug, s);
+    }
+    {
+        static unsigned char done[2 * GROUP_SHAPES][16];
+        ProfScope ps("super_scatter", s);
+        TileScanArgs ts{};
+        auto launch = [&](auto kernel, int d, int threads) {
+            if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(kernel), GROUP_MAX_TILES * 4, done[d])) return e;
+            hipLaunchKernelGGL(kernel, dim3(nchunks), dim3(threads), lds, s, N, gxs, Ts, (const uint4 *)sv.rect, (const uint32_t *)sv.hist, (const uint2 *)sv.ranges,
+                               (const uint32_t *)nullptr, (uint32_t)capacity, (const uint32_t *)g.depth_bits, keys64, (const uint32_t *)g.tiles_touched,
+                               (const uint32_t *)w.chunk_sums, g.slot_base, pair_valid, ts);
+            return (int)LVDGS_OK;
+        };
+        if (int e = group_dispatch(group_shape_for(N), [&](auto threads_, auto owners_, auto per_, int d) {
+                constexpr int THREADS = decltype(threads_)::value, OWNERS = decltype(owners_)::value, PER = decltype(per_)::value;
+                return slot_scan ? launch(&scatter_pairs_kernel<THREADS, OWNERS, PER, true, false>, 2 * d, THREADS)
+                                 : launch(&scatter_pairs_kernel<THREADS, OWNERS, PER, false, false>, 2 * d + 1, THREADS);
+            })) return e;
+        LVDGS_LAUNCH_CHECK("super_scatter", a.debug, s);
+    }
+    return LVDGS_OK;
+}
+
+int launch_super_expand(const lvdgs_args &a, const GeomView &g, const SuperView &sv, const ImageView &im, const uint32_t *super_list, uint32_t *point_list,
+                        hipStream_t s) {
+    const int gx = (a.image_width + TILE - 1) / TILE, gy = (a.image_height + TILE - 1) / TILE;
+    const int gxs = cdiv(gx, SUPER), Ts = gxs * cdiv(gy, SUPER);
+    if (a.num_gaussians == 0 || Ts == 0) return LVDGS_OK;
+    ProfScope ps("super_expand", s);
+    hipLaunchKernelGGL(expand_super_kernel, dim3(Ts), dim3(64 * SUPER * SUPER), 0, s, gx, gy, gxs, (const uint2 *)sv.ranges, super_list, (const uint4 *)g.rect,
+                       (const uint2 *)im.ranges, point_list);
+    LVDGS_LAUNCH_CHECK("super_expand", a.debug, s);
     return LVDGS_OK;
 }
 

@@ -197,6 +197,17 @@ struct GeomView {
 struct PrepScratch {
     uint32_t *blocksums; // scan block sums
 };
+// Two-level grouping (LVDGS_FLAG_SUPER_TILES, binning.hip): the grid of SUPER x SUPER-tile super-tiles and its own counting state
+constexpr int SUPER = 4;
+struct SuperView {
+    uint4 *rect;           // N: a Gaussian's rectangle in super-tile units + which of them hold a listed tile
+    uint32_t *hist;        // [Gaussian chunk][super-tile]
+    uint32_t *totals;      // Ts (+4)
+    uint2 *ranges;         // Ts
+    uint32_t *long_count;  // 64: queue length, order-valid flag (as ImageView::long_count)
+    uint32_t *long_tiles;  // 2 Ts: queue of super-tiles with lists beyond one wave's sort, the super-tiles by list length
+    uint32_t *total;       // 4: super pair count, longest queued list, queue length
+};
 struct RenderScratch {
     uint32_t *blocksums; // same place as PrepScratch::blocksums: the counting path's first kernel still reads them
     uint32_t *keys;  // D (alternate tile-key buffer of the radix path; 64-bit keys of over-long tile segments)
@@ -206,6 +217,7 @@ struct RenderScratch {
     uint32_t *group_hist;   // counting path: [Gaussian chunk][tile] pair counts, then exclusive prefixes over the chunks
     uint32_t *group_totals; // counting path: pairs per tile
     uint32_t *chunk_sums;   // counting path: pairs per Gaussian chunk (left by the projection kernel that counts, read by the slot scan in the scatter)
+    SuperView super;        // counting path: the two-level grouping's state
 };
 struct BinView {
     uint32_t *point_list; // D
@@ -297,6 +309,14 @@ int launch_group_scatter(const lvdgs_args &a, const GeomView &g, const ImageView
                          int64_t capacity, bool slot_scan, uint8_t *pair_valid, hipStream_t s, uint32_t *total_out = nullptr, uint32_t *host_out = nullptr,
                          uint32_t host_seq = 0);
 int launch_emit_pairs(const lvdgs_args &a, const GeomView &g, uint32_t *tile_keys, uint32_t *ids, int64_t capacity, hipStream_t s);
+// two-level grouping (binning.hip): is it in use for this call; super_count + scans + scatter of the super grid; the expansion of the
+// sorted super lists into the tiles' segments of point_list
+bool super_tiles_in_use(const lvdgs_args &a);
+int super_tiles_of(int W, int H);
+int launch_super_group(const lvdgs_args &a, const GeomView &g, const SuperView &sv, const RenderScratch &w, unsigned long long *keys64, int64_t capacity,
+                       bool slot_scan, uint8_t *pair_valid, uint32_t *host_hints, hipStream_t s);
+int launch_super_expand(const lvdgs_args &a, const GeomView &g, const SuperView &sv, const ImageView &im, const uint32_t *super_list, uint32_t *point_list,
+                        hipStream_t s);
 // Sorts the segment of every tile in [t_lo, t_hi) by (view-depth bits, id) and leaves the ids in point_list.  keys64 holds
 // D 64-bit keys: already filled per segment (counting path, keys_ready; the queue of segments longer than
 // tile_sort_wave_limit() is then filled too), or scratch for over-long segments whose keys are gathered from the ids in

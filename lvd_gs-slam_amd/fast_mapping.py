@@ -221,6 +221,9 @@ class MapViewPass:
         a.bg, a.viewmatrix, a.projmatrix, a.projmatrix_raw, a.campos = (_P(t) for t in cam)
         a.activations = _rz.ACT_EXP_SCALES | _rz.ACT_NORMALIZE_ROTATIONS | _rz.ACT_SIGMOID_OPACITIES
         a.flags = _lib.FLAG_LIST_ALL_TILES if _rz.LIST_ALL_TILES else 0
+        # (two-level grouping: hinted by the pair count of the pass's previous view of a map of this size -- rasterizer.super_tiles_flag)
+        a.flags |= _rz.super_tiles_flag(N, int(a.num_rendered) if getattr(self, "_pairs_of_n", None) == N else None)
+        self._pairs_of_n = N
         a.tile_row_begin, a.tile_row_end = (0, 0) if band is None else (int(band[0]), int(band[1]))
         if band is not None and (image_loss is not None or masked_loss is not None or not 0 <= band[0] < band[1]):
             raise _lib.LvdgsError("MapViewPass: a band needs 0 <= row0 < row1 and the built-in mapping loss")

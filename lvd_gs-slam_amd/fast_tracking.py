@@ -206,6 +206,8 @@ class TrackingSession:
             # objective is the loss: d/d loss = 1), and on small grids the two blend passes of a tile share a launch
             # (lvdgs_forward_backward_fused_loss); the loss's final reduction, the pose gradient's and the pose step share the
             # iteration's last launch
+            # (the two-level grouping hint follows the previous iteration's pair count: rasterizer.super_tiles_flag)
+            a.flags = (a.flags & ~_lib.FLAG_SUPER_TILES) | _rz.super_tiles_flag(self.N, self.num_rendered)
             status = L.lvdgs_forward_backward_fused_loss(C.byref(a), C.byref(self.la), int(_rz.PROPAGATE_OPACITY_GRAD), C.byref(num), stream)
             D = int(num.value)
             if status == _lib.E_CAPACITY:   # more pairs than the buffers hold: grow them and redo binning + blend, then the backward

@@ -21,6 +21,8 @@ All compute happens in ``lib/liblvdgs.so`` (HIP, gfx950) through the C ABI in
 import ctypes as C
 from typing import NamedTuple
 
+import os
+
 import torch
 from torch import nn
 
@@ -102,6 +104,28 @@ def _stream(device=None):
     return C.c_void_p(torch._C._cuda_getCurrentRawStream(idx))
 
 
+# Two-level grouping (include/lvdgs.h: LVDGS_FLAG_SUPER_TILES): worth it when a Gaussian is listed on many tiles -- the opaque surfaces of
+# large flat Gaussians SLAM maps are made of (70-80 tiles each) -- and a loss on scenes of small blobs (3 tiles each), so the hint is set
+# from what the PREVIOUS frame of the same caller looked like: pairs per Gaussian at or above SUPER_TILES_MIN_PAIRS_PER_GAUSSIAN.  Outputs
+# are the same bits either way.  LVDGS_SUPER_TILES=0 / 1 in the environment: never / always (A/B measurements, tests).
+SUPER_TILES_MIN_PAIRS_PER_GAUSSIAN = 16.0
+_SUPER_TILES_ENV = os.environ.get("LVDGS_SUPER_TILES", "auto")
+
+
+def super_tiles_flag(num_gaussians, last_num_rendered):
+    """The flag bit for a frame of ``num_gaussians`` whose predecessor listed ``last_num_rendered`` pairs (None / 0: unknown)."""
+    if _SUPER_TILES_ENV == "0" or LIST_ALL_TILES:
+        return 0
+    if _SUPER_TILES_ENV == "1":
+        return _lib.FLAG_SUPER_TILES
+    if not last_num_rendered or num_gaussians <= 0:
+        return 0
+    return _lib.FLAG_SUPER_TILES if last_num_rendered >= SUPER_TILES_MIN_PAIRS_PER_GAUSSIAN * num_gaussians else 0
+
+
+_LAST_PAIRS = {}   # device index -> (N, D) of the last frame through the autograd API on that device
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, theta, rho,
@@ -128,6 +152,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         a.num_gaussians = N
         a.activations = int(activations)
         a.flags = _lib.FLAG_LIST_ALL_TILES if LIST_ALL_TILES else 0
+        _key = dev.index if dev.index is not None else torch.cuda.current_device()
+        _last = _LAST_PAIRS.get(_key)
+        a.flags |= super_tiles_flag(N, _last[1] if (_last is not None and _last[0] == N) else None)
         a.sh_coeffs = int(shs.shape[1]) if shs is not None else 0
         a.means3D, a.opacities, a.scales, a.rotations = _ptr(m3), _ptr(op), _ptr(sc), _ptr(rot)
         a.cov3D_precomp, a.shs, a.colors_precomp = _ptr(cov), _ptr(shs), _ptr(col)
@@ -169,6 +196,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             _lib.check(L.lvdgs_forward_render(C.byref(a), stream), "lvdgs_forward_render")
         else:
             _lib.check(status, "lvdgs_forward")
+        _LAST_PAIRS[_key] = (N, D)
         if N > 0 and 4 * D > 3 * cap:
             _PAIR_CAPACITY[key] = max(cap, D + D // 2)
         else:

@@ -94,14 +94,18 @@ def test_sequence_with_the_map_growing_under_the_batched_window(half_kitti_runs)
     # trajectory: ~0.86 units of travel, ATE after Umeyama with scale (monocular) under 2 % of it
     assert rec["ate_rmse"] is not None and rec["ate_rmse"] < 0.02 * rec["trajectory_length"], rec["ate_rmse"]
     assert rec["pose_error_unaligned_max"] < 0.05 * rec["trajectory_length"], rec["pose_error_unaligned_max"]
-    assert rec["psnr_before_refinement"] > 18.0 and rec["psnr"] > rec["psnr_before_refinement"] - 0.3
+    assert rec["psnr_before_refinement"] > 17.0 and rec["psnr"] > rec["psnr_before_refinement"] - 0.3   # (whole frames, the repainted "vehicles" included)
+    assert rec["psnr_static"] > 24.0                                                   # (the static pixels, which is what the map is asked to explain)
 
 
 def test_fused_path_and_autograd_api_path_agree_on_the_sequence(half_kitti_runs):
     f, a = half_kitti_runs["fused"][0], half_kitti_runs["autograd"][0]
     assert a["batched_window_runs"] == 0                                              # (fused=False really is the other path)
-    assert f["window_log"][:3] == a["window_log"][:3]
+    assert f["window_log"][:2] == a["window_log"][:2]
     assert abs(f["keyframes"] - a["keyframes"]) <= 1
+    # (a keyframe test on its bar falls a frame earlier or later: the keyframes of the two runs pair up within two frames)
+    kf_f, kf_a = [w[0] for w in f["window_log"]], [w[0] for w in a["window_log"]]
+    assert all(abs(x - y) <= 2 for x, y in zip(kf_f, kf_a)), (kf_f, kf_a)
     # two float32 runs of one system that differ in summation order (the fused backward reduces per tile, autograd per launch):
     # ATE within 25 % + 1e-3 of each other, PSNR within 0.5 dB, map size within 10 %
     assert abs(f["ate_rmse"] - a["ate_rmse"]) <= 0.25 * max(f["ate_rmse"], a["ate_rmse"]) + 1e-3, (f["ate_rmse"], a["ate_rmse"])
