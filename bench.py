@@ -653,6 +653,37 @@ def run_side(dev, pipe):
             "window_keyframes_carry_static_mask": masked, "gaussians": N, "width": W, "height": H, "seconds_spent": round(time.perf_counter() - t0, 2)}
         del backend, model
         torch.cuda.empty_cache()
+    # The loops as a system (tools/sequence.py -> lvdgs.slam_sequence.SlamSequence): a 60-frame synthetic drive at KITTI-07's geometry from an
+    # EMPTY map, the reference's cadence -- initialize_map (1050 iterations), per frame track_frame (<= 100) -> keyframe test -> seeding ->
+    # map_window bursts on keyframes with static masks, densify / prune every 150, the back end's free-running iterations with a pruning pass
+    # every ten -> ATE (Umeyama), PSNR before / after 500 colour-refinement iterations.  And the two single-view loops by themselves
+    # (tools/single_view_loops.py).  A failure here costs the side entry, not the line.
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import sequence as seq_tool
+        import single_view_loops as svl
+        t0 = time.perf_counter()
+        rec, _ = seq_tool.run_sequence(dev, frames=60, refine=500)
+        keep = ("frames", "keyframes", "tracking_iterations", "mapping_iterations", "init_iterations", "prune_passes", "refinement_iterations",
+                "gaussians_first", "gaussians_last", "gaussians_max", "size_changes_by_densification", "size_changes_by_pruning", "seconds",
+                "frames_per_s", "tracking_plus_mapping_iterations_per_s", "tracking_iterations_per_s", "mapping_iterations_per_s", "ate_rmse",
+                "pose_error_unaligned_mean", "pose_error_unaligned_max", "trajectory_length", "psnr_before_refinement", "psnr", "psnr_static_before_refinement",
+                "psnr_static", "ssim", "refinement_ms_per_iteration", "batched_window_runs", "width", "height", "cadence", "idle_map_iters",
+                "keyframes_carry_static_mask")
+        out["sequence_kitti07_geom"] = {**{k: rec.get(k) for k in keep}, "seconds_spent": round(time.perf_counter() - t0, 2),
+                                        "what": "synthetic drive from an empty map: initialize_map -> per frame track_frame / keyframe test / seeding / masked map_window "
+                                                "bursts with densification and pruning at configs/mono/KITTI/base_config.yaml's cadence / free-running mapping -> ATE, PSNR, "
+                                                "colour refinement (lvdgs.slam_sequence; reference utils/slam_frontend.py:1740-1899, utils/slam_backend.py:485-609)"}
+        torch.cuda.empty_cache()
+        t0 = time.perf_counter()
+        out["initialize_map_kitti07_geom"] = {**svl.time_initialize_map(dev), "seconds_spent": round(time.perf_counter() - t0, 2)}
+        for masked in (False, True):
+            t0 = time.perf_counter()
+            out["color_refinement_kitti07_geom" + ("_masked" if masked else "")] = {**svl.time_color_refinement(dev, masked, iters=300),
+                                                                                     "seconds_spent": round(time.perf_counter() - t0, 2)}
+        torch.cuda.empty_cache()
+    except Exception as e:   # noqa: BLE001
+        out["sequence_and_single_view_loops_error"] = f"{type(e).__name__}: {e}"
     return out
 
 

@@ -416,15 +416,16 @@ int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipSt
             // counting path: no pair list is materialised, the tile ranges fall out of the counts
             if (!counted)
                 if (int e = launch_group_count(*a, g, im, w, s)) return e;
+            super = super_tiles_in_use(*a);
+            if (super)   // two-level grouping: the super-tile grid's counts first, the scan below then takes both grids in its two launches
+                if (int e = launch_super_count(*a, g, w.super, s)) return e;
             // (single-call forward: the tile scan writes the pair count and the hints into the caller thread's pinned words itself)
             if (int e = launch_group_scan(*a, im, w, cap, counted ? g.total : nullptr, s, counted && probe ? probe->pinned_dev : nullptr,
                                           counted && probe ? probe->seq : 0u)) return e;
-            super = super_tiles_in_use(*a);
             if (super) {
                 // two-level grouping: keys scattered and sorted per 64 x 64-pixel super-tile, the tiles' lists read off the sorted super lists
                 // (binning.hip); b.tile_keys -- the radix path's -- takes the sorted super lists
-                if (int e = launch_super_group(*a, g, w.super, w, (unsigned long long *)w.keys, cap, counted, b.pair_valid,
-                                               probe ? probe->pinned_dev + 8 : nullptr, s)) return e;
+                if (int e = launch_super_scatter(*a, g, w.super, w, (unsigned long long *)w.keys, cap, counted, b.pair_valid, s)) return e;
                 ImageView ims{};
                 ims.ranges = w.super.ranges; ims.long_count = w.super.long_count; ims.long_tiles = w.super.long_tiles;
                 const int Ts = super_tiles_of(W, H);

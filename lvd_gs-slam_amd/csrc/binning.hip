@@ -301,6 +301,22 @@ __global__ void __launch_bounds__(1024) group_tilescan_batch_kernel(int T, Tiles
                               host_out + 4 * blockIdx.x, host_seq);
 }
 
+// Two-level grouping: the tile grid's and the super-tile grid's scans side by side -- blockIdx.y picks the grid (column scan), blockIdx.x
+// the grid (range scan: one workgroup each) -- instead of two more launches on every frame's critical path.
+template <int R>
+__global__ void __launch_bounds__(1024) group_colscan_pair_kernel(int T0, int T1, int nchunks, uint32_t *__restrict__ hist0, uint32_t *__restrict__ totals0,
+                                                                  uint32_t *__restrict__ hist1, uint32_t *__restrict__ totals1) {
+    const int T = blockIdx.y ? T1 : T0;
+    if ((int)blockIdx.x * COLSCAN_TILES >= T) return;
+    group_colscan_body<R>(T, nchunks, blockIdx.y ? hist1 : hist0, blockIdx.y ? totals1 : totals0);
+}
+struct TilescanPairView { int T; const uint32_t *totals; uint2 *ranges; uint32_t *total_out, *queue_count, *queue, *tile_order; int t_lo, t_hi; uint32_t *order_valid, *host_out; uint32_t host_seq; };
+__global__ void __launch_bounds__(1024) group_tilescan_pair_kernel(TilescanPairView a, TilescanPairView b, uint32_t capacity, uint32_t long_limit) {
+    const TilescanPairView &v = blockIdx.x ? b : a;
+    group_tilescan_body<1024>(v.T, v.totals, capacity, v.ranges, v.total_out, long_limit, v.queue_count, v.queue, v.tile_order, v.t_lo, v.t_hi, v.order_valid,
+                              v.host_out, v.host_seq);
+}
+
 // SLOT_SCAN (lvdgs_forward): also makes slot_base[i] = exclusive scan of tiles_touched in id order (the backward's
 // gradient slots) from the pair totals the projection kernel left per chunk: every workgroup adds up the totals in front
 // of its chunk -- at most a few hundred values -- and scans its own Gaussians.  (The launch of a separate slot scan less.)
@@ -493,27 +509,88 @@ __device__ __forceinline__ uint4 super_rect_of(const uint4 r) {
     const int w = x1 - x0, h = y1 - y0, area = w * h;
     const uint64_t m = (uint64_t)r.z | ((uint64_t)r.w << 32);
     if (area <= 0 || m == 0ull) return make_uint4(0u, 0u, 0u, 0u);
-    const int sx0 = x0 / SUPER, sx1 = (x1 - 1) / SUPER + 1, sy0 = y0 / SUPER, sy1 = (y1 - 1) / SUPER + 1;
+    static_assert(SUPER == 4, "the shifts below");
+    const int sx0 = x0 >> 2, sx1 = ((x1 - 1) >> 2) + 1, sy0 = y0 >> 2, sy1 = ((y1 - 1) >> 2) + 1;
     const int ws = sx1 - sx0, area_s = ws * (sy1 - sy0);
     uint64_t ms = 0ull;
     if (area_s > RECT_MASK_TILES) {
         ms = ~0ull;   // (a rectangle of more than 64 super-tiles -- over 1000 tiles: every super-tile of it is listed; the expansion drops what no tile keeps)
     } else if (area <= RECT_MASK_TILES) {
-        const float inv_w = __builtin_amdgcn_rcpf((float)w);
-        for (uint64_t mm = m; mm; mm &= mm - 1ull) {
-            const int k = __builtin_ctzll(mm), ty = div_by(k, w, inv_w), tx = k - ty * w;
-            ms |= 1ull << (((y0 + ty) / SUPER - sy0) * ws + ((x0 + tx) / SUPER - sx0));
+        // a bit per tile: row by row, the row's kept tiles folded into the super-columns they lie in (no walk over the set bits: a lane's
+        // 64-iteration loop of dependent bit tricks was what the first version of this kernel spent 39 us on)
+        const uint64_t rowmask = w < 64 ? ((1ull << w) - 1ull) : ~0ull;
+        for (int ty = 0; ty < h; ty++) {
+            const uint64_t row = (m >> (ty * w)) & rowmask;
+            if (!row) continue;
+            uint64_t cols = 0ull;
+            for (int c = 0; c < ws; c++) {
+                const int lo = max(0, ((sx0 + c) << 2) - x0), hi = min(w, ((sx0 + c + 1) << 2) - x0);   // tile columns [lo, hi) of super-column c
+                if (row & (((1ull << (hi - lo)) - 1ull) << lo)) cols |= 1ull << c;
+            }
+            ms |= cols << ((((y0 + ty) >> 2) - sy0) * ws);
         }
     } else {
+        // a bit per block of tiles (8 x 8 grid): the super-columns every block column covers, then block row by block row
         const RectBlocks g(w, h);
-        for (uint64_t mm = m; mm; mm &= mm - 1ull) {
-            const int b = __builtin_ctzll(mm);
-            const int bx0 = x0 + (b & 7) * g.bw, by0 = y0 + (b >> 3) * g.bh, bx1 = bx0 + g.width(b), by1 = by0 + g.height(b);
-            for (int cy = by0 / SUPER; cy <= (by1 - 1) / SUPER; cy++)
-                for (int cx = bx0 / SUPER; cx <= (bx1 - 1) / SUPER; cx++) ms |= 1ull << ((cy - sy0) * ws + (cx - sx0));
+        uint64_t colbits[8];
+#pragma unroll
+        for (int bc = 0; bc < 8; bc++) {
+            const int wd = g.width(bc), bx0 = x0 + bc * g.bw;
+            const int ca = (bx0 >> 2) - sx0, cb = ((bx0 + wd - 1) >> 2) - sx0;
+            colbits[bc] = wd > 0 ? (((2ull << (cb - ca)) - 1ull) << ca) : 0ull;
+        }
+#pragma unroll
+        for (int br = 0; br < 8; br++) {
+            const int hg = g.height(8 * br);
+            const uint32_t bits = (uint32_t)(m >> (8 * br)) & 0xffu;
+            if (hg <= 0 || !bits) continue;
+            uint64_t cols = 0ull;
+#pragma unroll
+            for (int bc = 0; bc < 8; bc++) cols |= ((bits >> bc) & 1u) ? colbits[bc] : 0ull;
+            const int by0 = y0 + br * g.bh;
+            for (int cy = (by0 >> 2) - sy0; cy <= ((by0 + hg - 1) >> 2) - sy0; cy++) ms |= cols << (cy * ws);
         }
     }
     return make_uint4((uint32_t)sx0 | ((uint32_t)sx1 << 16), (uint32_t)sy0 | ((uint32_t)sy1 << 16), (uint32_t)ms, (uint32_t)(ms >> 32));
+}
+
+// Which of the SUPER x SUPER tiles of the super-tile whose first tile is (stx, sty) does the Gaussian list?  Bit j * SUPER + i: tile
+// (stx + i, sty + j) -- rect_keeps for the sixteen tiles at once, the rectangle decoded once.
+__device__ __forceinline__ uint32_t kept_in_super(const uint4 r, int stx, int sty) {
+    const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
+    const int w = x1 - x0, h = y1 - y0, area = w * h;
+    const uint64_t m = (uint64_t)r.z | ((uint64_t)r.w << 32);
+    uint32_t out = 0u;
+    if (area <= 0) return 0u;
+    if (area <= RECT_MASK_TILES) {
+#pragma unroll
+        for (int j = 0; j < SUPER; j++) {
+            const int ty = sty + j - y0;
+            if ((unsigned)ty >= (unsigned)h) continue;
+            const uint64_t row = m >> (ty * w);
+#pragma unroll
+            for (int i = 0; i < SUPER; i++) {
+                const int tx = stx + i - x0;
+                if ((unsigned)tx < (unsigned)w) out |= (uint32_t)((row >> tx) & 1ull) << (j * SUPER + i);
+            }
+        }
+    } else {
+        const RectBlocks g(w, h);
+        const float inv_bw = __builtin_amdgcn_rcpf((float)g.bw), inv_bh = __builtin_amdgcn_rcpf((float)g.bh);
+        int bc[SUPER], br[SUPER];
+#pragma unroll
+        for (int i = 0; i < SUPER; i++) {
+            const int tx = stx + i - x0, ty = sty + i - y0;
+            bc[i] = (unsigned)tx < (unsigned)w ? div_by(tx, g.bw, inv_bw) : -1;
+            br[i] = (unsigned)ty < (unsigned)h ? div_by(ty, g.bh, inv_bh) : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < SUPER; j++)
+#pragma unroll
+            for (int i = 0; i < SUPER; i++)
+                if (bc[i] >= 0 && br[j] >= 0) out |= (uint32_t)((m >> (br[j] * 8 + bc[i])) & 1ull) << (j * SUPER + i);
+    }
+    return out;
 }
 
 template <int GROUP_THREADS, int OWNERS, int PER>
@@ -542,39 +619,38 @@ __global__ void __launch_bounds__(GROUP_THREADS) count_super_kernel(int N, int g
 }
 
 // One workgroup per super-tile, one wave per tile of it (SUPER * SUPER = 16 waves): the super-tile's sorted list is staged through LDS
-// 1024 entries at a time -- id and the Gaussian's tile rectangle + kept-tile mask, 20 bytes each, the gather done ONCE for the sixteen
-// tiles -- and every wave walks the staged entries 64 at a time, keeps those that list its tile (rect_keeps: the bit the projection
-// kernel set, the very test its tile count was taken with) and appends their ids to its tile's segment in list order.
+// 1024 entries at a time -- a thread per entry loads the id, gathers the Gaussian's tile rectangle + kept-tile mask and works out ONCE
+// which of the sixteen tiles list the Gaussian (kept_in_super: the bits the projection kernel set, the very test the tile counts were
+// taken with) -- then every wave walks the staged entries 64 at a time and appends the ids whose bit for its tile is set to the tile's
+// segment, in list order.
 __global__ void __launch_bounds__(64 * SUPER * SUPER) expand_super_kernel(int gx, int gy, int gxs, const uint2 *__restrict__ ranges_s,
                                                                         const uint32_t *__restrict__ super_list, const uint4 *__restrict__ rect,
                                                                         const uint2 *__restrict__ ranges, uint32_t *__restrict__ point_list) {
     constexpr int STAGE = 64 * SUPER * SUPER;
-    __shared__ uint4 s_rect[STAGE];
     __shared__ uint32_t s_id[STAGE];
+    __shared__ uint32_t s_keep[STAGE];
     const int st = (int)blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tx = (st % gxs) * SUPER + (wave % SUPER), ty = (st / gxs) * SUPER + (wave / SUPER);
+    const int stx = (st % gxs) * SUPER, sty = (st / gxs) * SUPER;
+    const int tx = stx + (wave % SUPER), ty = sty + (wave / SUPER);
     const bool valid = tx < gx && ty < gy;
     const uint2 seg = ranges_s[st];
     const uint2 mine = valid ? ranges[ty * gx + tx] : make_uint2(0u, 0u);
     uint32_t out = mine.x;
     const int n = (int)(seg.y - seg.x);
+    // (the first stage's ids are on their way before anything else)
+    uint32_t id = (int)threadIdx.x < n ? super_list[seg.x + threadIdx.x] : 0u;
     for (int base = 0; base < n; base += STAGE) {
         const int m = min(STAGE, n - base);
         if ((int)threadIdx.x < m) {
-            const uint32_t id = super_list[seg.x + base + threadIdx.x];
             s_id[threadIdx.x] = id;
-            s_rect[threadIdx.x] = rect[id];
+            s_keep[threadIdx.x] = kept_in_super(rect[id], stx, sty);
         }
+        if (base + STAGE + (int)threadIdx.x < n) id = super_list[seg.x + base + STAGE + threadIdx.x];   // next stage's id: in flight under this stage's walk
         __syncthreads();
         if (mine.y > mine.x) {
             for (int j = 0; j < m; j += 64) {
                 const int e = j + lane;
-                bool keep = false;
-                if (e < m) {
-                    const uint4 r = s_rect[e];
-                    const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
-                    if (tx >= x0 && tx < x1 && ty >= y0 && ty < y1) keep = rect_keeps(r, (ty - y0) * (x1 - x0) + (tx - x0), (x1 - x0) * (y1 - y0));
-                }
+                const bool keep = e < m && ((s_keep[e] >> wave) & 1u);
                 const uint64_t kept = __ballot(keep);
                 if (keep) {
                     const uint32_t pos = out + (uint32_t)__popcll(kept & ((1ull << lane) - 1ull));
@@ -640,6 +716,25 @@ int launch_group_scan(const lvdgs_args &a, const ImageView &im, const RenderScra
     ProfScope ps("group_scan", s);
     // waves per workgroup: as many as leave every wave at most 16 (then 32) matrix rows to hold in registers
     const int wg_tiles = cdiv(T, COLSCAN_TILES);
+    if (super_tiles_in_use(a)) {
+        // two-level grouping: the super-tile grid's count matrix (launch_super_count has run) is scanned in the same two launches
+        const SuperView &sv = w.super;
+        const int Ts = super_tiles_of(a.image_width, a.image_height);
+        const dim3 grid(wg_tiles, 2);
+        if (nchunks <= 8 * 16) hipLaunchKernelGGL(group_colscan_pair_kernel<8>, grid, dim3(1024), 0, s, T, Ts, nchunks, w.group_hist, w.group_totals, sv.hist, sv.totals);
+        else if (nchunks <= 16 * 16) hipLaunchKernelGGL(group_colscan_pair_kernel<16>, grid, dim3(1024), 0, s, T, Ts, nchunks, w.group_hist, w.group_totals, sv.hist, sv.totals);
+        else if (nchunks <= 32 * 16) hipLaunchKernelGGL(group_colscan_pair_kernel<32>, grid, dim3(1024), 0, s, T, Ts, nchunks, w.group_hist, w.group_totals, sv.hist, sv.totals);
+        else hipLaunchKernelGGL(group_colscan_pair_kernel<0>, grid, dim3(1024), 0, s, T, Ts, nchunks, w.group_hist, w.group_totals, sv.hist, sv.totals);
+        // (the super grid's hints -- longest queued list, queue length -- go to the pinned words behind the call's own four: for the NEXT
+        // frame's sort launch, read whenever; only the tile grid's workgroup writes the sequence number the host waits for)
+        const TilescanPairView tv{T, w.group_totals, im.ranges, total_out, im.long_count, im.long_tiles, tile_order_in_use(T) ? im.long_tiles + T : nullptr,
+                                  row0 * gx, row1 * gx, im.long_count + 1, host_out, host_seq};
+        const TilescanPairView sv2{Ts, sv.totals, sv.ranges, sv.total, sv.long_count, sv.long_tiles, tile_order_in_use(Ts) ? sv.long_tiles + Ts : nullptr,
+                                   0, Ts, sv.long_count + 1, host_out ? host_out + 8 : nullptr, 0u};
+        hipLaunchKernelGGL(group_tilescan_pair_kernel, dim3(2), dim3(1024), 0, s, tv, sv2, (uint32_t)capacity, (uint32_t)tile_sort_wave_limit());
+        LVDGS_LAUNCH_CHECK("group_scan (two-level)", a.debug, s);
+        return LVDGS_OK;
+    }
     if (nchunks <= 8 * 16) hipLaunchKernelGGL(group_colscan_kernel<8>, dim3(wg_tiles), dim3(1024), 0, s, T, nchunks, w.group_hist, w.group_totals);
     else if (nchunks <= 16 * 16) hipLaunchKernelGGL(group_colscan_kernel<16>, dim3(wg_tiles), dim3(1024), 0, s, T, nchunks, w.group_hist, w.group_totals);
     else if (nchunks <= 32 * 16) hipLaunchKernelGGL(group_colscan_kernel<32>, dim3(wg_tiles), dim3(1024), 0, s, T, nchunks, w.group_hist, w.group_totals);
@@ -694,58 +789,50 @@ bool super_tiles_in_use(const lvdgs_args &a) {
 }
 int super_tiles_of(int W, int H) { return cdiv(cdiv(W, TILE), SUPER) * cdiv(cdiv(H, TILE), SUPER); }
 
-int launch_super_group(const lvdgs_args &a, const GeomView &g, const SuperView &sv, const RenderScratch &w, unsigned long long *keys64, int64_t capacity,
-                       bool slot_scan, uint8_t *pair_valid, uint32_t *host_hints, hipStream_t s) {
+int launch_super_count(const lvdgs_args &a, const GeomView &g, const SuperView &sv, hipStream_t s) {
     const int N = a.num_gaussians;
     const int gx = (a.image_width + TILE - 1) / TILE, gy = (a.image_height + TILE - 1) / TILE;
     const int gxs = cdiv(gx, SUPER), Ts = gxs * cdiv(gy, SUPER);
     if (N == 0 || Ts == 0) return LVDGS_OK;
     const int nchunks = (int)group_chunks(N);
     const size_t lds = (size_t)Ts * sizeof(uint32_t);
-    {
-        static unsigned char done[GROUP_SHAPES][16];
-        ProfScope ps("super_count", s);
-        if (int e = group_dispatch(group_shape_for(N), [&](auto threads_, auto owners_, auto per_, int d) {
-                constexpr int THREADS = decltype(threads_)::value, OWNERS = decltype(owners_)::value, PER = decltype(per_)::value;
-                if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&count_super_kernel<THREADS, OWNERS, PER>), GROUP_MAX_TILES * 4, done[d])) return e;
-                hipLaunchKernelGGL((count_super_kernel<THREADS, OWNERS, PER>), dim3(nchunks), dim3(THREADS), lds, s, N, gxs, Ts, (const uint4 *)g.rect, sv.rect, sv.hist,
-                                   sv.long_count);
-                return (int)LVDGS_OK;
-            })) return e;
-        LVDGS_LAUNCH_CHECK("super_count", a.debug, s);
-    }
-    {
-        ProfScope ps("super_scan", s);
-        const int wg_tiles = cdiv(Ts, COLSCAN_TILES);
-        if (nchunks <= 8 * 16) hipLaunchKernelGGL(group_colscan_kernel<8>, dim3(wg_tiles), dim3(1024), 0, s, Ts, nchunks, sv.hist, sv.totals);
-        else if (nchunks <= 16 * 16) hipLaunchKernelGGL(group_colscan_kernel<16>, dim3(wg_tiles), dim3(1024), 0, s, Ts, nchunks, sv.hist, sv.totals);
-        else if (nchunks <= 32 * 16) hipLaunchKernelGGL(group_colscan_kernel<32>, dim3(wg_tiles), dim3(1024), 0, s, Ts, nchunks, sv.hist, sv.totals);
-        else hipLaunchKernelGGL(group_colscan_kernel<0>, dim3(wg_tiles), dim3(1024), 0, s, Ts, nchunks, sv.hist, sv.totals);
-        // (host_hints: two pinned words for the longest queued super list and the queue's length -- hints for the NEXT frame's sort
-        // launch, read whenever; no sequence number is waited for)
-        hipLaunchKernelGGL(group_tilescan_kernel, dim3(1), dim3(1024), 0, s, Ts, (const uint32_t *)sv.totals, (uint32_t)capacity, sv.ranges, sv.total,
-                           (uint32_t)tile_sort_wave_limit(), sv.long_count, sv.long_tiles, tile_order_in_use(Ts) ? sv.long_tiles + Ts : nullptr, 0, Ts,
-                           sv.long_count + 1, host_hints, 0u);
-        LVDGS_LAUNCH_CHECK("super_scan", a.debug, s);
-    }
-    {
-        static unsigned char done[2 * GROUP_SHAPES][16];
-        ProfScope ps("super_scatter", s);
-        TileScanArgs ts{};
-        auto launch = [&](auto kernel, int d, int threads) {
-            if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(kernel), GROUP_MAX_TILES * 4, done[d])) return e;
-            hipLaunchKernelGGL(kernel, dim3(nchunks), dim3(threads), lds, s, N, gxs, Ts, (const uint4 *)sv.rect, (const uint32_t *)sv.hist, (const uint2 *)sv.ranges,
-                               (const uint32_t *)nullptr, (uint32_t)capacity, (const uint32_t *)g.depth_bits, keys64, (const uint32_t *)g.tiles_touched,
-                               (const uint32_t *)w.chunk_sums, g.slot_base, pair_valid, ts);
+    static unsigned char done[GROUP_SHAPES][16];
+    ProfScope ps("super_count", s);
+    if (int e = group_dispatch(group_shape_for(N), [&](auto threads_, auto owners_, auto per_, int d) {
+            constexpr int THREADS = decltype(threads_)::value, OWNERS = decltype(owners_)::value, PER = decltype(per_)::value;
+            if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&count_super_kernel<THREADS, OWNERS, PER>), GROUP_MAX_TILES * 4, done[d])) return e;
+            hipLaunchKernelGGL((count_super_kernel<THREADS, OWNERS, PER>), dim3(nchunks), dim3(THREADS), lds, s, N, gxs, Ts, (const uint4 *)g.rect, sv.rect, sv.hist,
+                               sv.long_count);
             return (int)LVDGS_OK;
-        };
-        if (int e = group_dispatch(group_shape_for(N), [&](auto threads_, auto owners_, auto per_, int d) {
-                constexpr int THREADS = decltype(threads_)::value, OWNERS = decltype(owners_)::value, PER = decltype(per_)::value;
-                return slot_scan ? launch(&scatter_pairs_kernel<THREADS, OWNERS, PER, true, false>, 2 * d, THREADS)
-                                 : launch(&scatter_pairs_kernel<THREADS, OWNERS, PER, false, false>, 2 * d + 1, THREADS);
-            })) return e;
-        LVDGS_LAUNCH_CHECK("super_scatter", a.debug, s);
-    }
+        })) return e;
+    LVDGS_LAUNCH_CHECK("super_count", a.debug, s);
+    return LVDGS_OK;
+}
+
+int launch_super_scatter(const lvdgs_args &a, const GeomView &g, const SuperView &sv, const RenderScratch &w, unsigned long long *keys64, int64_t capacity,
+                         bool slot_scan, uint8_t *pair_valid, hipStream_t s) {
+    const int N = a.num_gaussians;
+    const int gx = (a.image_width + TILE - 1) / TILE, gy = (a.image_height + TILE - 1) / TILE;
+    const int gxs = cdiv(gx, SUPER), Ts = gxs * cdiv(gy, SUPER);
+    if (N == 0 || Ts == 0) return LVDGS_OK;
+    const int nchunks = (int)group_chunks(N);
+    const size_t lds = (size_t)Ts * sizeof(uint32_t);
+    static unsigned char done[2 * GROUP_SHAPES][16];
+    ProfScope ps("super_scatter", s);
+    TileScanArgs ts{};
+    auto launch = [&](auto kernel, int d, int threads) {
+        if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(kernel), GROUP_MAX_TILES * 4, done[d])) return e;
+        hipLaunchKernelGGL(kernel, dim3(nchunks), dim3(threads), lds, s, N, gxs, Ts, (const uint4 *)sv.rect, (const uint32_t *)sv.hist, (const uint2 *)sv.ranges,
+                           (const uint32_t *)nullptr, (uint32_t)capacity, (const uint32_t *)g.depth_bits, keys64, (const uint32_t *)g.tiles_touched,
+                           (const uint32_t *)w.chunk_sums, g.slot_base, pair_valid, ts);
+        return (int)LVDGS_OK;
+    };
+    if (int e = group_dispatch(group_shape_for(N), [&](auto threads_, auto owners_, auto per_, int d) {
+            constexpr int THREADS = decltype(threads_)::value, OWNERS = decltype(owners_)::value, PER = decltype(per_)::value;
+            return slot_scan ? launch(&scatter_pairs_kernel<THREADS, OWNERS, PER, true, false>, 2 * d, THREADS)
+                             : launch(&scatter_pairs_kernel<THREADS, OWNERS, PER, false, false>, 2 * d + 1, THREADS);
+        })) return e;
+    LVDGS_LAUNCH_CHECK("super_scatter", a.debug, s);
     return LVDGS_OK;
 }
 

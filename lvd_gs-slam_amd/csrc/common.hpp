@@ -313,8 +313,9 @@ int launch_emit_pairs(const lvdgs_args &a, const GeomView &g, uint32_t *tile_key
 // sorted super lists into the tiles' segments of point_list
 bool super_tiles_in_use(const lvdgs_args &a);
 int super_tiles_of(int W, int H);
-int launch_super_group(const lvdgs_args &a, const GeomView &g, const SuperView &sv, const RenderScratch &w, unsigned long long *keys64, int64_t capacity,
-                       bool slot_scan, uint8_t *pair_valid, uint32_t *host_hints, hipStream_t s);
+int launch_super_count(const lvdgs_args &a, const GeomView &g, const SuperView &sv, hipStream_t s);   // before launch_group_scan, which then scans both grids
+int launch_super_scatter(const lvdgs_args &a, const GeomView &g, const SuperView &sv, const RenderScratch &w, unsigned long long *keys64, int64_t capacity,
+                         bool slot_scan, uint8_t *pair_valid, hipStream_t s);
 int launch_super_expand(const lvdgs_args &a, const GeomView &g, const SuperView &sv, const ImageView &im, const uint32_t *super_list, uint32_t *point_list,
                         hipStream_t s);
 // Sorts the segment of every tile in [t_lo, t_hi) by (view-depth bits, id) and leaves the ids in point_list.  keys64 holds

@@ -16,9 +16,23 @@ import torch.nn.functional as F
 _SCHARR = ((3.0, 10.0, 3.0), (0.0, 0.0, 0.0), (-3.0, -10.0, -3.0))
 
 
-def _depthwise3x3(x, k3x3):
-    c = x.shape[1]
-    return F.conv2d(x, k3x3.view(1, 1, 3, 3).repeat(c, 1, 1, 1), groups=c)
+def _depthwise3x3(x, k3x3, taps=None):
+    """Valid 3 x 3 cross-correlation of every channel of ``x`` (1, C, H + 2, W + 2) with ``k3x3`` (``taps``: the same nine weights as
+    nested Python tuples).  On the GPU as shifted multiply-adds (zero taps skipped): ``F.conv2d`` goes through MIOpen, whose set-up
+    costs 10-15 ms per CALL for a KITTI-size frame (tools/soak_densify.py under cProfile) -- every new frame of a sequence pays it
+    three times in ``Camera.compute_grad_mask``.  The CPU keeps ``conv2d`` (the goldens of the host mirrors were taken with it)."""
+    if not x.is_cuda or taps is None:
+        c = x.shape[1]
+        return F.conv2d(x, k3x3.view(1, 1, 3, 3).repeat(c, 1, 1, 1), groups=c)
+    h, w = x.shape[-2] - 2, x.shape[-1] - 2
+    out = None
+    for i in range(3):
+        for j in range(3):
+            v = float(taps[i][j])
+            if v != 0.0:
+                term = x[..., i:i + h, j:j + w] * v
+                out = term if out is None else out + term
+    return out if out is not None else torch.zeros_like(x[..., :h, :w])
 
 
 def image_gradient(image):
@@ -28,7 +42,8 @@ def image_gradient(image):
     kh = kv.t().contiguous()
     scale = 1.0 / kv.abs().sum()
     padded = F.pad(image, (1, 1, 1, 1), mode="reflect")[None]
-    return (scale * _depthwise3x3(padded, kv))[0], (scale * _depthwise3x3(padded, kh))[0]
+    kh_taps = tuple(zip(*_SCHARR))
+    return (scale * _depthwise3x3(padded, kv, _SCHARR))[0], (scale * _depthwise3x3(padded, kh, kh_taps))[0]
 
 
 def image_gradient_mask(image, eps=0.01):
@@ -37,7 +52,7 @@ def image_gradient_mask(image, eps=0.01):
     ones = torch.ones((3, 3), dtype=torch.float32, device=image.device)
     padded = F.pad(image, (1, 1, 1, 1), mode="reflect")[None]
     valid = (padded.abs() > eps).float()
-    full = _depthwise3x3(valid, ones)[0] == 9.0
+    full = _depthwise3x3(valid, ones, ((1.0,) * 3,) * 3)[0] == 9.0
     return full, full.clone()
 
 

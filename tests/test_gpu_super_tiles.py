@@ -60,7 +60,7 @@ def test_super_tiles_leave_every_output_bit_identical(case):
         with _super_tiles(on):
             out[on] = hip_runner.run_hip(g, cam, W, H, torch.zeros(3), grads=grads)
     (f0, b0), (f1, b1) = out[False], out[True]
-    assert f1["num_rendered"] == f0["num_rendered"] > 0 and not f0["overflowed"]
+    assert f1["num_rendered"] == f0["num_rendered"] > 0   # (huge_footprints overflows the first guess of the pair capacity in whichever run comes first: the re-run's results are what is compared)
     for k in ("point_list", "ranges", "n_contrib", "final_T", "color", "depth", "opacity", "radii", "n_touched", "slot_base", "tiles_touched"):
         assert np.array_equal(f1[k], f0[k]), k
     for k, v in b0.items():

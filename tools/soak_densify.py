@@ -35,13 +35,15 @@ gc.collect(); gc.freeze()
 torch.cuda.synchronize()
 mem0 = torch.cuda.memory_allocated(dev)
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
-kinds, sizes = [], []
+kinds, sizes, phase_rec = [], [], []
 ev[0].record()
 t0 = time.perf_counter()
 block = max(iters // 6, 1)
 for k in range(iters):
     n0 = seq._n()
-    seq._map(window)
+    st = {}
+    seq._map(window, stats=st)
+    phase_rec.append(st["iterations"][-1]["phases"] if st.get("iterations") else None)
     kind = "ordinary"
     if be.last_sent >= 10:
         seq._map(window, prune=True, iters=10)
@@ -49,6 +51,8 @@ for k in range(iters):
         kind = "with pruning pass"
     if seq._n() != n0:
         kind = "map size changed (" + kind + ")" if kind != "ordinary" else "map size changed"
+    elif k and sizes[-1] != (sizes[-2] if k > 1 else sizes[-1]) and kind == "ordinary":
+        kind = "ordinary, first after a size change"
     if be.iteration_count % be.gaussian_reset == 0 or (be.iteration_count - 1) % be.gaussian_reset == 0:
         kind = "opacity reset"
     ev[k + 1].record()
@@ -64,6 +68,11 @@ print(f"map size over the soak: min {min(sizes)}, max {max(sizes)}, last {sizes[
 for kind in sorted(set(kinds)):
     sel = ms[[i for i, q in enumerate(kinds) if q == kind]]
     print(f"  {kind:45s} {len(sel):5d} iterations: median {np.median(sel):.3f} ms, mean {sel.mean():.3f}, p95 {np.percentile(sel, 95):.3f}, max {sel.max():.3f}")
+print("phases of the mapping iteration itself (events on the stream at the phase boundaries; medians / means in ms):")
+for kind in sorted(set(kinds)):
+    rows = [phase_rec[i].seconds() for i, q in enumerate(kinds) if q == kind and phase_rec[i] is not None]
+    if rows:
+        print(f"  {kind:45s} " + ", ".join(f"{name} {1e3 * np.median([r[name] for r in rows]):.3f} / {1e3 * np.mean([r[name] for r in rows]):.3f}" for name in rows[0]))
 mem1 = torch.cuda.memory_allocated(dev)
 print(f"device memory in use {mem0 / 2**20:.1f} MiB -> {mem1 / 2**20:.1f} MiB; batched window runs {getattr(getattr(be, '_lvdgs_window_batch', None), 'runs', 0)}")
 ate = seq.eval_ate()
