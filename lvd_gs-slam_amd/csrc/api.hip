@@ -417,7 +417,7 @@ int enqueue_render(const lvdgs_args *a, int64_t cap, bool count_on_device, hipSt
             if (!counted)
                 if (int e = launch_group_count(*a, g, im, w, s)) return e;
             super = super_tiles_in_use(*a);
-            if (super)   // two-level grouping: the super-tile grid's counts first, the scan below then takes both grids in its two launches
+            if (super && !counted)   // two-level grouping: the super-tile grid's counts first (single-call forward: the projection kernel has made them), the scan below then takes both grids in its two launches
                 if (int e = launch_super_count(*a, g, w.super, s)) return e;
             // (single-call forward: the tile scan writes the pair count and the hints into the caller thread's pinned words itself)
             if (int e = launch_group_scan(*a, im, w, cap, counted ? g.total : nullptr, s, counted && probe ? probe->pinned_dev : nullptr,

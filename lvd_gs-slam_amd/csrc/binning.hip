@@ -504,56 +504,6 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t *__rest
 //   tile sort on ranges_s: sorted ids into super_list
 //   expand: one workgroup per super-tile, one WAVE per tile of it
 // The tile-level count (the projection kernel's), colscan and tilescan run as always: they make ranges[] and the pair count.
-__device__ __forceinline__ uint4 super_rect_of(const uint4 r) {
-    const int x0 = (int)(r.x & 0xffffu), x1 = (int)(r.x >> 16), y0 = (int)(r.y & 0xffffu), y1 = (int)(r.y >> 16);
-    const int w = x1 - x0, h = y1 - y0, area = w * h;
-    const uint64_t m = (uint64_t)r.z | ((uint64_t)r.w << 32);
-    if (area <= 0 || m == 0ull) return make_uint4(0u, 0u, 0u, 0u);
-    static_assert(SUPER == 4, "the shifts below");
-    const int sx0 = x0 >> 2, sx1 = ((x1 - 1) >> 2) + 1, sy0 = y0 >> 2, sy1 = ((y1 - 1) >> 2) + 1;
-    const int ws = sx1 - sx0, area_s = ws * (sy1 - sy0);
-    uint64_t ms = 0ull;
-    if (area_s > RECT_MASK_TILES) {
-        ms = ~0ull;   // (a rectangle of more than 64 super-tiles -- over 1000 tiles: every super-tile of it is listed; the expansion drops what no tile keeps)
-    } else if (area <= RECT_MASK_TILES) {
-        // a bit per tile: row by row, the row's kept tiles folded into the super-columns they lie in (no walk over the set bits: a lane's
-        // 64-iteration loop of dependent bit tricks was what the first version of this kernel spent 39 us on)
-        const uint64_t rowmask = w < 64 ? ((1ull << w) - 1ull) : ~0ull;
-        for (int ty = 0; ty < h; ty++) {
-            const uint64_t row = (m >> (ty * w)) & rowmask;
-            if (!row) continue;
-            uint64_t cols = 0ull;
-            for (int c = 0; c < ws; c++) {
-                const int lo = max(0, ((sx0 + c) << 2) - x0), hi = min(w, ((sx0 + c + 1) << 2) - x0);   // tile columns [lo, hi) of super-column c
-                if (row & (((1ull << (hi - lo)) - 1ull) << lo)) cols |= 1ull << c;
-            }
-            ms |= cols << ((((y0 + ty) >> 2) - sy0) * ws);
-        }
-    } else {
-        // a bit per block of tiles (8 x 8 grid): the super-columns every block column covers, then block row by block row
-        const RectBlocks g(w, h);
-        uint64_t colbits[8];
-#pragma unroll
-        for (int bc = 0; bc < 8; bc++) {
-            const int wd = g.width(bc), bx0 = x0 + bc * g.bw;
-            const int ca = (bx0 >> 2) - sx0, cb = ((bx0 + wd - 1) >> 2) - sx0;
-            colbits[bc] = wd > 0 ? (((2ull << (cb - ca)) - 1ull) << ca) : 0ull;
-        }
-#pragma unroll
-        for (int br = 0; br < 8; br++) {
-            const int hg = g.height(8 * br);
-            const uint32_t bits = (uint32_t)(m >> (8 * br)) & 0xffu;
-            if (hg <= 0 || !bits) continue;
-            uint64_t cols = 0ull;
-#pragma unroll
-            for (int bc = 0; bc < 8; bc++) cols |= ((bits >> bc) & 1u) ? colbits[bc] : 0ull;
-            const int by0 = y0 + br * g.bh;
-            for (int cy = (by0 >> 2) - sy0; cy <= ((by0 + hg - 1) >> 2) - sy0; cy++) ms |= cols << (cy * ws);
-        }
-    }
-    return make_uint4((uint32_t)sx0 | ((uint32_t)sx1 << 16), (uint32_t)sy0 | ((uint32_t)sy1 << 16), (uint32_t)ms, (uint32_t)(ms >> 32));
-}
-
 // Which of the SUPER x SUPER tiles of the super-tile whose first tile is (stx, sty) does the Gaussian list?  Bit j * SUPER + i: tile
 // (stx + i, sty + j) -- rect_keeps for the sixteen tiles at once, the rectangle decoded once.
 __device__ __forceinline__ uint32_t kept_in_super(const uint4 r, int stx, int sty) {

@@ -170,6 +170,8 @@ struct FwdParams {
     uint4 *rect;
     int32_t *radii;
     uint32_t *blocksums;   // per workgroup: sum of tiles_touched (first level of the slot scan, sortscan.hip)
+    // two-level grouping (LVDGS_FLAG_SUPER_TILES; preprocess_count_kernel<..., true>): the super-tile grid's rectangles, count matrix, queue counters
+    uint4 *super_rect; uint32_t *super_hist, *super_queue_counts; int super_gx, super_T;
 };
 
 // What the projection reads of one Gaussian whatever becomes of it, requested in ONE round of loads (position, then --
@@ -218,7 +220,11 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(FwdParams p) {
 // row of the [chunk][tile] count matrix and the chunk's pair total -- the grouping's first kernel and its re-read of
 // every rectangle are gone from the single-call forward (lvdgs_forward).  Also clears what the later kernels of the
 // frame accumulate into (n_touched, the tile-sort queue counters).
-template <int GROUP_THREADS, int OWNERS, int PER>
+// SUPER_COUNT (two-level grouping, binning.hip): the chunk's row of the SUPER-TILE grid's count matrix and the Gaussians' super
+// rectangles are made here too -- a second set of LDS counters behind the tiles', a second walk over (far fewer) cells -- instead of
+// by a kernel of their own that re-reads every rectangle (17 us on the opaque-surface workload).  A template parameter: the default
+// instantiation is the kernel it was.
+template <int GROUP_THREADS, int OWNERS, int PER, bool SUPER_COUNT = false>
 __device__ __forceinline__ void preprocess_count_body(const FwdParams &p, int T, uint32_t *__restrict__ hist,
                                                       uint32_t *__restrict__ chunk_sums, int32_t *__restrict__ n_touched,
                                                       uint32_t *__restrict__ queue_counts) {
@@ -232,8 +238,13 @@ __device__ __forceinline__ void preprocess_count_body(const FwdParams &p, int T,
     const int i_first = blockIdx.x * (OWNERS * PER) + (int)threadIdx.x;
     RawGaussian raw{};
     if (owner && i_first < p.N) raw = load_raw(p, i_first);
-    for (int t = threadIdx.x; t < T; t += GROUP_THREADS) s_tile[t] = 0u;
-    if (blockIdx.x == 0 && threadIdx.x < 64) queue_counts[threadIdx.x] = 0u;
+    const int T_all = SUPER_COUNT ? T + p.super_T : T;   // (the super-tile counters lie behind the tiles')
+    uint32_t *s_super = s_tile + T;
+    for (int t = threadIdx.x; t < T_all; t += GROUP_THREADS) s_tile[t] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        queue_counts[threadIdx.x] = 0u;
+        if constexpr (SUPER_COUNT) p.super_queue_counts[threadIdx.x] = 0u;
+    }
     if (threadIdx.x == 0) s_big.count = 0u;
     __syncthreads();
     uint32_t mine = 0;
@@ -250,6 +261,18 @@ __device__ __forceinline__ void preprocess_count_body(const FwdParams &p, int T,
         mine += tiles;
         if constexpr (HELPERS) for_each_pair_of_rect_wg(rect, i, p.cam.gx, 0u, s_big, [&](int tile, uint32_t, uint32_t) { atomicAdd(&s_tile[tile], 1u); });
         else for_each_pair_of_rect(rect, i, p.cam.gx, 0u, [&](int tile, uint32_t, uint32_t) { atomicAdd(&s_tile[tile], 1u); });
+        if constexpr (SUPER_COUNT) {
+            const uint4 rs = super_rect_of(rect);
+            if (owner && i < p.N) p.super_rect[i] = rs;
+            if constexpr (HELPERS) {
+                __syncthreads();                         // (every wave is done with the queue of the tile walk)
+                if (threadIdx.x == 0) s_big.count = 0u;
+                __syncthreads();
+                for_each_pair_of_rect_wg(rs, i, p.super_gx, 0u, s_big, [&](int cell, uint32_t, uint32_t) { atomicAdd(&s_super[cell], 1u); });
+            } else {
+                for_each_pair_of_rect(rs, i, p.super_gx, 0u, [&](int cell, uint32_t, uint32_t) { atomicAdd(&s_super[cell], 1u); });
+            }
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mine += (uint32_t)__shfl_xor((int)mine, off, 64);
@@ -263,13 +286,17 @@ __device__ __forceinline__ void preprocess_count_body(const FwdParams &p, int T,
     }
     uint32_t *row = hist + (size_t)blockIdx.x * T;
     for (int t = threadIdx.x; t < T; t += GROUP_THREADS) row[t] = s_tile[t];
+    if constexpr (SUPER_COUNT) {
+        uint32_t *row_s = p.super_hist + (size_t)blockIdx.x * p.super_T;
+        for (int t = threadIdx.x; t < p.super_T; t += GROUP_THREADS) row_s[t] = s_super[t];
+    }
 }
 
-template <int GROUP_THREADS, int OWNERS, int PER>
+template <int GROUP_THREADS, int OWNERS, int PER, bool SUPER_COUNT = false>
 __global__ void __launch_bounds__(GROUP_THREADS, 8) preprocess_count_kernel(FwdParams p, int T, uint32_t *__restrict__ hist,
                                                                         uint32_t *__restrict__ chunk_sums, int32_t *__restrict__ n_touched,
                                                                         uint32_t *__restrict__ queue_counts) {
-    preprocess_count_body<GROUP_THREADS, OWNERS, PER>(p, T, hist, chunk_sums, n_touched, queue_counts);
+    preprocess_count_body<GROUP_THREADS, OWNERS, PER, SUPER_COUNT>(p, T, hist, chunk_sums, n_touched, queue_counts);
 }
 // The views of a mapping window in ONE launch (lvdgs_forward_batch; blockIdx.y: the view -- same map, same image size, a camera,
 // state buffers and count matrix each).  A KITTI-size frame's projection is 391 workgroups of latency-bound work on 256 CUs: ten
@@ -1114,6 +1141,7 @@ Cam make_cam(const lvdgs_args &a) {
 static FwdParams make_fwd_params(const lvdgs_args &a, const GeomView &g) {
     FwdParams p;
     p.blocksums = nullptr;
+    p.super_rect = nullptr; p.super_hist = p.super_queue_counts = nullptr; p.super_gx = p.super_T = 0;
     p.cam = make_cam(a); p.N = a.num_gaussians; p.act = a.activations;
     p.tile_cull = !(a.flags & LVDGS_FLAG_LIST_ALL_TILES);
     tile_row_band(a, &p.row_begin, &p.row_end);
@@ -1139,11 +1167,22 @@ int launch_preprocess_count(const lvdgs_args &a, const GeomView &g, const ImageV
     FwdParams p = make_fwd_params(a, g);
     const int T = p.cam.gx * p.cam.gy;
     const int nchunks = (int)group_chunks(N);
-    const size_t lds = (size_t)T * sizeof(uint32_t);
-    static unsigned char done[GROUP_SHAPES][16];
+    const bool super = super_tiles_in_use(a);   // two-level grouping: the super-tile grid is counted here too (launch_super_count is for the two-call API)
+    if (super) {
+        p.super_rect = w.super.rect; p.super_hist = w.super.hist; p.super_queue_counts = w.super.long_count;
+        p.super_gx = cdiv(p.cam.gx, SUPER); p.super_T = super_tiles_of(a.image_width, a.image_height);
+    }
+    const size_t lds = (size_t)(T + (super ? p.super_T : 0)) * sizeof(uint32_t);
+    static unsigned char done[2 * GROUP_SHAPES][16];
     ProfScope ps("preprocess_fwd", s);
     if (int e = group_dispatch(group_shape_for(N), [&](auto threads_, auto owners_, auto per_, int d) {
             constexpr int THREADS = decltype(threads_)::value, OWNERS = decltype(owners_)::value, PER = decltype(per_)::value;
+            if (super) {
+                if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&preprocess_count_kernel<THREADS, OWNERS, PER, true>), (GROUP_MAX_TILES + GROUP_MAX_TILES / (SUPER * SUPER) + 64) * 4, done[GROUP_SHAPES + d])) return e;
+                hipLaunchKernelGGL((preprocess_count_kernel<THREADS, OWNERS, PER, true>), dim3(nchunks), dim3(THREADS), lds, s, p, T, w.group_hist, w.chunk_sums, a.n_touched,
+                                   im.long_count);
+                return (int)LVDGS_OK;
+            }
             if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&preprocess_count_kernel<THREADS, OWNERS, PER>), GROUP_MAX_TILES * 4, done[d])) return e;
             hipLaunchKernelGGL((preprocess_count_kernel<THREADS, OWNERS, PER>), dim3(nchunks), dim3(THREADS), lds, s, p, T, w.group_hist, w.chunk_sums, a.n_touched,
                                im.long_count);
