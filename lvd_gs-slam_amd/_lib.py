@@ -278,6 +278,10 @@ def set_gc_policy(policy):
     global _gc_policy
     if policy not in ("scoped", "process", "off"):
         raise ValueError("gc policy: 'scoped', 'process' or 'off'")
+    if policy == "process" and _gc_policy != "process":
+        import gc
+        gc.collect()
+        gc.freeze()
     _gc_policy = policy
 
 

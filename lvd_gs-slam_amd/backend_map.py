@@ -1025,9 +1025,11 @@ def _map_window(backend, current_window, prune, iters, up_pose, group, reducer, 
                 if n_window == cfg["Training"]["window_size"]:
                     prune_mode = cfg["Training"]["prune_mode"]
                     prune_coviz = cfg["Training"]["prune_num"]
-                    G.n_obs.fill_(0)
-                    for _, visibility in backend.occ_aware_visibility.items():
-                        G.n_obs += visibility.cpu()
+                    # (`n_obs += visibility.cpu()` per window keyframe: the same integer sums, made on the device and fetched once --
+                    # eight blocking copies fewer in a pass the free-running back end makes every ten iterations)
+                    rows = list(backend.occ_aware_visibility.values())
+                    summed = torch.stack(rows).sum(0) if all(r.is_cuda for r in rows) else sum(r.cpu() for r in rows)
+                    G.n_obs.copy_(summed.cpu().to(G.n_obs.dtype))
                     to_prune = None
                     if prune_mode == "odometry":
                         to_prune = G.n_obs < 3

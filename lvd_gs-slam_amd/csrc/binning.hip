@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(GROUP_THREADS) count_pairs_kernel(int N, int g
 // R = 0: more than 32 rows per wave (maps beyond 2 M Gaussians): the rows are read twice, eight at a time.
 constexpr int COLSCAN_TILES = 64;
 template <int R>
-__device__ __forceinline__ void group_colscan_body(int T, int nchunks, uint32_t *__restrict__ hist, uint32_t *__restrict__ totals) {
+__device__ __forceinline__ void group_colscan_body(int T, int nchunks, uint32_t *__restrict__ hist, uint32_t *__restrict__ totals, bool write_prefixes = true) {
     __shared__ uint32_t s_part[16][COLSCAN_TILES];
     const int tl = threadIdx.x & 63, cg = threadIdx.x >> 6, groups = blockDim.x >> 6;
     const int t = blockIdx.x * COLSCAN_TILES + tl;
@@ -113,6 +113,10 @@ __device__ __forceinline__ void group_colscan_body(int T, int nchunks, uint32_t 
         total += x;
     }
     if (t >= T) return;
+    if (!write_prefixes) {   // (two-level grouping: nothing scatters into the TILE grid's segments; only the totals are wanted of it)
+        if (cg == 0) totals[t] = total;
+        return;
+    }
     if constexpr (R > 0) {
 #pragma unroll
         for (int k = 0; k < R; k++) {
@@ -308,7 +312,7 @@ __global__ void __launch_bounds__(1024) group_colscan_pair_kernel(int T0, int T1
                                                                   uint32_t *__restrict__ hist1, uint32_t *__restrict__ totals1) {
     const int T = blockIdx.y ? T1 : T0;
     if ((int)blockIdx.x * COLSCAN_TILES >= T) return;
-    group_colscan_body<R>(T, nchunks, blockIdx.y ? hist1 : hist0, blockIdx.y ? totals1 : totals0);
+    group_colscan_body<R>(T, nchunks, blockIdx.y ? hist1 : hist0, blockIdx.y ? totals1 : totals0, blockIdx.y != 0);   // (grid 0: the tiles' -- totals only)
 }
 struct TilescanPairView { int T; const uint32_t *totals; uint2 *ranges; uint32_t *total_out, *queue_count, *queue, *tile_order; int t_lo, t_hi; uint32_t *order_valid, *host_out; uint32_t host_seq; };
 __global__ void __launch_bounds__(1024) group_tilescan_pair_kernel(TilescanPairView a, TilescanPairView b, uint32_t capacity, uint32_t long_limit) {

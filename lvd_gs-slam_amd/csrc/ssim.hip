@@ -317,40 +317,33 @@ __global__ void __launch_bounds__(SSIM_THREADS) ssim_l1_kernel(SsimParams p) {
     }
     __syncthreads();
 
-    // ---- 4b. vertical pass, 3 outputs per item (32 columns x 11 row groups = 352 items, the last group overlaps its neighbour), and
-    //      the gradient of this tile.  A wave's two half-waves read rows THREE apart: 3 x 33 words = 35 banks on, so the 32 columns of
-    //      one half and the 32 of the other fall in disjoint banks but for three (round 5 took 2 outputs per item -- rows two apart,
-    //      66 words = 2 banks on: 30 of a wave's 64 lanes collided on every read, which is where the kernel's 31 % of LDS conflict cycles
-    //      came from) -- and an output costs 13 / 3 row reads instead of 12 / 2.  The same multiply-adds in the same order per output. ----
+    // ---- 4b. vertical pass, 2 outputs per item (32 columns x 16 row pairs = 512 items), and the gradient of this tile ----
     float *__restrict__ G = v.d_x + plane_off;
-    constexpr int BOUT = 3, BNIN = BOUT + SW - 1, BGROUPS = (ST + BOUT - 1) / BOUT;   // 11 row groups
-    static_assert(ST * BGROUPS <= SSIM_THREADS, "one round");
-    if (tid < ST * BGROUPS) {
-        const int c = tid % ST, rfirst = (tid / ST) * BOUT, r0 = min(rfirst, ST - BOUT);   // (the last group starts at row 29: row 30 is written twice, with the same value)
+    for (int item = tid; item < ST * (ST / 2); item += SSIM_THREADS) {
+        const int c = item % ST, r0 = (item / ST) * 2;
         // the pixels' own values (for 2 x (w * dm/dS) + y (w * dm/dZ) and the L1 sign): requested before the passes' LDS reads
-        float own_x[BOUT], own_y[BOUT];
-        bool own_keep[BOUT];
-        const int gx = tx0 + c;
+        float own_x[2] = {0.f, 0.f}, own_y[2] = {0.f, 0.f};
+        bool own_keep[2] = {false, false};
 #pragma unroll
-        for (int o = 0; o < BOUT; o++) {
-            const int gy = ty0 + r0 + o;
-            own_x[o] = own_y[o] = 0.f; own_keep[o] = false;
+        for (int o = 0; o < 2; o++) {
+            const int gy = ty0 + r0 + o, gx = tx0 + c;
             if (gy < p.H && gx < p.W) {
                 const size_t off = (size_t)gy * p.W + gx;
                 own_keep[o] = !(v.keep && !v.keep[off]);
                 own_x[o] = X[off]; own_y[o] = Y[off];
             }
         }
-        float va[BNIN], vs[BNIN], vz[BNIN];
+        float va[12], vs[12], vz[12];
 #pragma unroll
-        for (int i = 0; i < BNIN; i++) {
+        for (int i = 0; i < 12; i++) {
             const int d = (r0 + i) * P3 + c;
             va[i] = s_h[d];
             vs[i] = s_h[S2 * P3 + d];
             vz[i] = s_h[2 * S2 * P3 + d];
         }
+        const int gx = tx0 + c;
 #pragma unroll
-        for (int o = 0; o < BOUT; o++) {
+        for (int o = 0; o < 2; o++) {
             float a = w[0] * va[o], s = w[0] * vs[o], z = w[0] * vz[o];
 #pragma unroll
             for (int k = 1; k < SW; k++) {

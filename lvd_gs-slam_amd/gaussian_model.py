@@ -295,13 +295,19 @@ class GaussianModel:
     def prune_points(self, mask):
         """Remove the Gaussians where ``mask`` is True (slam_backend.py:89, :339)."""
         keep = ~mask.to(device=self._xyz.device, dtype=torch.bool)
-        self._rebuild_groups(lambda n, t: t[keep], lambda n, t: t[keep])
-        self.xyz_gradient_accum = self.xyz_gradient_accum[keep]
-        self.denom = self.denom[keep]
-        self.max_radii2D = self.max_radii2D[keep]
-        keep_cpu = keep.cpu()
-        self.unique_kfIDs = self.unique_kfIDs[keep_cpu]
-        self.n_obs = self.n_obs[keep_cpu]
+        # The surviving rows as INDICES, found once: every `t[keep]` with a boolean mask is a count on the device the host waits for before
+        # it can size the result -- eighteen of them here (six parameters, twelve Adam moments) plus the three statistics, each a
+        # round trip of its own behind whatever is queued (tools/stall_probe.py: 50 ms per call of this function in the mapping loop of
+        # the synthetic drive).  index_select with the same rows in the same order: the same tensors.
+        idx = torch.nonzero(keep).squeeze(1)
+        pick = lambda n, t: t.index_select(0, idx)
+        self._rebuild_groups(pick, pick)
+        self.xyz_gradient_accum = self.xyz_gradient_accum.index_select(0, idx)
+        self.denom = self.denom.index_select(0, idx)
+        self.max_radii2D = self.max_radii2D.index_select(0, idx)
+        idx_cpu = idx.cpu()
+        self.unique_kfIDs = self.unique_kfIDs.index_select(0, idx_cpu)
+        self.n_obs = self.n_obs.index_select(0, idx_cpu)
 
     def densification_postfix(self, new_xyz, new_features_dc, new_features_rest, new_opacities, new_scaling, new_rotation,
                               new_kf_ids=None, new_n_obs=None):
@@ -400,34 +406,40 @@ class GaussianModel:
 
     def densify_and_clone(self, grads, grad_threshold, scene_extent):
         sel = (torch.norm(grads, dim=-1) >= grad_threshold) & (self.get_scaling.max(dim=1).values <= self.percent_dense * scene_extent)
-        sel_cpu = sel.cpu()
-        self.densification_postfix(self._xyz[sel], self._features_dc[sel], self._features_rest[sel], self._opacity[sel],
-                                   self._scaling[sel], self._rotation[sel],
-                                   new_kf_ids=self.unique_kfIDs[sel_cpu], new_n_obs=self.n_obs[sel_cpu])
+        idx = torch.nonzero(sel).squeeze(1)     # (one count-and-wait instead of one per tensor: see prune_points)
+        idx_cpu = idx.cpu()
+        take = lambda t: t.index_select(0, idx)
+        self.densification_postfix(take(self._xyz), take(self._features_dc), take(self._features_rest), take(self._opacity),
+                                   take(self._scaling), take(self._rotation),
+                                   new_kf_ids=self.unique_kfIDs.index_select(0, idx_cpu), new_n_obs=self.n_obs.index_select(0, idx_cpu))
 
     def densify_and_split(self, grads, grad_threshold, scene_extent, N=2):
         n_init = self._xyz.shape[0]
         padded = torch.zeros(n_init, device=self.device)
         padded[: grads.shape[0]] = grads.squeeze()
         sel = (padded >= grad_threshold) & (self.get_scaling.max(dim=1).values > self.percent_dense * scene_extent)
-        stds = self.get_scaling[sel].repeat(N, 1)
+        idx = torch.nonzero(sel).squeeze(1)     # (one count-and-wait instead of one per tensor: see prune_points)
+        idx_cpu = idx.cpu()
+        take = lambda t: t.index_select(0, idx)
+        scaling_sel = take(self.get_scaling)
+        stds = scaling_sel.repeat(N, 1)
         if self.generator is not None and self.generator.device.type == "cpu":
             samples = torch.randn(stds.shape, generator=self.generator).to(stds.device) * stds
         else:
             samples = torch.randn(stds.shape, device=stds.device, generator=self.generator) * stds
-        rots = build_rotation(self._rotation[sel]).repeat(N, 1, 1)
-        new_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + self._xyz[sel].repeat(N, 1)
-        new_scaling = self.scaling_inverse_activation(self.get_scaling[sel].repeat(N, 1) / (0.8 * N))
-        sel_cpu = sel.cpu()
-        self.densification_postfix(new_xyz, self._features_dc[sel].repeat(N, 1, 1), self._features_rest[sel].repeat(N, 1, 1),
-                                   self._opacity[sel].repeat(N, 1), new_scaling, self._rotation[sel].repeat(N, 1),
-                                   new_kf_ids=self.unique_kfIDs[sel_cpu].repeat(N), new_n_obs=self.n_obs[sel_cpu].repeat(N))
-        self.prune_points(torch.cat((sel, torch.zeros(N * int(sel.sum()), device=self.device, dtype=torch.bool))))
+        rotation_sel = take(self._rotation)
+        rots = build_rotation(rotation_sel).repeat(N, 1, 1)
+        new_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + take(self._xyz).repeat(N, 1)
+        new_scaling = self.scaling_inverse_activation(scaling_sel.repeat(N, 1) / (0.8 * N))
+        self.densification_postfix(new_xyz, take(self._features_dc).repeat(N, 1, 1), take(self._features_rest).repeat(N, 1, 1),
+                                   take(self._opacity).repeat(N, 1), new_scaling, rotation_sel.repeat(N, 1),
+                                   new_kf_ids=self.unique_kfIDs.index_select(0, idx_cpu).repeat(N), new_n_obs=self.n_obs.index_select(0, idx_cpu).repeat(N))
+        self.prune_points(torch.cat((sel, torch.zeros(N * int(idx.numel()), device=self.device, dtype=torch.bool))))
 
     def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size):
         """slam_backend.py:132-137, :364-369."""
         grads = self.xyz_gradient_accum / self.denom
-        grads[grads.isnan()] = 0.0
+        grads = torch.where(grads.isnan(), torch.zeros_like(grads), grads)   # (`grads[grads.isnan()] = 0.0` without the host waiting for the count of NaNs)
         self.densify_and_clone(grads, max_grad, extent)
         self.densify_and_split(grads, max_grad, extent)
         prune = (self.get_opacity < min_opacity).squeeze(-1)

@@ -21,6 +21,10 @@ M = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
 dev = torch.device("cuda", 0)
 pipe = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False)
 
+import gc  # noqa: E402
+from lvdgs import _lib  # noqa: E402
+_lib.set_gc_policy("process")   # (a benchmark process: one collect + freeze for its life, as every round up to 5 did implicitly; the library's default is scoped)
+gc.collect(); gc.freeze()
 model, cam, _, (N, W, H) = bench.build_scene("kitti07_geom", 0, dev)
 # converged_threshold < 0: the sticky "converged" flag is never raised, so EVERY iteration's pose step is applied (round 3's soak
 # converged after a few dozen iterations and soaked render + backward with a no-op optimiser step behind them)

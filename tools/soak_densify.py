@@ -35,12 +35,13 @@ gc.collect(); gc.freeze()
 torch.cuda.synchronize()
 mem0 = torch.cuda.memory_allocated(dev)
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
-kinds, sizes, phase_rec = [], [], []
+kinds, sizes, phase_rec, host_ms = [], [], [], []
 ev[0].record()
 t0 = time.perf_counter()
 block = max(iters // 6, 1)
 for k in range(iters):
     n0 = seq._n()
+    th = time.perf_counter()
     st = {}
     seq._map(window, stats=st)
     phase_rec.append(st["iterations"][-1]["phases"] if st.get("iterations") else None)
@@ -56,6 +57,7 @@ for k in range(iters):
     if be.iteration_count % be.gaussian_reset == 0 or (be.iteration_count - 1) % be.gaussian_reset == 0:
         kind = "opacity reset"
     ev[k + 1].record()
+    host_ms.append(1e3 * (time.perf_counter() - th))
     kinds.append(kind); sizes.append(seq._n())
     if (k + 1) % block == 0:
         torch.cuda.synchronize()
@@ -68,6 +70,9 @@ print(f"map size over the soak: min {min(sizes)}, max {max(sizes)}, last {sizes[
 for kind in sorted(set(kinds)):
     sel = ms[[i for i, q in enumerate(kinds) if q == kind]]
     print(f"  {kind:45s} {len(sel):5d} iterations: median {np.median(sel):.3f} ms, mean {sel.mean():.3f}, p95 {np.percentile(sel, 95):.3f}, max {sel.max():.3f}")
+hm = np.array(host_ms)
+print(f"host time per iteration (enqueueing + its own waits, no synchronisation added): median {np.median(hm):.3f} ms, mean {hm.mean():.3f}, "
+      f"over 20 ms: {(hm > 20).sum()} of {len(hm)} (sum {hm[hm > 20].sum():.0f} ms); event time: median {np.median(ms):.3f}, mean {ms.mean():.3f}, over 20 ms: {(ms > 20).sum()} (sum {ms[ms > 20].sum():.0f} ms)")
 print("phases of the mapping iteration itself (events on the stream at the phase boundaries; medians / means in ms):")
 for kind in sorted(set(kinds)):
     rows = [phase_rec[i].seconds() for i, q in enumerate(kinds) if q == kind and phase_rec[i] is not None]
