@@ -1041,10 +1041,11 @@ def _map_window(backend, current_window, prune, iters, up_pose, group, reducer, 
                         to_prune = torch.logical_and(G.n_obs <= prune_coviz, mask)
                     if to_prune is not None and backend.monocular:
                         G.prune_points(to_prune.to(dev))
-                        keep = ~to_prune.to(dev)
+                        # (the rows that stay, as indices found once: a boolean mask per keyframe is a device count the host waits for each time)
+                        keep_idx = torch.nonzero(~to_prune.to(dev)).squeeze(1)
                         for idx in range(n_window):
                             k = current_window[idx]
-                            backend.occ_aware_visibility[k] = backend.occ_aware_visibility[k][keep]
+                            backend.occ_aware_visibility[k] = backend.occ_aware_visibility[k].index_select(0, keep_idx.to(backend.occ_aware_visibility[k].device))
                     if not backend.initialized:
                         backend.initialized = True
                 return False
