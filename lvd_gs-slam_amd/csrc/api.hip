@@ -656,7 +656,7 @@ int lvdgs_forward_batch(const lvdgs_args *const *views, int32_t count, int64_t *
         if (a->num_gaussians != N || a->image_width != W || a->image_height != H || a->tile_row_begin != a0->tile_row_begin || a->tile_row_end != a0->tile_row_end ||
             a->means3D != a0->means3D || a->opacities != a0->opacities || a->scales != a0->scales || a->rotations != a0->rotations ||
             a->cov3D_precomp != a0->cov3D_precomp || a->shs != a0->shs || a->colors_precomp != a0->colors_precomp || a->sh_coeffs != a0->sh_coeffs ||
-            a->activations != a0->activations || ((a->flags ^ a0->flags) & (LVDGS_FLAG_LIST_ALL_TILES | LVDGS_FLAG_NO_BLEND))) {
+            a->activations != a0->activations || ((a->flags ^ a0->flags) & (LVDGS_FLAG_LIST_ALL_TILES | LVDGS_FLAG_NO_BLEND | LVDGS_FLAG_SUPER_TILES))) {
             set_error("forward batch: the views differ in map (means3D / opacities / scales / rotations / cov3D_precomp / shs / colors_precomp / activations), image size, band or flags"); return LVDGS_E_INVALID;
         }
         const int64_t cap = a->pair_capacity;
@@ -680,7 +680,11 @@ int lvdgs_forward_batch(const lvdgs_args *const *views, int32_t count, int64_t *
         if (int e = launch_preprocess_count_batch(av, &g[first], &im[first], &w[first], m, s)) return e;
         if (int e = launch_group_scan_batch(av, &g[first], &im[first], &w[first], &caps[first], m, words_dev, probe->seq, s)) return e;
         if (int e = launch_group_scatter_batch(av, &g[first], &im[first], &w[first], &b[first], &caps[first], m, s)) return e;
-        if (int e = launch_tile_depth_sort_batch(av, &g[first], &im[first], &w[first], &b[first], m, probe->longest, probe->queued, s)) return e;
+        const bool super = super_tiles_in_use(*a0);   // two-level grouping: the launches above worked on the super-tile grid; the tiles' lists are read off the sorted super lists
+        if (int e = launch_tile_depth_sort_batch(av, &g[first], &im[first], &w[first], &b[first], m, super ? probe->longest_super : probe->longest,
+                                                 super ? probe->queued_super : probe->queued, s)) return e;
+        if (super)
+            if (int e = launch_super_expand_batch(av, &g[first], &im[first], &w[first], &b[first], m, s)) return e;
         if (!(a0->flags & LVDGS_FLAG_NO_BLEND))
             if (int e = launch_blend_fwd_batch(av, &g[first], &b[first], &im[first], m, probe->longest > 0, s)) return e;
         // everything is enqueued: now the counts (the GPU is busy with the scatter, the sorts and the blend meanwhile)
@@ -690,6 +694,7 @@ int lvdgs_forward_batch(const lvdgs_args *const *views, int32_t count, int64_t *
             num_rendered[first + k] = (int64_t)words[4 * k];
             longest = std::max(longest, (int)words[4 * k + 1]); queued = std::max(queued, (int)words[4 * k + 2]);
         }
+        if (super) { probe->longest_super = (int)probe->pinned[8 + 1]; probe->queued_super = (int)probe->pinned[8 + 2]; }   // (hints; possibly still the previous call's)
         if (m < count) { probe->seq++; if (probe->seq == 0u) probe->seq = 1u; }   // (the next group of views re-uses the words)
         if (longest >= probe->longest || probe->keep == 0) { probe->longest = longest; probe->queued = queued; probe->keep = longest ? 32 : 0; }
         else probe->keep--;

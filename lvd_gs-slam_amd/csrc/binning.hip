@@ -321,6 +321,26 @@ __global__ void __launch_bounds__(1024) group_tilescan_pair_kernel(TilescanPairV
                               v.host_out, v.host_seq);
 }
 
+// lvdgs_forward_batch with two-level grouping: both grids of every view (blockIdx.y = 2 * view + grid; blockIdx.x likewise for the range scan)
+struct ColscanPairBatch { uint32_t *hist[2 * FWD_BATCH_VIEWS], *totals[2 * FWD_BATCH_VIEWS]; };
+template <int R>
+__global__ void __launch_bounds__(1024) group_colscan_pair_batch_kernel(int T0, int T1, int nchunks, ColscanPairBatch b) {
+    const int grid = blockIdx.y & 1, T = grid ? T1 : T0;
+    if ((int)blockIdx.x * COLSCAN_TILES >= T) return;
+    group_colscan_body<R>(T, nchunks, b.hist[blockIdx.y], b.totals[blockIdx.y], grid != 0);
+}
+struct TilescanPairBatch { TilescanView v[2 * FWD_BATCH_VIEWS]; };
+static_assert(sizeof(TilescanPairBatch) <= 3600, "kernel arguments");
+__global__ void __launch_bounds__(1024) group_tilescan_pair_batch_kernel(int T0, int T1, TilescanPairBatch b, uint32_t long_limit, int t_lo, int t_hi,
+                                                                         uint32_t *host_out, uint32_t host_seq, uint32_t *host_super) {
+    const TilescanView &v = b.v[blockIdx.x];
+    const int grid = blockIdx.x & 1, view = blockIdx.x >> 1;
+    // (the tile grid's workgroup writes the view's four pinned words -- count, hints, the sequence number the host waits for; of the
+    // super grids the first view's leaves its hints -- longest queued list, queue length -- for the next call's sort launch)
+    group_tilescan_body<1024>(grid ? T1 : T0, v.totals, v.capacity, v.ranges, v.total_out, long_limit, v.queue_count, v.queue, v.tile_order,
+                              grid ? 0 : t_lo, grid ? T1 : t_hi, v.order_valid, grid ? (view == 0 ? host_super : nullptr) : host_out + 4 * view, grid ? 0u : host_seq);
+}
+
 // SLOT_SCAN (lvdgs_forward): also makes slot_base[i] = exclusive scan of tiles_touched in id order (the backward's
 // gradient slots) from the pair totals the projection kernel left per chunk: every workgroup adds up the totals in front
 // of its chunk -- at most a few hundred values -- and scans its own Gaussians.  (The launch of a separate slot scan less.)
@@ -577,9 +597,8 @@ __global__ void __launch_bounds__(GROUP_THREADS) count_super_kernel(int N, int g
 // which of the sixteen tiles list the Gaussian (kept_in_super: the bits the projection kernel set, the very test the tile counts were
 // taken with) -- then every wave walks the staged entries 64 at a time and appends the ids whose bit for its tile is set to the tile's
 // segment, in list order.
-__global__ void __launch_bounds__(64 * SUPER * SUPER) expand_super_kernel(int gx, int gy, int gxs, const uint2 *__restrict__ ranges_s,
-                                                                        const uint32_t *__restrict__ super_list, const uint4 *__restrict__ rect,
-                                                                        const uint2 *__restrict__ ranges, uint32_t *__restrict__ point_list) {
+__device__ __forceinline__ void expand_super_body(int gx, int gy, int gxs, const uint2 *__restrict__ ranges_s, const uint32_t *__restrict__ super_list,
+                                                  const uint4 *__restrict__ rect, const uint2 *__restrict__ ranges, uint32_t *__restrict__ point_list) {
     constexpr int STAGE = 64 * SUPER * SUPER;
     __shared__ uint32_t s_id[STAGE];
     __shared__ uint32_t s_keep[STAGE];
@@ -615,6 +634,19 @@ __global__ void __launch_bounds__(64 * SUPER * SUPER) expand_super_kernel(int gx
         }
         __syncthreads();
     }
+}
+__global__ void __launch_bounds__(64 * SUPER * SUPER) expand_super_kernel(int gx, int gy, int gxs, const uint2 *__restrict__ ranges_s,
+                                                                        const uint32_t *__restrict__ super_list, const uint4 *__restrict__ rect,
+                                                                        const uint2 *__restrict__ ranges, uint32_t *__restrict__ point_list) {
+    expand_super_body(gx, gy, gxs, ranges_s, super_list, rect, ranges, point_list);
+}
+
+// lvdgs_forward_batch (blockIdx.y: the view)
+struct ExpandView { const uint2 *ranges_s; const uint32_t *super_list; const uint4 *rect; const uint2 *ranges; uint32_t *point_list; };
+struct ExpandBatch { ExpandView v[FWD_BATCH_VIEWS]; };
+__global__ void __launch_bounds__(64 * SUPER * SUPER) expand_super_batch_kernel(int gx, int gy, int gxs, ExpandBatch b) {
+    const ExpandView &v = b.v[blockIdx.y];
+    expand_super_body(gx, gy, gxs, v.ranges_s, v.super_list, v.rect, v.ranges, v.point_list);
 }
 
 }  // namespace
@@ -819,6 +851,30 @@ int launch_group_scan_batch(const lvdgs_args *const *a, const GeomView *g, const
                                tile_order_in_use(T) ? im[k].long_tiles + T : nullptr, im[k].long_count + 1};
     }
     ProfScope ps("group_scan", s);
+    if (super_tiles_in_use(*a[0])) {
+        // two-level grouping: the tile grid's and the super-tile grid's count matrices of every view in the same two launches
+        const int Ts = super_tiles_of(a[0]->image_width, a[0]->image_height);
+        ColscanPairBatch cpb{};
+        TilescanPairBatch tpb{};
+        for (int k = 0; k < n; k++) {
+            const SuperView &sv = w[k].super;
+            cpb.hist[2 * k] = w[k].group_hist; cpb.totals[2 * k] = w[k].group_totals;
+            cpb.hist[2 * k + 1] = sv.hist; cpb.totals[2 * k + 1] = sv.totals;
+            tpb.v[2 * k] = TilescanView{w[k].group_totals, (uint32_t)caps[k], im[k].ranges, g[k].total, im[k].long_count, im[k].long_tiles,
+                                        tile_order_in_use(T) ? im[k].long_tiles + T : nullptr, im[k].long_count + 1};
+            tpb.v[2 * k + 1] = TilescanView{sv.totals, (uint32_t)caps[k], sv.ranges, sv.total, sv.long_count, sv.long_tiles,
+                                            tile_order_in_use(Ts) ? sv.long_tiles + Ts : nullptr, sv.long_count + 1};
+        }
+        const dim3 grid2(cdiv(T, COLSCAN_TILES), 2 * n);
+        if (nchunks <= 8 * 16) hipLaunchKernelGGL(group_colscan_pair_batch_kernel<8>, grid2, dim3(1024), 0, s, T, Ts, nchunks, cpb);
+        else if (nchunks <= 16 * 16) hipLaunchKernelGGL(group_colscan_pair_batch_kernel<16>, grid2, dim3(1024), 0, s, T, Ts, nchunks, cpb);
+        else if (nchunks <= 32 * 16) hipLaunchKernelGGL(group_colscan_pair_batch_kernel<32>, grid2, dim3(1024), 0, s, T, Ts, nchunks, cpb);
+        else hipLaunchKernelGGL(group_colscan_pair_batch_kernel<0>, grid2, dim3(1024), 0, s, T, Ts, nchunks, cpb);
+        hipLaunchKernelGGL(group_tilescan_pair_batch_kernel, dim3(2 * n), dim3(1024), 0, s, T, Ts, tpb, (uint32_t)tile_sort_wave_limit(), row0 * gx, row1 * gx, host_words,
+                           host_seq, host_words ? host_words - 8 : nullptr);   // (the call's pinned words: [8..11] the super grid's hints, [16 + 4 k..] view k's)
+        LVDGS_LAUNCH_CHECK("group_scan (batch, two-level)", a[0]->debug, s);
+        return LVDGS_OK;
+    }
     const dim3 grid(cdiv(T, COLSCAN_TILES), n);
     if (nchunks <= 8 * 16) hipLaunchKernelGGL(group_colscan_batch_kernel<8>, grid, dim3(1024), 0, s, T, nchunks, cb);
     else if (nchunks <= 16 * 16) hipLaunchKernelGGL(group_colscan_batch_kernel<16>, grid, dim3(1024), 0, s, T, nchunks, cb);
@@ -835,20 +891,37 @@ int launch_group_scatter_batch(const lvdgs_args *const *a, const GeomView *g, co
     const int gx = (a[0]->image_width + TILE - 1) / TILE, gy = (a[0]->image_height + TILE - 1) / TILE, T = gx * gy;
     if (N == 0 || T == 0 || n == 0) return LVDGS_OK;
     const int nchunks = (int)group_chunks(N);
-    const size_t lds = (size_t)T * sizeof(uint32_t);
+    const bool super = super_tiles_in_use(*a[0]);   // two-level grouping: the same kernel on the super-tile grid (its rectangles, counts and ranges)
+    const int gxs = cdiv(gx, SUPER), Ts = gxs * cdiv(gy, SUPER);
+    const size_t lds = (size_t)(super ? Ts : T) * sizeof(uint32_t);
     ScatterBatch sb{};
     for (int k = 0; k < n; k++)
-        sb.v[k] = ScatterView{(const uint4 *)g[k].rect, w[k].group_hist, im[k].ranges, (uint32_t)caps[k], g[k].depth_bits, (unsigned long long *)w[k].keys,
-                              g[k].tiles_touched, w[k].chunk_sums, g[k].slot_base, b[k].pair_valid};
+        sb.v[k] = super ? ScatterView{(const uint4 *)w[k].super.rect, w[k].super.hist, w[k].super.ranges, (uint32_t)caps[k], g[k].depth_bits, (unsigned long long *)w[k].keys,
+                                      g[k].tiles_touched, w[k].chunk_sums, g[k].slot_base, b[k].pair_valid}
+                        : ScatterView{(const uint4 *)g[k].rect, w[k].group_hist, im[k].ranges, (uint32_t)caps[k], g[k].depth_bits, (unsigned long long *)w[k].keys,
+                                      g[k].tiles_touched, w[k].chunk_sums, g[k].slot_base, b[k].pair_valid};
     static unsigned char done[GROUP_SHAPES][16];
-    ProfScope ps("group_scatter", s);
+    ProfScope ps(super ? "super_scatter" : "group_scatter", s);
     if (int e = group_dispatch(group_shape_for(N), [&](auto threads_, auto owners_, auto per_, int d) {
             constexpr int THREADS = decltype(threads_)::value, OWNERS = decltype(owners_)::value, PER = decltype(per_)::value;
             if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&scatter_pairs_batch_kernel<THREADS, OWNERS, PER>), GROUP_MAX_TILES * 4, done[d])) return e;
-            hipLaunchKernelGGL((scatter_pairs_batch_kernel<THREADS, OWNERS, PER>), dim3((nchunks + 7) & ~7, n), dim3(THREADS), lds, s, N, gx, T, nchunks, sb);
+            hipLaunchKernelGGL((scatter_pairs_batch_kernel<THREADS, OWNERS, PER>), dim3((nchunks + 7) & ~7, n), dim3(THREADS), lds, s, N, super ? gxs : gx, super ? Ts : T,
+                               nchunks, sb);
             return (int)LVDGS_OK;
         })) return e;
     LVDGS_LAUNCH_CHECK("group_scatter (batch)", a[0]->debug, s);
+    return LVDGS_OK;
+}
+
+int launch_super_expand_batch(const lvdgs_args *const *a, const GeomView *g, const ImageView *im, const RenderScratch *w, const BinView *b, int n, hipStream_t s) {
+    const int gx = (a[0]->image_width + TILE - 1) / TILE, gy = (a[0]->image_height + TILE - 1) / TILE;
+    const int gxs = cdiv(gx, SUPER), Ts = gxs * cdiv(gy, SUPER);
+    if (a[0]->num_gaussians == 0 || Ts == 0 || n == 0) return LVDGS_OK;
+    ExpandBatch eb{};
+    for (int k = 0; k < n; k++) eb.v[k] = ExpandView{(const uint2 *)w[k].super.ranges, b[k].tile_keys, (const uint4 *)g[k].rect, (const uint2 *)im[k].ranges, b[k].point_list};
+    ProfScope ps("super_expand", s);
+    hipLaunchKernelGGL(expand_super_batch_kernel, dim3(Ts, n), dim3(64 * SUPER * SUPER), 0, s, gx, gy, gxs, eb);
+    LVDGS_LAUNCH_CHECK("super_expand (batch)", a[0]->debug, s);
     return LVDGS_OK;
 }
 

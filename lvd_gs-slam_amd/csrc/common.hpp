@@ -316,6 +316,7 @@ int super_tiles_of(int W, int H);
 int launch_super_count(const lvdgs_args &a, const GeomView &g, const SuperView &sv, hipStream_t s);   // before launch_group_scan, which then scans both grids
 int launch_super_scatter(const lvdgs_args &a, const GeomView &g, const SuperView &sv, const RenderScratch &w, unsigned long long *keys64, int64_t capacity,
                          bool slot_scan, uint8_t *pair_valid, hipStream_t s);
+int launch_super_expand_batch(const lvdgs_args *const *a, const GeomView *g, const ImageView *im, const RenderScratch *w, const BinView *b, int n, hipStream_t s);
 int launch_super_expand(const lvdgs_args &a, const GeomView &g, const SuperView &sv, const ImageView &im, const uint32_t *super_list, uint32_t *point_list,
                         hipStream_t s);
 // Sorts the segment of every tile in [t_lo, t_hi) by (view-depth bits, id) and leaves the ids in point_list.  keys64 holds

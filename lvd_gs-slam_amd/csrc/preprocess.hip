@@ -303,11 +303,11 @@ __global__ void __launch_bounds__(GROUP_THREADS, 8) preprocess_count_kernel(FwdP
 // of them side by side cost little more than one.
 struct PrepCountView { FwdParams p; uint32_t *hist, *chunk_sums; int32_t *n_touched; uint32_t *queue_counts; };
 struct PrepCountBatch { PrepCountView v[FWD_BATCH_VIEWS]; };
-static_assert(sizeof(PrepCountBatch) <= 4000, "kernel arguments");
-template <int GROUP_THREADS, int OWNERS, int PER>
+static_assert(sizeof(PrepCountBatch) <= 4064, "kernel arguments");
+template <int GROUP_THREADS, int OWNERS, int PER, bool SUPER_COUNT = false>
 __global__ void __launch_bounds__(GROUP_THREADS, 8) preprocess_count_batch_kernel(PrepCountBatch b, int T) {
     const PrepCountView &v = b.v[blockIdx.y];
-    preprocess_count_body<GROUP_THREADS, OWNERS, PER>(v.p, T, v.hist, v.chunk_sums, v.n_touched, v.queue_counts);
+    preprocess_count_body<GROUP_THREADS, OWNERS, PER, SUPER_COUNT>(v.p, T, v.hist, v.chunk_sums, v.n_touched, v.queue_counts);
 }
 
 __device__ __forceinline__ void preprocess_one(const FwdParams &p, int i, const RawGaussian &raw, uint32_t &tiles_out, uint4 &rect_out) {
@@ -1198,14 +1198,27 @@ int launch_preprocess_count_batch(const lvdgs_args *const *a, const GeomView *g,
     if (N == 0 || n == 0) return LVDGS_OK;
     if (n > FWD_BATCH_VIEWS) { set_error("internal: more than %d views in one forward batch", FWD_BATCH_VIEWS); return LVDGS_E_INVALID; }
     PrepCountBatch batch{};
-    for (int k = 0; k < n; k++) batch.v[k] = PrepCountView{make_fwd_params(*a[k], g[k]), w[k].group_hist, w[k].chunk_sums, a[k]->n_touched, im[k].long_count};
+    const bool super = super_tiles_in_use(*a[0]);   // two-level grouping: the super-tile grid is counted here too
+    for (int k = 0; k < n; k++) {
+        batch.v[k] = PrepCountView{make_fwd_params(*a[k], g[k]), w[k].group_hist, w[k].chunk_sums, a[k]->n_touched, im[k].long_count};
+        if (super) {
+            FwdParams &p = batch.v[k].p;
+            p.super_rect = w[k].super.rect; p.super_hist = w[k].super.hist; p.super_queue_counts = w[k].super.long_count;
+            p.super_gx = cdiv(p.cam.gx, SUPER); p.super_T = super_tiles_of(a[k]->image_width, a[k]->image_height);
+        }
+    }
     const int T = batch.v[0].p.cam.gx * batch.v[0].p.cam.gy;
     const int nchunks = (int)group_chunks(N);
-    const size_t lds = (size_t)T * sizeof(uint32_t);
-    static unsigned char done[GROUP_SHAPES][16];
+    const size_t lds = (size_t)(T + (super ? batch.v[0].p.super_T : 0)) * sizeof(uint32_t);
+    static unsigned char done[2 * GROUP_SHAPES][16];
     ProfScope ps("preprocess_fwd", s);
     if (int e = group_dispatch(group_shape_for(N), [&](auto threads_, auto owners_, auto per_, int d) {
             constexpr int THREADS = decltype(threads_)::value, OWNERS = decltype(owners_)::value, PER = decltype(per_)::value;
+            if (super) {
+                if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&preprocess_count_batch_kernel<THREADS, OWNERS, PER, true>), (GROUP_MAX_TILES + GROUP_MAX_TILES / (SUPER * SUPER) + 64) * 4, done[GROUP_SHAPES + d])) return e;
+                hipLaunchKernelGGL((preprocess_count_batch_kernel<THREADS, OWNERS, PER, true>), dim3(nchunks, n), dim3(THREADS), lds, s, batch, T);
+                return (int)LVDGS_OK;
+            }
             if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&preprocess_count_batch_kernel<THREADS, OWNERS, PER>), GROUP_MAX_TILES * 4, done[d])) return e;
             hipLaunchKernelGGL((preprocess_count_batch_kernel<THREADS, OWNERS, PER>), dim3(nchunks, n), dim3(THREADS), lds, s, batch, T);
             return (int)LVDGS_OK;

@@ -372,10 +372,11 @@ int launch_tile_depth_sort(const ImageView &im, int num_tiles, int t_lo, int t_h
 
 int launch_tile_depth_sort_batch(const lvdgs_args *const *a, const GeomView *g, const ImageView *im, const RenderScratch *w, const BinView *b, int n,
                                  int longest_expected, int queue_expected, hipStream_t s) {
-    const int gx = cdiv(a[0]->image_width, TILE), num_tiles = gx * cdiv(a[0]->image_height, TILE);
+    const bool super = super_tiles_in_use(*a[0]);   // two-level grouping: the super-tile lists are what is sorted, into b.tile_keys (binning.hip)
+    const int gx = cdiv(a[0]->image_width, TILE), num_tiles = super ? super_tiles_of(a[0]->image_width, a[0]->image_height) : gx * cdiv(a[0]->image_height, TILE);
     int row0, row1;
     tile_row_band(*a[0], &row0, &row1);
-    const int t_lo = row0 * gx, t_hi = row1 * gx;
+    const int t_lo = super ? 0 : row0 * gx, t_hi = super ? num_tiles : row1 * gx;
     if (num_tiles == 0 || t_hi <= t_lo || n == 0) return LVDGS_OK;
     static unsigned char lds_done[16];
     if (int e = allow_dynamic_lds(reinterpret_cast<const void *>(&tile_depth_sort_long_kernel), CLASS_B * 8, lds_done)) return e;
@@ -387,8 +388,10 @@ int launch_tile_depth_sort_batch(const lvdgs_args *const *a, const GeomView *g, 
     const int solo_wgs = (LVDGS_SORT_SOLO && tile_order_in_use(num_tiles)) ? t_hi - t_lo : 0;
     TileSortBatch batch{};
     for (int k = 0; k < n; k++)
-        batch.v[k] = TileSortView{(const uint2 *)im[k].ranges, KeySource{g[k].rec, b[k].point_list, (const u64 *)w[k].keys}, b[k].point_list, im[k].long_count,
-                                  im[k].long_tiles, tile_order_in_use(num_tiles) ? im[k].long_tiles + num_tiles : nullptr, (u64 *)w[k].keys};
+        batch.v[k] = super ? TileSortView{(const uint2 *)w[k].super.ranges, KeySource{g[k].rec, b[k].tile_keys, (const u64 *)w[k].keys}, b[k].tile_keys, w[k].super.long_count,
+                                          w[k].super.long_tiles, tile_order_in_use(num_tiles) ? w[k].super.long_tiles + num_tiles : nullptr, (u64 *)w[k].keys}
+                           : TileSortView{(const uint2 *)im[k].ranges, KeySource{g[k].rec, b[k].point_list, (const u64 *)w[k].keys}, b[k].point_list, im[k].long_count,
+                                          im[k].long_tiles, tile_order_in_use(num_tiles) ? im[k].long_tiles + num_tiles : nullptr, (u64 *)w[k].keys};
     {
         ProfScope ps("tile_sort", s);
         hipLaunchKernelGGL(tile_depth_sort_wave_batch_kernel, dim3(group_wgs + solo_wgs + sort_wgs + LONG_WGS, n), dim3(64 * SORT_WAVES), 0, s, batch, t_lo, t_hi,
@@ -398,8 +401,8 @@ int launch_tile_depth_sort_batch(const lvdgs_args *const *a, const GeomView *g, 
     if (big)   // segments beyond what the launch above takes (rare: a kernel per view, as in the single-view call)
         for (int k = 0; k < n; k++) {
             ProfScope ps("tile_sort_long", s);
-            hipLaunchKernelGGL(tile_depth_sort_long_kernel, dim3(256), dim3(1024), CLASS_B * 8, s, (const uint2 *)im[k].ranges, batch.v[k].src, b[k].point_list,
-                               (const uint32_t *)im[k].long_count, (const uint32_t *)im[k].long_tiles, (unsigned long long *)w[k].keys, CLASS_G);
+            hipLaunchKernelGGL(tile_depth_sort_long_kernel, dim3(256), dim3(1024), CLASS_B * 8, s, batch.v[k].ranges, batch.v[k].src, batch.v[k].point_list,
+                               (const uint32_t *)batch.v[k].queue_count, (const uint32_t *)batch.v[k].queue, (unsigned long long *)w[k].keys, CLASS_G);
             LVDGS_LAUNCH_CHECK("tile_sort_long", a[0]->debug, s);
         }
     return LVDGS_OK;

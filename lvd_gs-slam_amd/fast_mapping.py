@@ -450,9 +450,14 @@ class MapWindowBatch:
         fwd_batch = os.environ.get("LVDGS_MAP_FWD_BATCH", "1") != "0"
         with _lib.on_device(dev):
             stream = _lib.raw_stream(dev)
+            # (two-level grouping -- rasterizer.super_tiles_flag -- for all views alike: hinted by the largest pair count the passes saw last time)
+            N_now = int(G._xyz.shape[0])
+            last_pairs = max((int(p.a.num_rendered) for p in self.passes[:n]), default=0) if getattr(self, "_pairs_of_n", None) == N_now else None
+            self._pairs_of_n = N_now
+            sflag = _rz.super_tiles_flag(N_now, last_pairs)
             for k, vp in enumerate(viewpoints):
                 ctxs.append(self.passes[k]._begin_for_batch(backend, vp, initialization, first if k == 0 else None,
-                                                            None if k == 0 else ctxs[0]["into"], stream, masked[k], forward=not fwd_batch))
+                                                            None if k == 0 else ctxs[0]["into"], stream, masked[k], forward=not fwd_batch, super_flag=sflag))
             # (the pointer arrays over the passes' argument blocks are made once per window shape: nothing to allocate per iteration)
             key = (n, tuple(m is not None for m in masked))
             ct = getattr(self, "_ct", {}).get(key)
@@ -511,7 +516,7 @@ def _after_forward(self, D, overflow, stream):
     a.num_rendered = D
 
 
-def _begin_for_batch(self, backend, viewpoint, initialization, first, lead_into, stream, masked_loss=None, forward=True):
+def _begin_for_batch(self, backend, viewpoint, initialization, first, lead_into, stream, masked_loss=None, forward=True, super_flag=0):
     """``MapViewPass.run`` up to the forward call (whole view, built-in or static-mask loss, SH degree 0), with LVDGS_FLAG_NO_BLEND."""
     G, cfg, dev, L = backend.gaussians, backend.config, self.dev, self.L
     T = cfg["Training"]
@@ -550,7 +555,7 @@ def _begin_for_batch(self, backend, viewpoint, initialization, first, lead_into,
         into = {n: getattr(G, n).grad for n in fields} if accumulate else (self.first if first is None else first)
     else:                   # a later view: added to where the first view's gradients are (being) written
         accumulate, install, into = True, False, lead_into
-    a.flags = _lib.FLAG_NO_BLEND | (_lib.FLAG_ACCUMULATE_PARAM_GRADS if accumulate else 0)
+    a.flags = _lib.FLAG_NO_BLEND | (_lib.FLAG_ACCUMULATE_PARAM_GRADS if accumulate else 0) | int(super_flag)
     a.dL_dmeans3D, a.dL_dopacities, a.dL_dscales = _P(into["_xyz"]), _P(into["_opacity"]), _P(into["_scaling"])
     a.dL_drotations, a.dL_dshs = _P(into["_rotation"]), _P(into["_features_dc"])
     d_tau, d_a, d_b, d_m2 = e(6), e(1), e(1), e(N, 3)

@@ -112,20 +112,27 @@ def test_tracking_session_and_mapping_window_with_super_tiles():
                 s.step()
             s.finish()
             track = [t.detach().clone() for t in (s.R, s.T, cam.exposure_a, cam.exposure_b, s.color, s.depth, s.d_m3, s.d_sc, s.loss)]
-            before = os.environ.get("LVDGS_MAP_BATCH")
-            os.environ["LVDGS_MAP_BATCH"] = "0"     # (lvdgs_forward_batch ignores the hint: the view-by-view passes are what is under test)
-            try:
-                model2, _, _, _ = bench.build_scene(workload, 0, dev)
-                be, window = bench.build_window(workload, 6, dev, model2, n_window=4, masked=True)
-                for _ in range(3):
-                    backend_map.map_window(be, window, iters=1)
-            finally:
-                if before is None:
-                    os.environ.pop("LVDGS_MAP_BATCH", None)
-                else:
-                    os.environ["LVDGS_MAP_BATCH"] = before
-            torch.cuda.synchronize()
-            res[on] = track + [p.detach().clone() for p in be.gaussians.parameters()]
+            maps = []
+            for batch in ("0", "1"):      # the mapping window view by view (lvdgs_forward per view) and batched (lvdgs_forward_batch)
+                before = os.environ.get("LVDGS_MAP_BATCH")
+                os.environ["LVDGS_MAP_BATCH"] = batch
+                try:
+                    torch.manual_seed(0)
+                    model2, _, _, _ = bench.build_scene(workload, 0, dev)
+                    be, window = bench.build_window(workload, 6, dev, model2, n_window=4, masked=True)
+                    for _ in range(3):
+                        backend_map.map_window(be, window, iters=1)
+                finally:
+                    if before is None:
+                        os.environ.pop("LVDGS_MAP_BATCH", None)
+                    else:
+                        os.environ["LVDGS_MAP_BATCH"] = before
+                torch.cuda.synchronize()
+                maps += [p.detach().clone() for p in be.gaussians.parameters()]
+                if batch == "1":
+                    wb = be._lvdgs_window_batch
+                    assert all(bool(p_.a.flags & _lib.FLAG_SUPER_TILES) is on for p_ in wb.passes[:6])
+            res[on] = track + maps
             flag_in_session = bool(s.a.flags & _lib.FLAG_SUPER_TILES)
             assert flag_in_session is on
     for a, b in zip(res[False], res[True]):
