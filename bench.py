@@ -579,6 +579,16 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline, "steady_state": steady,
             "kernels_us_per_step": {k: round(v["us_per_step"], 2) for k, v in kernels.items()},
         }
+        # the loops as a system, once more at the END of the line in short (a record that keeps only the line's tail still shows it):
+        # config.side.sequence_kitti07_geom has the full entry
+        sq = (side or {}).get("sequence_kitti07_geom")
+        if sq:
+            out["sequence_kitti07_geom_summary"] = {k: sq.get(k) for k in (
+                "frames", "keyframes", "tracking_iterations", "mapping_iterations", "gaussians_first", "gaussians_max", "gaussians_last",
+                "tracking_plus_mapping_iterations_per_s", "frames_per_s", "ate_rmse", "trajectory_length", "psnr_static", "psnr")}
+            for k in ("initialize_map_kitti07_geom", "color_refinement_kitti07_geom", "color_refinement_kitti07_geom_masked"):
+                if k in side:
+                    out["sequence_kitti07_geom_summary"][k + "_ms_per_iteration"] = side[k].get("ms_per_iteration")
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
@@ -622,7 +632,7 @@ def run_side(dev, pipe):
     # (utils/slam_frontend.py:1218,1429-1433) -- so the eight window views take the L1 + SSIM + masked-depth branch of the mapping loss
     # (utils/slam_backend.py:196-261); without: every view get_loss_mapping
     for w, masked in (("kitti07_geom", False), ("kitti07_geom", True), ("cfg3_500k_1920x1080", False), ("cfg3_500k_1920x1080", True),
-                      ("cfg5_2m_1920x1280", False), ("cfg5_2m_1920x1280", True)):
+                      ("cfg5_2m_1920x1280", False), ("cfg5_2m_1920x1280", True), ("surface_100k_1920x1080", True)):
         t0 = time.perf_counter()
         torch.manual_seed(0)
         model, _, _, (N, W, H) = build_scene(w, 0, dev)
@@ -635,7 +645,7 @@ def run_side(dev, pipe):
         gc.collect()
         gc.freeze()
         torch.cuda.synchronize()
-        iters = 40 if w == "kitti07_geom" else (25 if w == "cfg3_500k_1920x1080" else 12)
+        iters = 40 if w == "kitti07_geom" else (25 if w == "cfg3_500k_1920x1080" else (16 if w.startswith("surface") else 12))
         # three timed blocks, the MEDIAN reported (all three printed): a bounded side run of a few dozen iterations is otherwise at the
         # mercy of one host-side stall -- a first-use code-object load, an allocator growth, a garbage collection: single iterations of
         # 20-80 ms were seen in this 1.7 ms loop (tools/side_stall_diag.py) and put 3.4 ms into a line whose kernels ran as always
