@@ -924,8 +924,7 @@ def _map_window(backend, current_window, prune, iters, up_pose, group, reducer, 
                 batch = backend._lvdgs_window_batch = MapWindowBatch(vpass)
             for (v, r0, _), (pkg, l) in zip(together, batch.run(backend, [views[v] for v, _, _ in together], first=first,
                                                                  stats=[vs.targets(v, r0) for v, r0, _ in together],
-                                                                 masked=[masked_of[v] for v, _, _ in together],
-                                                                 reuse_outputs=os.environ.get("LVDGS_MAP_REUSE", "1") != "0")):   # (this function is done with a view's package before the iteration ends)
+                                                                 masked=[masked_of[v] for v, _, _ in together])):
                 pkgs.append((v, r0, pkg))
                 direct_losses.append(l)
         for v, r0, r1 in [pc for pc in mine if pc not in together]:

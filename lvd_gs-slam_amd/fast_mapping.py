@@ -433,13 +433,9 @@ class MapWindowBatch:
         return int(L.lvdgs_geom_bytes(N) + L.lvdgs_binning_bytes(cap) + L.lvdgs_image_bytes(W, H) + scratch + L.lvdgs_loss_scratch_bytes(W, H)
                    + L.lvdgs_masked_loss_scratch_bytes(W, H) + 4 * (3 + 5) * W * H + 4 * (2 + 3) * N)
 
-    def run(self, backend, viewpoints, initialization=False, first=None, stats=None, masked=None, reuse_outputs=False):
+    def run(self, backend, viewpoints, initialization=False, first=None, stats=None, masked=None):
         """-> [(pkg, loss)] in the order of ``viewpoints`` (``stats[k]``: ``MapViewPass.run``'s ``stats`` of view k, ``masked[k]``: its
-        ``masked_loss`` -- None for a view scored by ``get_loss_mapping``).
-        ``reuse_outputs`` (``backend_map.map_window`` sets it: it is done with a view's package before the iteration ends): a pass that finds
-        the SAME view of the SAME map as in its previous call -- every pointer its argument blocks hold compared, ``_arm_key`` -- keeps those
-        blocks and its output tensors instead of rebuilding them (about 0.09 ms of Python per view: most of the host's time in a
-        mapping iteration on a small map); the images and gradients of the previous call are then overwritten in place."""
+        ``masked_loss`` -- None for a view scored by ``get_loss_mapping``)."""
         lead = self.passes[0]
         dev, L = lead.dev, lead.L
         while len(self.passes) < len(viewpoints):
@@ -461,8 +457,7 @@ class MapWindowBatch:
             sflag = _rz.super_tiles_flag(N_now, last_pairs)
             for k, vp in enumerate(viewpoints):
                 ctxs.append(self.passes[k]._begin_for_batch(backend, vp, initialization, first if k == 0 else None,
-                                                            None if k == 0 else ctxs[0]["into"], stream, masked[k], forward=not fwd_batch, super_flag=sflag,
-                                                            reuse=reuse_outputs and fwd_batch))
+                                                            None if k == 0 else ctxs[0]["into"], stream, masked[k], forward=not fwd_batch, super_flag=sflag))
             # (the pointer arrays over the passes' argument blocks are made once per window shape: nothing to allocate per iteration)
             key = (n, tuple(m is not None for m in masked))
             ct = getattr(self, "_ct", {}).get(key)
@@ -521,32 +516,8 @@ def _after_forward(self, D, overflow, stream):
     a.num_rendered = D
 
 
-def _arm_key(self, backend, viewpoint, initialization, first, lead_into, masked_loss):
-    """Everything ``_begin_for_batch`` reads that decides what it writes into the pass's argument blocks: identities and device
-    addresses, sizes, modes.  Two calls with equal keys build identical blocks (pointed at identical inputs)."""
-    G, vp = backend.gaussians, viewpoint
-    m = getattr(vp, "static_mask", None)
-    md = getattr(vp, "mono_depth", None)
-    g0 = G._xyz.grad
-    T = backend.config["Training"]
-    return (id(vp), G._xyz.data_ptr(), G._opacity.data_ptr(), G._scaling.data_ptr(), G._rotation.data_ptr(), G._features_dc.data_ptr(),
-            int(G._xyz.shape[0]), int(G._features_rest.shape[1]), int(G.active_sh_degree), int(vp.image_height), int(vp.image_width), vp.FoVx, vp.FoVy,
-            vp.world_view_transform.data_ptr(), vp.full_proj_transform.data_ptr(), vp.camera_center.data_ptr(), vp.projection_matrix.data_ptr(),
-            backend.background.data_ptr(), vp.exposure_a.data_ptr(), vp.exposure_b.data_ptr(), vp.original_image.data_ptr(), id(md),
-            id(m), m._version if torch.is_tensor(m) else None, masked_loss, bool(initialization), id(first), id(lead_into),
-            None if g0 is None else g0.data_ptr(), T["rgb_boundary_threshold"], T.get("alpha", 0.95))
-
-
-def _begin_for_batch(self, backend, viewpoint, initialization, first, lead_into, stream, masked_loss=None, forward=True, super_flag=0, reuse=False):
+def _begin_for_batch(self, backend, viewpoint, initialization, first, lead_into, stream, masked_loss=None, forward=True, super_flag=0):
     """``MapViewPass.run`` up to the forward call (whole view, built-in or static-mask loss, SH degree 0), with LVDGS_FLAG_NO_BLEND."""
-    key = None
-    if reuse and not forward:
-        key = self._arm_key(backend, viewpoint, initialization, first, lead_into, masked_loss)
-        armed = getattr(self, "_armed", None)
-        if armed is not None and armed[0] == key:
-            self.a.flags = (self.a.flags & ~_lib.FLAG_SUPER_TILES) | int(super_flag)
-            return armed[1]
-    self._armed = None
     G, cfg, dev, L = backend.gaussians, backend.config, self.dev, self.L
     T = cfg["Training"]
     N, K = int(G._xyz.shape[0]), 1 + int(G._features_rest.shape[1])
@@ -615,15 +586,8 @@ def _begin_for_batch(self, backend, viewpoint, initialization, first, lead_into,
         if status != _lib.E_CAPACITY:
             _lib.check(status, "lvdgs_forward")
         self._after_forward(int(num.value), status == _lib.E_CAPACITY, stream)
-    ctx = dict(color=color, depth=depth, opacity=opacity, radii=radii, n_touched=n_touched, d_tau=d_tau, d_a=d_a, d_b=d_b, d_m2=d_m2,
-               loss=loss, into=into, install=install, fields=fields, initialization=initialization, masked=masked_loss is not None)
-    if key is not None:
-        # (only inputs that were used as they are can be found again by address -- a converted copy is a new tensor every time -- and the
-        # objects whose id() the key holds are kept alive with it, so that no other object can come to bear the same id)
-        srcs = (backend.background, viewpoint.world_view_transform, viewpoint.full_proj_transform, viewpoint.projection_matrix, viewpoint.camera_center)
-        if all(t.data_ptr() == u.data_ptr() for t, u in zip(cam, srcs)) and _gpu_f32c(viewpoint.original_image, dev):
-            self._armed = (key, ctx, viewpoint, first, lead_into, getattr(viewpoint, "mono_depth", None), getattr(viewpoint, "static_mask", None))
-    return ctx
+    return dict(color=color, depth=depth, opacity=opacity, radii=radii, n_touched=n_touched, d_tau=d_tau, d_a=d_a, d_b=d_b, d_m2=d_m2,
+                loss=loss, into=into, install=install, fields=fields, initialization=initialization, masked=masked_loss is not None)
 
 
 def _backward_for_batch(self, ctx, stats, stream, tail=True, gaussian_pass=True):
@@ -668,7 +632,6 @@ def _finish_for_batch(self, backend, viewpoint, ctx):
 
 
 MapViewPass._begin_for_batch = _begin_for_batch
-MapViewPass._arm_key = _arm_key
 MapViewPass._after_forward = _after_forward
 MapViewPass._backward_for_batch = _backward_for_batch
 MapViewPass._finish_for_batch = _finish_for_batch
