@@ -103,7 +103,8 @@ class SlamSequence:
     """See the module's docstring.  ``run()`` processes the whole dataset and returns the record ``summary()`` builds."""
 
     def __init__(self, config, dataset, gaussians, pipeline_params, background, *, fused="auto", render_fn=render, view_loss_fn=None,
-                 refine_loss_fn=None, keyframe_depth=None, idle_map_iters=0, camera_cls=None, cameras_extent=6.0, on_event=None):
+                 refine_loss_fn=None, keyframe_depth=None, idle_map_iters=0, camera_cls=None, cameras_extent=6.0, on_event=None,
+                 group=None, aux_group=None, bands_ok=None):
         from .backend_map import map_window
         if camera_cls is None:
             from .camera_utils import Camera as camera_cls
@@ -113,6 +114,10 @@ class SlamSequence:
         self.keyframe_depth = keyframe_depth if keyframe_depth is not None else self.default_keyframe_depth
         self.idle_map_iters, self.camera_cls, self.on_event = int(idle_map_iters), camera_cls, on_event
         self._map_window = map_window
+        # several ranks (torch.distributed initialised): every rank runs the whole sequence -- tracking, map initialisation and colour
+        # refinement are one view per iteration: replicas -- and the mapping windows' views are sharded over
+        # `group` (backend_map.map_window); the replicas stay bit-identical, so every rank ends with the same map and trajectory
+        self.group, self.aux_group, self.bands_ok = group, aux_group, bands_ok
         T = config["Training"]
         self.monocular = T["monocular"]
         self.tracking_itr_num, self.kf_interval, self.window_size = T["tracking_itr_num"], T["kf_interval"], T["window_size"]
@@ -169,6 +174,8 @@ class SlamSequence:
         it0, n0 = be.iteration_count, self._n()
         if self.view_loss_fn is not None:
             kw["view_loss_fn"] = self.view_loss_fn
+        if self.group is not None or self.aux_group is not None or self.bands_ok is not None:
+            kw.update(group=self.group, aux_group=self.aux_group, bands_ok=self.bands_ok)
         runs0 = getattr(getattr(be, "_lvdgs_window_batch", None), "runs", 0)
         out = self._map_window(be, window, render_fn=self.render_fn, fused=self.fused is not False, **kw)
         if getattr(getattr(be, "_lvdgs_window_batch", None), "runs", 0) > runs0:

@@ -113,3 +113,48 @@ def test_fused_path_and_autograd_api_path_agree_on_the_sequence(half_kitti_runs)
     assert abs(f["gaussians_last"] - a["gaussians_last"]) <= 0.10 * a["gaussians_last"]
     # and the point of the fused path
     assert f["tracking_plus_mapping_iterations_per_s"] > 1.5 * a["tracking_plus_mapping_iterations_per_s"]
+
+
+def _two_rank_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, os.path.join(HERE, ".."))
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(HERE, "..", "tools"))
+    import lvdgs  # noqa: F401
+    import sequence as tool
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # (both ranks on the box's one GPU: collectives through the host)
+    try:
+        dev = torch.device("cuda", 0)
+        rec, seq = tool.run_sequence(dev, frames=24, scale=0.5, cadence="short", idle=4, refine=20, masks=True, window_size=4, bands_ok=True)
+        G = seq.gaussians
+        q.put((rank, dict(state={k: v.detach().cpu().numpy() for k, v in G._params_by_name().items()},
+                          poses=[(c.R.detach().cpu().numpy(), c.T.detach().cpu().numpy()) for _, c in sorted(seq.cameras.items())],
+                          rec={k: rec[k] for k in ("keyframes", "ate_rmse", "psnr_static", "gaussians_last", "size_changes_by_densification", "window_log")})))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sequence_on_two_ranks_sharing_the_gpu_keeps_the_replicas_bit_identical():
+    """BASELINE configs[3] in miniature on the HIP path: 24 half-size frames, every rank tracking and seeding as a replica, the mapping
+    windows' views (masked keyframes whole, the random views in bands) sharded over two gloo ranks that share the box's GPU.  The ranks end
+    with the same map and trajectory bit for bit."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30900 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=900) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    a, b = got[0], got[1]
+    assert a["rec"] == b["rec"] and a["rec"]["keyframes"] >= 3 and a["rec"]["size_changes_by_densification"] >= 1
+    for k in a["state"]:
+        assert np.array_equal(a["state"][k], b["state"][k]), k
+    for (Ra, Ta), (Rb, Tb) in zip(a["poses"], b["poses"]):
+        assert np.array_equal(Ra, Rb) and np.array_equal(Ta, Tb)
+    assert a["rec"]["ate_rmse"] is not None and a["rec"]["ate_rmse"] < 0.02

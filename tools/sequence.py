@@ -88,13 +88,13 @@ def kitti_sequence(dev, frames=60, scale=1.0, cadence="reference", masks=True, n
 
 
 def run_sequence(dev, frames=60, scale=1.0, cadence="reference", fused="auto", idle=10, refine=500, masks=True, seed=0, training=None,
-                 window_size=None, on_event=None):
+                 window_size=None, on_event=None, **sequence_kwargs):
     torch.manual_seed(seed)
     random.seed(seed)
     cfg, ds, truth = kitti_sequence(dev, frames, scale, cadence, masks, seed=seed, training=training, window_size=window_size)
     del truth
     m = empty_map(cfg, dev)
-    seq = SlamSequence(cfg, ds, m, PIPE, torch.zeros(3, device=dev), fused=fused, idle_map_iters=idle, on_event=on_event)
+    seq = SlamSequence(cfg, ds, m, PIPE, torch.zeros(3, device=dev), fused=fused, idle_map_iters=idle, on_event=on_event, **sequence_kwargs)
     seq.run()
     out = seq.summary()
     out["ate_rmse"] = seq.eval_ate()
