@@ -244,7 +244,13 @@ class MapViewPass:
         fields = [n for n in _PARAM_FIELDS if getattr(G, n).numel() > 0]
         has = [getattr(G, n).grad is not None for n in fields]
         if any(has) and not all(has):
-            raise _lib.LvdgsError("MapViewPass: some of the model's parameters carry a gradient and some do not")
+            # A parameter without a gradient next to parameters with one: its gradient so far is zero.  (The sharded loop gets here: a pruning
+            # pass leaves its gradients in place -- reference utils/slam_backend.py:318-348 returns before the step -- and on the rank that
+            # holds the isotropic term but was dealt no view of that pass, the scales alone carry one.)
+            for n in fields:
+                if getattr(G, n).grad is None:
+                    getattr(G, n).grad = torch.zeros_like(getattr(G, n))
+            has = [True] * len(fields)
         if has[0] and any(not _gpu_f32c(getattr(G, n).grad, dev) for n in fields):
             raise _lib.LvdgsError("MapViewPass: the model's existing gradients are not contiguous float32 tensors on the GPU")
         # A later view of the iteration ADDS its parameter gradients to the ones that are there, inside the backward's last
@@ -548,7 +554,13 @@ def _begin_for_batch(self, backend, viewpoint, initialization, first, lead_into,
     if lead_into is None:   # the batch's first view: as MapViewPass.run decides
         has = [getattr(G, n).grad is not None for n in fields]
         if any(has) and not all(has):
-            raise _lib.LvdgsError("MapViewPass: some of the model's parameters carry a gradient and some do not")
+            # A parameter without a gradient next to parameters with one: its gradient so far is zero.  (The sharded loop gets here: a pruning
+            # pass leaves its gradients in place -- reference utils/slam_backend.py:318-348 returns before the step -- and on the rank that
+            # holds the isotropic term but was dealt no view of that pass, the scales alone carry one.)
+            for n in fields:
+                if getattr(G, n).grad is None:
+                    getattr(G, n).grad = torch.zeros_like(getattr(G, n))
+            has = [True] * len(fields)
         if has[0] and any(not _gpu_f32c(getattr(G, n).grad, dev) for n in fields):
             raise _lib.LvdgsError("MapViewPass: the model's existing gradients are not contiguous float32 tensors on the GPU")
         accumulate, install = has[0], not has[0]

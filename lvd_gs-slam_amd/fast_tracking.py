@@ -266,6 +266,12 @@ class TrackingSession:
                 return True
         return False
 
+    def converged(self):
+        """Has the device's sticky converged flag been raised?  (After ``finish()``: a plain read.)"""
+        if self.host_flags is not None:
+            return float(self.host_flags[0]) != 0.0
+        return float(self.pose_state[17].item()) != 0.0
+
     def finish(self):
         """Synchronise, write the pose back into the viewpoint, return the number of iterations the reference's loop
         would have run (it breaks at the first converged one)."""
@@ -294,6 +300,13 @@ def track_frame_fused(viewpoint, gaussians, config, pipeline_params, background,
             if sess.converged_lagging(poll_lag):
                 break
         applied = sess.finish()
+        # The images a converged frame leaves must not depend on how far the host happened to be ahead of the device: when the flag
+        # was seen before anything else was enqueued behind the converging iteration, one more iteration is (its pose step is a no-op
+        # once the flag stands) -- the package is then ALWAYS the render at the converged pose.  Replicas of a tracker on several
+        # ranks take their keyframe decisions from it and must agree.
+        if applied < n_iter and sess.iterations_enqueued == applied and sess.converged():
+            sess.step()
+            sess.finish()
     if on_iteration is not None:
         for it, v in enumerate(losses[:applied].cpu()):
             on_iteration(it, v, None)
