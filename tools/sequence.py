@@ -65,17 +65,26 @@ SHORT = dict(init_itr_num=210, init_gaussian_update=20, init_gaussian_reset=100,
              mapping_itr_nosingle=10, initial_ba_itr_num=60, gaussian_update_every=30, gaussian_update_offset=10, gaussian_reset=401)
 
 
-def kitti_sequence(dev, frames=60, scale=1.0, cadence="reference", masks=True, n_true=None, seed=0, training=None, window_size=None):
-    """(config, dataset, true map): KITTI-07's frame geometry (x ``scale``), the merged KITTI-07 config with the chosen cadence."""
-    W, H = int(round(1226 * scale)), int(round(370 * scale))
-    fx = fy = 707.0912 * scale
-    cx, cy = 601.8873 * scale, 183.1104 * scale
+# frame geometries: KITTI-07 (configs/mono/KITTI/07.yaml:8-18) and the waymo segment of BASELINE configs[4]'s size (configs/mono/waymo/405841.yaml:5-16,
+# whose Training block also runs 30 mapping iterations per keyframe instead of 10)
+GEOMETRY = {"kitti07": dict(W=1226, H=370, fx=707.0912, cx=601.8873, cy=183.1104, training={}),
+            "waymo": dict(W=1920, H=1280, fx=2066.697564417299, cx=950.5512774150723, cy=641.1870541472169, training={"mapping_itr_nosingle": 30})}
+
+
+def kitti_sequence(dev, frames=60, scale=1.0, cadence="reference", masks=True, n_true=None, seed=0, training=None, window_size=None, geometry="kitti07"):
+    """(config, dataset, true map): a frame geometry of ``GEOMETRY`` (x ``scale``), the merged KITTI-07 config with the chosen cadence."""
+    geo = GEOMETRY[geometry]
+    W, H = int(round(geo["W"] * scale)), int(round(geo["H"] * scale))
+    fx = fy = geo["fx"] * scale
+    cx, cy = geo["cx"] * scale, geo["cy"] * scale
     tr = dict(SHORT) if cadence == "short" else {}
+    tr.update(geo["training"])
     if window_size is not None:
         tr.update(window_size=window_size, pose_window=min(3, window_size - 1))
     tr.update(training or {})
     cfg = sequence_config(W, H, **tr)
     cfg["Dataset"]["Calibration"].update(fx=fx, fy=fy, cx=cx, cy=cy)
+    n_true = int(600_000 * scale * scale * (W * H) / (1226.0 * scale * 370.0 * scale) * (707.0912 / geo["fx"]) ** 2) if n_true is None and geometry != "kitti07" else n_true
     n_true = int(600_000 * scale * scale) if n_true is None else n_true
     # opaque surfaces of 1.5..16-pixel footprints (x scale) -- texture at the scale of a few pixels, which is what keeps a SLAM map's
     # Gaussians small and many (the 4..64-pixel footprints of the surface WORKLOADS render to a blur that a few hundred large Gaussians
@@ -88,10 +97,10 @@ def kitti_sequence(dev, frames=60, scale=1.0, cadence="reference", masks=True, n
 
 
 def run_sequence(dev, frames=60, scale=1.0, cadence="reference", fused="auto", idle=10, refine=500, masks=True, seed=0, training=None,
-                 window_size=None, on_event=None, **sequence_kwargs):
+                 window_size=None, on_event=None, geometry="kitti07", **sequence_kwargs):
     torch.manual_seed(seed)
     random.seed(seed)
-    cfg, ds, truth = kitti_sequence(dev, frames, scale, cadence, masks, seed=seed, training=training, window_size=window_size)
+    cfg, ds, truth = kitti_sequence(dev, frames, scale, cadence, masks, seed=seed, training=training, window_size=window_size, geometry=geometry)
     del truth
     m = empty_map(cfg, dev)
     seq = SlamSequence(cfg, ds, m, PIPE, torch.zeros(3, device=dev), fused=fused, idle_map_iters=idle, on_event=on_event, **sequence_kwargs)
@@ -113,7 +122,7 @@ def run_sequence(dev, frames=60, scale=1.0, cadence="reference", fused="auto", i
                                          for i in range(len(ds) - 1)))
     out["window_log"] = seq.window_log
     out["batched_window_runs"] = int(getattr(getattr(seq.backend, "_lvdgs_window_batch", None), "runs", 0))
-    out.update(width=ds.width, height=ds.height, cadence=cadence, fused=fused, idle_map_iters=idle, keyframes_carry_static_mask=masks)
+    out.update(geometry=geometry, width=ds.width, height=ds.height, cadence=cadence, fused=fused, idle_map_iters=idle, keyframes_carry_static_mask=masks)
     return out, seq
 
 
@@ -127,13 +136,14 @@ def main():
     ap.add_argument("--refine", type=int, default=500)
     ap.add_argument("--no-masks", action="store_true")
     ap.add_argument("--window-size", type=int, default=None)
+    ap.add_argument("--geometry", choices=sorted(GEOMETRY), default="kitti07")
     ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     t0 = time.perf_counter()
     ev = (lambda e, s: print(f"  frame {s.counts['frames']:3d} {e:16s} N = {s._n()}", file=sys.stderr)) if a.verbose else None
     out, _ = run_sequence(dev, a.frames, a.scale, a.cadence, False if a.no_fused else "auto", a.idle, a.refine, not a.no_masks,
-                          window_size=a.window_size, on_event=ev)
+                          window_size=a.window_size, on_event=ev, geometry=a.geometry)
     out["tool_seconds"] = round(time.perf_counter() - t0, 2)
     print(json.dumps(out))
 
