@@ -33,6 +33,9 @@ from types import SimpleNamespace
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# (the pool's host driver supports dmabuf IPC only: without this RCCL's buffer sharing between the ranks of a node fails with
+# `hipIpcGetMemHandle: invalid argument`; exported by the environment already, kept here for a launcher that drops it)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 
