@@ -71,7 +71,8 @@ GEOMETRY = {"kitti07": dict(W=1226, H=370, fx=707.0912, cx=601.8873, cy=183.1104
             "waymo": dict(W=1920, H=1280, fx=2066.697564417299, cx=950.5512774150723, cy=641.1870541472169, training={"mapping_itr_nosingle": 30})}
 
 
-def kitti_sequence(dev, frames=60, scale=1.0, cadence="reference", masks=True, n_true=None, seed=0, training=None, window_size=None, geometry="kitti07"):
+def kitti_sequence(dev, frames=60, scale=1.0, cadence="reference", masks=True, n_true=None, seed=0, training=None, window_size=None, geometry="kitti07",
+                   pcd_downsample=None):
     """(config, dataset, true map): a frame geometry of ``GEOMETRY`` (x ``scale``), the merged KITTI-07 config with the chosen cadence."""
     geo = GEOMETRY[geometry]
     W, H = int(round(geo["W"] * scale)), int(round(geo["H"] * scale))
@@ -84,6 +85,8 @@ def kitti_sequence(dev, frames=60, scale=1.0, cadence="reference", masks=True, n
     tr.update(training or {})
     cfg = sequence_config(W, H, **tr)
     cfg["Dataset"]["Calibration"].update(fx=fx, fy=fy, cx=cx, cy=cy)
+    if pcd_downsample is not None:   # (init, later keyframes): seeds per keyframe = valid pixels / this (configs/mono/KITTI/base_config.yaml:13-14: 32, 64)
+        cfg["Dataset"].update(pcd_downsample_init=int(pcd_downsample[0]), pcd_downsample=int(pcd_downsample[1]))
     n_true = int(600_000 * scale * scale * (W * H) / (1226.0 * scale * 370.0 * scale) * (707.0912 / geo["fx"]) ** 2) if n_true is None and geometry != "kitti07" else n_true
     n_true = int(600_000 * scale * scale) if n_true is None else n_true
     # opaque surfaces of 1.5..16-pixel footprints (x scale) -- texture at the scale of a few pixels, which is what keeps a SLAM map's
@@ -97,10 +100,11 @@ def kitti_sequence(dev, frames=60, scale=1.0, cadence="reference", masks=True, n
 
 
 def run_sequence(dev, frames=60, scale=1.0, cadence="reference", fused="auto", idle=10, refine=500, masks=True, seed=0, training=None,
-                 window_size=None, on_event=None, geometry="kitti07", **sequence_kwargs):
+                 window_size=None, on_event=None, geometry="kitti07", pcd_downsample=None, **sequence_kwargs):
     torch.manual_seed(seed)
     random.seed(seed)
-    cfg, ds, truth = kitti_sequence(dev, frames, scale, cadence, masks, seed=seed, training=training, window_size=window_size, geometry=geometry)
+    cfg, ds, truth = kitti_sequence(dev, frames, scale, cadence, masks, seed=seed, training=training, window_size=window_size, geometry=geometry,
+                                    pcd_downsample=pcd_downsample)
     del truth
     m = empty_map(cfg, dev)
     seq = SlamSequence(cfg, ds, m, PIPE, torch.zeros(3, device=dev), fused=fused, idle_map_iters=idle, on_event=on_event, **sequence_kwargs)
@@ -137,13 +141,15 @@ def main():
     ap.add_argument("--no-masks", action="store_true")
     ap.add_argument("--window-size", type=int, default=None)
     ap.add_argument("--geometry", choices=sorted(GEOMETRY), default="kitti07")
+    ap.add_argument("--pcd-downsample", type=int, nargs=2, default=None, metavar=("INIT", "KEYFRAME"),
+                    help="seed one Gaussian per INIT valid pixels of frame 0 and per KEYFRAME of every later keyframe (the config's 32 / 64): smaller = a larger map")
     ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     t0 = time.perf_counter()
     ev = (lambda e, s: print(f"  frame {s.counts['frames']:3d} {e:16s} N = {s._n()}", file=sys.stderr)) if a.verbose else None
     out, _ = run_sequence(dev, a.frames, a.scale, a.cadence, False if a.no_fused else "auto", a.idle, a.refine, not a.no_masks,
-                          window_size=a.window_size, on_event=ev, geometry=a.geometry)
+                          window_size=a.window_size, on_event=ev, geometry=a.geometry, pcd_downsample=a.pcd_downsample)
     out["tool_seconds"] = round(time.perf_counter() - t0, 2)
     print(json.dumps(out))
 
