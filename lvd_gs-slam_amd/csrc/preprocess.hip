@@ -469,6 +469,12 @@ constexpr int BIG_RUN = 64;      // a Gaussian with more pairs than this is summ
 #define LVDGS_PBWD_BIG_UNROLL 2
 #endif
 constexpr int BIG_UNROLL = LVDGS_PBWD_BIG_UNROLL;   // ... LVDGS_PBWD_BIG_UNROLL records per lane and trip
+#ifndef LVDGS_PBWD_SEG
+#define LVDGS_PBWD_SEG 512   // slots of a large-footprint wave's region swept per round (sum_region_compacted): 512 or 1024
+#endif
+// a wave's LDS staging area: WAVE_CHUNK records of the streaming path, or the compacted sweep's pass of records + its lists
+template <int PF>
+constexpr int STAGE_BYTES = (WAVE_CHUNK * PF * 4 > 128 * PF * 4 + LVDGS_PBWD_SEG * 2 + 256 ? WAVE_CHUNK * PF * 4 : (128 * PF * 4 + LVDGS_PBWD_SEG * 2 + 256 + 15) / 16 * 16);
 
 #ifndef LVDGS_PBWD_WGS
 #define LVDGS_PBWD_WGS 5
@@ -518,35 +524,44 @@ __device__ LVDGS_BIG_PATH_ATTR PairSums sum_region_compacted(const float *__rest
         //   3. every lane adds up ITS Gaussian's records of the pass from LDS, in slot order (the order of the streaming path);
         //      a Gaussian with more than 64 records in the pass is summed by the whole wave (lane l: records l, l + 64, ...) and
         //      folded in a fixed order.
-        constexpr uint32_t SEG = 512u;
-        constexpr int AUX_BYTES = (int)SEG * 2 + 64 * 2 + 64;                                   // list, per-lane prefix, per-lane flag bits
+        constexpr uint32_t SEG = LVDGS_PBWD_SEG;
+        constexpr uint32_t FL = SEG / 64u;   // flags (slots) per lane
+        static_assert(FL == 8u || FL == 16u, "one 8- or 16-byte load of flags per lane");
+        constexpr int AUX_BYTES = (int)SEG * 2 + 64 * 2 + 64 * 2;                               // list, per-lane prefix, per-lane flag bits
         constexpr uint32_t CAP = 128u;   // records per pass: the same number in both forms of the kernel, so that both add in the same order
-        static_assert(CAP * PF * 4 + AUX_BYTES <= WAVE_CHUNK * PF * 4, "fits the wave's staging area");
+        static_assert(CAP * PF * 4 + AUX_BYTES <= STAGE_BYTES<PF>, "fits the wave's staging area");
         float2 *const s_rec = reinterpret_cast<float2 *>(s_mem);
         uint16_t *const s_list = reinterpret_cast<uint16_t *>(s_mem + CAP * PF * 4);   // offsets (in the segment) of the slots with a record
         uint16_t *const s_before = s_list + SEG;                                                  // records of the segment in front of lane l's eight slots
-        uint8_t *const s_bits = reinterpret_cast<uint8_t *>(s_before + 64);                       // lane l's eight flags
+        uint16_t *const s_bits = s_before + 64;                                                   // lane l's FL flags
         const float2 *pg = reinterpret_cast<const float2 *>(pair_grads);
-        const uint32_t w_lo = w_first & ~7u;   // w_first rounded down to the flags' 8-byte loads
+        const uint32_t w_lo = w_first & ~(FL - 1u);   // w_first rounded down to the flags' 8- / 16-byte loads
+        struct Flags { uint32_t w[FL / 4]; };
         auto flags_of = [&](uint32_t seg) {   // (pair_valid is padded by 16 bytes)
-            const uint32_t s0 = seg + 8u * (uint32_t)lane;
-            return s0 < w_hi ? *reinterpret_cast<const uint2 *>(pair_valid + s0) : make_uint2(0u, 0u);
+            const uint32_t s0 = seg + FL * (uint32_t)lane;
+            Flags f{};
+            if (s0 < w_hi) {
+                if constexpr (FL == 8u) { const uint2 v = *reinterpret_cast<const uint2 *>(pair_valid + s0); f.w[0] = v.x; f.w[1] = v.y; }
+                else { const uint4 v = *reinterpret_cast<const uint4 *>(pair_valid + s0); f.w[0] = v.x; f.w[1] = v.y; f.w[2] = v.z; f.w[3] = v.w; }
+            }
+            return f;
         };
-        uint2 fl_next = w_lo < w_hi ? flags_of(w_lo) : make_uint2(0u, 0u);
+        Flags fl_next = w_lo < w_hi ? flags_of(w_lo) : Flags{};
         for (uint32_t seg = w_lo; seg < w_hi; seg += SEG) {
-            const uint2 fl = fl_next;
+            const Flags fl = fl_next;
             if (seg + SEG < w_hi) fl_next = flags_of(seg + SEG);
             // ---- 1. which of the segment's slots hold a record ----
-            uint32_t mine = 0;   // bit b: slot seg + 8 lane + b
+            uint32_t mine = 0;   // bit b: slot seg + FL lane + b
 #pragma unroll
-            for (int b = 0; b < 4; b++) {
-                if ((fl.x >> (8 * b)) & 0xffu) mine |= 1u << b;
-                if ((fl.y >> (8 * b)) & 0xffu) mine |= 16u << b;
-            }
+            for (int w = 0; w < (int)(FL / 4); w++)
+#pragma unroll
+                for (int b = 0; b < 4; b++)
+                    if ((fl.w[w] >> (8 * b)) & 0xffu) mine |= 1u << (4 * w + b);
             {   // slots outside the wave's region are other waves' (or, behind the frame's last pair, nobody's: their flags are stale)
-                const uint32_t s0 = seg + 8u * (uint32_t)lane;
-                const uint32_t keep_hi = s0 >= w_hi ? 0u : (w_hi - s0 >= 8u ? 0xffu : (1u << (w_hi - s0)) - 1u);
-                const uint32_t keep_lo = s0 >= w_first ? 0xffu : (w_first - s0 >= 8u ? 0u : (0xffu << (w_first - s0)) & 0xffu);
+                constexpr uint32_t ALL = (1u << FL) - 1u;
+                const uint32_t s0 = seg + FL * (uint32_t)lane;
+                const uint32_t keep_hi = s0 >= w_hi ? 0u : (w_hi - s0 >= FL ? ALL : (1u << (w_hi - s0)) - 1u);
+                const uint32_t keep_lo = s0 >= w_first ? ALL : (w_first - s0 >= FL ? 0u : (ALL << (w_first - s0)) & ALL);
                 mine &= keep_hi & keep_lo;
             }
             const uint32_t cnt = (uint32_t)__popc(mine);
@@ -560,8 +575,8 @@ __device__ LVDGS_BIG_PATH_ATTR PairSums sum_region_compacted(const float *__rest
             {
                 uint32_t at = inc - cnt;
                 s_before[lane] = (uint16_t)at;
-                s_bits[lane] = (uint8_t)mine;
-                for (uint32_t m = mine; m; m &= m - 1u) s_list[at++] = (uint16_t)(8u * (uint32_t)lane + (uint32_t)__builtin_ctz(m));
+                s_bits[lane] = (uint16_t)mine;
+                for (uint32_t m = mine; m; m &= m - 1u) s_list[at++] = (uint16_t)(FL * (uint32_t)lane + (uint32_t)__builtin_ctz(m));
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -570,7 +585,7 @@ __device__ LVDGS_BIG_PATH_ATTR PairSums sum_region_compacted(const float *__rest
             auto records_before = [&](uint32_t slot) {   // slot in [seg, seg + SEG]
                 const uint32_t o = slot - seg;
                 if (o >= SEG) return total;
-                return (uint32_t)s_before[o >> 3] + (uint32_t)__popc((uint32_t)s_bits[o >> 3] & ((1u << (o & 7u)) - 1u));
+                return (uint32_t)s_before[o / FL] + (uint32_t)__popc((uint32_t)s_bits[o / FL] & ((1u << (o % FL)) - 1u));
             };
             uint32_t lo = 0u, hi = 0u;
             if (first < last && first < seg + SEG && last > seg) { lo = records_before(max(first, seg)); hi = records_before(min(last, seg + SEG)); }
@@ -752,7 +767,7 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p, GradAcc 
     // the rotation matrix -- and land while it runs: with the workgroup-wide staging of before (two workgroup barriers per
     // chunk) the kernel was the sum of a memory phase and an arithmetic phase, every resident workgroup in the same one
     // (ablation builds: 26.7 us without the arithmetic, 28.9 without the sums, 49.5 together).
-    __shared__ float4 s_pg4[4][WAVE_CHUNK * PF / 4];   // (the last load instruction of a chunk is masked to the lanes inside it)
+    __shared__ float4 s_pg4[4][STAGE_BYTES<PF> / 16];   // (the last load instruction of a chunk is masked to the lanes inside it)
     __shared__ uint32_t s_valid4[4][WAVE_CHUNK / 4];
     float A[10];
 #pragma unroll

@@ -143,13 +143,15 @@ def main():
     ap.add_argument("--geometry", choices=sorted(GEOMETRY), default="kitti07")
     ap.add_argument("--pcd-downsample", type=int, nargs=2, default=None, metavar=("INIT", "KEYFRAME"),
                     help="seed one Gaussian per INIT valid pixels of frame 0 and per KEYFRAME of every later keyframe (the config's 32 / 64): smaller = a larger map")
+    ap.add_argument("--seed", type=int, default=0, help="scene, trajectory noise, dynamic objects and the loops' random draws")
     ap.add_argument("--verbose", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     t0 = time.perf_counter()
     ev = (lambda e, s: print(f"  frame {s.counts['frames']:3d} {e:16s} N = {s._n()}", file=sys.stderr)) if a.verbose else None
-    out, _ = run_sequence(dev, a.frames, a.scale, a.cadence, False if a.no_fused else "auto", a.idle, a.refine, not a.no_masks,
+    out, _ = run_sequence(dev, a.frames, a.scale, a.cadence, False if a.no_fused else "auto", a.idle, a.refine, not a.no_masks, seed=a.seed,
                           window_size=a.window_size, on_event=ev, geometry=a.geometry, pcd_downsample=a.pcd_downsample)
+    out["seed"] = a.seed
     out["tool_seconds"] = round(time.perf_counter() - t0, 2)
     print(json.dumps(out))
 
