@@ -469,12 +469,15 @@ constexpr int BIG_RUN = 64;      // a Gaussian with more pairs than this is summ
 #define LVDGS_PBWD_BIG_UNROLL 2
 #endif
 constexpr int BIG_UNROLL = LVDGS_PBWD_BIG_UNROLL;   // ... LVDGS_PBWD_BIG_UNROLL records per lane and trip
+#ifndef LVDGS_PBWD_TAKE
+#define LVDGS_PBWD_TAKE 2   // records a lane of the compacted sweep requests from LDS before it adds the first (sum_region_compacted, step 3)
+#endif
 #ifndef LVDGS_PBWD_SEG
 #define LVDGS_PBWD_SEG 512   // slots of a large-footprint wave's region swept per round (sum_region_compacted): 512 or 1024
 #endif
 // a wave's LDS staging area: WAVE_CHUNK records of the streaming path, or the compacted sweep's pass of records + its lists
 template <int PF>
-constexpr int STAGE_BYTES = (WAVE_CHUNK * PF * 4 > 128 * PF * 4 + LVDGS_PBWD_SEG * 2 + 256 ? WAVE_CHUNK * PF * 4 : (128 * PF * 4 + LVDGS_PBWD_SEG * 2 + 256 + 15) / 16 * 16);
+constexpr int STAGE_BYTES = (WAVE_CHUNK * PF * 4 > 128 * PF * 4 + LVDGS_PBWD_SEG * 2 + 320 ? WAVE_CHUNK * PF * 4 : (128 * PF * 4 + LVDGS_PBWD_SEG * 2 + 320 + 15) / 16 * 16);
 
 #ifndef LVDGS_PBWD_WGS
 #define LVDGS_PBWD_WGS 5
@@ -494,7 +497,28 @@ __device__ __forceinline__ void loads_complete_here(int32_t &radius, uint32_t &s
 // The pair sums of a wave that holds large-footprint Gaussians (a function of its own so that it can be built as a call,
 // LVDGS_PBWD_INLINE_BIG = 0: measured, slower).
 // s_mem: the wave's LDS staging area.
+#ifdef LVDGS_DIAG_PBWD
+// diagnostic build (tools/pbwd_diag.py): clocks of the compacted sweep per wave (registers; one row of eight values per wave and launch,
+// no atomics -- thousands of waves adding to the same eight words cost more than the kernel).
+// [0] 1, [1] whole sweep, [2] flags -> list (wait, masks, scan, list, barrier), [3] gather (requests -> LDS, barrier), [4] sums,
+// [5] segments, [6] passes, [7] records
+constexpr int PBWD_DIAG_WAVES = 4096;
+constexpr int PBWD_DIAG_VALUES = 12;   // [8] trips of the lanes' own loop (the longest lane's), [9] Gaussians summed by the whole wave, [10] clocks of those
+__device__ unsigned long long g_pbwd_diag[PBWD_DIAG_WAVES * PBWD_DIAG_VALUES];
+#define PBWD_CLK(x) const unsigned long long x = __builtin_readcyclecounter()
+#define PBWD_ADD(k, v) (diag[k] += (unsigned long long)(v))
+#else
+#define PBWD_CLK(x)
+#define PBWD_ADD(k, v)
+#endif
 struct PairSums { float A[10]; };
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <bool POSE_ONLY>
+__device__ __forceinline__ void unpack_sums(const v2f (&P)[POSE_ONLY ? PAIR_FLOATS_POSE / 2 : PAIR_FLOATS / 2], float (&A)[10]) {
+    A[0] = P[0].x; A[1] = P[0].y; A[2] = P[1].x; A[3] = P[1].y; A[4] = P[2].x;
+    if constexpr (POSE_ONLY) { A[5] = 0.f; A[6] = 0.f; A[7] = 0.f; A[8] = 0.f; A[9] = P[2].y; }
+    else { A[5] = P[2].y; A[6] = P[3].x; A[7] = P[3].y; A[8] = P[4].x; A[9] = P[4].y; }
+}
 #ifndef LVDGS_PBWD_INLINE_BIG
 #define LVDGS_PBWD_INLINE_BIG 1   // A/B builds: 0 = a function call (same box, config 3 / opaque surfaces: 50.5 / 96 us against 44.5 / 74.3 inlined: the spills around the call cost more than the separate register allocation returns)
 #endif
@@ -508,9 +532,11 @@ __device__ LVDGS_BIG_PATH_ATTR PairSums sum_region_compacted(const float *__rest
                                                                    uint32_t first, uint32_t last, uint32_t w_first, uint32_t w_hi) {
     constexpr int PF = POSE_ONLY ? PAIR_FLOATS_POSE : PAIR_FLOATS;
     const int lane = threadIdx.x & 63;
-    float A[10];
+    // the ten sums as packed pairs, in the record's own layout ([0,1] [2,3] [4,5] [6,7] [8,9]; pose-only [0,1] [2,3] [4,9]): a record is
+    // added with PF / 2 v_pk_add_f32 -- the same IEEE additions, two per instruction
+    v2f A2[PF / 2];
 #pragma unroll
-    for (int k = 0; k < 10; k++) A[k] = 0.f;
+    for (int k = 0; k < PF / 2; k++) A2[k] = v2f{0.f, 0.f};
     {
         // A wave that holds large-footprint Gaussians (hundreds of pairs each: the stuff opaque surfaces are made of).  Of their
         // records only those in front of their tiles' last contributors exist -- a tenth on opaque surfaces -- and a lane that
@@ -527,13 +553,19 @@ __device__ LVDGS_BIG_PATH_ATTR PairSums sum_region_compacted(const float *__rest
         constexpr uint32_t SEG = LVDGS_PBWD_SEG;
         constexpr uint32_t FL = SEG / 64u;   // flags (slots) per lane
         static_assert(FL == 8u || FL == 16u, "one 8- or 16-byte load of flags per lane");
-        constexpr int AUX_BYTES = (int)SEG * 2 + 64 * 2 + 64 * 2;                               // list, per-lane prefix, per-lane flag bits
+        constexpr int AUX_BYTES = (int)SEG * 2 + 64 * 2 + 64 * 2 + PF * 4;                      // list, per-lane prefix, per-lane flag bits, a record of zeros
         constexpr uint32_t CAP = 128u;   // records per pass: the same number in both forms of the kernel, so that both add in the same order
         static_assert(CAP * PF * 4 + AUX_BYTES <= STAGE_BYTES<PF>, "fits the wave's staging area");
         float2 *const s_rec = reinterpret_cast<float2 *>(s_mem);
         uint16_t *const s_list = reinterpret_cast<uint16_t *>(s_mem + CAP * PF * 4);   // offsets (in the segment) of the slots with a record
         uint16_t *const s_before = s_list + SEG;                                                  // records of the segment in front of lane l's eight slots
         uint16_t *const s_bits = s_before + 64;                                                   // lane l's FL flags
+        // a record of zeros behind them (8-byte aligned): what the lanes of step 3 read where their run has ended -- adding +0 to a sum
+        // that started at +0 leaves its bits as they are -- so that TAKE records can be requested from LDS before the first is added
+        float2 *const s_zero = reinterpret_cast<float2 *>(s_bits + 64);
+        constexpr uint32_t ZERO_AT = (uint32_t)((CAP * PF * 4 + SEG * 2 + 64 * 2 + 64 * 2) / 8);   // s_zero as an index of s_rec's float2
+        static_assert((CAP * PF * 4 + SEG * 2 + 64 * 2 + 64 * 2) % 8 == 0, "aligned");
+        if (lane < PF / 2) s_zero[lane] = make_float2(0.f, 0.f);
         const float2 *pg = reinterpret_cast<const float2 *>(pair_grads);
         const uint32_t w_lo = w_first & ~(FL - 1u);   // w_first rounded down to the flags' 8- / 16-byte loads
         struct Flags { uint32_t w[FL / 4]; };
@@ -547,7 +579,14 @@ __device__ LVDGS_BIG_PATH_ATTR PairSums sum_region_compacted(const float *__rest
             return f;
         };
         Flags fl_next = w_lo < w_hi ? flags_of(w_lo) : Flags{};
+#ifdef LVDGS_DIAG_PBWD
+        unsigned long long diag[PBWD_DIAG_VALUES] = {};
+#endif
+        PBWD_CLK(t_begin);
+        PBWD_ADD(0, 1);
         for (uint32_t seg = w_lo; seg < w_hi; seg += SEG) {
+            PBWD_CLK(t_seg);
+            PBWD_ADD(5, 1);
             const Flags fl = fl_next;
             if (seg + SEG < w_hi) fl_next = flags_of(seg + SEG);
             // ---- 1. which of the segment's slots hold a record ----
@@ -565,13 +604,16 @@ __device__ LVDGS_BIG_PATH_ATTR PairSums sum_region_compacted(const float *__rest
                 mine &= keep_hi & keep_lo;
             }
             const uint32_t cnt = (uint32_t)__popc(mine);
+            // inclusive prefix over the wave: row_shr:1,2,4,8 inside the 16-lane rows, row_bcast:15 / :31 chain the rows (six DPP adds
+            // instead of six ds_bpermute round trips)
             uint32_t inc = cnt;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t x = (uint32_t)__shfl_up((int)inc, off, 64);
-                if (lane >= off) inc += x;
-            }
-            const uint32_t total = (uint32_t)__shfl((int)inc, 63, 64);
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, false);
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, false);
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, false);
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, false);
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xa, 0xf, false);
+            inc += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xc, 0xf, false);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
             {
                 uint32_t at = inc - cnt;
                 s_before[lane] = (uint16_t)at;
@@ -589,7 +631,12 @@ __device__ LVDGS_BIG_PATH_ATTR PairSums sum_region_compacted(const float *__rest
             };
             uint32_t lo = 0u, hi = 0u;
             if (first < last && first < seg + SEG && last > seg) { lo = records_before(max(first, seg)); hi = records_before(min(last, seg + SEG)); }
+            PBWD_CLK(t_list);
+            PBWD_ADD(2, t_list - t_seg);
+            PBWD_ADD(7, total);
             for (uint32_t p0 = 0; p0 < total; p0 += CAP) {
+                PBWD_CLK(t_pass);
+                PBWD_ADD(6, 1);
                 const uint32_t n = min(CAP, total - p0);
                 // ---- 2. the pass's records, densely into LDS ----
                 for (uint32_t j0 = (uint32_t)lane; j0 < n; j0 += 64u * BIG_UNROLL) {
@@ -614,27 +661,53 @@ __device__ LVDGS_BIG_PATH_ATTR PairSums sum_region_compacted(const float *__rest
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 // ---- 3. every Gaussian's share of the pass ----
+                PBWD_CLK(t_gathered);
+                PBWD_ADD(3, t_gathered - t_pass);
                 const uint32_t a = max(lo, p0), b = min(hi, p0 + n);   // (empty when a >= b)
                 const bool wide = b > a && b - a > 64u;
-                auto take = [&](float (&S)[10], uint32_t t) {
-                    const float2 *r = s_rec + (PF / 2) * (t - p0);
-                    const float2 a0 = r[0], a1 = r[1], a2 = r[2];
-                    S[0] += a0.x; S[1] += a0.y; S[2] += a1.x; S[3] += a1.y; S[4] += a2.x;
-                    if constexpr (POSE_ONLY) S[9] += a2.y;
-                    else {
-                        const float2 a3 = r[3], a4 = r[4];
-                        S[5] += a2.y; S[6] += a3.x; S[7] += a3.y; S[8] += a4.x; S[9] += a4.y;
-                    }
+                auto take = [&](v2f (&S)[PF / 2], uint32_t t) {
+                    const v2f *r = reinterpret_cast<const v2f *>(s_rec) + (PF / 2) * (t - p0);
+#pragma unroll
+                    for (int k = 0; k < PF / 2; k++) S[k] += r[k];
                 };
-                if (!wide)
-                    for (uint32_t t = a; t < b; t++) take(A, t);
+                if (!wide) {
+                    // TAKE records requested before the first is added (a lane's run is a chain of LDS round trips otherwise: the
+                    // lane with the longest run of the pass -- tens of records where a near surface fills its tiles -- sets the
+                    // wave's time); the additions are the same ones in the same order
+                    constexpr int TAKE = LVDGS_PBWD_TAKE;
+                    for (uint32_t t = a; t < b; t += TAKE) {
+                        v2f v[TAKE][PF / 2];
+#pragma unroll
+                        for (int u = 0; u < TAKE; u++) {
+                            const v2f *r = reinterpret_cast<const v2f *>(s_rec) + (t + u < b ? (PF / 2) * (t + u - p0) : ZERO_AT);
+#pragma unroll
+                            for (int k = 0; k < PF / 2; k++) v[u][k] = r[k];
+                        }
+#pragma unroll
+                        for (int u = 0; u < TAKE; u++) {
+#pragma unroll
+                            for (int k = 0; k < PF / 2; k++) A2[k] += v[u][k];
+                        }
+                    }
+                }
+#ifdef LVDGS_DIAG_PBWD
+                {
+                    int trips = (!wide && b > a) ? (int)((b - a + LVDGS_PBWD_TAKE - 1) / LVDGS_PBWD_TAKE) : 0;
+                    for (int off = 32; off; off >>= 1) trips = max(trips, __shfl_xor(trips, off, 64));
+                    PBWD_ADD(8, trips);
+                    PBWD_ADD(9, __popcll(__ballot(wide)));
+                }
+#endif
+                PBWD_CLK(t_wide);
                 for (uint64_t todo = __ballot(wide); todo; todo &= todo - 1) {
                     const int src = __builtin_ctzll(todo);
-                    const uint32_t wa = (uint32_t)__shfl((int)a, src, 64), wb = (uint32_t)__shfl((int)b, src, 64);
-                    float S[10];
+                    const uint32_t wa = (uint32_t)__builtin_amdgcn_readlane((int)a, src), wb = (uint32_t)__builtin_amdgcn_readlane((int)b, src);   // (src is wave-uniform)
+                    v2f S2[PF / 2];
 #pragma unroll
-                    for (int k = 0; k < 10; k++) S[k] = 0.f;
-                    for (uint32_t t = wa + (uint32_t)lane; t < wb; t += 64u) take(S, t);
+                    for (int k = 0; k < PF / 2; k++) S2[k] = v2f{0.f, 0.f};
+                    for (uint32_t t = wa + (uint32_t)lane; t < wb; t += 64u) take(S2, t);
+                    float S[10];
+                    unpack_sums<POSE_ONLY>(S2, S);
                     // the 64 partial sums of every value, folded in a fixed order: halves of the wave, pairs of rows, then inside the rows
                     float b0 = fold16(fold32(S[0], S[1]), fold32(S[2], S[3]));   // rows: S0 S2 S1 S3
                     float b1 = fold16(fold32(S[4], S[5]), fold32(S[6], S[7]));   // rows: S4 S6 S5 S7
@@ -644,18 +717,32 @@ __device__ LVDGS_BIG_PATH_ATTR PairSums sum_region_compacted(const float *__rest
                     auto at_lane = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
                     const float tot[10] = {at_lane(b0, 15), at_lane(b0, 47), at_lane(b0, 31), at_lane(b0, 63), at_lane(b1, 15), at_lane(b1, 47),
                                            at_lane(b1, 31), at_lane(b1, 63), at_lane(b2, 15), at_lane(b2, 47)};
-#pragma unroll
-                    for (int k = 0; k < 10; k++)
-                        if (lane == src) A[k] += tot[k];
+                    if (lane == src) {   // (tot[5..8] are zero in the pose-only form)
+                        A2[0] += v2f{tot[0], tot[1]}; A2[1] += v2f{tot[2], tot[3]};
+                        if constexpr (POSE_ONLY) A2[2] += v2f{tot[4], tot[9]};
+                        else { A2[2] += v2f{tot[4], tot[5]}; A2[3] += v2f{tot[6], tot[7]}; A2[4] += v2f{tot[8], tot[9]}; }
+                    }
                 }
+                PBWD_CLK(t_wide_done);
+                PBWD_ADD(10, t_wide_done - t_wide);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
+                PBWD_CLK(t_summed);
+                PBWD_ADD(4, t_summed - t_gathered);
             }
         }
+        PBWD_CLK(t_end);
+        PBWD_ADD(1, t_end - t_begin);
+#ifdef LVDGS_DIAG_PBWD
+        {
+            const int w = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+            if (lane == 0 && w < PBWD_DIAG_WAVES)
+                for (int k = 0; k < PBWD_DIAG_VALUES; k++) g_pbwd_diag[PBWD_DIAG_VALUES * w + k] += diag[k];
+        }
+#endif
     }
     PairSums out;
-#pragma unroll
-    for (int k = 0; k < 10; k++) out.A[k] = A[k];
+    unpack_sums<POSE_ONLY>(A2, out.A);
     return out;
 }
 
@@ -1315,3 +1402,15 @@ int launch_mark_visible(int N, const float *means3D, const float *view, uint8_t 
 }
 
 }  // namespace lvdgs
+
+#ifdef LVDGS_DIAG_PBWD
+extern "C" int lvdgs_diag_pbwd(unsigned long long *out_4096x8, int reset) {   // (rows of PBWD_DIAG_VALUES = 12)
+    constexpr size_t BYTES = (size_t)lvdgs::PBWD_DIAG_WAVES * lvdgs::PBWD_DIAG_VALUES * sizeof(unsigned long long);
+    if (out_4096x8 && hipMemcpyFromSymbol(out_4096x8, HIP_SYMBOL(lvdgs::g_pbwd_diag), BYTES) != hipSuccess) return LVDGS_E_HIP;
+    if (reset) {
+        void *dptr = nullptr;
+        if (hipGetSymbolAddress(&dptr, HIP_SYMBOL(lvdgs::g_pbwd_diag)) != hipSuccess || hipMemset(dptr, 0, BYTES) != hipSuccess) return LVDGS_E_HIP;
+    }
+    return LVDGS_OK;
+}
+#endif

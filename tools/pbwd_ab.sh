@@ -5,7 +5,7 @@ OUT=${OUT:-gpurun_out/pbwd_ab}
 mkdir -p $OUT
 for n in "$@"; do
   L=$PWD/lvd_gs-slam_amd/lib_$n/liblvdgs.so; [ "$n" = default ] && L=$PWD/lvd_gs-slam_amd/lib/liblvdgs.so
-  for W in surface_100k_1920x1080; do
+  for W in ${WORKLOADS:-surface_100k_1920x1080}; do
     LVDGS_LIB=$L LVDGS_BENCH_WORKLOAD=$W python3 bench.py --steps 100 --warmup 60 --no-cpu-baseline --no-side 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
