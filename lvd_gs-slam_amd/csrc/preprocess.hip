@@ -502,7 +502,7 @@ __device__ __forceinline__ void loads_complete_here(int32_t &radius, uint32_t &s
 // no atomics -- thousands of waves adding to the same eight words cost more than the kernel).
 // [0] 1, [1] whole sweep, [2] flags -> list (wait, masks, scan, list, barrier), [3] gather (requests -> LDS, barrier), [4] sums,
 // [5] segments, [6] passes, [7] records
-constexpr int PBWD_DIAG_WAVES = 4096;
+constexpr int PBWD_DIAG_WAVES = 8192;
 constexpr int PBWD_DIAG_VALUES = 12;   // [8] trips of the lanes' own loop (the longest lane's), [9] Gaussians summed by the whole wave, [10] clocks of those
 __device__ unsigned long long g_pbwd_diag[PBWD_DIAG_WAVES * PBWD_DIAG_VALUES];
 #define PBWD_CLK(x) const unsigned long long x = __builtin_readcyclecounter()
@@ -527,16 +527,14 @@ __device__ __forceinline__ void unpack_sums(const v2f (&P)[POSE_ONLY ? PAIR_FLOA
 #else
 #define LVDGS_BIG_PATH_ATTR __attribute__((noinline))
 #endif
+// A2: the ten sums as packed pairs, in the record's own layout ([0,1] [2,3] [4,5] [6,7] [8,9]; pose-only [0,1] [2,3] [4,9]): a record is
+// added with PF / 2 v_pk_add_f32 -- the same IEEE additions, two per instruction.  The records of [w_first, w_hi) are added to what A2 holds.
 template <bool POSE_ONLY>
-__device__ LVDGS_BIG_PATH_ATTR PairSums sum_region_compacted(const float *__restrict__ pair_grads, const uint8_t *__restrict__ pair_valid, char *s_mem,
-                                                                   uint32_t first, uint32_t last, uint32_t w_first, uint32_t w_hi) {
+__device__ LVDGS_BIG_PATH_ATTR void sum_region_compacted(const float *__restrict__ pair_grads, const uint8_t *__restrict__ pair_valid, char *s_mem,
+                                                              uint32_t first, uint32_t last, uint32_t w_first, uint32_t w_hi,
+                                                              v2f (&A2)[POSE_ONLY ? PAIR_FLOATS_POSE / 2 : PAIR_FLOATS / 2]) {
     constexpr int PF = POSE_ONLY ? PAIR_FLOATS_POSE : PAIR_FLOATS;
     const int lane = threadIdx.x & 63;
-    // the ten sums as packed pairs, in the record's own layout ([0,1] [2,3] [4,5] [6,7] [8,9]; pose-only [0,1] [2,3] [4,9]): a record is
-    // added with PF / 2 v_pk_add_f32 -- the same IEEE additions, two per instruction
-    v2f A2[PF / 2];
-#pragma unroll
-    for (int k = 0; k < PF / 2; k++) A2[k] = v2f{0.f, 0.f};
     {
         // A wave that holds large-footprint Gaussians (hundreds of pairs each: the stuff opaque surfaces are made of).  Of their
         // records only those in front of their tiles' last contributors exist -- a tenth on opaque surfaces -- and a lane that
@@ -735,15 +733,12 @@ __device__ LVDGS_BIG_PATH_ATTR PairSums sum_region_compacted(const float *__rest
         PBWD_ADD(1, t_end - t_begin);
 #ifdef LVDGS_DIAG_PBWD
         {
-            const int w = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+            const int w = (int)blockIdx.x * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);   // (helper waves have rows of their own)
             if (lane == 0 && w < PBWD_DIAG_WAVES)
                 for (int k = 0; k < PBWD_DIAG_VALUES; k++) g_pbwd_diag[PBWD_DIAG_VALUES * w + k] += diag[k];
         }
 #endif
     }
-    PairSums out;
-    unpack_sums<POSE_ONLY>(A2, out.A);
-    return out;
 }
 
 // POSE_ONLY (LVDGS_FLAG_POSE_ONLY): the pose gradient alone -- six-float pair records (d/d 2-D mean, conic, view depth), no
@@ -754,13 +749,20 @@ __device__ LVDGS_BIG_PATH_ATTR PairSums sum_region_compacted(const float *__rest
 // thread's registers over the views (acc) and written once by the caller.  The additions are the ones the view-after-view launches
 // make, in the same order: `assign` (the launch's first view when its gradients are not added to what the buffers hold) assigns.
 struct GradAcc { float opac, m3[3], sc[3], rot[4], sh[3]; bool touched; };
-template <bool POSE_ONLY, bool IN_REGS = false>
+// HELPERS (preprocess_bwd_helpers_kernel: frames whose Gaussians have large footprints, LVDGS_FLAG_SUPER_TILES): workgroups of EIGHT
+// waves -- wave 4 + w owns nothing and sweeps the second part of wave w's region of pair records while wave w sweeps the first.  The sums
+// of a large-footprint wave are DEFINED in two parts, (records in front of the split) + (records behind it), the split a function of
+// the region alone: without helpers the wave sweeps the parts one after the other, so both forms add the same numbers in the same order.
+template <bool POSE_ONLY, bool IN_REGS = false, bool HELPERS = false>
 __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p, GradAcc *acc = nullptr, bool assign = false) {
     static_assert(!(POSE_ONLY && IN_REGS), "the pose-only pass has no parameter gradients to keep");
+    static_assert(!(HELPERS && IN_REGS), "the views of a window: no helper waves");
+    constexpr int AREAS = HELPERS ? 8 : 4;   // LDS staging areas: one per wave
+    const bool helper = HELPERS && threadIdx.x >= 256;
     constexpr int PF = POSE_ONLY ? PAIR_FLOATS_POSE : PAIR_FLOATS;   // floats per pair record
     __shared__ float s_tau[4][6];
     if (p.pair_total && *p.pair_total > p.pair_capacity) return;   // (uniform over the launch)
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x * 256 + (threadIdx.x & 255);   // (a helper thread: its owner's Gaussian)
     const Cam &c = p.cam;
     // The camera's matrices, read once into scalar registers (the compiler reads them with vector loads where they are
     // used -- the pointers are not known to be invariant -- and such a load's first use would end the overlap below).
@@ -776,13 +778,15 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p, GradAcc 
     // EVERYTHING outstanding (vmcnt(0)) at the first use of an ordinary load's result while LDS-DMA loads are in flight,
     // so nothing loaded the ordinary way may be used for the first time between the request and the sums.  (Parameters of
     // Gaussians that turn out invisible are read for nothing: 44 bytes each.)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, area = threadIdx.x >> 6;
     const bool in_map = i < p.N;
     int32_t radius_i = 0;
     uint32_t slot_i = 0u, tiles_i = 0u;
     float pos[3] = {0.f, 0.f, 0.f}, opac_raw = 0.f, c6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sc[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f};
     if (in_map) {
         radius_i = p.radii[i]; slot_i = p.slot_base[i]; tiles_i = p.tiles_touched[i];
+    }
+    if (in_map && !helper) {
         pos[0] = p.means3D[3 * i]; pos[1] = p.means3D[3 * i + 1]; pos[2] = p.means3D[3 * i + 2];
         if constexpr (!POSE_ONLY) opac_raw = p.opacities[i];
         if (p.cov3D_precomp) {
@@ -798,7 +802,8 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p, GradAcc 
     loads_complete_here(radius_i, slot_i, tiles_i, pos, opac_raw, sc, q, c6);
     // (a visible Gaussian without a listed pair -- none of its tiles in the band being rendered, or every tile ruled out by the
     // reach test -- has all-zero sums, and every output is linear in them: zeros are written and the arithmetic left out)
-    const bool live = in_map && radius_i > 0 && tiles_i > 0u;
+    const bool has_run = in_map && radius_i > 0 && tiles_i > 0u;   // (its records: slots slot_i ... slot_i + tiles_i - 1)
+    const bool live = has_run && !helper;
     // gradients w.r.t. the parameters: written, or (a later view of a mapping iteration) added to what is there
     const bool accumulate = p.accumulate != 0;
     // (r: the value's place in the registers of an IN_REGS pass)
@@ -829,7 +834,7 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p, GradAcc 
         }
     };
     if constexpr (IN_REGS) { if (live) acc->touched = true; }
-    if (!POSE_ONLY && i < p.N && !live) {
+    if (!POSE_ONLY && i < p.N && !live && !helper) {
 #pragma unroll
         for (int k = 0; k < 3; k++) p.dmeans2D[3 * (size_t)i + k] = 0.f;
         if (!IN_REGS && !accumulate) {   // (adding zero: nothing to do; IN_REGS: the caller writes what the registers hold)
@@ -854,18 +859,18 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p, GradAcc 
     // the rotation matrix -- and land while it runs: with the workgroup-wide staging of before (two workgroup barriers per
     // chunk) the kernel was the sum of a memory phase and an arithmetic phase, every resident workgroup in the same one
     // (ablation builds: 26.7 us without the arithmetic, 28.9 without the sums, 49.5 together).
-    __shared__ float4 s_pg4[4][STAGE_BYTES<PF> / 16];   // (the last load instruction of a chunk is masked to the lanes inside it)
+    __shared__ float4 s_pg4[AREAS][STAGE_BYTES<PF> / 16];   // (the last load instruction of a chunk is masked to the lanes inside it)
     __shared__ uint32_t s_valid4[4][WAVE_CHUNK / 4];
     float A[10];
 #pragma unroll
     for (int k = 0; k < 10; k++) A[k] = 0.f;
-    const uint32_t first = live ? slot_i : 0u, npairs = live ? tiles_i : 0u, last = first + npairs;
+    const uint32_t first = has_run ? slot_i : 0u, npairs = has_run ? tiles_i : 0u, last = first + npairs;
     const bool big = npairs > BIG_RUN;
     const bool stream = __ballot(big) == 0ull;   // (wave-uniform)
     // the wave's region: from the first slot of its first Gaussian to the end of its last one's (slot_base is the running
     // sum of tiles_touched over ALL Gaussians, visible or not)
     uint32_t r_lo = 0u, r_hi = 0u;
-    if (stream && i - lane < p.N) {
+    if (stream && !helper && i - lane < p.N) {
         const int last_lane = min(63, p.N - 1 - (i - lane));
         r_lo = (uint32_t)__shfl((int)slot_i, 0, 64) & ~3u;   // a chunk starts at a multiple of 4 records: on a 16-byte boundary of the records and a word of flags
         r_hi = (uint32_t)__shfl((int)(slot_i + tiles_i), last_lane, 64);
@@ -945,9 +950,48 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p, GradAcc 
             w_first = (uint32_t)__shfl((int)slot_i, 0, 64);
             w_hi = (uint32_t)__shfl((int)(slot_i + tiles_i), last_lane, 64);
         }
-        const PairSums sums = sum_region_compacted<POSE_ONLY>(p.pair_grads, p.pair_valid, reinterpret_cast<char *>(s_pg4[wave]), first, last, w_first, w_hi);
+        // the two parts of the region (the template's comment): the split half-way, at a whole number of sweep segments from the start
+        const uint32_t split = min(w_hi, w_first + ((w_hi - w_first) / 2u + (uint32_t)LVDGS_PBWD_SEG - 1u) / (uint32_t)LVDGS_PBWD_SEG * (uint32_t)LVDGS_PBWD_SEG);
+        char *const stage = reinterpret_cast<char *>(s_pg4[area]);
+        v2f A2[PF / 2];
 #pragma unroll
-        for (int k = 0; k < 10; k++) A[k] = sums.A[k];
+        for (int k = 0; k < PF / 2; k++) A2[k] = v2f{0.f, 0.f};
+        if constexpr (HELPERS) {
+            sum_region_compacted<POSE_ONLY>(p.pair_grads, p.pair_valid, stage, first, last, helper ? split : w_first, helper ? w_hi : split, A2);
+            unpack_sums<POSE_ONLY>(A2, A);
+            if (helper) {   // the second part's sums, to the owner: lane l's ten values side by side in this wave's staging area
+                float *out = reinterpret_cast<float *>(stage) + 10 * lane;
+#pragma unroll
+                for (int k = 0; k < 10; k++) out[k] = A[k];
+            }
+        } else {
+            // one part after the other.  A run lies in one part -- the other part's sum is +0, and x + 0 is x (no sum is ever -0: they
+            // start at +0) -- except the ONE run that holds the split: that lane's first-part sums wait in scalar registers while its
+            // registers start the second part at zero, and are added in front afterwards.
+            sum_region_compacted<POSE_ONLY>(p.pair_grads, p.pair_valid, stage, first, last, w_first, split, A2);
+            const uint64_t across = __ballot(first < split && last > split);
+            const int owner_lane = across ? __builtin_ctzll(across) : 0;
+            float kept[PF];
+#pragma unroll
+            for (int k = 0; k < PF / 2; k++) {
+                kept[2 * k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(A2[k].x), owner_lane));
+                kept[2 * k + 1] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(A2[k].y), owner_lane));
+                if (across && lane == owner_lane) A2[k] = v2f{0.f, 0.f};
+            }
+            sum_region_compacted<POSE_ONLY>(p.pair_grads, p.pair_valid, stage, first, last, split, w_hi, A2);
+#pragma unroll
+            for (int k = 0; k < PF / 2; k++)
+                if (across && lane == owner_lane) A2[k] = v2f{kept[2 * k], kept[2 * k + 1]} + A2[k];
+            unpack_sums<POSE_ONLY>(A2, A);
+        }
+    }
+    if constexpr (HELPERS) {
+        __syncthreads();   // (every wave of the workgroup, whichever path it took)
+        if (!stream && !helper) {
+            const float *in = reinterpret_cast<const float *>(s_pg4[area + 4]) + 10 * lane;
+#pragma unroll
+            for (int k = 0; k < 10; k++) A[k] = A[k] + in[k];
+        }
     }
 #endif
 #if LVDGS_PBWD_ABLATE == 2
@@ -1139,7 +1183,7 @@ __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p, GradAcc 
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         const float s = wave_sum_to_lane63(tau[k]);
-        if (lane == 63) s_tau[wave][k] = s;
+        if (lane == 63 && !helper) s_tau[wave][k] = s;
     }
     __syncthreads();
     if (threadIdx.x < 6)
@@ -1154,6 +1198,9 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS) preprocess_bwd_kernel(Bwd
 #define LVDGS_PBWD_WGS_POSE 5   // (6: 80 VGPRs with 7 spilled; same box 25.1 against 24.1 us at config 3)
 #endif
 __global__ void __launch_bounds__(256, LVDGS_PBWD_WGS_POSE) preprocess_bwd_pose_kernel(BwdParams p) { preprocess_bwd_body<true>(p); }
+// ... with helper waves (512 threads: the body's comment)
+__global__ void __launch_bounds__(512, 2) preprocess_bwd_helpers_kernel(BwdParams p) { preprocess_bwd_body<false, false, true>(p); }
+__global__ void __launch_bounds__(512, 2) preprocess_bwd_pose_helpers_kernel(BwdParams p) { preprocess_bwd_body<true, false, true>(p); }
 
 // The per-Gaussian passes of up to PBWD_VIEWS views of one map in ONE launch (lvdgs_gaussian_backward_batch: the views of a mapping
 // window behind their batched blend pass).  A thread walks its Gaussian through the views in order with the parameter gradients in
@@ -1344,8 +1391,15 @@ int launch_preprocess_bwd(const lvdgs_args &a, const GeomView &g, const BwdScrat
         p.dcolors = a.dL_dcolors; p.tau_part = b.tau_part; p.accumulate = (a.flags & LVDGS_FLAG_ACCUMULATE_PARAM_GRADS) ? 1 : 0;
         p.pair_total = pair_total; p.pair_capacity = pair_capacity;
         ProfScope ps("preprocess_bwd", s);
-        if (a.flags & LVDGS_FLAG_POSE_ONLY) hipLaunchKernelGGL(preprocess_bwd_pose_kernel, dim3(nblk), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(256), 0, s, p);
+        // helper waves where the caller expects large footprints (the two-level grouping's hint): the same sums, bit for bit, sooner
+        const bool helpers = (a.flags & LVDGS_FLAG_SUPER_TILES) != 0;
+        if (a.flags & LVDGS_FLAG_POSE_ONLY) {
+            if (helpers) hipLaunchKernelGGL(preprocess_bwd_pose_helpers_kernel, dim3(nblk), dim3(512), 0, s, p);
+            else hipLaunchKernelGGL(preprocess_bwd_pose_kernel, dim3(nblk), dim3(256), 0, s, p);
+        } else {
+            if (helpers) hipLaunchKernelGGL(preprocess_bwd_helpers_kernel, dim3(nblk), dim3(512), 0, s, p);
+            else hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(256), 0, s, p);
+        }
         LVDGS_LAUNCH_CHECK("preprocess_bwd", a.debug, s);
     }
     if (a.dL_dtau) {   // NULL: the partials stay in the scratch for lvdgs_tracking_tail
@@ -1404,9 +1458,9 @@ int launch_mark_visible(int N, const float *means3D, const float *view, uint8_t 
 }  // namespace lvdgs
 
 #ifdef LVDGS_DIAG_PBWD
-extern "C" int lvdgs_diag_pbwd(unsigned long long *out_4096x8, int reset) {   // (rows of PBWD_DIAG_VALUES = 12)
+extern "C" int lvdgs_diag_pbwd(unsigned long long *out_8192x12, int reset) {
     constexpr size_t BYTES = (size_t)lvdgs::PBWD_DIAG_WAVES * lvdgs::PBWD_DIAG_VALUES * sizeof(unsigned long long);
-    if (out_4096x8 && hipMemcpyFromSymbol(out_4096x8, HIP_SYMBOL(lvdgs::g_pbwd_diag), BYTES) != hipSuccess) return LVDGS_E_HIP;
+    if (out_8192x12 && hipMemcpyFromSymbol(out_8192x12, HIP_SYMBOL(lvdgs::g_pbwd_diag), BYTES) != hipSuccess) return LVDGS_E_HIP;
     if (reset) {
         void *dptr = nullptr;
         if (hipGetSymbolAddress(&dptr, HIP_SYMBOL(lvdgs::g_pbwd_diag)) != hipSuccess || hipMemset(dptr, 0, BYTES) != hipSuccess) return LVDGS_E_HIP;

@@ -101,9 +101,10 @@ def test_sequence_with_the_map_growing_under_the_batched_window(half_kitti_runs)
 def test_fused_path_and_autograd_api_path_agree_on_the_sequence(half_kitti_runs):
     f, a = half_kitti_runs["fused"][0], half_kitti_runs["autograd"][0]
     assert a["batched_window_runs"] == 0                                              # (fused=False really is the other path)
-    assert f["window_log"][:2] == a["window_log"][:2]
+    assert f["window_log"][0] == a["window_log"][0] == [0]
     assert abs(f["keyframes"] - a["keyframes"]) <= 1
-    # (a keyframe test on its bar falls a frame earlier or later: the keyframes of the two runs pair up within two frames)
+    # (a keyframe test on its bar falls a frame earlier or later -- the second keyframe already: frame 9 in one run, 10 in the other --:
+    # the keyframes of the two runs pair up within two frames)
     kf_f, kf_a = [w[0] for w in f["window_log"]], [w[0] for w in a["window_log"]]
     assert all(abs(x - y) <= 2 for x, y in zip(kf_f, kf_a)), (kf_f, kf_a)
     # two float32 runs of one system that differ in summation order (the fused backward reduces per tile, autograd per launch):

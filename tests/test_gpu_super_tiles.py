@@ -2,7 +2,10 @@
 super-tile, the tiles' lists read off the sorted super lists.  A hint: the sorted pair list, the tile ranges, every image, every
 gradient must be the SAME BITS with and without it -- on opaque surfaces (where it pays), on small blobs (where it does not), on a frame
 whose size is no multiple of the super-tile, on rectangles of more than 64 tiles and of more than 64 super-tiles, when the pair
-capacity overflows, through the autograd API, the tracking session and the mapping window."""
+capacity overflows, through the autograd API, the tracking session and the mapping window.
+
+In the backward the same flag selects preprocess_bwd's helper-wave kernels (csrc/preprocess.hip: the second half of a large-footprint wave's
+pair records summed by a wave of its own): the gradient comparisons below are also "helper waves == one wave, part after part"."""
 import os
 import sys
 

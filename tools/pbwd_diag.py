@@ -22,7 +22,7 @@ for w in (sys.argv[1:] or ["surface_100k_1920x1080"]):
         s.step()
     torch.cuda.synchronize()
     import numpy as np
-    rows = np.zeros((4096, 12), dtype=np.uint64)
+    rows = np.zeros((8192, 12), dtype=np.uint64)
     L.lvdgs_diag_pbwd(rows.ctypes.data_as(C.c_void_p), 1)
     steps = 50
     for _ in range(steps):
