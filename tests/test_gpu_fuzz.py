@@ -29,7 +29,10 @@ def _case(rng):
     return c
 
 
-@pytest.mark.parametrize("case_seed", list(range(int(os.environ.get("LVDGS_FUZZ_CASES", "80")))))  # more: set the variable
+_FIRST = int(os.environ.get("LVDGS_FUZZ_FIRST", "0"))   # (a sweep over other scenes than the first LVDGS_FUZZ_CASES)
+
+
+@pytest.mark.parametrize("case_seed", list(range(_FIRST, _FIRST + int(os.environ.get("LVDGS_FUZZ_CASES", "80")))))  # more: set the variable
 def test_random_scene_matches_oracle(case_seed):
     _check_case(_case(np.random.default_rng(1000 + case_seed)))
 
