@@ -756,7 +756,6 @@ struct GradAcc { float opac, m3[3], sc[3], rot[4], sh[3]; bool touched; };
 template <bool POSE_ONLY, bool IN_REGS = false, bool HELPERS = false>
 __device__ __forceinline__ void preprocess_bwd_body(const BwdParams &p, GradAcc *acc = nullptr, bool assign = false) {
     static_assert(!(POSE_ONLY && IN_REGS), "the pose-only pass has no parameter gradients to keep");
-    static_assert(!(HELPERS && IN_REGS), "the views of a window: no helper waves");
     constexpr int AREAS = HELPERS ? 8 : 4;   // LDS staging areas: one per wave
     const bool helper = HELPERS && threadIdx.x >= 256;
     constexpr int PF = POSE_ONLY ? PAIR_FLOATS_POSE : PAIR_FLOATS;   // floats per pair record
@@ -1216,8 +1215,10 @@ static_assert(sizeof(BwdViews) <= 4000, "kernel arguments");
 #ifndef LVDGS_PBWD_VIEWS_WGS
 #define LVDGS_PBWD_VIEWS_WGS 4
 #endif
-__global__ void __launch_bounds__(256, LVDGS_PBWD_VIEWS_WGS) preprocess_bwd_views_kernel(BwdViews b) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+template <bool HELPERS>
+__device__ __forceinline__ void preprocess_bwd_views_body(const BwdViews &b) {
+    const bool owner = !HELPERS || threadIdx.x < 256;   // (helper waves: the body's comment; they own no Gaussian and hold no gradients)
+    const int i = owner ? (int)blockIdx.x * 256 + (int)threadIdx.x : b.common.N;
     const bool add_to_memory = b.common.accumulate != 0;   // (the launch's sums are added to what the buffers hold)
     GradAcc acc{};
     if (add_to_memory && i < b.common.N) {
@@ -1232,7 +1233,7 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_VIEWS_WGS) preprocess_bwd_view
         const BwdView &v = b.v[k];
         p.cam = v.cam; p.radii = v.radii; p.rec = v.rec; p.tiles_touched = v.tiles_touched; p.slot_base = v.slot_base;
         p.pair_grads = v.pair_grads; p.pair_valid = v.pair_valid; p.dmeans2D = v.dmeans2D; p.tau_part = v.tau_part;
-        preprocess_bwd_body<false, true>(p, &acc, k == 0 && !add_to_memory);
+        preprocess_bwd_body<false, true, HELPERS>(p, &acc, k == 0 && !add_to_memory);
         __syncthreads();   // (the next view's pass uses the workgroup's LDS again)
     }
     if (i < b.common.N && (acc.touched || !add_to_memory)) {   // (a Gaussian no view of the launch saw: zeros, or what was there)
@@ -1245,6 +1246,8 @@ __global__ void __launch_bounds__(256, LVDGS_PBWD_VIEWS_WGS) preprocess_bwd_view
         *reinterpret_cast<f4 *>(&b.common.drot[4 * (size_t)i]) = f4{acc.rot[0], acc.rot[1], acc.rot[2], acc.rot[3]};
     }
 }
+__global__ void __launch_bounds__(256, LVDGS_PBWD_VIEWS_WGS) preprocess_bwd_views_kernel(BwdViews b) { preprocess_bwd_views_body<false>(b); }
+__global__ void __launch_bounds__(512, 4) preprocess_bwd_views_helpers_kernel(BwdViews b) { preprocess_bwd_views_body<true>(b); }
 
 // fixed-order reduction of the per-workgroup pose partials (strided per-thread sums, then a wave fold and a four-term sum:
 // two barriers fewer than an LDS tree, the order of the additions fixed by the code either way)
@@ -1434,7 +1437,8 @@ int launch_preprocess_bwd_views(const lvdgs_args *const *a, const GeomView *g, c
             bv.v[k] = BwdView{make_cam(*a[v]), a[v]->radii, g[v].rec, g[v].tiles_touched, g[v].slot_base, w[v].pair_grads, b[v].pair_valid, a[v]->dL_dmeans2D, w[v].tau_part};
         }
         ProfScope ps("preprocess_bwd", s);
-        hipLaunchKernelGGL(preprocess_bwd_views_kernel, dim3(nblk), dim3(256), 0, s, bv);
+        if (a0.flags & LVDGS_FLAG_SUPER_TILES) hipLaunchKernelGGL(preprocess_bwd_views_helpers_kernel, dim3(nblk), dim3(512), 0, s, bv);   // (as in launch_preprocess_bwd)
+        else hipLaunchKernelGGL(preprocess_bwd_views_kernel, dim3(nblk), dim3(256), 0, s, bv);
         LVDGS_LAUNCH_CHECK("preprocess_bwd (views)", a0.debug, s);
     }
     for (int v = 0; v < n; v++)
