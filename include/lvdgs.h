@@ -154,7 +154,7 @@ enum {
                                       ranges and every output are the same bits with and without it; worth setting when num_rendered exceeds ~16 pairs per
                                       Gaussian (lvdgs.rasterizer decides from the previous frame's count).  Ignored with LVDGS_FLAG_LIST_ALL_TILES, with a
                                       band of tile rows and on frames of fewer than 64 tiles; the views of lvdgs_forward_batch must agree on it.
-                                      B: the per-Gaussian pass of lvdgs_backward* runs with helper waves (workgroups of eight waves: the second half of a
+                                      B: the per-Gaussian pass of lvdgs_backward*, lvdgs_forward_backward_fused_loss and lvdgs_gaussian_backward_batch runs with helper waves (workgroups of eight waves: the second half of a
                                       large-footprint wave's pair records is summed beside the first) -- the same sums in the same order, sooner. */
     LVDGS_FLAG_POSE_ONLY = 4,      /* B: only the camera-pose gradient (dL_dtau, or its partial sums for lvdgs_tracking_tail) and --
                                       lvdgs_backward_fused_loss -- the loss value and exposure gradients are produced.  The
